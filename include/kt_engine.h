@@ -1,0 +1,164 @@
+/*
+ * kt_engine.h — C-ABI of the MI355X-native throttle-evaluation engine (libkt_engine.so).
+ *
+ * kube-throttler has no FFI of any kind today (pure Go, CGO_ENABLED=0 — Makefile:3,10), so this is a
+ * NEW seam.  It is cut exactly where the Go plugin does its per-pod x per-throttle work, and each
+ * entry point names the reference code whose body it replaces.  The outer plugin API stays untouched:
+ *   PluginName / NewPlugin / PreFilter / Reserve / Unreserve  (pkg/scheduler_plugin/plugin.go:45,63,148,217,240)
+ * The cgo stubs a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int32_t: KT_OK (0) or a negative KT_ERR_*; text via kt_last_error().
+ *   - the caller owns every pointer it passes; the engine copies during the call and retains nothing
+ *     (cgo rule: C must not keep Go memory).  Output buffers are caller-allocated.
+ *   - strings never cross: labels, namespaces, resource names are interned to ids by the caller
+ *     (include/kt_snapshot.h documents the id spaces and the flat batch format).
+ *   - rows are caller-managed dense indices: pod row in [0, pod_capacity), throttle row in
+ *     [0, throttle_capacity), namespace id in [0, namespace_capacity).  Upserting a row replaces it.
+ *   - `stream` arguments are a hipStream_t (NULL = the engine's own stream).  *_launch calls are
+ *     asynchronous on that stream; results stay in HBM until a *_fetch call copies them out.
+ *   - all entry points may be called from any OS thread; calls on one engine are serialised internally.
+ */
+#ifndef KT_ENGINE_H
+#define KT_ENGINE_H
+
+#include <stdint.h>
+#include "kt_snapshot.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KT_OK 0
+#define KT_ERR_INVALID_ARGUMENT (-1)
+#define KT_ERR_OUT_OF_RANGE (-2)   /* row / id / dimension outside the configured capacity */
+#define KT_ERR_DEVICE (-3)         /* HIP runtime error (message has the hipError string) */
+#define KT_ERR_OVERFLOW_RISK (-4)  /* a per-dimension sum could leave the exact int64 range: rescale the dimension */
+#define KT_ERR_NOT_READY (-5)      /* fetch without a preceding launch */
+#define KT_ERR_NO_DEVICE (-6)      /* no gfx950 device visible: there is NO CPU fallback */
+
+/* per (pod, throttle) status — v1alpha1.CheckThrottleStatus (throttle_types.go:119-126) + not-affected / error */
+#define KT_STATUS_NOT_AFFECTED 0
+#define KT_STATUS_NOT_THROTTLED 1
+#define KT_STATUS_ACTIVE 2
+#define KT_STATUS_INSUFFICIENT 3
+#define KT_STATUS_POD_REQUESTS_EXCEEDS_THRESHOLD 4
+#define KT_STATUS_ERROR 255
+
+/* per-pod summary word: what KubeThrottler.PreFilter derives (plugin.go:148-215).
+ * bits 0-1  verdict: 0 framework.Success, 1 UnschedulableAndUnresolvable, 2 framework.Error
+ * bits 4-23 #throttles[pod-requests-exceeds-threshold], 24-43 #throttles[active], 44-63 #throttles[insufficient] */
+#define KT_VERDICT_SUCCESS 0
+#define KT_VERDICT_UNSCHEDULABLE 1
+#define KT_VERDICT_ERROR 2
+#define KT_SUMMARY_VERDICT(w) ((uint32_t)((w) & 3u))
+#define KT_SUMMARY_EXCEEDS(w) ((uint32_t)(((w) >> 4) & 0xFFFFFu))
+#define KT_SUMMARY_ACTIVE(w) ((uint32_t)(((w) >> 24) & 0xFFFFFu))
+#define KT_SUMMARY_INSUFFICIENT(w) ((uint32_t)(((w) >> 44) & 0xFFFFFu))
+
+typedef struct kt_engine kt_engine; /* opaque */
+
+typedef struct kt_config {
+  int32_t n_dims;             /* D: resource dimensions (<= KT_MAX_DIMS) */
+  int32_t max_labels;         /* labels kept per pod (<= KT_MAX_LABELS) */
+  int64_t pod_capacity;       /* pod rows held in HBM */
+  int32_t throttle_capacity;  /* Throttle + ClusterThrottle rows (< 2^20) */
+  int32_t namespace_capacity;
+  int32_t device;             /* HIP device ordinal; -1 = current device */
+  int32_t kernel_variant;     /* 0 = default (indexed); 1 = dense P x T scan (reference shape, for cross-checks) */
+} kt_config;
+
+/* Library / device facts (for logs and bench JSON). */
+const char* kt_version(void);
+
+/* Replaces the controller construction in NewPlugin (plugin.go:63-146) for the evaluation state:
+ * allocates the SoA tables in HBM.  Fails with KT_ERR_NO_DEVICE when no GPU is present. */
+int32_t kt_engine_create(const kt_config* cfg, kt_engine** out);
+int32_t kt_engine_destroy(kt_engine* e);
+/* Last error text of this engine (or of kt_engine_create when e == NULL); valid until the next call. */
+const char* kt_last_error(kt_engine* e);
+
+/* ---- state feed: what the informer event handlers push (throttle_controller.go:400-536,
+ *      clusterthrottle_controller.go:428-570).  A batch is a kt_snapshot whose sections may be empty
+ *      (n_ns / n_pods / n_thr = 0).  rows == NULL means batch index i -> row i. ------------------------ */
+int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* batch, const int32_t* ns_rows);
+/* Pods: the effective request of each pod is computed ON DEVICE from the batch's containers —
+ * resourcelist.PodRequestResourceList (pkg/resourcelist/resourcelist.go:27-46) + ResourceAmountOfPod
+ * (resource_amount.go:71-76).  */
+int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* batch, const int64_t* pod_rows);
+/* Throttles: spec (threshold, overrides, selector), stored status and reserved amounts of each row. */
+int32_t kt_upsert_throttles(kt_engine* e, const kt_snapshot* batch, const int32_t* thr_rows);
+int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* ns_rows);
+int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* pod_rows);
+int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* thr_rows);
+/* Clears everything and ingests a whole snapshot (rows = indices). */
+int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s);
+
+/* Scheduler-side reserved amounts per throttle — the value reservedResourceAmount(nn) returns
+ * (pkg/controllers/reserved_resource_amounts.go:113-126,148-156); the pod map itself stays in Go. */
+int32_t kt_set_reserved(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt_amounts* reserved);
+/* Stored CR status as the informer cache holds it (what CheckThrottledFor reads, throttle_types.go:128-153). */
+typedef struct kt_status {
+  kt_amounts used;           /* status.used */
+  kt_amounts calc;           /* status.calculatedThreshold.threshold */
+  uint8_t* calc_at_nonzero;  /* !status.calculatedThreshold.calculatedAt.IsZero() ; as an OUTPUT: calculatedThreshold replaced, calculatedAt := now */
+  uint32_t* thrl_flag;       /* status.throttled.resourceRequests values */
+  uint32_t* thrl_has;        /* ... keys */
+  uint8_t* thrl_pod;         /* status.throttled.resourceCounts.pod */
+  uint64_t* msgs_fp;         /* fingerprint of status.calculatedThreshold.messages (0 = none); input only */
+  uint8_t* error;            /* output only: reconcile returned an error for this throttle (selector) */
+} kt_status;
+int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt_status* status);
+
+/* ---- reconcile: [Cluster]ThrottleController.reconcile, aggregation part (throttle_controller.go:103-133,
+ *      clusterthrottle_controller.go:106-136) for EVERY responsible throttle in one pass:
+ *      affectedPods (:221-246 / :224-270) -> used = fold ResourceAmount.Add (resource_amount.go:91-110)
+ *      -> CalculateThreshold(now) (throttle_types.go:65-106) -> throttled = IsThrottled(used, true)
+ *      (resource_amount.go:127-159).  kt_reconcile_launch = aggregate + finalize on one GPU.
+ *      Multi-GPU (pods row-sharded, throttles replicated): kt_aggregate_launch, all-reduce(sum, int64)
+ *      over the buffer kt_partial_used_buffer returns, then kt_finalize_launch. -------------------------- */
+#define KT_RECONCILE_APPLY 0x1u /* store the new status as the engine's stored status (UpdateStatus) */
+int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
+int32_t kt_aggregate_launch(kt_engine* e, void* stream);
+int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64);
+int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
+/* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
+int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out);
+
+/* ---- check: KubeThrottler.PreFilter (plugin.go:148-215) = ThrottleController.CheckThrottled
+ *      (throttle_controller.go:349-397) + ClusterThrottleController.CheckThrottled
+ *      (clusterthrottle_controller.go:378-425) -> [Cluster]Throttle.CheckThrottledFor
+ *      (throttle_types.go:128-153, clusterthrottle_types.go:30-55) for n pods at once against the stored
+ *      status + reserved amounts.  pod_rows == NULL checks rows [0, n).  on_equal is the
+ *      isThrottledOnEqual argument (PreFilter passes false). ------------------------------------------- */
+#define KT_CHECK_STATUS_MATRIX 0x1u /* also produce the n x throttle_rows status matrix (parity / reason strings) */
+int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
+                        void* stream);
+/* out_summary [n] ; out_status [n][n_throttle_rows] (nullable; needs KT_CHECK_STATUS_MATRIX), where
+ * n_throttle_rows = 1 + highest throttle row ever upserted (kt_throttle_rows). Synchronises. */
+int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status);
+int32_t kt_throttle_rows(kt_engine* e, int32_t* out_rows);
+/* Device pointer of the per-pod summary words of the last check (stays valid until the next check). */
+int32_t kt_check_device_summary(kt_engine* e, void** device_ptr);
+
+/* Effective per-pod requests as held in HBM (parity of the resourcelist summation): out_v [n][D]. */
+int32_t kt_fetch_pod_requests(kt_engine* e, int64_t n, const int64_t* pod_rows, int64_t* out_v, uint32_t* out_present);
+
+/* ---- measurement: HIP-event timing of the engine's own kernels on the stream they run on. ------------- */
+#define KT_KERNEL_CHECK 0
+#define KT_KERNEL_AGGREGATE 1
+#define KT_KERNEL_FINALIZE 2
+#define KT_KERNEL_PREPARE 3
+#define KT_KERNEL_COUNT 4
+int32_t kt_timing_enable(kt_engine* e, int32_t on);
+/* Sum of durations (ms) and launch count since the last reset for one kernel family; synchronises. */
+int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* launches);
+int32_t kt_timing_reset(kt_engine* e);
+int32_t kt_synchronize(kt_engine* e, void* stream);
+/* name of the HIP kernel symbol behind a family (to match rocprofv3 kernel-trace rows) */
+const char* kt_kernel_name(kt_engine* e, int32_t kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KT_ENGINE_H */

@@ -1,0 +1,108 @@
+// kt_device.h — device-visible table descriptors shared by the HIP kernels and the host engine.
+// gfx950 only (wave64); no CUDA / multi-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kt {
+
+constexpr int kWave = 64;
+constexpr int64_t kInf = INT64_MAX;
+
+// pod_flags word in HBM: bits 0-3 = KT_POD_* state, bits 16-31 = request-key presence mask.
+constexpr uint32_t kPodValid = 0x1u, kPodSchedMatch = 0x2u, kPodScheduled = 0x4u, kPodFinished = 0x8u;
+constexpr int kPresentShift = 16;
+
+constexpr uint32_t kThrValid = 0x1u, kThrCluster = 0x2u, kThrResponsible = 0x4u, kThrCalcAtNonzero = 0x8u,
+                   kThrThrottledPod = 0x10u;
+constexpr uint8_t kTermPodSelInvalid = 0x1u, kTermNsSelInvalid = 0x2u;
+constexpr uint8_t kOpIn = 0, kOpNotIn = 1, kOpExists = 2, kOpDoesNotExist = 3;
+constexpr uint8_t kOvrParseError = 0x1u;
+constexpr int64_t kZeroTimeS = -62135596800LL;
+
+// Pod state: one plane per field, pod row is the fastest index (lane = pod => coalesced loads).
+struct PodTable {
+  uint32_t* ns;     // [cap]
+  uint32_t* flags;  // [cap]
+  int64_t* req;     // [D][cap]   effective request (ResourceAmountOfPod), 0 where absent
+  uint32_t* lpair;  // [L][cap]   (key,value) pair ids, 0 = empty slot
+  uint32_t* lkey;   // [L][cap]   key ids
+  int64_t cap;
+  int32_t D, L;
+};
+
+// ResourceAmount rows, row-major [n][D] like kt_amounts.
+struct AmountTab {
+  int64_t* v;
+  uint32_t* present;
+  int64_t* count;
+  uint8_t* has_count;
+};
+
+// Compiled selector program of all throttles (rebuilt by the host whenever throttles/namespaces change).
+struct SelProgram {
+  const uint32_t* thr_term_off;  // [T+1] terms of throttle t: [off[t], off[t+1])
+  const uint32_t* term_thr;      // [G]   owning throttle row
+  const uint8_t* term_flags;     // [G]   kTerm*
+  const uint32_t* term_req_off;  // [G+1] podSelector requirements
+  const uint8_t* req_op;         // [R]
+  const uint32_t* req_key;       // [R]
+  const uint32_t* req_val_off;   // [R+1]
+  const uint32_t* req_val;       // pair ids
+  // bit g of row ns: term g can apply to pods of namespace ns, i.e. the owning throttle is valid and
+  // responsible AND (Throttle: ns == thr.ns | ClusterThrottle: ns object exists and the term's
+  // namespaceSelector converts and matches it).
+  const uint32_t* ns_term_ok;    // [n_ns][gw]
+  const uint8_t* ns_valid;       // [n_ns] Namespace object exists
+  uint32_t gw;                   // words per ns row
+  int32_t T;                     // throttle rows in use (1 + highest row)
+  int32_t G;                     // terms
+  int32_t n_ns;
+};
+
+// Throttle tables (row-major, T rows).
+struct ThrTables {
+  uint32_t* flags;  // kThr*
+  AmountTab spec, calc, used, reserved;
+  uint32_t* thrl_flag;
+  uint32_t* thrl_has;
+  uint64_t* status_msgs_fp;
+  const uint64_t* spec_msgs_fp;
+  const uint32_t* ovr_off;  // [T+1]
+  const int64_t* ovr_begin_s;
+  const int32_t* ovr_begin_ns;
+  const int64_t* ovr_end_s;
+  const int32_t* ovr_end_ns;
+  const uint8_t* ovr_flags;
+  AmountTab ovr_thr;
+};
+
+// Result of one reconcile pass (device), T rows.
+struct ReconcileOut {
+  AmountTab used, calc;
+  uint8_t* calc_updated;
+  uint32_t* thrl_flag;
+  uint32_t* thrl_has;
+  uint8_t* thrl_pod;
+  uint8_t* error;
+};
+
+// Per-throttle record the check kernels consume (built by kt_prepare_check):
+//   thr[d]   effective threshold, +inf where the threshold has no such key
+//   head[d]  threshold - used - reserved  (minus 1 when isThrottledOnEqual), +inf likewise
+// so that CheckThrottledFor's steps 1 and 4 become  nz(pod,d) && pod[d] > thr[d] / head[d]
+// and steps 2+3 collapse into one bitmask (see DESIGN.md "Check algebra").
+constexpr uint32_t kRecExceedsByCount = 0x1u, kRecActiveByCount = 0x2u, kRecInsufficientByCount = 0x4u;
+template <int DT>
+struct alignas(16) CheckRec {
+  int64_t thr[DT];
+  int64_t head[DT];
+  uint32_t flags;
+  uint32_t active_mask;
+  uint32_t pad[2];
+};
+
+// layout of one throttle's row in the partial-used buffer (int64 words): v[D], present_count[D], pods, errors
+__host__ __device__ inline int partial_stride(int D) { return 2 * D + 2; }
+
+}  // namespace kt

@@ -1,0 +1,1204 @@
+// kt_engine.cpp — host side of libkt_engine.so: the C-ABI of include/kt_engine.h over the HIP kernels.
+//
+// Responsibilities: own every device allocation (SoA pod planes, throttle tables, selector program,
+// index, result buffers), validate and stage caller batches (the caller's memory is never retained),
+// compile throttles + namespaces into the device selector program, launch kernels on the caller's
+// stream, time them with HIP events.  No compute happens here: without a gfx950 device
+// kt_engine_create fails (KT_ERR_NO_DEVICE) — there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kt_engine.h"
+#include "kt_index.h"
+#include "kt_launch.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Req {
+  uint8_t op;
+  uint32_t key;
+  std::vector<uint32_t> vals;
+};
+struct Term {
+  uint8_t flags = 0;
+  std::vector<Req> preq, nreq;
+};
+struct HostAmount {
+  int64_t v[KT_MAX_DIMS] = {0};
+  uint32_t present = 0;
+  int64_t count = 0;
+  uint8_t has_count = 0;
+};
+struct Override {
+  int64_t begin_s, end_s;
+  int32_t begin_ns, end_ns;
+  uint8_t flags;
+  HostAmount thr;
+};
+struct HostThrottle {
+  uint32_t flags = 0;  // KT_THR_* (0 = empty row)
+  uint32_t ns = 0;
+  HostAmount spec, calc, used, reserved;
+  uint32_t thrl_flag = 0, thrl_has = 0;
+  uint64_t status_fp = 0, spec_fp = 0;
+  std::vector<Override> ovr;
+  std::vector<Term> terms;
+};
+struct HostNamespace {
+  bool valid = false;
+  std::vector<std::pair<uint32_t, uint32_t>> labels;  // (key id, pair id)
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(n, 16);
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct AmountDev {
+  DevBuf<int64_t> v;
+  DevBuf<uint32_t> present;
+  DevBuf<int64_t> count;
+  DevBuf<uint8_t> has_count;
+  hipError_t reserve(size_t n, int D) {
+    hipError_t e;
+    if ((e = v.reserve(n * D)) != hipSuccess) return e;
+    if ((e = present.reserve(n)) != hipSuccess) return e;
+    if ((e = count.reserve(n)) != hipSuccess) return e;
+    return has_count.reserve(n);
+  }
+  kt::AmountTab tab() const { return kt::AmountTab{v.p, present.p, count.p, has_count.p}; }
+  void release() { v.release(); present.release(); count.release(); has_count.release(); }
+};
+
+struct AmountHostFlat {
+  std::vector<int64_t> v;
+  std::vector<uint32_t> present;
+  std::vector<int64_t> count;
+  std::vector<uint8_t> has_count;
+  void resize(size_t n, int D) {
+    v.assign(n * D, 0);
+    present.assign(n, 0);
+    count.assign(n, 0);
+    has_count.assign(n, 0);
+  }
+  void set(size_t i, int D, const HostAmount& a) {
+    for (int d = 0; d < D; ++d) v[i * D + d] = (a.present >> d) & 1u ? a.v[d] : 0;
+    present[i] = a.present;
+    count[i] = a.has_count ? a.count : 0;
+    has_count[i] = a.has_count;
+  }
+  void get(size_t i, int D, HostAmount& a) const {
+    for (int d = 0; d < D; ++d) a.v[d] = v[i * D + d];
+    a.present = present[i];
+    a.count = count[i];
+    a.has_count = has_count[i];
+  }
+};
+
+struct TimingFamily {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+};
+
+}  // namespace
+
+struct kt_engine {
+  kt_config cfg{};
+  std::mutex mu;
+  std::string err;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  int D = 0, L = 0;
+
+  // ---- pods (device only)
+  kt::PodTable pods{};
+  int64_t pod_rows_hi = 0;             // 1 + highest row ever upserted
+  unsigned __int128 max_abs[KT_MAX_DIMS] = {0};  // max |effective request| bound per dimension
+
+  // ---- host mirrors of the small tables
+  std::vector<HostNamespace> ns;
+  int32_t ns_rows_hi = 0;
+  std::vector<HostThrottle> thr;
+  int32_t thr_rows_hi = 0;
+  bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
+  bool status_host_dirty = true;  // host status/reserved rows newer than device
+  bool status_dev_newer = false;  // device status newer than host (after reconcile with APPLY)
+
+  // ---- compiled program (device)
+  DevBuf<uint32_t> d_thr_term_off, d_term_thr, d_term_req_off, d_req_key, d_req_val_off, d_req_val, d_ns_term_ok;
+  DevBuf<uint8_t> d_term_flags, d_req_op, d_ns_valid;
+  kt::SelProgram sp{};
+  bool uses_keys = false;
+  kt::HostIndex hindex;
+  kt::IndexDev dindex;
+
+  // ---- throttle tables (device)
+  DevBuf<uint32_t> d_thr_flags, d_thrl_flag, d_thrl_has, d_ovr_off;
+  DevBuf<uint64_t> d_status_fp, d_spec_fp;
+  AmountDev d_spec, d_calc, d_used, d_reserved, d_ovr_thr;
+  DevBuf<int64_t> d_ovr_begin_s, d_ovr_end_s;
+  DevBuf<int32_t> d_ovr_begin_ns, d_ovr_end_ns;
+  DevBuf<uint8_t> d_ovr_flags;
+  kt::ThrTables tt{};
+
+  // ---- reconcile state
+  DevBuf<unsigned long long> d_partial;
+  AmountDev d_out_used, d_out_calc;
+  DevBuf<uint8_t> d_out_calc_updated, d_out_thrl_pod, d_out_error;
+  DevBuf<uint32_t> d_out_thrl_flag, d_out_thrl_has;
+  bool reconcile_ready = false;
+
+  // ---- check state
+  DevBuf<uint8_t> d_recs;
+  DevBuf<uint64_t> d_summary;
+  DevBuf<uint8_t> d_status;
+  DevBuf<int64_t> d_rows;
+  int64_t check_n = 0;
+  bool check_has_status = false;
+  bool check_ready = false;
+  hipStream_t last_stream = nullptr;
+
+  // ---- staging
+  DevBuf<uint8_t> d_stage;
+
+  // ---- timing
+  bool timing = false;
+  TimingFamily fam[KT_KERNEL_COUNT];
+
+  int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+#define KT_HIP(e, call)                                                                          \
+  do {                                                                                           \
+    hipError_t _r = (call);                                                                      \
+    if (_r != hipSuccess) return (e)->fail(KT_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(_r)); \
+  } while (0)
+
+namespace {
+
+hipStream_t pick_stream(kt_engine* e, void* s) { return s ? (hipStream_t)s : e->own_stream; }
+
+struct TimedLaunch {
+  kt_engine* e;
+  int family;
+  hipStream_t s;
+  hipEvent_t stop = nullptr;
+  TimedLaunch(kt_engine* e_, int family_, hipStream_t s_) : e(e_), family(family_), s(s_) {
+    if (!e->timing) return;
+    TimingFamily& f = e->fam[family];
+    if (f.used == f.pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      f.pool.emplace_back(a, b);
+    }
+    auto& pr = f.pool[f.used++];
+    (void)hipEventRecord(pr.first, s);
+    stop = pr.second;
+  }
+  ~TimedLaunch() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
+
+// ---- host-side label selector evaluation (namespace selectors only; pods are matched on device) -----
+bool ns_selector_matches(const std::vector<Req>& reqs, const HostNamespace& n) {
+  for (const Req& r : reqs) {
+    bool has = false, in = false;
+    for (auto& kv : n.labels) {
+      if (kv.first == r.key) has = true;
+      for (uint32_t v : r.vals) in |= kv.second == v;
+    }
+    bool ok;
+    switch (r.op) {
+      case KT_OP_IN: ok = in; break;
+      case KT_OP_NOT_IN: ok = !in; break;
+      case KT_OP_EXISTS: ok = has; break;
+      case KT_OP_DOES_NOT_EXIST: ok = !has; break;
+      default: ok = false;
+    }
+    if (!ok) return false;
+  }
+  return true;
+}
+
+template <class T>
+int32_t upload(kt_engine* e, DevBuf<T>& d, const std::vector<T>& h, hipStream_t s) {
+  KT_HIP(e, d.reserve(h.size() + 1));
+  if (!h.empty()) KT_HIP(e, hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return KT_OK;
+}
+int32_t upload_amounts(kt_engine* e, AmountDev& d, const AmountHostFlat& h, size_t n, int D, hipStream_t s) {
+  KT_HIP(e, d.reserve(n + 1, D));
+  if (n) {
+    KT_HIP(e, hipMemcpyAsync(d.v.p, h.v.data(), n * D * 8, hipMemcpyHostToDevice, s));
+    KT_HIP(e, hipMemcpyAsync(d.present.p, h.present.data(), n * 4, hipMemcpyHostToDevice, s));
+    KT_HIP(e, hipMemcpyAsync(d.count.p, h.count.data(), n * 8, hipMemcpyHostToDevice, s));
+    KT_HIP(e, hipMemcpyAsync(d.has_count.p, h.has_count.data(), n, hipMemcpyHostToDevice, s));
+  }
+  return KT_OK;
+}
+int32_t download_amounts(kt_engine* e, const AmountDev& d, AmountHostFlat& h, size_t n, int D, hipStream_t s) {
+  h.resize(n, D);
+  if (n) {
+    KT_HIP(e, hipMemcpyAsync(h.v.data(), d.v.p, n * D * 8, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(h.present.data(), d.present.p, n * 4, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(h.count.data(), d.count.p, n * 8, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(h.has_count.data(), d.has_count.p, n, hipMemcpyDeviceToHost, s));
+  }
+  return KT_OK;
+}
+
+// Pull the device-resident status back into the host mirrors (after a reconcile with APPLY).
+int32_t sync_status_to_host(kt_engine* e) {
+  if (!e->status_dev_newer) return KT_OK;
+  const size_t T = (size_t)e->thr_rows_hi;
+  const int D = e->D;
+  hipStream_t s = e->own_stream;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  AmountHostFlat used, calc;
+  std::vector<uint32_t> flags(T), tf(T), th(T);
+  std::vector<uint64_t> fp(T);
+  int32_t rc;
+  if ((rc = download_amounts(e, e->d_used, used, T, D, s)) != KT_OK) return rc;
+  if ((rc = download_amounts(e, e->d_calc, calc, T, D, s)) != KT_OK) return rc;
+  if (T) {
+    KT_HIP(e, hipMemcpyAsync(flags.data(), e->d_thr_flags.p, T * 4, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(tf.data(), e->d_thrl_flag.p, T * 4, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(th.data(), e->d_thrl_has.p, T * 4, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(fp.data(), e->d_status_fp.p, T * 8, hipMemcpyDeviceToHost, s));
+  }
+  KT_HIP(e, hipStreamSynchronize(s));
+  for (size_t t = 0; t < T; ++t) {
+    HostThrottle& h = e->thr[t];
+    if (!(h.flags & KT_THR_VALID)) continue;
+    used.get(t, D, h.used);
+    calc.get(t, D, h.calc);
+    h.flags = flags[t];
+    h.thrl_flag = tf[t];
+    h.thrl_has = th[t];
+    h.status_fp = fp[t];
+  }
+  e->status_dev_newer = false;
+  return KT_OK;
+}
+
+// Flatten status + reserved rows and push them to the device.
+int32_t upload_status(kt_engine* e, hipStream_t s) {
+  const size_t T = (size_t)e->thr_rows_hi;
+  const int D = e->D;
+  AmountHostFlat calc, used, res;
+  calc.resize(T, D);
+  used.resize(T, D);
+  res.resize(T, D);
+  std::vector<uint32_t> flags(T), tf(T), th(T);
+  std::vector<uint64_t> fp(T);
+  for (size_t t = 0; t < T; ++t) {
+    const HostThrottle& h = e->thr[t];
+    calc.set(t, D, h.calc);
+    used.set(t, D, h.used);
+    res.set(t, D, h.reserved);
+    flags[t] = h.flags;
+    tf[t] = h.thrl_flag;
+    th[t] = h.thrl_has;
+    fp[t] = h.status_fp;
+  }
+  int32_t rc;
+  if ((rc = upload_amounts(e, e->d_calc, calc, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload_amounts(e, e->d_used, used, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload_amounts(e, e->d_reserved, res, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload(e, e->d_thr_flags, flags, s)) != KT_OK) return rc;
+  if ((rc = upload(e, e->d_thrl_flag, tf, s)) != KT_OK) return rc;
+  if ((rc = upload(e, e->d_thrl_has, th, s)) != KT_OK) return rc;
+  if ((rc = upload(e, e->d_status_fp, fp, s)) != KT_OK) return rc;
+  KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
+  e->status_host_dirty = false;
+  return KT_OK;
+}
+
+// Compile throttles + namespaces into the device selector program, spec tables and index.
+int32_t compile_program(kt_engine* e, hipStream_t s) {
+  const int D = e->D;
+  const size_t T = (size_t)e->thr_rows_hi;
+  const size_t NS = (size_t)e->cfg.namespace_capacity;
+  std::vector<uint32_t> thr_term_off(T + 1, 0), term_thr, term_req_off{0}, req_key, req_val_off{0}, req_val;
+  std::vector<uint8_t> term_flags, req_op;
+  std::vector<uint32_t> ovr_off(T + 1, 0);
+  std::vector<int64_t> ob_s, oe_s;
+  std::vector<int32_t> ob_ns, oe_ns;
+  std::vector<uint8_t> o_flags;
+  std::vector<uint64_t> spec_fp(T);
+  AmountHostFlat spec, ovr_thr;
+  spec.resize(T, D);
+  size_t n_ovr = 0;
+  for (size_t t = 0; t < T; ++t) n_ovr += e->thr[t].ovr.size();
+  ovr_thr.resize(n_ovr, D);
+  e->uses_keys = false;
+  size_t o = 0;
+  for (size_t t = 0; t < T; ++t) {
+    const HostThrottle& h = e->thr[t];
+    spec.set(t, D, h.spec);
+    spec_fp[t] = h.spec_fp;
+    for (const Override& ov : h.ovr) {
+      ob_s.push_back(ov.begin_s);
+      ob_ns.push_back(ov.begin_ns);
+      oe_s.push_back(ov.end_s);
+      oe_ns.push_back(ov.end_ns);
+      o_flags.push_back(ov.flags);
+      ovr_thr.set(o++, D, ov.thr);
+    }
+    ovr_off[t + 1] = (uint32_t)o;
+    if (h.flags & KT_THR_VALID)
+      for (const Term& tm : h.terms) {
+        term_thr.push_back((uint32_t)t);
+        term_flags.push_back(tm.flags);
+        for (const Req& r : tm.preq) {
+          req_op.push_back(r.op);
+          req_key.push_back(r.key);
+          for (uint32_t v : r.vals) req_val.push_back(v);
+          req_val_off.push_back((uint32_t)req_val.size());
+          if (r.op == KT_OP_EXISTS || r.op == KT_OP_DOES_NOT_EXIST) e->uses_keys = true;
+        }
+        term_req_off.push_back((uint32_t)req_op.size());
+      }
+    thr_term_off[t + 1] = (uint32_t)term_thr.size();
+  }
+  const size_t G = term_thr.size();
+  const uint32_t gw = (uint32_t)((G + 31) / 32 + 1);
+  // ns x term applicability bitmap
+  std::vector<uint32_t> ns_term_ok(NS * gw, 0u);
+  std::vector<uint8_t> ns_valid(NS, 0);
+  for (size_t n = 0; n < NS; ++n) ns_valid[n] = n < e->ns.size() && e->ns[n].valid;
+  for (size_t t = 0; t < T; ++t) {
+    const HostThrottle& h = e->thr[t];
+    const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
+    if ((h.flags & need) != need) continue;
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
+      const Term& tm = h.terms[g - thr_term_off[t]];
+      if (!(h.flags & KT_THR_CLUSTER)) {
+        // Throttles(pod.Namespace).List: implicit namespace equality, no Namespace object needed
+        if (h.ns < NS) ns_term_ok[(size_t)h.ns * gw + (g >> 5)] |= 1u << (g & 31);
+      } else {
+        if (tm.flags & KT_TERM_NS_SEL_INVALID) continue;  // swallowed to "no match" (clusterthrottle_selector.go:63-69)
+        for (size_t n = 0; n < NS && n < e->ns.size(); ++n)
+          if (e->ns[n].valid && ns_selector_matches(tm.nreq, e->ns[n])) ns_term_ok[n * gw + (g >> 5)] |= 1u << (g & 31);
+      }
+    }
+  }
+  int32_t rc;
+#define UP(dev, host) if ((rc = upload(e, e->dev, host, s)) != KT_OK) return rc
+  UP(d_thr_term_off, thr_term_off);
+  UP(d_term_thr, term_thr);
+  UP(d_term_flags, term_flags);
+  UP(d_term_req_off, term_req_off);
+  UP(d_req_op, req_op);
+  UP(d_req_key, req_key);
+  UP(d_req_val_off, req_val_off);
+  UP(d_req_val, req_val);
+  UP(d_ns_term_ok, ns_term_ok);
+  UP(d_ns_valid, ns_valid);
+  UP(d_ovr_off, ovr_off);
+  UP(d_ovr_begin_s, ob_s);
+  UP(d_ovr_begin_ns, ob_ns);
+  UP(d_ovr_end_s, oe_s);
+  UP(d_ovr_end_ns, oe_ns);
+  UP(d_ovr_flags, o_flags);
+  UP(d_spec_fp, spec_fp);
+#undef UP
+  if ((rc = upload_amounts(e, e->d_spec, spec, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
+  // result / scratch buffers sized by T
+  KT_HIP(e, e->d_partial.reserve(T * kt::partial_stride(D) + 1));
+  KT_HIP(e, e->d_out_used.reserve(T + 1, D));
+  KT_HIP(e, e->d_out_calc.reserve(T + 1, D));
+  KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
+  KT_HIP(e, e->d_out_thrl_pod.reserve(T + 1));
+  KT_HIP(e, e->d_out_error.reserve(T + 1));
+  KT_HIP(e, e->d_out_thrl_flag.reserve(T + 1));
+  KT_HIP(e, e->d_out_thrl_has.reserve(T + 1));
+  KT_HIP(e, e->d_recs.reserve((T + 1) * sizeof(kt::CheckRec<16>)));
+  // index for the work ~ (pods + matches) kernels
+  kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val,
+                  [&](uint32_t t) {
+                    const HostThrottle& h = e->thr[t];
+                    const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
+                    kt::ThrInfo ti;
+                    ti.live = (h.flags & need) == need;
+                    ti.cluster = (h.flags & KT_THR_CLUSTER) != 0;
+                    ti.ns = h.ns;
+                    return ti;
+                  },
+                  (uint32_t)NS);
+  {
+    hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
+    if (he != hipSuccess) return e->fail(KT_ERR_DEVICE, "upload_index: %s", hipGetErrorString(he));
+  }
+  KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
+  e->sp.thr_term_off = e->d_thr_term_off.p;
+  e->sp.term_thr = e->d_term_thr.p;
+  e->sp.term_flags = e->d_term_flags.p;
+  e->sp.term_req_off = e->d_term_req_off.p;
+  e->sp.req_op = e->d_req_op.p;
+  e->sp.req_key = e->d_req_key.p;
+  e->sp.req_val_off = e->d_req_val_off.p;
+  e->sp.req_val = e->d_req_val.p;
+  e->sp.ns_term_ok = e->d_ns_term_ok.p;
+  e->sp.ns_valid = e->d_ns_valid.p;
+  e->sp.gw = gw;
+  e->sp.T = (int32_t)T;
+  e->sp.G = (int32_t)G;
+  e->sp.n_ns = (int32_t)NS;
+  e->program_dirty = false;
+  return KT_OK;
+}
+
+int32_t ensure_ready(kt_engine* e, hipStream_t s) {
+  int32_t rc;
+  if (e->program_dirty || e->status_host_dirty) {
+    // uploads reallocate/overwrite device tables that an in-flight kernel of the last stream may read
+    if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  }
+  if (e->program_dirty) {
+    if ((rc = sync_status_to_host(e)) != KT_OK) return rc;
+    if ((rc = compile_program(e, e->own_stream)) != KT_OK) return rc;
+    e->status_host_dirty = true;
+  }
+  if (e->status_host_dirty) {
+    if ((rc = upload_status(e, e->own_stream)) != KT_OK) return rc;
+  }
+  e->tt.flags = e->d_thr_flags.p;
+  e->tt.spec = e->d_spec.tab();
+  e->tt.calc = e->d_calc.tab();
+  e->tt.used = e->d_used.tab();
+  e->tt.reserved = e->d_reserved.tab();
+  e->tt.thrl_flag = e->d_thrl_flag.p;
+  e->tt.thrl_has = e->d_thrl_has.p;
+  e->tt.status_msgs_fp = e->d_status_fp.p;
+  e->tt.spec_msgs_fp = e->d_spec_fp.p;
+  e->tt.ovr_off = e->d_ovr_off.p;
+  e->tt.ovr_begin_s = e->d_ovr_begin_s.p;
+  e->tt.ovr_begin_ns = e->d_ovr_begin_ns.p;
+  e->tt.ovr_end_s = e->d_ovr_end_s.p;
+  e->tt.ovr_end_ns = e->d_ovr_end_ns.p;
+  e->tt.ovr_flags = e->d_ovr_flags.p;
+  e->tt.ovr_thr = e->d_ovr_thr.tab();
+  (void)s;
+  return KT_OK;
+}
+
+void amount_from_table(const kt_amounts& a, size_t i, int D, HostAmount& h) {
+  h.present = a.present ? a.present[i] & ((1u << D) - 1u) : 0;
+  for (int d = 0; d < D; ++d) h.v[d] = ((h.present >> d) & 1u) ? a.v[i * D + d] : 0;
+  h.has_count = a.has_count ? (a.has_count[i] != 0) : 0;
+  h.count = h.has_count ? a.count[i] : 0;
+}
+
+constexpr unsigned __int128 kSumBound = (unsigned __int128)1 << 60;
+inline unsigned __int128 uabs(int64_t x) { return x < 0 ? (unsigned __int128)(-(__int128)x) : (unsigned __int128)x; }
+
+bool amount_in_bound(const HostAmount& a, int D) {
+  for (int d = 0; d < D; ++d)
+    if (((a.present >> d) & 1u) && uabs(a.v[d]) > kSumBound) return false;
+  return uabs(a.count) <= kSumBound;
+}
+
+void reqs_from_pool(const kt_reqs& pool, uint32_t b, uint32_t e_, std::vector<Req>& out) {
+  out.clear();
+  for (uint32_t r = b; r < e_; ++r) {
+    Req q;
+    q.op = pool.op[r];
+    q.key = pool.key[r];
+    q.vals.assign(pool.val + pool.val_off[r], pool.val + pool.val_off[r + 1]);
+    out.push_back(std::move(q));
+  }
+}
+
+}  // namespace
+
+// ===================================================================================================
+// C-ABI
+// ===================================================================================================
+extern "C" {
+
+const char* kt_version(void) { return "kt-engine 0.1 (gfx950, HIP)"; }
+
+const char* kt_last_error(kt_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return KT_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  if (cfg->n_dims < 1 || cfg->n_dims > KT_MAX_DIMS || cfg->max_labels < 1 || cfg->max_labels > KT_MAX_LABELS ||
+      cfg->pod_capacity < 1 || cfg->throttle_capacity < 1 || cfg->throttle_capacity >= (1 << 20) ||
+      cfg->namespace_capacity < 1) {
+    g_create_error = "invalid kt_config";
+    return KT_ERR_INVALID_ARGUMENT;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device visible: the engine has no CPU fallback";
+    return KT_ERR_NO_DEVICE;
+  }
+  int dev = cfg->device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  }
+  if (dev >= ndev) {
+    g_create_error = "device ordinal out of range";
+    return KT_ERR_INVALID_ARGUMENT;
+  }
+  kt_engine* e = new kt_engine();
+  e->cfg = *cfg;
+  e->device = dev;
+  e->D = cfg->n_dims;
+  e->L = cfg->max_labels;
+  hipError_t r = hipSetDevice(dev);
+  if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+  const size_t cap = (size_t)cfg->pod_capacity;
+  e->pods.cap = cfg->pod_capacity;
+  e->pods.D = e->D;
+  e->pods.L = e->L;
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.ns, cap * 4);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.flags, cap * 4);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.req, cap * 8 * e->D);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lpair, cap * 4 * e->L);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lkey, cap * 4 * e->L);
+  if (r == hipSuccess) r = hipMemsetAsync(e->pods.flags, 0, cap * 4, e->own_stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
+  if (r != hipSuccess) {
+    g_create_error = std::string("device setup failed: ") + hipGetErrorString(r);
+    kt_engine_destroy(e);
+    return KT_ERR_DEVICE;
+  }
+  e->ns.resize((size_t)cfg->namespace_capacity);
+  e->thr.resize((size_t)cfg->throttle_capacity);
+  *out = e;
+  return KT_OK;
+}
+
+int32_t kt_engine_destroy(kt_engine* e) {
+  if (!e) return KT_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  if (e->pods.ns) (void)hipFree(e->pods.ns);
+  if (e->pods.flags) (void)hipFree(e->pods.flags);
+  if (e->pods.req) (void)hipFree(e->pods.req);
+  if (e->pods.lpair) (void)hipFree(e->pods.lpair);
+  if (e->pods.lkey) (void)hipFree(e->pods.lkey);
+  DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
+                              &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
+                              &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
+  for (auto* b : u32s) b->release();
+  DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage};
+  for (auto* b : u8s) b->release();
+  e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
+  e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
+  e->d_partial.release();
+  AmountDev* ams[] = {&e->d_spec, &e->d_calc, &e->d_used, &e->d_reserved, &e->d_ovr_thr, &e->d_out_used, &e->d_out_calc};
+  for (auto* a : ams) a->release();
+  kt::release_index(e->dindex);
+  for (auto& f : e->fam)
+    for (auto& pr : f.pool) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+  return KT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// state feed
+// ---------------------------------------------------------------------------------------------------
+int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* b, const int32_t* rows) {
+  if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (int32_t i = 0; i < b->n_ns; ++i) {
+    const int32_t row = rows ? rows[i] : i;
+    if (row < 0 || row >= e->cfg.namespace_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "namespace row %d", row);
+  }
+  for (int32_t i = 0; i < b->n_ns; ++i) {
+    HostNamespace& n = e->ns[(size_t)(rows ? rows[i] : i)];
+    n.valid = b->ns_valid ? b->ns_valid[i] != 0 : true;
+    n.labels.clear();
+    for (uint32_t k = b->ns_label_off[i]; k < b->ns_label_off[i + 1]; ++k)
+      n.labels.emplace_back(b->ns_label_key[k], b->ns_label_pair[k]);
+    e->ns_rows_hi = std::max(e->ns_rows_hi, (rows ? rows[i] : i) + 1);
+  }
+  if (b->n_ns > 0) e->program_dirty = true;
+  return KT_OK;
+}
+
+int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* rows) {
+  if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (int32_t i = 0; i < n; ++i) {
+    if (rows[i] < 0 || rows[i] >= e->cfg.namespace_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "namespace row %d", rows[i]);
+    e->ns[(size_t)rows[i]] = HostNamespace();
+  }
+  if (n > 0) e->program_dirty = true;
+  return KT_OK;
+}
+
+static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
+  const int D = e->D;
+  if (b->D != D) return e->fail(KT_ERR_INVALID_ARGUMENT, "batch D=%d, engine D=%d", b->D, D);
+  const int64_t n = b->n_pods;
+  if (n <= 0) return KT_OK;
+  // ---- validation + overflow bound (host pass over the batch; the data is copied once, below)
+  int64_t hi = e->pod_rows_hi;
+  unsigned __int128 batch_max[KT_MAX_DIMS] = {0};
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t row = rows ? rows[i] : i;
+    if (row < 0 || row >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)row);
+    if (b->pod_ns[i] >= (uint32_t)e->cfg.namespace_capacity)
+      return e->fail(KT_ERR_OUT_OF_RANGE, "pod %lld: namespace id %u", (long long)i, b->pod_ns[i]);
+    if (b->pod_label_off[i + 1] - b->pod_label_off[i] > (uint32_t)e->L)
+      return e->fail(KT_ERR_OUT_OF_RANGE, "pod %lld has %u labels, engine keeps %d", (long long)i,
+                     b->pod_label_off[i + 1] - b->pod_label_off[i], e->L);
+    hi = std::max(hi, row + 1);
+    unsigned __int128 sum[KT_MAX_DIMS] = {0};
+    for (uint32_t k = b->pod_ctr_off[i]; k < b->pod_ctr_off[i + 1]; ++k)
+      for (int d = 0; d < D; ++d)
+        if ((b->ctr_present[k] >> d) & 1u) sum[d] += uabs(b->ctr_req[(size_t)k * D + d]);
+    if (b->pod_ovh_present[i] >> 31)
+      for (int d = 0; d < D; ++d)
+        if ((b->pod_ovh_present[i] >> d) & 1u) sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
+    for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]);
+  }
+  for (int d = 0; d < D; ++d) {
+    const unsigned __int128 m = std::max(batch_max[d], e->max_abs[d]);
+    if (m * (unsigned __int128)e->cfg.pod_capacity > kSumBound)
+      return e->fail(KT_ERR_OVERFLOW_RISK,
+                     "dimension %d: max |request| x pod_capacity exceeds 2^60; use a coarser scale for it", d);
+  }
+  for (int d = 0; d < D; ++d) e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
+  // ---- stage + ingest in chunks
+  hipStream_t s = e->own_stream;
+  const int64_t chunk = 1 << 20;
+  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const int64_t cn = std::min(chunk, n - c0);
+    const uint32_t lb = b->pod_label_off[c0], le = b->pod_label_off[c0 + cn];
+    const uint32_t kb = b->pod_ctr_off[c0], ke = b->pod_ctr_off[c0 + cn];
+    // layout of the staging buffer (8-byte aligned sections)
+    size_t off = 0;
+    auto sect = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_rows = sect(rows ? cn * 8 : 0), o_ns = sect(cn * 4), o_fl = sect(cn * 4), o_lo = sect((cn + 1) * 4),
+                 o_lk = sect((size_t)(le - lb) * 4), o_lp = sect((size_t)(le - lb) * 4), o_co = sect((cn + 1) * 4),
+                 o_ci = sect(ke - kb), o_cp = sect((size_t)(ke - kb) * 4), o_cr = sect((size_t)(ke - kb) * 8 * D),
+                 o_op = sect(cn * 4), o_ov = sect((size_t)cn * 8 * D);
+    KT_HIP(e, e->d_stage.reserve(off + 16));
+    uint8_t* st = e->d_stage.p;
+#define CP(o, src, bytes) if ((bytes) > 0) KT_HIP(e, hipMemcpyAsync(st + (o), (src), (bytes), hipMemcpyHostToDevice, s))
+    if (rows) CP(o_rows, rows + c0, (size_t)cn * 8);
+    CP(o_ns, b->pod_ns + c0, (size_t)cn * 4);
+    CP(o_fl, b->pod_flags + c0, (size_t)cn * 4);
+    CP(o_lo, b->pod_label_off + c0, (size_t)(cn + 1) * 4);
+    CP(o_lk, b->pod_label_key + lb, (size_t)(le - lb) * 4);
+    CP(o_lp, b->pod_label_pair + lb, (size_t)(le - lb) * 4);
+    CP(o_co, b->pod_ctr_off + c0, (size_t)(cn + 1) * 4);
+    CP(o_ci, b->ctr_init + kb, (size_t)(ke - kb));
+    CP(o_cp, b->ctr_present + kb, (size_t)(ke - kb) * 4);
+    CP(o_cr, b->ctr_req + (size_t)kb * D, (size_t)(ke - kb) * 8 * D);
+    CP(o_op, b->pod_ovh_present + c0, (size_t)cn * 4);
+    CP(o_ov, b->pod_ovh + (size_t)c0 * D, (size_t)cn * 8 * D);
+#undef CP
+    kt::PodBatchDev pb{};
+    pb.n = cn;
+    pb.rows = rows ? (const int64_t*)(st + o_rows) : nullptr;
+    pb.row0 = c0;
+    pb.ns = (const uint32_t*)(st + o_ns);
+    pb.flags = (const uint32_t*)(st + o_fl);
+    pb.label_off = (const uint32_t*)(st + o_lo);
+    pb.label_key = (const uint32_t*)(st + o_lk);
+    pb.label_pair = (const uint32_t*)(st + o_lp);
+    pb.label_base = lb;
+    pb.ctr_off = (const uint32_t*)(st + o_co);
+    pb.ctr_init = (const uint8_t*)(st + o_ci);
+    pb.ctr_present = (const uint32_t*)(st + o_cp);
+    pb.ctr_req = (const int64_t*)(st + o_cr);
+    pb.ctr_base = kb;
+    pb.ovh_present = (const uint32_t*)(st + o_op);
+    pb.ovh = (const int64_t*)(st + o_ov);
+    kt::launch_ingest_pods(e->pods, pb, s);
+    KT_HIP(e, hipGetLastError());
+    KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+  }
+  e->pod_rows_hi = hi;
+  return KT_OK;
+}
+
+int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
+  if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  return upsert_pods_locked(e, b, rows);
+}
+
+int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
+  if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  for (int64_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)rows[i]);
+  if (n <= 0) return KT_OK;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  KT_HIP(e, e->d_rows.reserve((size_t)n));
+  KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
+  kt::launch_delete_pods(e->pods, n, e->d_rows.p, e->own_stream);
+  KT_HIP(e, hipStreamSynchronize(e->own_stream));
+  return KT_OK;
+}
+
+static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const int32_t* rows) {
+  const int D = e->D;
+  if (b->n_thr > 0 && b->D != D) return e->fail(KT_ERR_INVALID_ARGUMENT, "batch D=%d, engine D=%d", b->D, D);
+  for (int32_t i = 0; i < b->n_thr; ++i) {
+    const int32_t row = rows ? rows[i] : i;
+    if (row < 0 || row >= e->cfg.throttle_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", row);
+    if (!(b->thr_flags[i] & KT_THR_CLUSTER) && b->thr_ns[i] >= (uint32_t)e->cfg.namespace_capacity)
+      return e->fail(KT_ERR_OUT_OF_RANGE, "throttle %d: namespace id %u", i, b->thr_ns[i]);
+  }
+  if (b->n_thr <= 0) return KT_OK;
+  int32_t rc = sync_status_to_host(e);
+  if (rc != KT_OK) return rc;
+  for (int32_t i = 0; i < b->n_thr; ++i) {
+    HostThrottle h;
+    h.flags = b->thr_flags[i];
+    h.ns = b->thr_ns[i];
+    amount_from_table(b->thr_spec, (size_t)i, D, h.spec);
+    amount_from_table(b->thr_calc, (size_t)i, D, h.calc);
+    amount_from_table(b->thr_used, (size_t)i, D, h.used);
+    amount_from_table(b->thr_reserved, (size_t)i, D, h.reserved);
+    if (!amount_in_bound(h.used, D) || !amount_in_bound(h.reserved, D))
+      return e->fail(KT_ERR_OVERFLOW_RISK, "throttle %d: status.used / reserved beyond 2^60", i);
+    h.thrl_flag = b->thr_thrl_flag[i] & ((1u << D) - 1u);
+    h.thrl_has = b->thr_thrl_has[i] & ((1u << D) - 1u);
+    h.status_fp = b->thr_status_msgs_fp[i];
+    h.spec_fp = b->thr_spec_msgs_fp[i];
+    for (uint32_t o = b->thr_ovr_off[i]; o < b->thr_ovr_off[i + 1]; ++o) {
+      Override ov;
+      ov.begin_s = b->ovr_begin_s[o];
+      ov.begin_ns = b->ovr_begin_ns[o];
+      ov.end_s = b->ovr_end_s[o];
+      ov.end_ns = b->ovr_end_ns[o];
+      ov.flags = b->ovr_flags[o];
+      amount_from_table(b->ovr_thr, (size_t)o, D, ov.thr);
+      h.ovr.push_back(ov);
+    }
+    for (uint32_t g = b->thr_term_off[i]; g < b->thr_term_off[i + 1]; ++g) {
+      Term tm;
+      tm.flags = b->term_flags[g];
+      reqs_from_pool(b->preq, b->term_preq_off[g], b->term_preq_off[g + 1], tm.preq);
+      reqs_from_pool(b->nreq, b->term_nreq_off[g], b->term_nreq_off[g + 1], tm.nreq);
+      h.terms.push_back(std::move(tm));
+    }
+    const int32_t row = rows ? rows[i] : i;
+    e->thr[(size_t)row] = std::move(h);
+    e->thr_rows_hi = std::max(e->thr_rows_hi, row + 1);
+  }
+  e->program_dirty = true;
+  e->status_host_dirty = true;
+  return KT_OK;
+}
+
+int32_t kt_upsert_throttles(kt_engine* e, const kt_snapshot* b, const int32_t* rows) {
+  if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  return upsert_throttles_locked(e, b, rows);
+}
+
+int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* rows) {
+  if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  for (int32_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= e->cfg.throttle_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
+  if (n <= 0) return KT_OK;
+  int32_t rc = sync_status_to_host(e);
+  if (rc != KT_OK) return rc;
+  for (int32_t i = 0; i < n; ++i) e->thr[(size_t)rows[i]] = HostThrottle();
+  e->program_dirty = true;
+  e->status_host_dirty = true;
+  return KT_OK;
+}
+
+int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
+  if (!e || !s) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (s->n_ns > e->cfg.namespace_capacity || s->n_pods > e->cfg.pod_capacity || s->n_thr > e->cfg.throttle_capacity)
+    return e->fail(KT_ERR_OUT_OF_RANGE, "snapshot larger than the configured capacity");
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  // clear
+  KT_HIP(e, hipMemsetAsync(e->pods.flags, 0, (size_t)e->cfg.pod_capacity * 4, e->own_stream));
+  KT_HIP(e, hipStreamSynchronize(e->own_stream));
+  e->pod_rows_hi = 0;
+  for (auto& m : e->max_abs) m = 0;
+  for (auto& n : e->ns) n = HostNamespace();
+  for (auto& t : e->thr) t = HostThrottle();
+  e->ns_rows_hi = 0;
+  e->thr_rows_hi = 0;
+  e->status_dev_newer = false;
+  e->program_dirty = true;
+  e->status_host_dirty = true;
+  e->reconcile_ready = e->check_ready = false;
+  for (int32_t i = 0; i < s->n_ns; ++i) {
+    HostNamespace& n = e->ns[(size_t)i];
+    n.valid = s->ns_valid ? s->ns_valid[i] != 0 : true;
+    for (uint32_t k = s->ns_label_off[i]; k < s->ns_label_off[i + 1]; ++k)
+      n.labels.emplace_back(s->ns_label_key[k], s->ns_label_pair[k]);
+  }
+  e->ns_rows_hi = s->n_ns;
+  int32_t rc = upsert_throttles_locked(e, s, nullptr);
+  if (rc != KT_OK) return rc;
+  return upsert_pods_locked(e, s, nullptr);
+}
+
+int32_t kt_set_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt_amounts* reserved) {
+  if (!e || !reserved || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  for (int32_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
+  int32_t rc = sync_status_to_host(e);
+  if (rc != KT_OK) return rc;
+  for (int32_t i = 0; i < n; ++i) {
+    HostAmount a;
+    amount_from_table(*reserved, (size_t)i, e->D, a);
+    if (!amount_in_bound(a, e->D)) return e->fail(KT_ERR_OVERFLOW_RISK, "reserved amount beyond 2^60");
+    e->thr[(size_t)rows[i]].reserved = a;
+  }
+  e->status_host_dirty = true;
+  return KT_OK;
+}
+
+int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* rows, const kt_status* st) {
+  if (!e || !st || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  for (int32_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
+  int32_t rc = sync_status_to_host(e);
+  if (rc != KT_OK) return rc;
+  const uint32_t dm = (1u << e->D) - 1u;
+  for (int32_t i = 0; i < n; ++i) {
+    HostThrottle& h = e->thr[(size_t)rows[i]];
+    HostAmount u, c;
+    amount_from_table(st->used, (size_t)i, e->D, u);
+    amount_from_table(st->calc, (size_t)i, e->D, c);
+    if (!amount_in_bound(u, e->D)) return e->fail(KT_ERR_OVERFLOW_RISK, "status.used beyond 2^60");
+    h.used = u;
+    h.calc = c;
+    h.thrl_flag = st->thrl_flag ? st->thrl_flag[i] & dm : 0;
+    h.thrl_has = st->thrl_has ? st->thrl_has[i] & dm : 0;
+    h.flags &= ~(uint32_t)(KT_THR_CALC_AT_NONZERO | KT_THR_THROTTLED_POD);
+    if (st->calc_at_nonzero && st->calc_at_nonzero[i]) h.flags |= KT_THR_CALC_AT_NONZERO;
+    if (st->thrl_pod && st->thrl_pod[i]) h.flags |= KT_THR_THROTTLED_POD;
+    h.status_fp = st->msgs_fp ? st->msgs_fp[i] : 0;
+  }
+  e->status_host_dirty = true;
+  return KT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reconcile
+// ---------------------------------------------------------------------------------------------------
+static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
+  int32_t rc = ensure_ready(e, s);
+  if (rc != KT_OK) return rc;
+  const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  if (words) KT_HIP(e, hipMemsetAsync(e->d_partial.p, 0, words * 8, s));
+  {
+    TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
+    if (e->cfg.kernel_variant == 1)
+      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->d_partial.p, s);
+    else
+      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->d_partial.p, s);
+  }
+  KT_HIP(e, hipGetLastError());
+  e->last_stream = s;
+  return KT_OK;
+}
+
+static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s) {
+  int32_t rc = ensure_ready(e, s);
+  if (rc != KT_OK) return rc;
+  kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
+                       e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p};
+  {
+    TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
+    kt::launch_finalize(e->tt, e->sp, e->D, e->d_partial.p, now_s, now_ns, (flags & KT_RECONCILE_APPLY) != 0, out, s);
+  }
+  KT_HIP(e, hipGetLastError());
+  if (flags & KT_RECONCILE_APPLY) e->status_dev_newer = true;
+  e->reconcile_ready = true;
+  e->last_stream = s;
+  return KT_OK;
+}
+
+int32_t kt_aggregate_launch(kt_engine* e, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  return aggregate_locked(e, pick_stream(e, stream));
+}
+
+int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64) {
+  if (!e || !device_ptr || !n_int64) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  int32_t rc = ensure_ready(e, e->own_stream);
+  if (rc != KT_OK) return rc;
+  *device_ptr = e->d_partial.p;
+  *n_int64 = (int64_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  return KT_OK;
+}
+
+int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  return finalize_locked(e, now_s, now_ns, flags, pick_stream(e, stream));
+}
+
+int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = pick_stream(e, stream);
+  int32_t rc = aggregate_locked(e, s);
+  if (rc != KT_OK) return rc;
+  return finalize_locked(e, now_s, now_ns, flags, s);
+}
+
+int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
+  if (!e || !out) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch before a reconcile launch");
+  if (n < 0 || n > e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows=%d", n, e->thr_rows_hi);
+  hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
+  const size_t N = (size_t)n;
+  const int D = e->D;
+  if (N) {
+#define DL(dst, src, bytes) if (dst) KT_HIP(e, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
+    DL(out->used.v, e->d_out_used.v.p, N * D * 8);
+    DL(out->used.present, e->d_out_used.present.p, N * 4);
+    DL(out->used.count, e->d_out_used.count.p, N * 8);
+    DL(out->used.has_count, e->d_out_used.has_count.p, N);
+    DL(out->calc.v, e->d_out_calc.v.p, N * D * 8);
+    DL(out->calc.present, e->d_out_calc.present.p, N * 4);
+    DL(out->calc.count, e->d_out_calc.count.p, N * 8);
+    DL(out->calc.has_count, e->d_out_calc.has_count.p, N);
+    DL(out->calc_at_nonzero, e->d_out_calc_updated.p, N);
+    DL(out->thrl_flag, e->d_out_thrl_flag.p, N * 4);
+    DL(out->thrl_has, e->d_out_thrl_has.p, N * 4);
+    DL(out->thrl_pod, e->d_out_thrl_pod.p, N);
+    DL(out->error, e->d_out_error.p, N);
+#undef DL
+  }
+  KT_HIP(e, hipStreamSynchronize(s));
+  return KT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// check
+// ---------------------------------------------------------------------------------------------------
+int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
+  if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = pick_stream(e, stream);
+  if (pod_rows) {
+    for (int64_t i = 0; i < n; ++i)
+      if (pod_rows[i] < 0 || pod_rows[i] >= e->cfg.pod_capacity)
+        return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)pod_rows[i]);
+  } else if (n > e->cfg.pod_capacity) {
+    return e->fail(KT_ERR_OUT_OF_RANGE, "n=%lld > pod_capacity", (long long)n);
+  }
+  int32_t rc = ensure_ready(e, s);
+  if (rc != KT_OK) return rc;
+  const bool want_status = (flags & KT_CHECK_STATUS_MATRIX) != 0;
+  const size_t T = (size_t)e->thr_rows_hi;
+  if (e->d_summary.cap < (size_t)n + 1 || (want_status && e->d_status.cap < (size_t)n * T + 1) ||
+      (pod_rows && e->d_rows.cap < (size_t)n + 1)) {
+    if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));  // buffers may still be in use
+    KT_HIP(e, e->d_summary.reserve((size_t)n + 1));
+    if (want_status) KT_HIP(e, e->d_status.reserve((size_t)n * T + 1));
+    if (pod_rows) KT_HIP(e, e->d_rows.reserve((size_t)n + 1));
+  }
+  if (pod_rows && n) {
+    KT_HIP(e, hipMemcpyAsync(e->d_rows.p, pod_rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    KT_HIP(e, hipStreamSynchronize(s));  // caller memory must not be referenced after return
+  }
+  const int DT = kt::dt_bucket(e->D);
+  {
+    TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
+    kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, s);
+  }
+  {
+    TimedLaunch tl(e, KT_KERNEL_CHECK, s);
+    if (e->cfg.kernel_variant == 1)
+      kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->d_recs.p,
+                             e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+    else
+      kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->dindex, e->uses_keys,
+                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+  }
+  KT_HIP(e, hipGetLastError());
+  e->check_n = n;
+  e->check_has_status = want_status;
+  e->check_ready = true;
+  e->last_stream = s;
+  return KT_OK;
+}
+
+int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->check_ready) return e->fail(KT_ERR_NOT_READY, "kt_check_fetch before kt_check_launch");
+  if (n < 0 || n > e->check_n) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%lld, last check had %lld pods", (long long)n, (long long)e->check_n);
+  if (out_status && !e->check_has_status) return e->fail(KT_ERR_NOT_READY, "status matrix was not requested at launch");
+  hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
+  if (n && out_summary) KT_HIP(e, hipMemcpyAsync(out_summary, e->d_summary.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (n && out_status && e->thr_rows_hi)
+    KT_HIP(e, hipMemcpyAsync(out_status, e->d_status.p, (size_t)n * (size_t)e->thr_rows_hi, hipMemcpyDeviceToHost, s));
+  KT_HIP(e, hipStreamSynchronize(s));
+  return KT_OK;
+}
+
+int32_t kt_throttle_rows(kt_engine* e, int32_t* out_rows) {
+  if (!e || !out_rows) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  *out_rows = e->thr_rows_hi;
+  return KT_OK;
+}
+
+int32_t kt_check_device_summary(kt_engine* e, void** device_ptr) {
+  if (!e || !device_ptr) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->check_ready) return e->fail(KT_ERR_NOT_READY, "no check launched yet");
+  *device_ptr = e->d_summary.p;
+  return KT_OK;
+}
+
+int32_t kt_fetch_pod_requests(kt_engine* e, int64_t n, const int64_t* pod_rows, int64_t* out_v, uint32_t* out_present) {
+  if (!e || n < 0 || !out_v || !out_present) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (n == 0) return KT_OK;
+  if (!pod_rows && n > e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "n > pod_capacity");
+  if (pod_rows)
+    for (int64_t i = 0; i < n; ++i)
+      if (pod_rows[i] < 0 || pod_rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row");
+  hipStream_t s = e->own_stream;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  const int D = e->D;
+  size_t bytes = (size_t)n * 8 * D + (size_t)n * 4 + (pod_rows ? (size_t)n * 8 : 0) + 64;
+  KT_HIP(e, e->d_stage.reserve(bytes));
+  int64_t* dv = (int64_t*)e->d_stage.p;
+  int64_t* drows = dv + (size_t)n * D;
+  uint32_t* dp = (uint32_t*)(drows + (pod_rows ? n : 0));
+  if (pod_rows) KT_HIP(e, hipMemcpyAsync(drows, pod_rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  kt::launch_gather_pod_requests(e->pods, n, pod_rows ? drows : nullptr, dv, dp, s);
+  KT_HIP(e, hipMemcpyAsync(out_v, dv, (size_t)n * 8 * D, hipMemcpyDeviceToHost, s));
+  KT_HIP(e, hipMemcpyAsync(out_present, dp, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  KT_HIP(e, hipStreamSynchronize(s));
+  return KT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------------
+int32_t kt_timing_enable(kt_engine* e, int32_t on) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->timing = on != 0;
+  return KT_OK;
+}
+
+int32_t kt_timing_reset(kt_engine* e) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  for (auto& f : e->fam) f.used = 0;
+  return KT_OK;
+}
+
+int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* launches) {
+  if (!e || kernel < 0 || kernel >= KT_KERNEL_COUNT || !total_ms || !launches) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  double tot = 0;
+  TimingFamily& f = e->fam[kernel];
+  for (size_t i = 0; i < f.used; ++i) {
+    float ms = 0;
+    KT_HIP(e, hipEventElapsedTime(&ms, f.pool[i].first, f.pool[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)f.used;
+  return KT_OK;
+}
+
+int32_t kt_synchronize(kt_engine* e, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  KT_HIP(e, hipStreamSynchronize(pick_stream(e, stream)));
+  return KT_OK;
+}
+
+const char* kt_kernel_name(kt_engine* e, int32_t kernel) {
+  const int v = e ? e->cfg.kernel_variant : 0;
+  switch (kernel) {
+    case KT_KERNEL_CHECK: return kt::kernel_name_check(v);
+    case KT_KERNEL_AGGREGATE: return kt::kernel_name_aggregate(v);
+    case KT_KERNEL_FINALIZE: return "kt_finalize";
+    case KT_KERNEL_PREPARE: return "kt_prepare_check";
+    default: return "";
+  }
+}
+
+}  // extern "C"

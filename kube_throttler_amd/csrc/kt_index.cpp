@@ -1,0 +1,124 @@
+// kt_index.cpp — host-side construction and upload of the label-atom -> term index (see kt_index.h).
+#include "kt_index.h"
+
+#include <algorithm>
+#include <unordered_map>
+
+#include "../../include/kt_snapshot.h"
+
+namespace kt {
+
+void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
+                 const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
+                 const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
+                 const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
+                 const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns) {
+  out = HostIndex();
+  const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> lists;
+  std::vector<std::vector<uint32_t>> uni_ns(n_ns);
+  for (size_t t = 0; t < T; ++t) {
+    const ThrInfo ti = thr_info((uint32_t)t);
+    if (!ti.live) continue;
+    // a reachable unconvertible podSelector makes term ORDER matter: walk this throttle densely
+    bool slow = false;
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
+      if ((term_flags[g] & KT_TERM_POD_SEL_INVALID) && !(ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID))) slow = true;
+    if (slow) {
+      out.slow_thr.push_back((uint32_t)t);
+      continue;
+    }
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
+      if (ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID)) continue;  // never matches any namespace
+      if (!ti.cluster && ti.ns >= n_ns) continue;
+      // anchor: the In requirement with the fewest values, else an Exists requirement
+      int64_t best = -1;
+      size_t best_cost = ~(size_t)0;
+      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
+        size_t cost;
+        if (req_op[r] == KT_OP_IN) cost = req_val_off[r + 1] - req_val_off[r];
+        else if (req_op[r] == KT_OP_EXISTS) cost = 1u << 20;
+        else continue;
+        if (cost < best_cost) best_cost = cost, best = r;
+      }
+      const uint64_t scope = ti.cluster ? 0ull : (uint64_t)(ti.ns + 1);
+      if (best < 0) {
+        if (ti.cluster) out.uni_cluster.push_back(g);
+        else uni_ns[ti.ns].push_back(g);
+        continue;
+      }
+      if (req_op[best] == KT_OP_IN) {
+        std::vector<uint32_t> vals(req_val.begin() + req_val_off[best], req_val.begin() + req_val_off[best + 1]);
+        std::sort(vals.begin(), vals.end());
+        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+        for (uint32_t v : vals) lists[scope << 32 | v].push_back(g);  // an empty value set files nothing: never matches
+      } else {
+        lists[scope << 32 | (kKeyAtom | req_key[best])].push_back(g);
+        out.has_key_atoms = true;
+      }
+    }
+  }
+  size_t n_slots = 16;
+  while (n_slots < lists.size() * 2 + 1) n_slots <<= 1;
+  out.slots.assign(n_slots, IndexSlot{0, 0, 0});
+  out.mask = (uint32_t)(n_slots - 1);
+  // deterministic order: sort keys
+  std::vector<uint64_t> keys;
+  keys.reserve(lists.size());
+  for (auto& kv : lists) keys.push_back(kv.first);
+  std::sort(keys.begin(), keys.end());
+  for (uint64_t k : keys) {
+    const std::vector<uint32_t>& l = lists[k];
+    uint32_t h = index_hash(k, out.mask);
+    while (out.slots[h].key != 0) h = (h + 1) & out.mask;
+    out.slots[h] = IndexSlot{k, (uint32_t)out.postings.size(), (uint32_t)l.size()};
+    out.postings.insert(out.postings.end(), l.begin(), l.end());
+  }
+  out.uni_ns_off.assign((size_t)n_ns + 1, 0);
+  for (uint32_t n = 0; n < n_ns; ++n) {
+    out.uni_ns.insert(out.uni_ns.end(), uni_ns[n].begin(), uni_ns[n].end());
+    out.uni_ns_off[n + 1] = (uint32_t)out.uni_ns.size();
+  }
+}
+
+template <class T>
+static hipError_t up(T*& dev, size_t& cap, const std::vector<T>& h, hipStream_t s) {
+  const size_t need = h.size() + 1;
+  if (need > cap || !dev) {
+    if (dev) (void)hipFree(dev);
+    dev = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void**)&dev, need * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = need;
+  }
+  if (!h.empty()) return hipMemcpyAsync(dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  return hipSuccess;
+}
+
+hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
+  hipError_t e;
+  if ((e = up(d.slots, d.cap_slots, h.slots, s)) != hipSuccess) return e;
+  if ((e = up(d.postings, d.cap_postings, h.postings, s)) != hipSuccess) return e;
+  if ((e = up(d.uni_ns_off, d.cap_uni_ns_off, h.uni_ns_off, s)) != hipSuccess) return e;
+  if ((e = up(d.uni_ns, d.cap_uni_ns, h.uni_ns, s)) != hipSuccess) return e;
+  if ((e = up(d.uni_cluster, d.cap_uni_cluster, h.uni_cluster, s)) != hipSuccess) return e;
+  if ((e = up(d.slow_thr, d.cap_slow, h.slow_thr, s)) != hipSuccess) return e;
+  d.mask = h.mask;
+  d.n_uni_cluster = (uint32_t)h.uni_cluster.size();
+  d.n_slow = (uint32_t)h.slow_thr.size();
+  d.has_key_atoms = h.has_key_atoms ? 1u : 0u;
+  return hipSuccess;
+}
+
+void release_index(IndexDev& d) {
+  if (d.slots) (void)hipFree(d.slots);
+  if (d.postings) (void)hipFree(d.postings);
+  if (d.uni_ns_off) (void)hipFree(d.uni_ns_off);
+  if (d.uni_ns) (void)hipFree(d.uni_ns);
+  if (d.uni_cluster) (void)hipFree(d.uni_cluster);
+  if (d.slow_thr) (void)hipFree(d.slow_thr);
+  d = IndexDev();
+}
+
+}  // namespace kt

@@ -1,0 +1,467 @@
+// kt_kernels.hip — hand-written HIP kernels for gfx950 (CDNA4, wave64): pod ingest, per-throttle
+// finalize / check-record preparation, and the DENSE pod x throttle scans (reference loop shape).
+// The indexed (work ~ pods + matches) scans live in kt_kernels_index.hip.
+//
+// Everything here is integer / compare work on SoA planes in HBM: no MFMA, no floating point.
+#include "kt_kernels_common.h"
+#include "kt_launch.h"
+
+namespace kt {
+
+constexpr int kBlock = 256;
+
+static inline int grid_for(int64_t n, int per_block = kBlock, int max_blocks = 256 * 8) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pod ingest: staged row-major batch -> planes, computing the pod's effective request on the way.
+// Restates resourcelist.PodRequestResourceList (pkg/resourcelist/resourcelist.go:27-46):
+//   ic = SetMax over initContainers (missing key => copy, :76-84); c = Add over containers (key created
+//   even for +0, :48-54); c.SetMax(ic); c.Add(overhead) when overhead != nil.
+// One thread per pod; D and the container count are tiny, the kernel is bound by the plane writes.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatchDev b) {
+  const int D = pods.D, L = pods.L;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = b.rows ? b.rows[i] : b.row0 + i;
+    int64_t c[16], ic[16];
+    uint32_t cp = 0, icp = 0;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) c[d] = 0, ic[d] = 0;
+    const uint32_t k0 = b.ctr_off[i] - b.ctr_base, k1 = b.ctr_off[i + 1] - b.ctr_base;
+    for (uint32_t k = k0; k < k1; ++k) {
+      const uint32_t pm = b.ctr_present[k];
+      const bool init = b.ctr_init[k] != 0;
+      for (int d = 0; d < D; ++d) {
+        if (!((pm >> d) & 1u)) continue;
+        const int64_t q = b.ctr_req[(int64_t)k * D + d];
+        if (init) {
+          ic[d] = ((icp >> d) & 1u) ? (ic[d] >= q ? ic[d] : q) : q;
+        } else {
+          c[d] += q;
+        }
+      }
+      if (init) icp |= pm; else cp |= pm;
+    }
+    for (int d = 0; d < D; ++d)
+      if ((icp >> d) & 1u) c[d] = ((cp >> d) & 1u) ? (c[d] >= ic[d] ? c[d] : ic[d]) : ic[d];
+    cp |= icp;
+    const uint32_t op = b.ovh_present[i];
+    if (op >> 31) {
+      for (int d = 0; d < D; ++d)
+        if ((op >> d) & 1u) c[d] += b.ovh[i * D + d];
+      cp |= op & 0xFFFFu;
+    }
+    for (int d = 0; d < D; ++d) pods.req[(int64_t)d * pods.cap + row] = ((cp >> d) & 1u) ? c[d] : 0;
+    pods.ns[row] = b.ns[i];
+    pods.flags[row] = (b.flags[i] & 0xFu) | (cp << kPresentShift);
+    const uint32_t l0 = b.label_off[i] - b.label_base, l1 = b.label_off[i + 1] - b.label_base;
+    for (int l = 0; l < L; ++l) {
+      const bool have = l0 + l < l1;
+      pods.lpair[(int64_t)l * pods.cap + row] = have ? b.label_pair[l0 + l] : 0u;
+      pods.lkey[(int64_t)l * pods.cap + row] = have ? b.label_key[l0 + l] : 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void kt_delete_pods(PodTable pods, int64_t n, const int64_t* rows) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    pods.flags[rows[i]] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void kt_gather_pod_requests(PodTable pods, int64_t n, const int64_t* rows,
+                                                                int64_t* out_v, uint32_t* out_present) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = rows ? rows[i] : i;
+    for (int d = 0; d < pods.D; ++d) out_v[i * pods.D + d] = pods.req[(int64_t)d * pods.cap + row];
+    out_present[i] = pods.flags[row] >> kPresentShift;
+  }
+}
+
+void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {
+  if (b.n <= 0) return;
+  hipLaunchKernelGGL(kt_ingest_pods, dim3(grid_for(b.n)), dim3(kBlock), 0, s, pods, b);
+}
+void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(kt_delete_pods, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev);
+}
+void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
+                                uint32_t* out_present, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(kt_gather_pod_requests, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, out_v,
+                     out_present);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dense selector walk for one (pod lane, throttle t): terms in order, first match wins, an
+// unconvertible podSelector reached before a match is an error (throttle_selector.go:30-54,
+// clusterthrottle_selector.go:44-87).  t is wave-uniform => program loads are scalar.
+// ---------------------------------------------------------------------------------------------------
+template <int LT, bool KEYS>
+__device__ __forceinline__ void walk_terms(const SelProgram& sp, int t, const uint32_t* ns_row, bool lane_on,
+                                           const uint32_t (&lp)[LT], const uint32_t (&lk)[LT], uint32_t& cur_w,
+                                           uint32_t& cur_wi, bool& matched, bool& err) {
+  matched = false;
+  err = false;
+  bool open = lane_on;
+  const uint32_t g1 = sp.thr_term_off[t + 1];
+  for (uint32_t g = sp.thr_term_off[t]; g < g1; ++g) {
+    if ((g >> 5) != cur_wi) {
+      cur_wi = g >> 5;
+      cur_w = lane_on ? ns_row[cur_wi] : 0u;
+    }
+    const bool applies = open && ((cur_w >> (g & 31)) & 1u);
+    if (!__any(applies)) continue;  // wave-uniform skip: no lane's namespace admits this term
+    if (sp.term_flags[g] & kTermPodSelInvalid) {
+      err |= applies;
+      open &= !applies;
+      continue;
+    }
+    const bool m = term_match<LT, KEYS>(sp, g, lp, lk) && applies;
+    matched |= m;
+    open &= !m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_aggregate_dense — affectedPods + fold ResourceAmount.Add (throttle_controller.go:116-119,221-246;
+// clusterthrottle_controller.go:119-122,224-270; resource_amount.go:91-110) for all throttles.
+// lane = pod, throttles walked uniformly; matched lanes add their request vector, key-presence
+// counts and a pod count into partial[t][2D+2] (int64 sums: associative => any order, any #GPUs).
+// ---------------------------------------------------------------------------------------------------
+template <int DT, int LT, bool KEYS>
+__global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int64_t n_rows, SelProgram sp,
+                                                            unsigned long long* partial) {
+  const int D = pods.D, stride = partial_stride(D);
+  const int64_t n_round = (n_rows + kWave - 1) / kWave * kWave;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_round; p += (int64_t)gridDim.x * kBlock) {
+    const bool in = p < n_rows;
+    const uint32_t fl = in ? pods.flags[p] : 0u;
+    // shouldCountIn: schedulerName == target && nodeName != "" (throttle_controller.go:217-219)
+    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    if (!__any(countable)) continue;
+    PodRegs<DT, LT, KEYS> r;
+    if (countable) load_pod<DT, LT, KEYS>(pods, p, r, true);
+    else {
+      r.ns = 0;
+#pragma unroll
+      for (int l = 0; l < LT; ++l) r.lp[l] = 0, r.lk[l] = 0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) r.v[d] = 0;
+    }
+    const uint32_t present = fl >> kPresentShift;
+    const bool not_finished = !(fl & kPodFinished);  // isNotFinished (pod_util.go:26-28)
+    const uint32_t* ns_row = sp.ns_term_ok + (size_t)r.ns * sp.gw;
+    uint32_t cur_w = 0, cur_wi = 0xFFFFFFFFu;
+    for (int t = 0; t < sp.T; ++t) {
+      bool matched, err;
+      walk_terms<LT, KEYS>(sp, t, ns_row, countable, r.lp, r.lk, cur_w, cur_wi, matched, err);
+      unsigned long long* row = partial + (size_t)t * stride;
+      if (err) atomicAdd(row + 2 * D + 1, 1ull);
+      if (matched && not_finished) {
+        for (int d = 0; d < D; ++d)
+          if ((present >> d) & 1u) {
+            if (r.v[d] != 0) atomicAdd(row + d, (unsigned long long)r.v[d]);
+            atomicAdd(row + D + d, 1ull);
+          }
+        atomicAdd(row + 2 * D, 1ull);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_finalize — per throttle: used from the (all-reduced) partial sums, CalculateThreshold(now)
+// (throttle_types.go:65-106, temporary_threshold_override.go:57-70), replace-only-if-changed
+// (throttle_controller.go:122-132, Semantic.DeepEqual by value) and
+// throttled = calculatedThreshold.IsThrottled(used, true) (:133, resource_amount.go:127-159).
+// One thread per throttle (T is 10^3..10^4: a few waves; latency-bound, negligible next to the scans).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, int32_t bn) {
+  return as != bs ? (as < bs ? -1 : 1) : (an != bn ? (an < bn ? -1 : 1) : 0);
+}
+
+__global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
+                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T) return;
+  const int stride = partial_stride(D);
+  const uint32_t fl = tt.flags[t];
+  const unsigned long long* prow = partial + (size_t)t * stride;
+  const bool live = (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
+  const bool error = live && prow[2 * D + 1] != 0;
+  // ---- stored status (returned unchanged for rows that are not reconciled)
+  int64_t s_calc_v[16];
+  const uint32_t s_calc_p = tt.calc.present[t];
+  const bool s_calc_hc = tt.calc.has_count[t] != 0;
+  const int64_t s_calc_c = tt.calc.count[t];
+  for (int d = 0; d < D; ++d) s_calc_v[d] = tt.calc.v[(size_t)t * D + d];
+  if (!live || error) {
+    for (int d = 0; d < D; ++d) {
+      out.used.v[(size_t)t * D + d] = tt.used.v[(size_t)t * D + d];
+      out.calc.v[(size_t)t * D + d] = s_calc_v[d];
+    }
+    out.used.present[t] = tt.used.present[t];
+    out.used.count[t] = tt.used.count[t];
+    out.used.has_count[t] = tt.used.has_count[t];
+    out.calc.present[t] = s_calc_p;
+    out.calc.count[t] = s_calc_c;
+    out.calc.has_count[t] = s_calc_hc;
+    out.calc_updated[t] = 0;
+    out.thrl_flag[t] = tt.thrl_flag[t];
+    out.thrl_has[t] = tt.thrl_has[t];
+    out.thrl_pod[t] = (fl & kThrThrottledPod) ? 1 : 0;
+    out.error[t] = error ? 1 : 0;
+    return;
+  }
+  // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
+  int64_t u_v[16];
+  uint32_t u_p = 0;
+  const int64_t u_c = (int64_t)prow[2 * D];
+  const bool u_hc = u_c > 0;
+  for (int d = 0; d < D; ++d) {
+    const bool pr = prow[D + d] != 0;
+    u_p |= (pr ? 1u : 0u) << d;
+    u_v[d] = pr ? (int64_t)prow[d] : 0;
+  }
+  // ---- CalculateThreshold(now)
+  int64_t c_v[16];
+  uint32_t c_p = 0;
+  bool c_hc = false, active_found = false, any_err = false;
+  int64_t c_c = 0;
+  for (int d = 0; d < D; ++d) c_v[d] = 0;
+  for (uint32_t o = tt.ovr_off[t]; o < tt.ovr_off[t + 1]; ++o) {
+    if (tt.ovr_flags[o] & kOvrParseError) {
+      any_err = true;
+      continue;
+    }
+    const bool begin = instant_cmp(tt.ovr_begin_s[o], tt.ovr_begin_ns[o], now_s, now_ns) <= 0;
+    const bool end_zero = tt.ovr_end_s[o] == kZeroTimeS && tt.ovr_end_ns[o] == 0;
+    const bool end = end_zero || instant_cmp(now_s, now_ns, tt.ovr_end_s[o], tt.ovr_end_ns[o]) <= 0;
+    if (!(begin && end)) continue;
+    active_found = true;
+    if (!c_hc && tt.ovr_thr.has_count[o]) {  // first active override wins, per resource and for counts
+      c_hc = true;
+      c_c = tt.ovr_thr.count[o];
+    }
+    const uint32_t op = tt.ovr_thr.present[o];
+    for (int d = 0; d < D; ++d)
+      if (((op >> d) & 1u) && !((c_p >> d) & 1u)) {
+        c_p |= 1u << d;
+        c_v[d] = tt.ovr_thr.v[(size_t)o * D + d];
+      }
+  }
+  if (!active_found) {  // no active override: spec.threshold; otherwise the merged override REPLACES it
+    c_p = tt.spec.present[t];
+    c_hc = tt.spec.has_count[t] != 0;
+    c_c = tt.spec.count[t];
+    for (int d = 0; d < D; ++d) c_v[d] = ((c_p >> d) & 1u) ? tt.spec.v[(size_t)t * D + d] : 0;
+  }
+  const uint64_t c_fp = any_err ? tt.spec_msgs_fp[t] : 0ull;
+  // ---- replace the stored calculatedThreshold only if threshold or messages differ by value
+  bool same = (c_hc == s_calc_hc) && (!c_hc || c_c == s_calc_c) && (c_p == s_calc_p);
+  for (int d = 0; d < D; ++d)
+    if ((c_p >> d) & 1u) same &= c_v[d] == s_calc_v[d];
+  const bool replace = !same || tt.status_msgs_fp[t] != c_fp;
+  if (!replace) {
+    c_p = s_calc_p;
+    c_hc = s_calc_hc;
+    c_c = s_calc_c;
+    for (int d = 0; d < D; ++d) c_v[d] = s_calc_v[d];
+  }
+  // ---- throttled = calculatedThreshold.IsThrottled(used, onEqual = true)
+  const bool th_pod = c_hc && u_hc && u_c >= c_c;
+  uint32_t th_flag = 0;
+  for (int d = 0; d < D; ++d)
+    if (((c_p >> d) & 1u) && ((u_p >> d) & 1u) && u_v[d] >= c_v[d]) th_flag |= 1u << d;
+  // ---- outputs
+  for (int d = 0; d < D; ++d) {
+    out.used.v[(size_t)t * D + d] = u_v[d];
+    out.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
+  }
+  out.used.present[t] = u_p;
+  out.used.count[t] = u_hc ? u_c : 0;
+  out.used.has_count[t] = u_hc;
+  out.calc.present[t] = c_p;
+  out.calc.count[t] = c_hc ? c_c : 0;
+  out.calc.has_count[t] = c_hc;
+  out.calc_updated[t] = replace;
+  out.thrl_flag[t] = th_flag;
+  out.thrl_has[t] = c_p;
+  out.thrl_pod[t] = th_pod;
+  out.error[t] = 0;
+  if (apply) {  // UpdateStatus: the result becomes the stored status the next check reads
+    for (int d = 0; d < D; ++d) {
+      tt.used.v[(size_t)t * D + d] = u_v[d];
+      if (replace) tt.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
+    }
+    tt.used.present[t] = u_p;
+    tt.used.count[t] = u_hc ? u_c : 0;
+    tt.used.has_count[t] = u_hc;
+    uint32_t nf = fl & ~kThrThrottledPod;
+    if (th_pod) nf |= kThrThrottledPod;
+    if (replace) {
+      tt.calc.present[t] = c_p;
+      tt.calc.count[t] = c_hc ? c_c : 0;
+      tt.calc.has_count[t] = c_hc;
+      tt.status_msgs_fp[t] = c_fp;
+      nf |= kThrCalcAtNonzero;
+    }
+    tt.flags[t] = nf;
+    tt.thrl_flag[t] = th_flag;
+    tt.thrl_has[t] = c_p;
+  }
+}
+
+void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
+                     int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, hipStream_t s) {
+  if (sp.T <= 0) return;
+  hipLaunchKernelGGL(kt_finalize, dim3((sp.T + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tt, sp.T, D, partial, now_s,
+                     now_ns, apply ? 1 : 0, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_prepare_check — per throttle: fold everything CheckThrottledFor needs that does not depend on
+// the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T) return;
+  const uint32_t fl = tt.flags[t];
+  // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
+  const AmountTab& th = (fl & kThrCalcAtNonzero) ? tt.calc : tt.spec;
+  const uint32_t th_p = th.present[t];
+  const bool th_hc = th.has_count[t] != 0;
+  const int64_t th_c = th.count[t];
+  const uint32_t u_p = tt.used.present[t], r_p = tt.reserved.present[t];
+  const bool u_hc = tt.used.has_count[t] != 0, r_hc = tt.reserved.has_count[t] != 0;
+  const int64_t u_c = u_hc ? tt.used.count[t] : 0, r_c = r_hc ? tt.reserved.count[t] : 0;
+  const bool eq = on_equal != 0;
+  const bool eq3 = (fl & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
+  CheckRec<DT> rec;
+  uint32_t f = 0;
+  // step 1, counts: IsThrottled(podAmount{pod:1}, false).pod
+  if (th_hc && 1 > th_c) f |= kRecExceedsByCount;
+  // step 2: stored status.throttled ; step 3: IsThrottled(used + reserved, eq3)
+  uint32_t act_mask = tt.thrl_flag[t] & tt.thrl_has[t];
+  bool act_pod = (fl & kThrThrottledPod) != 0;
+  if (th_hc && (u_hc || r_hc) && cmp_eq(u_c + r_c, th_c, eq3)) act_pod = true;
+  // step 4, counts: used + pod(1) + reserved always has counts
+  if (th_hc && cmp_eq(u_c + 1 + r_c, th_c, eq)) f |= kRecInsufficientByCount;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    int64_t thr = kInf, head = kInf;
+    if (d < D && ((th_p >> d) & 1u)) {
+      const int64_t tv = th.v[(size_t)t * D + d];
+      const int64_t uv = ((u_p >> d) & 1u) ? tt.used.v[(size_t)t * D + d] : 0;
+      const int64_t rv = ((r_p >> d) & 1u) ? tt.reserved.v[(size_t)t * D + d] : 0;
+      if ((((u_p | r_p) >> d) & 1u) && cmp_eq(uv + rv, tv, eq3)) act_mask |= 1u << d;
+      thr = tv;
+      __int128 h = (__int128)tv - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
+      head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
+    }
+    rec.thr[d] = thr;
+    rec.head[d] = head;
+  }
+  if (act_pod) f |= kRecActiveByCount;
+  rec.flags = f;
+  rec.active_mask = act_mask;
+  rec.pad[0] = rec.pad[1] = 0;
+  recs[t] = rec;
+}
+
+void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s) {
+  if (T <= 0) return;
+  dim3 g((T + kBlock - 1) / kBlock), b(kBlock);
+  if (DT == 4) hipLaunchKernelGGL(kt_prepare_check<4>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<4>*)recs);
+  else if (DT == 8) hipLaunchKernelGGL(kt_prepare_check<8>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<8>*)recs);
+  else hipLaunchKernelGGL(kt_prepare_check<16>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<16>*)recs);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_check_dense — PreFilter for n pods: CheckThrottled of both controllers + CheckThrottledFor
+// (plugin.go:148-215, throttle_controller.go:349-397, clusterthrottle_controller.go:378-425).
+// lane = pod; throttles walked uniformly (records and selector program come through scalar loads).
+// ---------------------------------------------------------------------------------------------------
+template <int DT, int LT, bool KEYS>
+__global__ __launch_bounds__(kBlock) void kt_check_dense(PodTable pods, int64_t n, const int64_t* rows, SelProgram sp,
+                                                        const void* recs_, uint64_t* summary, uint8_t* status) {
+  const CheckRec<DT>* recs = (const CheckRec<DT>*)recs_;
+  const int64_t n_round = (n + kWave - 1) / kWave * kWave;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * kBlock) {
+    const bool in = i < n;
+    const int64_t p = in ? (rows ? rows[i] : i) : 0;
+    const uint32_t fl = in ? pods.flags[p] : 0u;
+    const bool on = (fl & kPodValid) != 0;
+    PodRegs<DT, LT, KEYS> r;
+    load_pod<DT, LT, KEYS>(pods, p, r, true);
+    if (!on) r.ns = 0;
+    // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
+    bool pod_err = on && !sp.ns_valid[r.ns];
+    const uint32_t* ns_row = sp.ns_term_ok + (size_t)r.ns * sp.gw;
+    uint32_t cur_w = 0, cur_wi = 0xFFFFFFFFu;
+    uint32_t n_exc = 0, n_act = 0, n_ins = 0;
+    for (int t = 0; t < sp.T; ++t) {
+      bool matched, err;
+      walk_terms<LT, KEYS>(sp, t, ns_row, on, r.lp, r.lk, cur_w, cur_wi, matched, err);
+      pod_err |= err;
+      uint32_t st = 0;
+      if (matched) {
+        st = classify<DT>(recs + t, r.v, r.nzmask);
+        n_exc += st == 4u;
+        n_act += st == 2u;
+        n_ins += st == 3u;
+      }
+      if (status && in) status[i * sp.T + t] = (uint8_t)st;
+    }
+    if (in) {
+      summary[i] = on ? pack_summary(n_exc, n_act, n_ins, pod_err) : 0ull;
+      if (status && pod_err)
+        for (int t = 0; t < sp.T; ++t) status[i * sp.T + t] = 255;
+    }
+  }
+}
+
+#define KT_DISPATCH(KERNEL, DT_, LT_, KEYS_, ...)                                                              \
+  do {                                                                                                         \
+    if (DT_ == 4 && LT_ == 8 && !KEYS_) hipLaunchKernelGGL((KERNEL<4, 8, false>), __VA_ARGS__);                \
+    else if (DT_ == 4 && LT_ == 8 && KEYS_) hipLaunchKernelGGL((KERNEL<4, 8, true>), __VA_ARGS__);             \
+    else if (DT_ == 4 && LT_ == 16 && !KEYS_) hipLaunchKernelGGL((KERNEL<4, 16, false>), __VA_ARGS__);         \
+    else if (DT_ == 4 && LT_ == 16 && KEYS_) hipLaunchKernelGGL((KERNEL<4, 16, true>), __VA_ARGS__);           \
+    else if (DT_ == 8 && LT_ == 8 && !KEYS_) hipLaunchKernelGGL((KERNEL<8, 8, false>), __VA_ARGS__);           \
+    else if (DT_ == 8 && LT_ == 8 && KEYS_) hipLaunchKernelGGL((KERNEL<8, 8, true>), __VA_ARGS__);             \
+    else if (DT_ == 8 && LT_ == 16 && !KEYS_) hipLaunchKernelGGL((KERNEL<8, 16, false>), __VA_ARGS__);         \
+    else if (DT_ == 8 && LT_ == 16 && KEYS_) hipLaunchKernelGGL((KERNEL<8, 16, true>), __VA_ARGS__);           \
+    else if (DT_ == 16 && LT_ == 8 && !KEYS_) hipLaunchKernelGGL((KERNEL<16, 8, false>), __VA_ARGS__);         \
+    else if (DT_ == 16 && LT_ == 8 && KEYS_) hipLaunchKernelGGL((KERNEL<16, 8, true>), __VA_ARGS__);           \
+    else if (DT_ == 16 && LT_ == 16 && !KEYS_) hipLaunchKernelGGL((KERNEL<16, 16, false>), __VA_ARGS__);       \
+    else hipLaunchKernelGGL((KERNEL<16, 16, true>), __VA_ARGS__);                                              \
+  } while (0)
+
+void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgram& sp, bool keys,
+                            unsigned long long* partial, hipStream_t s) {
+  if (n_rows <= 0 || sp.T <= 0) return;
+  const int DT = dt_bucket(pods.D), LT = lt_bucket(pods.L);
+  KT_DISPATCH(kt_aggregate_dense, DT, LT, keys, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+}
+
+void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
+                        const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s) {
+  if (n <= 0) return;
+  const int DT = dt_bucket(pods.D), LT = lt_bucket(pods.L);
+  KT_DISPATCH(kt_check_dense, DT, LT, keys, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, sp, recs, summary,
+              status);
+}
+
+const char* kernel_name_check(int variant) { return variant == 1 ? "kt_check_dense" : "kt_check_indexed"; }
+const char* kernel_name_aggregate(int variant) { return variant == 1 ? "kt_aggregate_dense" : "kt_aggregate_indexed"; }
+
+}  // namespace kt

@@ -1,0 +1,48 @@
+// kt_launch.h — host-callable launchers of the HIP kernels (implemented in kt_kernels*.hip).
+#pragma once
+#include "kt_device.h"
+
+namespace kt {
+
+// Staged pod batch in device memory (row-major, as in kt_snapshot).
+struct PodBatchDev {
+  int64_t n;
+  const int64_t* rows;  // nullable => row0 + i
+  int64_t row0;
+  const uint32_t* ns;
+  const uint32_t* flags;
+  const uint32_t* label_off;  // [n+1], relative to label_base
+  const uint32_t* label_key;
+  const uint32_t* label_pair;
+  uint32_t label_base;        // value of label_off[0] in the host batch (arrays are copied from there)
+  const uint32_t* ctr_off;    // [n+1]
+  const uint8_t* ctr_init;
+  const uint32_t* ctr_present;
+  const int64_t* ctr_req;     // [n_ctr][D]
+  uint32_t ctr_base;
+  const uint32_t* ovh_present;
+  const int64_t* ovh;         // [n][D]
+};
+
+struct IndexTables;  // kt_index.h
+
+void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s);
+void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
+void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
+                                uint32_t* out_present, hipStream_t s);
+
+void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgram& sp, bool keys,
+                            unsigned long long* partial, hipStream_t s);
+void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
+                     int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, hipStream_t s);
+void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s);
+void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
+                        const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s);
+
+const char* kernel_name_check(int variant);
+const char* kernel_name_aggregate(int variant);
+
+inline int dt_bucket(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : 16; }
+inline int lt_bucket(int L) { return L <= 8 ? 8 : 16; }
+
+}  // namespace kt

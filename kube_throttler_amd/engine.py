@@ -1,0 +1,292 @@
+"""ctypes binding of the C-ABI in include/kt_engine.h (libkt_engine.so, hand-written HIP for gfx950).
+
+There is no CPU fallback: a missing library or a box without a GPU raises :class:`EngineError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import snapshot as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libkt_engine.so")
+_LIB = None
+
+KT_OK = 0
+ERR_NAMES = {-1: "KT_ERR_INVALID_ARGUMENT", -2: "KT_ERR_OUT_OF_RANGE", -3: "KT_ERR_DEVICE", -4: "KT_ERR_OVERFLOW_RISK",
+             -5: "KT_ERR_NOT_READY", -6: "KT_ERR_NO_DEVICE"}
+RECONCILE_APPLY = 0x1
+CHECK_STATUS_MATRIX = 0x1
+KERNEL_CHECK, KERNEL_AGGREGATE, KERNEL_FINALIZE, KERNEL_PREPARE = 0, 1, 2, 3
+VARIANT_INDEXED, VARIANT_DENSE = 0, 1
+
+EXPORTS = [
+    "kt_version", "kt_engine_create", "kt_engine_destroy", "kt_last_error", "kt_upsert_namespaces", "kt_upsert_pods",
+    "kt_upsert_throttles", "kt_delete_namespaces", "kt_delete_pods", "kt_delete_throttles", "kt_load_snapshot",
+    "kt_set_reserved", "kt_set_status", "kt_reconcile_launch", "kt_aggregate_launch", "kt_partial_used_buffer",
+    "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
+    "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
+    "kt_synchronize", "kt_kernel_name",
+]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class KtConfig(C.Structure):
+    _fields_ = [("n_dims", C.c_int32), ("max_labels", C.c_int32), ("pod_capacity", C.c_int64),
+                ("throttle_capacity", C.c_int32), ("namespace_capacity", C.c_int32), ("device", C.c_int32),
+                ("kernel_variant", C.c_int32)]
+
+
+class KtStatus(C.Structure):
+    _fields_ = [("used", S.KtAmounts), ("calc", S.KtAmounts), ("calc_at_nonzero", C.POINTER(C.c_uint8)),
+                ("thrl_flag", C.POINTER(C.c_uint32)), ("thrl_has", C.POINTER(C.c_uint32)),
+                ("thrl_pod", C.POINTER(C.c_uint8)), ("msgs_fp", C.POINTER(C.c_uint64)),
+                ("error", C.POINTER(C.c_uint8))]
+
+
+def build(force: bool = False) -> str:
+    """Compile libkt_engine.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(-6, f"{LIB_PATH} is missing: build it with kube_throttler_amd.engine.build() "
+                                  "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.kt_version.restype = C.c_char_p
+        L.kt_last_error.restype = C.c_char_p
+        L.kt_last_error.argtypes = [C.c_void_p]
+        L.kt_kernel_name.restype = C.c_char_p
+        L.kt_kernel_name.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_engine_create.argtypes = [C.POINTER(KtConfig), C.POINTER(C.c_void_p)]
+        L.kt_engine_destroy.argtypes = [C.c_void_p]
+        for name in ("kt_upsert_namespaces", "kt_upsert_pods", "kt_upsert_throttles"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(S.KtSnapshot), C.c_void_p]
+        L.kt_delete_namespaces.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.kt_delete_pods.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.kt_delete_throttles.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.kt_load_snapshot.argtypes = [C.c_void_p, C.POINTER(S.KtSnapshot)]
+        L.kt_set_reserved.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(S.KtAmounts)]
+        L.kt_set_status.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(KtStatus)]
+        L.kt_reconcile_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_aggregate_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.kt_partial_used_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.kt_finalize_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_reconcile_fetch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KtStatus)]
+        L.kt_check_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_check_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.kt_fetch_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kt_timing_enable.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.kt_timing_reset.argtypes = [C.c_void_p]
+        L.kt_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class ReconcileResult:
+    """Rows [0, n) of a reconcile pass; attribute names as in the oracle's result."""
+
+    def __init__(self, n, D):
+        self.used, self.calc = S.Amounts(n, D), S.Amounts(n, D)
+        m = max(n, 1)
+        self.calc_updated = np.zeros(m, np.uint8)
+        self.thrl_flag = np.zeros(m, np.uint32)
+        self.thrl_has = np.zeros(m, np.uint32)
+        self.thrl_pod = np.zeros(m, np.uint8)
+        self.error = np.zeros(m, np.uint8)
+
+    def as_struct(self) -> KtStatus:
+        p8, p32 = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+        return KtStatus(self.used.as_struct(), self.calc.as_struct(), self.calc_updated.ctypes.data_as(p8),
+                        self.thrl_flag.ctypes.data_as(p32), self.thrl_has.ctypes.data_as(p32),
+                        self.thrl_pod.ctypes.data_as(p8), None, self.error.ctypes.data_as(p8))
+
+
+class Engine:
+    """One engine = one GPU's worth of pod rows plus the (replicated) throttle tables."""
+
+    def __init__(self, n_dims, max_labels, pod_capacity, throttle_capacity, namespace_capacity, device=-1,
+                 kernel_variant=VARIANT_INDEXED):
+        self._h = C.c_void_p()
+        self.D = n_dims
+        cfg = KtConfig(n_dims, max_labels, pod_capacity, throttle_capacity, namespace_capacity, device, kernel_variant)
+        rc = lib().kt_engine_create(C.byref(cfg), C.byref(self._h))
+        if rc != KT_OK:
+            raise EngineError(rc, lib().kt_last_error(None).decode())
+
+    @classmethod
+    def for_snapshot(cls, snap: S.Snapshot, kernel_variant=VARIANT_INDEXED, device=-1, pod_capacity=None):
+        e = cls(snap.D, max(snap.L, 1), pod_capacity or max(snap.n_pods, 1), max(snap.n_thr, 1), max(snap.n_ns, 1),
+                device, kernel_variant)
+        e.load_snapshot(snap)
+        return e
+
+    def close(self):
+        if self._h:
+            lib().kt_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != KT_OK:
+            raise EngineError(rc, lib().kt_last_error(self._h).decode())
+
+    # ---- state feed
+    def load_snapshot(self, snap: S.Snapshot):
+        st = snap.as_struct()
+        self._ck(lib().kt_load_snapshot(self._h, C.byref(st)))
+
+    @staticmethod
+    def _rows(rows, dtype):
+        if rows is None:
+            return None, None
+        a = np.ascontiguousarray(rows, dtype=dtype)
+        return a, a.ctypes.data
+
+    def upsert_namespaces(self, batch: S.Snapshot, rows=None):
+        st = batch.as_struct()
+        a, p = self._rows(rows, np.int32)
+        self._ck(lib().kt_upsert_namespaces(self._h, C.byref(st), p))
+
+    def upsert_pods(self, batch: S.Snapshot, rows=None):
+        st = batch.as_struct()
+        a, p = self._rows(rows, np.int64)
+        self._ck(lib().kt_upsert_pods(self._h, C.byref(st), p))
+
+    def upsert_throttles(self, batch: S.Snapshot, rows=None):
+        st = batch.as_struct()
+        a, p = self._rows(rows, np.int32)
+        self._ck(lib().kt_upsert_throttles(self._h, C.byref(st), p))
+
+    def delete_pods(self, rows):
+        a, p = self._rows(rows, np.int64)
+        self._ck(lib().kt_delete_pods(self._h, len(a), p))
+
+    def delete_throttles(self, rows):
+        a, p = self._rows(rows, np.int32)
+        self._ck(lib().kt_delete_throttles(self._h, len(a), p))
+
+    def delete_namespaces(self, rows):
+        a, p = self._rows(rows, np.int32)
+        self._ck(lib().kt_delete_namespaces(self._h, len(a), p))
+
+    def set_reserved(self, rows, amounts: S.Amounts):
+        a, p = self._rows(rows, np.int32)
+        st = amounts.as_struct()
+        self._ck(lib().kt_set_reserved(self._h, len(a), p, C.byref(st)))
+
+    def set_status(self, rows, used: S.Amounts, calc: S.Amounts, calc_at_nonzero, thrl_flag, thrl_has, thrl_pod,
+                   msgs_fp=None):
+        a, p = self._rows(rows, np.int32)
+        n = len(a)
+        keep = [np.ascontiguousarray(calc_at_nonzero, np.uint8), np.ascontiguousarray(thrl_flag, np.uint32),
+                np.ascontiguousarray(thrl_has, np.uint32), np.ascontiguousarray(thrl_pod, np.uint8),
+                np.ascontiguousarray(msgs_fp if msgs_fp is not None else np.zeros(n), np.uint64)]
+        st = KtStatus(used.as_struct(), calc.as_struct(), keep[0].ctypes.data_as(C.POINTER(C.c_uint8)),
+                      keep[1].ctypes.data_as(C.POINTER(C.c_uint32)), keep[2].ctypes.data_as(C.POINTER(C.c_uint32)),
+                      keep[3].ctypes.data_as(C.POINTER(C.c_uint8)), keep[4].ctypes.data_as(C.POINTER(C.c_uint64)), None)
+        self._ck(lib().kt_set_status(self._h, n, p, C.byref(st)))
+
+    # ---- reconcile
+    def reconcile_launch(self, now, apply=True, stream=None):
+        self._ck(lib().kt_reconcile_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, stream))
+
+    def aggregate_launch(self, stream=None):
+        self._ck(lib().kt_aggregate_launch(self._h, stream))
+
+    def partial_used_buffer(self):
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._ck(lib().kt_partial_used_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def finalize_launch(self, now, apply=True, stream=None):
+        self._ck(lib().kt_finalize_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, stream))
+
+    def throttle_rows(self) -> int:
+        n = C.c_int32()
+        self._ck(lib().kt_throttle_rows(self._h, C.byref(n)))
+        return n.value
+
+    def reconcile_fetch(self, n=None) -> ReconcileResult:
+        n = self.throttle_rows() if n is None else n
+        r = ReconcileResult(n, self.D)
+        st = r.as_struct()
+        self._ck(lib().kt_reconcile_fetch(self._h, n, C.byref(st)))
+        return r
+
+    def reconcile(self, now, apply=True) -> ReconcileResult:
+        self.reconcile_launch(now, apply)
+        return self.reconcile_fetch()
+
+    # ---- check
+    def check_launch(self, n, rows=None, on_equal=False, want_status=False, stream=None):
+        a, p = self._rows(rows, np.int64)
+        self._ck(lib().kt_check_launch(self._h, n, p, int(on_equal), CHECK_STATUS_MATRIX if want_status else 0, stream))
+
+    def check_fetch(self, n, want_status=False):
+        T = self.throttle_rows()
+        summary = np.zeros(max(n, 1), np.uint64)
+        status = np.zeros((max(n, 1), max(T, 1)), np.uint8) if want_status else None
+        self._ck(lib().kt_check_fetch(self._h, n, summary.ctypes.data, None if status is None else status.ctypes.data))
+        return (None if status is None else status[:n, :T]), summary[:n]
+
+    def check(self, rows=None, n=None, on_equal=False, want_status=True):
+        n = len(rows) if rows is not None else n
+        self.check_launch(n, rows, on_equal, want_status)
+        return self.check_fetch(n, want_status)
+
+    def check_device_summary(self) -> int:
+        ptr = C.c_void_p()
+        self._ck(lib().kt_check_device_summary(self._h, C.byref(ptr)))
+        return ptr.value
+
+    def fetch_pod_requests(self, rows=None, n=None):
+        a, p = self._rows(rows, np.int64)
+        n = len(a) if a is not None else n
+        v = np.zeros((max(n, 1), self.D), np.int64)
+        present = np.zeros(max(n, 1), np.uint32)
+        self._ck(lib().kt_fetch_pod_requests(self._h, n, p, v.ctypes.data, present.ctypes.data))
+        return v[:n], present[:n]
+
+    # ---- measurement
+    def timing_enable(self, on=True):
+        self._ck(lib().kt_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._ck(lib().kt_timing_reset(self._h))
+
+    def timing_read(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(lib().kt_timing_read(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self, stream=None):
+        self._ck(lib().kt_synchronize(self._h, stream))
+
+    def kernel_name(self, kernel) -> str:
+        return lib().kt_kernel_name(self._h, kernel).decode()

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Bit-exact bar: every per-(pod, throttle) status, every per-pod summary word, every `used` vector,
+presence mask, count, calculated threshold and throttled flag must be identical.
+"""
+import numpy as np
+import pytest
+
+from kube_throttler_amd import engine as E
+from kube_throttler_amd import snapshot as S
+from kube_throttler_amd import workload as W
+from scenario_runner import load_scenarios, run_scenario
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [E.VARIANT_INDEXED, E.VARIANT_DENSE]
+VIDS = ["indexed", "dense"]
+NOW = (1767225600, 0)
+
+
+class EngineBackend:
+    def __init__(self, variant):
+        self.variant = variant
+
+    def reconcile(self, built, now):
+        e = E.Engine.for_snapshot(built.snapshot, self.variant)
+        try:
+            return e.reconcile(now, apply=False)
+        finally:
+            e.close()
+
+    def check(self, built, rows, on_equal):
+        e = E.Engine.for_snapshot(built.snapshot, self.variant)
+        try:
+            return e.check(rows, on_equal=on_equal, want_status=True)
+        finally:
+            e.close()
+
+
+SCENARIOS = load_scenarios()
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+@pytest.mark.parametrize("sc", SCENARIOS, ids=[s["name"] for s in SCENARIOS])
+def test_golden_scenarios(sc, variant):
+    """The reference's integration scenarios (G1-G3, G5), on the GPU."""
+    run_scenario(sc, EngineBackend(variant))
+
+
+def assert_reconcile_equal(got, want, T, skip_error_rows=True):
+    err_g, err_w = got.error[:T], want.error[:T]
+    np.testing.assert_array_equal(err_g != 0, err_w != 0, err_msg="reconcile error flags")
+    ok = err_w[:T] == 0
+    for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod"):
+        np.testing.assert_array_equal(getattr(got, name)[:T][ok], getattr(want, name)[:T][ok], err_msg=name)
+    for tab in ("used", "calc"):
+        g, w = getattr(got, tab), getattr(want, tab)
+        np.testing.assert_array_equal(g.present[:T][ok], w.present[:T][ok], err_msg=f"{tab}.present")
+        np.testing.assert_array_equal(g.has_count[:T][ok], w.has_count[:T][ok], err_msg=f"{tab}.has_count")
+        np.testing.assert_array_equal(g.count[:T][ok], w.count[:T][ok], err_msg=f"{tab}.count")
+        np.testing.assert_array_equal(g.v[:T][ok], w.v[:T][ok], err_msg=f"{tab}.v")
+
+
+def responsible_rows(snap):
+    need = S.THR_VALID | S.THR_RESPONSIBLE
+    return np.nonzero((snap.thr_flags[:snap.n_thr] & need) == need)[0]
+
+
+def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True), nthreads=8):
+    """reconcile -> store status -> check, oracle vs engine, everything compared."""
+    T = snap.n_thr
+    o = oracle_mod.Oracle(snap)
+    eng = E.Engine.for_snapshot(snap, variant)
+    try:
+        # resourcelist.PodRequestResourceList parity
+        ov, op = o.pod_requests()
+        gv, gp = eng.fetch_pod_requests(n=snap.n_pods)
+        np.testing.assert_array_equal(gp, op, err_msg="pod request presence")
+        np.testing.assert_array_equal(gv, ov, err_msg="pod request values")
+        # reconcile (only responsible throttles are ever reconciled by the reference)
+        rows = responsible_rows(snap)
+        want = o.reconcile(now, rows=rows, nthreads=nthreads)
+        got_all = eng.reconcile(now, apply=True)
+        got = E.ReconcileResult(len(rows), snap.D)
+        for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+            getattr(got, name)[:len(rows)] = getattr(got_all, name)[rows]
+        for tab in ("used", "calc"):
+            for f in ("v", "present", "count", "has_count"):
+                getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
+        assert_reconcile_equal(got, want, len(rows))
+        # UpdateStatus on the oracle side, then check against the stored status
+        snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod,
+                          want.error, rows=rows)
+        for on_equal in on_equals:
+            st_w, sm_w = o.check(on_equal=on_equal, nthreads=nthreads)
+            st_g, sm_g = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w, err_msg=f"status matrix on_equal={on_equal}")
+            np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"summary on_equal={on_equal}")
+        return st_w, sm_w, want
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_small_rich(seed, variant, oracle_mod):
+    """Every selector operator, multi-term OR, overrides, reserved amounts, both kinds."""
+    snap = W.generate(W.small(seed=seed))
+    st, sm, rec = run_full_parity(snap, oracle_mod, variant)
+    assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED, S.ACTIVE}
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_random_selector_errors(variant, oracle_mod):
+    """Unconvertible podSelector terms (pod-level Error, reconcile error), swallowed namespaceSelector
+    errors, pods in namespaces without a Namespace object."""
+    snap = W.generate(W.small(seed=7, n_pods=3000, n_thr=96, n_cluster=48, n_invalid_pod_sel=6, n_invalid_ns_sel=4,
+                              n_missing_ns=2))
+    st, sm, rec = run_full_parity(snap, oracle_mod, variant)
+    verdict = S.summary_fields(sm)[0]
+    assert (verdict == S.VERDICT_ERROR).any() and (verdict != S.VERDICT_ERROR).any()
+    assert rec.error.any()
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_edge_shapes(variant, oracle_mod):
+    """D=1, D=16, L=16, terms without requirements, throttles without terms, tiny pod counts."""
+    for cfg in (W.small(seed=11, n_pods=1, n_thr=3, n_cluster=1, D=1, n_ns=1, K=2, V=2, L=1, terms=(0, 1), reqs=(0, 1)),
+                W.small(seed=12, n_pods=65, n_thr=40, n_cluster=20, D=16, n_ns=3, K=16, V=2, L=16, terms=(0, 3), reqs=(0, 4)),
+                W.small(seed=13, n_pods=300, n_thr=33, n_cluster=0, D=3, n_ns=2, K=4, V=2, L=2, terms=(1, 2), reqs=(0, 2),
+                        overrides=0)):
+        snap = W.generate(cfg)
+        run_full_parity(snap, oracle_mod, variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_config1_full(variant, oracle_mod):
+    """BASELINE.json configs[1]: 10k pods x 100 Throttles, D=4, single selectorTerm — full matrix."""
+    snap = W.generate(W.preset(1))
+    run_full_parity(snap, oracle_mod, variant)
+
+
+def test_empty_engine(oracle_mod):
+    """No throttles / no pods: everything is allowed, nothing crashes."""
+    snap = W.generate(W.small(seed=5, n_pods=10, n_thr=0, n_cluster=0))
+    eng = E.Engine.for_snapshot(snap)
+    st, sm = eng.check(n=10, want_status=False)
+    assert (sm == 0).all()
+    r = eng.reconcile(NOW)
+    eng.close()
+
+
+def test_incremental_feed_matches_bulk(oracle_mod):
+    """Upserting pods/throttles/namespaces row by row (out of order, with overwrites and deletes) ends
+    in the same state as a bulk load of the final snapshot."""
+    final = W.generate(W.small(seed=21, n_pods=1500, n_thr=48, n_cluster=24))
+    other = W.generate(W.small(seed=22, n_pods=1500, n_thr=48, n_cluster=24))
+    eng = E.Engine(final.D, final.L, 2000, 64, 16)
+    try:
+        eng.upsert_namespaces(other)
+        eng.upsert_throttles(other)
+        eng.upsert_pods(other)                      # garbage first ...
+        eng.reconcile(NOW, apply=True)              # ... including a device-resident status
+        eng.upsert_namespaces(final)                # then the real content, pods in reverse row order
+        rows = np.arange(final.n_pods)[::-1].copy()
+        rev = _permute_pods(final, rows)
+        eng.upsert_pods(rev, rows=rows)
+        eng.upsert_throttles(final)
+        extra = np.array([1700, 1701], dtype=np.int64)
+        eng.upsert_pods(_permute_pods(other, np.array([0, 1])), rows=extra)
+        eng.delete_pods(extra)
+        o = oracle_mod.Oracle(final)
+        rows_t = responsible_rows(final)
+        want = o.reconcile(NOW, rows=rows_t)
+        got = eng.reconcile(NOW, apply=True)
+        np.testing.assert_array_equal(got.used.v[rows_t], want.used.v[:len(rows_t)])
+        np.testing.assert_array_equal(got.used.count[rows_t], want.used.count[:len(rows_t)])
+        final.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod,
+                           want.error, rows=rows_t)
+        st_w, sm_w = o.check()
+        st_g, sm_g = eng.check(n=final.n_pods, want_status=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+        # explicit row lists (the n=1 drop-in shape of PreFilter)
+        pick = np.array([5, 999, 17, 5], dtype=np.int64)
+        st_g, sm_g = eng.check(rows=pick, want_status=True)
+        np.testing.assert_array_equal(st_g, st_w[pick])
+        np.testing.assert_array_equal(sm_g, sm_w[pick])
+    finally:
+        eng.close()
+
+
+def _permute_pods(snap, rows):
+    """A pods-only batch holding snap's pods in the order given by rows."""
+    rows = np.asarray(rows)
+    b = S.Snapshot(snap.D, snap.L)
+    b.alloc_namespaces(0, 0)
+    b.alloc_throttles(0, 0, 0)
+    nl = int(sum(snap.pod_label_off[r + 1] - snap.pod_label_off[r] for r in rows))
+    nc = int(sum(snap.pod_ctr_off[r + 1] - snap.pod_ctr_off[r] for r in rows))
+    b.alloc_pods(len(rows), nl, nc)
+    lo = co = 0
+    for i, r in enumerate(rows):
+        b.pod_ns[i], b.pod_flags[i] = snap.pod_ns[r], snap.pod_flags[r]
+        l0, l1 = int(snap.pod_label_off[r]), int(snap.pod_label_off[r + 1])
+        b.pod_label_key[lo:lo + l1 - l0] = snap.pod_label_key[l0:l1]
+        b.pod_label_pair[lo:lo + l1 - l0] = snap.pod_label_pair[l0:l1]
+        lo += l1 - l0
+        b.pod_label_off[i + 1] = lo
+        c0, c1 = int(snap.pod_ctr_off[r]), int(snap.pod_ctr_off[r + 1])
+        b.ctr_init[co:co + c1 - c0] = snap.ctr_init[c0:c1]
+        b.ctr_present[co:co + c1 - c0] = snap.ctr_present[c0:c1]
+        b.ctr_req[co:co + c1 - c0] = snap.ctr_req[c0:c1]
+        co += c1 - c0
+        b.pod_ctr_off[i + 1] = co
+        b.pod_ovh_present[i] = snap.pod_ovh_present[r]
+        b.pod_ovh[i] = snap.pod_ovh[r]
+    return b
+
+
+def test_set_status_and_reserved(oracle_mod):
+    """kt_set_status / kt_set_reserved feed what the informer cache / reserved cache hold."""
+    snap = W.generate(W.small(seed=31, n_pods=800, n_thr=40, n_cluster=20))
+    o = oracle_mod.Oracle(snap)
+    rows = responsible_rows(snap)
+    want = o.reconcile(NOW, rows=rows)
+    eng = E.Engine.for_snapshot(snap)     # engine still has the EMPTY stored status
+    try:
+        snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod,
+                          want.error, rows=rows)
+        T = snap.n_thr
+        allrows = np.arange(T, dtype=np.int32)
+        eng.set_status(allrows, snap.thr_used, snap.thr_calc, (snap.thr_flags[:T] & S.THR_CALC_AT_NONZERO) != 0,
+                       snap.thr_thrl_flag[:T], snap.thr_thrl_has[:T], (snap.thr_flags[:T] & S.THR_THROTTLED_POD) != 0,
+                       snap.thr_status_msgs_fp[:T])
+        # change some reservations on both sides
+        res = S.Amounts(3, snap.D)
+        for i in range(3):
+            res.set_row(i, {0: 1000 * (i + 1), 1: 1 << 30}, count=i + 1)
+            for f in ("v", "present", "count", "has_count"):
+                getattr(snap.thr_reserved, f)[rows[i]] = getattr(res, f)[i]
+        eng.set_reserved(rows[:3].astype(np.int32), res)
+        st_w, sm_w = o.check()
+        st_g, sm_g = eng.check(n=snap.n_pods, want_status=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+    finally:
+        eng.close()
+
+
+def test_overflow_guard():
+    """A dimension whose worst-case sum could leave int64 is refused at ingest, never wrapped."""
+    snap = W.generate(W.small(seed=41, n_pods=4, n_thr=2, n_cluster=0, D=2))
+    snap.ctr_req[0, 0] = 1 << 59
+    snap.ctr_present[0] |= 1
+    eng = E.Engine(2, snap.L, 4, 2, snap.n_ns)
+    with pytest.raises(E.EngineError) as ei:
+        eng.load_snapshot(snap)
+    assert ei.value.code == -4
+    eng.close()
+
+
+def test_api_errors():
+    snap = W.generate(W.small(seed=42, n_pods=8, n_thr=2, n_cluster=1))
+    eng = E.Engine.for_snapshot(snap)
+    with pytest.raises(E.EngineError) as ei:
+        eng.check_fetch(1)
+    assert ei.value.code == -5
+    with pytest.raises(E.EngineError) as ei:
+        eng.check(rows=np.array([99], dtype=np.int64))
+    assert ei.value.code == -2
+    eng.close()
