@@ -114,12 +114,17 @@ def test_random_small_rich(seed, variant, oracle_mod):
 def test_random_selector_errors(variant, oracle_mod):
     """Unconvertible podSelector terms (pod-level Error, reconcile error), swallowed namespaceSelector
     errors, pods in namespaces without a Namespace object."""
-    snap = W.generate(W.small(seed=7, n_pods=3000, n_thr=96, n_cluster=48, n_invalid_pod_sel=6, n_invalid_ns_sel=4,
+    # one bad namespaced Throttle: only the pods of its namespace that reach the bad term are in Error
+    snap = W.generate(W.small(seed=7, n_pods=3000, n_thr=96, n_cluster=48, n_invalid_pod_sel=1, n_invalid_ns_sel=4,
                               n_missing_ns=2))
     st, sm, rec = run_full_parity(snap, oracle_mod, variant)
     verdict = S.summary_fields(sm)[0]
     assert (verdict == S.VERDICT_ERROR).any() and (verdict != S.VERDICT_ERROR).any()
     assert rec.error.any()
+    # bad terms on ClusterThrottles too (their empty namespaceSelector reaches every namespace)
+    snap = W.generate(W.small(seed=8, n_pods=2000, n_thr=96, n_cluster=48, n_invalid_pod_sel=6, n_invalid_ns_sel=2))
+    st, sm, rec = run_full_parity(snap, oracle_mod, variant)
+    assert (S.summary_fields(sm)[0] == S.VERDICT_ERROR).any() and rec.error.any()
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
