@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py — pod x throttle admission decisions/sec of the MI355X throttle-evaluation engine.
+
+One "step" = one pass of the hot path over the whole synthetic snapshot resident in HBM:
+    reconcile  (kt_aggregate -> [RCCL all-reduce of the per-throttle `used` partials when N>1] -> kt_finalize,
+                result stored as the CR status)
+  + check      (kt_prepare_check + kt_check: PreFilter for EVERY pod against EVERY throttle)
+decisions per step = P_total x T  (the 5-state status of every (pod, throttle) pair is determined).
+
+Weak scaling: every rank holds `pods_per_gpu` pod rows of a job with P_total = N x pods_per_gpu pods;
+throttle tables are replicated; the only exchange is one int64 sum all-reduce of [T][2D+2] words.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    1: "configs[1]: 10k pods x 100 Throttles, D=4, single selectorTerm",
+    2: "configs[2]: 1M pods x 1k Throttle+ClusterThrottle, D=8",
+    3: "configs[3]: 1M pods x 1k throttles, temporaryThresholdOverrides active, D=8",
+    4: "configs[4]: 10M pods x 10k throttles, multi-term OR-of-AND selectors, D=8 (pods row-sharded)",
+}
+
+
+def algorithmic_bytes(snap, n_pods, L):
+    """SURVEY.md 8d / BASELINE.md: compulsory traffic of the logical records of one check pass."""
+    D, T = snap.D, snap.n_thr
+    b_pod = 8 + 4 * L + 8 * D
+    b_out = 8
+    n_req = len(snap.preq) + len(snap.nreq)
+    thr_bytes = T * (16 + (8 * D + 12) * 3 + 4) + 16 * n_req
+    return n_pods * (b_pod + b_out) + thr_bytes, b_pod, thr_bytes
+
+
+def aggregate_bytes(snap, n_counted, L):
+    D, T = snap.D, snap.n_thr
+    n_req = len(snap.preq) + len(snap.nreq)
+    return n_counted * (8 + 4 * L + 8 * D) + T * 16 + 16 * n_req + T * (2 * D + 1) * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i], i in 1..4 (default 2)")
+    ap.add_argument("--pods-per-gpu", type=int, default=0, help="override the per-GPU pod rows")
+    ap.add_argument("--variant", choices=["indexed", "dense"], default="indexed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from kube_throttler_amd import engine as E, snapshot as S, workload as W
+
+    # ---- workload: this rank's pod shard of a job with P_total = world x pods_per_gpu pods
+    cfg = W.preset(args.config)
+    if args.config == 4 and not args.pods_per_gpu:
+        per_gpu = cfg.n_pods_total // 8  # the config is defined on 8 GPUs: 1.25M rows each
+    else:
+        per_gpu = args.pods_per_gpu or cfg.n_pods_total
+    cfg.n_pods_total = per_gpu * world
+    cfg.pod_begin = per_gpu * rank
+    cfg.n_pods = per_gpu
+    t0 = time.time()
+    snap = W.generate(cfg)
+    t_gen = time.time() - t0
+    now = (cfg.now_s, 0)
+    T, D, L = snap.n_thr, snap.D, snap.L
+    P_total = cfg.n_pods_total
+
+    variant = E.VARIANT_INDEXED if args.variant == "indexed" else E.VARIANT_DENSE
+    t0 = time.time()
+    eng = E.Engine.for_snapshot(snap, variant, device=local_rank)
+    t_load = time.time() - t0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    partial = torch.zeros(eng.partial_words(), dtype=torch.int64, device="cuda")
+    eng.use_partial_buffer(partial.data_ptr(), partial.numel())
+
+    def step():
+        eng.aggregate_launch(stream)
+        if world > 1:
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM)  # RCCL over xGMI; int64 sums are order-independent
+        eng.finalize_launch(now, True, stream)
+        eng.check_launch(per_gpu, None, False, False, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    eng.timing_enable(False)
+
+    k_ms = {}
+    for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("finalize", E.KERNEL_FINALIZE),
+                      ("prepare", E.KERNEL_PREPARE)):
+        tot, n = eng.timing_read(fam)
+        k_ms[name] = tot / max(n, 1)
+
+    decisions_per_step = float(P_total) * float(T)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = decisions_per_step * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (per launch, this rank's shard)
+    flags = snap.pod_flags[:per_gpu]
+    need = S.POD_VALID | S.POD_SCHED_MATCH | S.POD_SCHEDULED
+    n_counted = int(((flags & need) == need).sum())
+    chk_bytes, b_pod, thr_bytes = algorithmic_bytes(snap, per_gpu, L)
+    agg_bytes = aggregate_bytes(snap, n_counted, L)
+    dominant = "check" if k_ms["check"] >= k_ms["aggregate"] else "aggregate"
+    dom_bytes = chk_bytes if dominant == "check" else agg_bytes
+    achieved = dom_bytes / (k_ms[dominant] * 1e-3) / 1e9 if k_ms[dominant] > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            ent = pmc.get(f"config{args.config}_{args.variant}", {}).get(eng.kernel_name(
+                E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE))
+            if ent:
+                traffic = ent.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": eng.kernel_name(E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE),
+        "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(k_ms[dominant], 6),
+        "per_kernel_ms": {k: round(v, 6) for k, v in k_ms.items()},
+        "check_GBps": round(chk_bytes / max(k_ms["check"], 1e-9) / 1e6, 3),
+        "aggregate_GBps": round(agg_bytes / max(k_ms["aggregate"], 1e-9) / 1e6, 3),
+    }
+
+    # ---- CPU baseline: the C restatement of the reference algorithm on this box's host cores (rank 0, N=1)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import kt_oracle as O  # test infrastructure: used here ONLY as the timed CPU baseline
+        rec = eng.reconcile_fetch()
+        snap.apply_status(rec.used, rec.calc, rec.calc_updated, rec.thrl_flag, rec.thrl_has, rec.thrl_pod, rec.error)
+        o = O.Oracle(snap)
+        cores = os.cpu_count() or 1
+        probe = np.arange(0, per_gpu, max(per_gpu // 2048, 1), dtype=np.int64)[:2048]
+        t0 = time.perf_counter()
+        o.check(rows=probe, want_status=False, nthreads=cores, mimic_log_args=True)
+        rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
+        n_sample = int(min(per_gpu, max(len(probe), rate * args.cpu_seconds)))
+        sample = np.linspace(0, per_gpu - 1, n_sample).astype(np.int64)
+        t0 = time.perf_counter()
+        _, sm_cpu = o.check(rows=sample, want_status=False, nthreads=cores, mimic_log_args=True)
+        dt = time.perf_counter() - t0
+        cpu_baseline = {
+            "value": round(len(sample) * T / dt, 1), "unit": "decisions/s", "cores": cores, "kind": "port",
+            "sample": f"PreFilter (CheckThrottled x2 + CheckThrottledFor) for {len(sample)} of {per_gpu} pods x {T} "
+                      f"throttles, {dt:.1f}s, C restatement of the reference algorithm (oracle/kt_oracle.c, OpenMP "
+                      f"over pods, klog eager-argument work included); NOT the reference Go binary",
+        }
+        if args.verify:
+            _, sm_gpu = eng.check(rows=sample, want_status=False)
+            assert np.array_equal(sm_gpu, sm_cpu), "GPU summaries differ from the oracle on the sample"
+
+    if rank == 0:
+        out = {
+            "metric": "pod_throttle_decisions_per_sec", "value": value, "unit": "decisions/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.config], "pods_total": P_total, "pods_per_gpu": per_gpu,
+                       "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
+                       "step": "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
+                       "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
+                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,9 @@ int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt
 int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
 int32_t kt_aggregate_launch(kt_engine* e, void* stream);
 int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64);
+/* Optional: aggregate into / finalize from a CALLER-owned device buffer of >= n_int64 words (e.g. the
+ * storage of a framework tensor handed to RCCL) instead of the engine's own. NULL restores the default. */
+int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64);
 int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out);

@@ -168,6 +168,9 @@ struct kt_engine {
 
   // ---- reconcile state
   DevBuf<unsigned long long> d_partial;
+  unsigned long long* ext_partial = nullptr;  // caller-owned partial buffer (kt_use_partial_buffer)
+  int64_t ext_partial_words = 0;
+  unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
   AmountDev d_out_used, d_out_calc;
   DevBuf<uint8_t> d_out_calc_updated, d_out_thrl_pod, d_out_error;
   DevBuf<uint32_t> d_out_thrl_flag, d_out_thrl_has;
@@ -945,13 +948,16 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
-  if (words) KT_HIP(e, hipMemsetAsync(e->d_partial.p, 0, words * 8, s));
+  if (e->ext_partial && (int64_t)words > e->ext_partial_words)
+    return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed",
+                   (long long)e->ext_partial_words, (long long)words);
+  if (words) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
     if (e->cfg.kernel_variant == 1)
-      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->d_partial.p, s);
+      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s);
     else
-      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->d_partial.p, s);
+      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->partial(), s);
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;
@@ -965,7 +971,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
                        e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p};
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
-    kt::launch_finalize(e->tt, e->sp, e->D, e->d_partial.p, now_s, now_ns, (flags & KT_RECONCILE_APPLY) != 0, out, s);
+    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, (flags & KT_RECONCILE_APPLY) != 0, out, s);
   }
   KT_HIP(e, hipGetLastError());
   if (flags & KT_RECONCILE_APPLY) e->status_dev_newer = true;
@@ -987,8 +993,18 @@ int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64
   KT_HIP(e, hipSetDevice(e->device));
   int32_t rc = ensure_ready(e, e->own_stream);
   if (rc != KT_OK) return rc;
-  *device_ptr = e->d_partial.p;
+  *device_ptr = e->partial();
   *n_int64 = (int64_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  return KT_OK;
+}
+
+int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64) {
+  if (!e || (device_ptr && n_int64 <= 0)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  e->ext_partial = (unsigned long long*)device_ptr;
+  e->ext_partial_words = device_ptr ? n_int64 : 0;
   return KT_OK;
 }
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "kt_version", "kt_engine_create", "kt_engine_destroy", "kt_last_error", "kt_upsert_namespaces", "kt_upsert_pods",
     "kt_upsert_throttles", "kt_delete_namespaces", "kt_delete_pods", "kt_delete_throttles", "kt_load_snapshot",
     "kt_set_reserved", "kt_set_status", "kt_reconcile_launch", "kt_aggregate_launch", "kt_partial_used_buffer",
-    "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
+    "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name",
 ]
@@ -88,6 +88,7 @@ def lib():
         L.kt_reconcile_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_aggregate_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.kt_partial_used_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.kt_use_partial_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.kt_finalize_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_reconcile_fetch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KtStatus)]
         L.kt_check_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
@@ -223,6 +224,12 @@ class Engine:
         ptr, n = C.c_void_p(), C.c_int64()
         self._ck(lib().kt_partial_used_buffer(self._h, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
+
+    def use_partial_buffer(self, device_ptr, n_int64):
+        self._ck(lib().kt_use_partial_buffer(self._h, device_ptr, n_int64))
+
+    def partial_words(self) -> int:
+        return self.throttle_rows() * (2 * self.D + 2)
 
     def finalize_launch(self, now, apply=True, stream=None):
         self._ck(lib().kt_finalize_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, stream))
