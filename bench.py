@@ -80,7 +80,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from kube_throttler_amd import engine as E, snapshot as S, workload as W
+    from kube_throttler_amd import distributed as KD, engine as E, snapshot as S, workload as W
 
     # ---- workload: this rank's pod shard of a job with P_total = world x pods_per_gpu pods
     cfg = W.preset(args.config)
@@ -110,7 +110,7 @@ def main():
     def step():
         eng.aggregate_launch(stream)
         if world > 1:
-            dist.all_reduce(partial, op=dist.ReduceOp.SUM)  # RCCL over xGMI; int64 sums are order-independent
+            KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
         eng.finalize_launch(now, True, stream)
         eng.check_launch(per_gpu, None, False, False, stream)
 

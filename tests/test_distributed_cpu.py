@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharding + all-reduce algebra that bench.py uses on RCCL.
+
+The HIP kernels cannot run here, so each rank produces its partial-`used` buffer with the CPU oracle on ITS
+pod shard; what is under test is everything around the kernels: the generator's shard determinism, the
+partial-buffer layout (presence as counts), the sum all-reduce, and that the reduced buffer reproduces the
+single-process result bit for bit.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pods, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kube_throttler_amd import workload as W, distributed as KD, snapshot as S
+    from oracle import kt_oracle as O
+    full_cfg = W.small(seed=77, n_pods=n_pods, n_thr=40, n_cluster=20)
+    snap = W.generate(full_cfg.shard(rank, world))
+    now = (full_cfg.now_s, 0)
+    r = O.Oracle(snap).reconcile(now)
+    buf = torch.from_numpy(KD.pack_partial(r.used.v, r.used.present, r.used.count, r.error, snap.D).copy())
+    KD.allreduce_partial(buf, dist)
+    if rank == 0:
+        q.put(buf.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pods", [2001])
+def test_two_rank_allreduce_matches_single_process(n_pods, oracle_mod):
+    from kube_throttler_amd import workload as W, distributed as KD
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pods, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    reduced = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = W.generate(W.small(seed=77, n_pods=n_pods, n_thr=40, n_cluster=20))
+    want = oracle_mod.Oracle(full).reconcile((full.cfg.now_s, 0))
+    v, present, count, has_count, err = KD.unpack_partial(reduced, full.D)
+    T = full.n_thr
+    np.testing.assert_array_equal(v, want.used.v[:T])
+    np.testing.assert_array_equal(present, want.used.present[:T])
+    np.testing.assert_array_equal(count, want.used.count[:T])
+    np.testing.assert_array_equal(has_count, want.used.has_count[:T] != 0)
+
+
+def test_shards_are_rows_of_the_full_snapshot():
+    from kube_throttler_amd import workload as W
+    cfg = W.small(seed=5, n_pods=1001, n_thr=16, n_cluster=8)
+    full = W.generate(cfg)
+    lo = 0
+    for r in range(3):
+        sh = W.generate(cfg.shard(r, 3))
+        n = sh.n_pods
+        np.testing.assert_array_equal(sh.pod_ns[:n], full.pod_ns[lo:lo + n])
+        np.testing.assert_array_equal(sh.pod_flags[:n], full.pod_flags[lo:lo + n])
+        a, b = int(full.pod_label_off[lo]), int(full.pod_label_off[lo + n])
+        np.testing.assert_array_equal(sh.pod_label_pair[:b - a], full.pod_label_pair[a:b])
+        a, b = int(full.pod_ctr_off[lo]), int(full.pod_ctr_off[lo + n])
+        np.testing.assert_array_equal(sh.ctr_req[:b - a], full.ctr_req[a:b])
+        np.testing.assert_array_equal(sh.pod_ovh[:n], full.pod_ovh[lo:lo + n])
+        # throttles are replicated bit for bit
+        np.testing.assert_array_equal(sh.thr_spec.v, full.thr_spec.v)
+        np.testing.assert_array_equal(sh.preq.val, full.preq.val)
+        lo += n
+    assert lo == 1001
