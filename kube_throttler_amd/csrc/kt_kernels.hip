@@ -164,8 +164,9 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int6
       unsigned long long* row = partial + (size_t)t * stride;
       if (err) atomicAdd(row + 2 * D + 1, 1ull);
       if (matched && not_finished) {
-        for (int d = 0; d < D; ++d)
-          if ((present >> d) & 1u) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          if (d < D && ((present >> d) & 1u)) {
             if (r.v[d] != 0) atomicAdd(row + d, (unsigned long long)r.v[d]);
             atomicAdd(row + D + d, 1ull);
           }

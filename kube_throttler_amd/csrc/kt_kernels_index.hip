@@ -40,19 +40,13 @@ struct Matcher {
   }
 };
 
-template <int LT, bool KEYS, class F>
-__device__ __forceinline__ void probe(const IndexDev& ix, uint64_t key, const Matcher<LT, KEYS>& m, bool check_ns, F&& on_match) {
+// One hash lookup: (begin, count) of the posting list filed under `key` (count 0 when absent).
+__device__ __forceinline__ uint2 lookup(const IndexDev& ix, uint64_t key) {
   uint32_t h = index_hash(key, ix.mask);
   for (;;) {
     const IndexSlot s = ix.slots[h];
-    if (s.key == key) {
-      for (uint32_t k = 0; k < s.count; ++k) {
-        uint32_t t;
-        if (m.owns_match(ix.postings[s.begin + k], check_ns, t)) on_match(t);
-      }
-      return;
-    }
-    if (s.key == 0) return;
+    if (s.key == key) return make_uint2(s.begin, s.count);
+    if (s.key == 0) return make_uint2(0u, 0u);
     h = (h + 1) & ix.mask;
   }
 }
@@ -62,16 +56,39 @@ __device__ __forceinline__ void enumerate_matches(const SelProgram& sp, const In
                                                   const uint32_t (&lp)[LT], const uint32_t (&lk)[LT], F&& on_match) {
   const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
   const uint64_t scope = (uint64_t)(ns + 1) << 32;
-#pragma unroll 1
+  // all lookups first (independent loads in flight together), then the posting walks
+  uint2 rn[LT], rc[LT];
+#pragma unroll
   for (int l = 0; l < LT; ++l) {
     const uint32_t pair = lp[l];
-    if (pair == 0) continue;
-    probe<LT, KEYS>(ix, scope | pair, m, false, on_match);  // Throttles of the pod's namespace
-    probe<LT, KEYS>(ix, (uint64_t)pair, m, true, on_match); // ClusterThrottles (namespaceSelector via ns_term_ok)
-    if (KEYS && ix.has_key_atoms) {
+    rn[l] = pair ? lookup(ix, scope | pair) : make_uint2(0u, 0u);          // Throttles of the pod's namespace
+    rc[l] = pair ? lookup(ix, (uint64_t)pair) : make_uint2(0u, 0u);        // ClusterThrottles
+  }
+#pragma unroll
+  for (int l = 0; l < LT; ++l) {
+    for (uint32_t k = 0; k < rn[l].y; ++k) {
+      uint32_t t;
+      if (m.owns_match(ix.postings[rn[l].x + k], false, t)) on_match(t);
+    }
+    for (uint32_t k = 0; k < rc[l].y; ++k) {
+      uint32_t t;
+      if (m.owns_match(ix.postings[rc[l].x + k], true, t)) on_match(t);
+    }
+  }
+  if (KEYS && ix.has_key_atoms) {
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      if (lk[l] == 0) continue;
       const uint32_t ka = kKeyAtom | lk[l];
-      probe<LT, KEYS>(ix, scope | ka, m, false, on_match);
-      probe<LT, KEYS>(ix, (uint64_t)ka, m, true, on_match);
+      const uint2 a = lookup(ix, scope | ka), b = lookup(ix, (uint64_t)ka);
+      for (uint32_t k = 0; k < a.y; ++k) {
+        uint32_t t;
+        if (m.owns_match(ix.postings[a.x + k], false, t)) on_match(t);
+      }
+      for (uint32_t k = 0; k < b.y; ++k) {
+        uint32_t t;
+        if (m.owns_match(ix.postings[b.x + k], true, t)) on_match(t);
+      }
     }
   }
   for (uint32_t k = ix.uni_ns_off[ns]; k < ix.uni_ns_off[ns + 1]; ++k) {
@@ -168,8 +185,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
     auto on_match = [&](uint32_t t) {
       if (!not_finished) return;  // terminated pods are matched but not counted (isNotFinished, pod_util.go:26-28)
       unsigned long long* row = partial + (size_t)t * stride;
-      for (int d = 0; d < D; ++d)
-        if ((present >> d) & 1u) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        if (d < D && ((present >> d) & 1u)) {
           if (r.v[d] != 0) atomicAdd(row + d, (unsigned long long)r.v[d]);
           atomicAdd(row + D + d, 1ull);
         }
