@@ -20,11 +20,13 @@ constexpr uint8_t kOpIn = 0, kOpNotIn = 1, kOpExists = 2, kOpDoesNotExist = 3;
 constexpr uint8_t kOvrParseError = 0x1u;
 constexpr int64_t kZeroTimeS = -62135596800LL;
 
-// Pod state: one plane per field, pod row is the fastest index (lane = pod => coalesced loads).
+// Pod state.  Selector-side fields are planes (pod row fastest: lane = pod => coalesced loads); the
+// request vector is one contiguous row per pod, because it is only ever GATHERED by (pod, throttle)
+// match — D lanes read one pod's row as a single 64-byte (D = 8) transaction.
 struct PodTable {
   uint32_t* ns;     // [cap]
   uint32_t* flags;  // [cap]
-  int64_t* req;     // [D][cap]   effective request (ResourceAmountOfPod), 0 where absent
+  int64_t* req;     // [cap][D]   effective request (ResourceAmountOfPod), 0 where absent
   uint32_t* lpair;  // [L][cap]   (key,value) pair ids, 0 = empty slot
   uint32_t* lkey;   // [L][cap]   key ids
   int64_t cap;

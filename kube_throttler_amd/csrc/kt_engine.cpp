@@ -168,6 +168,7 @@ struct kt_engine {
 
   // ---- reconcile state
   DevBuf<unsigned long long> d_partial;
+  DevBuf<uint8_t> d_slab;  // per-block LDS table spill area of kt_aggregate_indexed
   unsigned long long* ext_partial = nullptr;  // caller-owned partial buffer (kt_use_partial_buffer)
   int64_t ext_partial_words = 0;
   unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
@@ -444,6 +445,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
   // result / scratch buffers sized by T
   KT_HIP(e, e->d_partial.reserve(T * kt::partial_stride(D) + 1));
+  KT_HIP(e, e->d_slab.reserve(kt::aggregate_slab_bytes((int)T, D) + 16));
   KT_HIP(e, e->d_out_used.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
@@ -463,7 +465,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
                     ti.ns = h.ns;
                     return ti;
                   },
-                  (uint32_t)NS);
+                  (uint32_t)NS, ns_term_ok, gw);
   {
     hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
     if (he != hipSuccess) return e->fail(KT_ERR_DEVICE, "upload_index: %s", hipGetErrorString(he));
@@ -627,7 +629,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
   for (auto* b : u32s) b->release();
   DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
-                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage};
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage, &e->d_slab};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
@@ -957,7 +959,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     if (e->cfg.kernel_variant == 1)
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s);
     else
-      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->partial(), s);
+      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;
@@ -1085,7 +1087,8 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
     KT_HIP(e, hipMemcpyAsync(e->d_rows.p, pod_rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
     KT_HIP(e, hipStreamSynchronize(s));  // caller memory must not be referenced after return
   }
-  const int DT = kt::dt_bucket(e->D);
+  // the record layout follows the scan kernel that will read it
+  const int DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
   {
     TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
     kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, s);

@@ -12,11 +12,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
-                 const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns) {
+                 const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
+                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw) {
   out = HostIndex();
   const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
-  std::unordered_map<uint64_t, std::vector<uint32_t>> lists;
+  std::unordered_map<uint64_t, std::vector<Posting>> lists;
   std::vector<std::vector<uint32_t>> uni_ns(n_ns);
+
   for (size_t t = 0; t < T; ++t) {
     const ThrInfo ti = thr_info((uint32_t)t);
     if (!ti.live) continue;
@@ -47,13 +49,41 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         else uni_ns[ti.ns].push_back(g);
         continue;
       }
+      // inline description of the term for the posting fast path
+      Posting base{};
+      base.g = g;
+      base.t = (uint32_t)t;
+      if (thr_term_off[t + 1] - thr_term_off[t] > 1) base.flags |= kPostMulti;
+      if (ti.cluster) {
+        if (n_ns <= 64) {
+          base.flags |= kPostNsMask;
+          for (uint32_t n = 0; n < n_ns; ++n)
+            if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) base.nsmask |= 1ull << n;
+        } else {
+          base.flags |= kPostNsBitmap;
+        }
+      }
+      const uint32_t n_req = term_req_off[g + 1] - term_req_off[g];
+      bool simple = n_req <= 2 && req_op[best] == KT_OP_IN;
+      uint32_t other_pair = 0;
+      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1] && simple; ++r) {
+        if (req_op[r] != KT_OP_IN || req_val_off[r + 1] - req_val_off[r] != 1) simple = false;
+        else if ((int64_t)r != best) other_pair = req_val[req_val_off[r]];
+      }
+      if (!simple) base.flags |= kPostComplex;
+      else if (n_req == 2) {
+        base.flags |= kPostPair2;
+        base.pair2 = other_pair;
+      }
       if (req_op[best] == KT_OP_IN) {
         std::vector<uint32_t> vals(req_val.begin() + req_val_off[best], req_val.begin() + req_val_off[best + 1]);
         std::sort(vals.begin(), vals.end());
         vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        for (uint32_t v : vals) lists[scope << 32 | v].push_back(g);  // an empty value set files nothing: never matches
+        for (uint32_t v : vals) {
+          lists[scope << 32 | v].push_back(base);  // an empty value set files nothing: never matches
+        }
       } else {
-        lists[scope << 32 | (kKeyAtom | req_key[best])].push_back(g);
+        lists[scope << 32 | (kKeyAtom | req_key[best])].push_back(base);
         out.has_key_atoms = true;
       }
     }
@@ -68,7 +98,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   for (auto& kv : lists) keys.push_back(kv.first);
   std::sort(keys.begin(), keys.end());
   for (uint64_t k : keys) {
-    const std::vector<uint32_t>& l = lists[k];
+    const std::vector<Posting>& l = lists[k];
     uint32_t h = index_hash(k, out.mask);
     while (out.slots[h].key != 0) h = (h + 1) & out.mask;
     out.slots[h] = IndexSlot{k, (uint32_t)out.postings.size(), (uint32_t)l.size()};
@@ -108,6 +138,11 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.n_uni_cluster = (uint32_t)h.uni_cluster.size();
   d.n_slow = (uint32_t)h.slow_thr.size();
   d.has_key_atoms = h.has_key_atoms ? 1u : 0u;
+  d.n_slots = (uint32_t)h.slots.size();
+  d.n_postings = (uint32_t)h.postings.size();
+  d.n_cluster_postings = 0;
+  for (const IndexSlot& sl : h.slots)
+    if (sl.key != 0 && (sl.key >> 32) == 0) d.n_cluster_postings += sl.count;
   return hipSuccess;
 }
 

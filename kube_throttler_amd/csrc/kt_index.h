@@ -32,6 +32,24 @@ struct alignas(16) IndexSlot {
 
 constexpr uint32_t kKeyAtom = 0x80000000u;
 
+// One posting = one candidate term, with everything the common case needs to decide the match inline:
+// a term whose requirements are all single-value In (matchLabels with <= 2 pairs) is fully described by
+// its anchor pair (implied by the hash key) and `pair2`; ClusterThrottle terms carry the 64-bit
+// namespace admission mask when the engine holds <= 64 namespaces.
+constexpr uint32_t kPostComplex = 0x1u;   // needs the generic requirement walk (term_match)
+constexpr uint32_t kPostMulti = 0x2u;     // owning throttle has several terms: first-matching-term dedup
+constexpr uint32_t kPostNsMask = 0x4u;    // cluster term, namespace test = bit `ns` of nsmask
+constexpr uint32_t kPostNsBitmap = 0x8u;  // cluster term, namespace test = SelProgram::ns_term_ok
+constexpr uint32_t kPostPair2 = 0x10u;    // pod must also carry `pair2`
+struct alignas(16) Posting {
+  uint32_t g;      // term
+  uint32_t t;      // owning throttle row
+  uint32_t pair2;
+  uint32_t flags;
+  uint64_t nsmask;
+  uint64_t pad;
+};
+
 __host__ __device__ inline uint32_t index_hash(uint64_t key, uint32_t mask) {
   uint64_t h = key * 0x9E3779B97F4A7C15ull;
   h ^= h >> 29;
@@ -47,7 +65,7 @@ struct ThrInfo {
 struct HostIndex {
   std::vector<IndexSlot> slots;
   uint32_t mask = 0;
-  std::vector<uint32_t> postings;
+  std::vector<Posting> postings;
   std::vector<uint32_t> uni_ns_off;  // [n_ns + 1]
   std::vector<uint32_t> uni_ns;
   std::vector<uint32_t> uni_cluster;
@@ -57,13 +75,15 @@ struct HostIndex {
 
 struct IndexDev {
   IndexSlot* slots = nullptr;
-  uint32_t* postings = nullptr;
+  Posting* postings = nullptr;
   uint32_t* uni_ns_off = nullptr;
   uint32_t* uni_ns = nullptr;
   uint32_t* uni_cluster = nullptr;
   uint32_t* slow_thr = nullptr;
   uint32_t mask = 0, n_uni_cluster = 0, n_slow = 0;
   uint32_t has_key_atoms = 0;
+  uint32_t n_slots = 0, n_postings = 0;
+  uint32_t n_cluster_postings = 0;  // postings filed under scope 0 come first in the array
   size_t cap_slots = 0, cap_postings = 0, cap_uni_ns_off = 0, cap_uni_ns = 0, cap_uni_cluster = 0, cap_slow = 0;
 };
 
@@ -71,14 +91,17 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
-                 const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns);
+                 const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
+                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
 struct PodTable;
 struct SelProgram;
+// slab: scratch for the per-block LDS tables of the aggregate kernel (nullptr => global atomics only)
+size_t aggregate_slab_bytes(int T, int D);
 void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const IndexDev& ix,
-                              bool keys, unsigned long long* partial, hipStream_t s);
+                              bool keys, unsigned long long* partial, void* slab, hipStream_t s);
 void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const IndexDev& ix, bool keys, const void* recs, uint64_t* summary, uint8_t* status,
                           hipStream_t s);

@@ -1,0 +1,234 @@
+// kt_kernels_aggregate.hip — kt_aggregate_indexed + kt_reduce_partials: per-throttle `used` through the index.
+#include "kt_index_device.h"
+
+namespace kt {
+
+// ---------------------------------------------------------------------------------------------------
+// kt_aggregate_indexed — affectedPods + fold Add for all throttles (throttle_controller.go:116-119,
+// 221-246; clusterthrottle_controller.go:119-122,224-270) through the index.
+// LDS table layout per workgroup: int64 v[T][D] | uint32 cnt[T][D+2]  (presence counts, pods, errors).
+// ---------------------------------------------------------------------------------------------------
+// mode 1: counts are uint32 [T][D+2]; mode 2 (index also in LDS): counts are uint16 packed two per word
+__host__ __device__ inline size_t lds_table_bytes(int T, int D, bool cnt16) {
+  const size_t cnt = (size_t)T * (D + 2);
+  return (size_t)T * D * 8 + (cnt16 ? ((cnt + 1) / 2) * 4 : cnt * 4);
+}
+
+// AGG_MODE 0: no LDS table (global atomics), index through L2
+//          1: LDS table (u32 counts), index through L2
+//          2: LDS table (packed u16 counts) AND hash slots + postings staged in LDS
+template <int DT, int LT, bool KEYS, int AGG_MODE>
+__global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, int64_t n_rows, SelProgram sp,
+                                                                IndexDev ix, unsigned long long* partial,
+                                                                unsigned char* slab, uint32_t q_cap) {
+  constexpr bool LDSTAB = AGG_MODE != 0, CNT16 = AGG_MODE == 2, LDSIX = AGG_MODE == 2;
+  const int D = pods.D, stride = partial_stride(D), T = sp.T;
+  // LDS carve: [queue u32 x q_cap][q_count + pad][table: int64 v[T][D] | counts][index copy (mode 2)]
+  KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
+  lds_u32wp q = (lds_u32wp)lds;
+  lds_u32wp q_count = q + q_cap;
+  const uint32_t tab_off = q_cap * 4 + 16;
+  const uint32_t tab_bytes = LDSTAB ? (uint32_t)((lds_table_bytes(T, D, CNT16) + 15) & ~(size_t)15) : 0u;
+  lds_u64wp tv = (lds_u64wp)(lds + tab_off);
+  lds_u32wp tc = (lds_u32wp)(lds + tab_off + (uint32_t)T * D * 8);
+  lds_u4p l_slots = (lds_u4p)(lds + tab_off + tab_bytes);
+  lds_u4p l_posts = l_slots + ix.n_slots;
+  if (LDSTAB) {
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + tab_off))[i] = 0u;
+  }
+  if (LDSIX) {
+    KT_LDS u32x4* dst = (KT_LDS u32x4*)(lds + tab_off + tab_bytes);
+    const u32x4* src_s = (const u32x4*)ix.slots;
+    const u32x4* src_p = (const u32x4*)ix.postings;
+    const uint32_t ns16 = ix.n_slots, np16 = ix.n_postings * 2;
+    for (uint32_t i = threadIdx.x; i < ns16; i += kBlockIx) dst[i] = src_s[i];
+    for (uint32_t i = threadIdx.x; i < np16; i += kBlockIx) dst[ns16 + i] = src_p[i];
+  }
+  auto cnt_add = [&](uint32_t t, uint32_t j) {  // counts[t][j] += 1   (j < D: key presence, D: pods, D+1: errors)
+    const uint32_t idx = t * (uint32_t)(D + 2) + j;
+    if (CNT16) lds_add(tc + (idx >> 1), 1u << ((idx & 1u) * 16u));
+    else lds_add(tc + idx, 1u);
+  };
+  auto add_pod = [&](uint32_t t, int64_t p) {  // used[t] += ResourceAmountOfPod(p): lane-serial form (overflow path)
+    const uint32_t present = pods.flags[p] >> kPresentShift;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      if (d < D && ((present >> d) & 1u)) {
+        const int64_t v = pods.req[(int64_t)p * D + d];
+        if (LDSTAB) {
+          if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
+          cnt_add(t, (uint32_t)d);
+        } else {
+          if (v != 0) atomicAdd(partial + (size_t)t * stride + d, (unsigned long long)v);
+          atomicAdd(partial + (size_t)t * stride + D + d, 1ull);
+        }
+      }
+    if (LDSTAB) cnt_add(t, (uint32_t)D);
+    else atomicAdd(partial + (size_t)t * stride + 2 * D, 1ull);
+  };
+  const int64_t n_tiles = (n_rows + kBlockIx - 1) / kBlockIx;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t p = tile * kBlockIx + threadIdx.x;
+    if (threadIdx.x == 0) *q_count = 0u;
+    __syncthreads();
+    // ---- phase 1: lane = pod: enumerate matches of counted pods
+    const uint32_t fl = p < n_rows ? pods.flags[p] : 0u;
+    // shouldCountIn (throttle_controller.go:217-219)
+    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    const bool not_finished = !(fl & kPodFinished);  // isNotFinished (pod_util.go:26-28)
+    if (countable && (not_finished || ix.n_slow != 0)) {  // terminated pods only matter for error detection
+      uint32_t lp[LT], lk[LT];
+      const uint32_t ns = pods.ns[p];
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
+        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
+      }
+      auto on_match = [&](uint32_t t) {
+        if (!not_finished) return;  // matched but not counted
+        // wave-aggregated push (one LDS atomic per wave); a full queue folds the pod in directly
+        const uint64_t mask = __ballot(true);
+        const uint32_t lane = __lane_id();
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (base < q_cap) q[base] = (uint32_t)threadIdx.x << 20 | t;
+        else add_pod(t, p);
+      };
+      if (not_finished) {
+        if (LDSIX) enumerate_matches<LT, KEYS>(sp, ix, l_slots, l_posts, ns, lp, lk, on_match);
+        else enumerate_matches<LT, KEYS>(sp, ix, (const u32x4*)ix.slots, (const u32x4*)ix.postings, ns, lp, lk, on_match);
+      }
+      const uint32_t* ns_row = sp.ns_term_ok + (size_t)ns * sp.gw;
+      for (uint32_t k = 0; k < ix.n_slow; ++k) {
+        bool matched, err;
+        const int t = (int)ix.slow_thr[k];
+        walk_slow<LT, KEYS>(sp, t, ns_row, true, lp, lk, matched, err);
+        if (err) {
+          if (LDSTAB) cnt_add((uint32_t)t, (uint32_t)D + 1u);
+          else atomicAdd(partial + (size_t)t * stride + 2 * D + 1, 1ull);
+        }
+        if (matched) on_match((uint32_t)t);
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (match, dimension): fold the pod's amount into the table
+    const uint32_t qn = min(*q_count, q_cap);
+    {
+      constexpr int MPW = kWave / DT;
+      const uint32_t lane = threadIdx.x & (kWave - 1), d = lane % DT, ml = lane / DT;
+      const uint32_t wave = threadIdx.x / kWave;
+      for (uint32_t base = wave * MPW; base < qn; base += (kBlockIx / kWave) * MPW) {
+        const uint32_t j = base + ml;
+        if (j >= qn) continue;
+        const uint32_t e = q[j];
+        const uint32_t t = e & 0xFFFFFu;
+        const int64_t mp = tile * kBlockIx + (e >> 20);
+        const uint32_t present = pods.flags[mp] >> kPresentShift;
+        if ((int)d < D && ((present >> d) & 1u)) {
+          const int64_t v = pods.req[(int64_t)mp * D + d];
+          if (LDSTAB) {
+            if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
+            cnt_add(t, d);
+          } else {
+            if (v != 0) atomicAdd(partial + (size_t)t * stride + d, (unsigned long long)v);
+            atomicAdd(partial + (size_t)t * stride + D + d, 1ull);
+          }
+        }
+        if (d == 0) {
+          if (LDSTAB) cnt_add(t, (uint32_t)D);
+          else atomicAdd(partial + (size_t)t * stride + 2 * D, 1ull);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (LDSTAB) {  // spill this workgroup's table (coalesced 16-byte stores); kt_reduce_partials sums the slabs
+    __syncthreads();
+    u32x4* dst = (u32x4*)(slab + (size_t)blockIdx.x * tab_bytes);
+    lds_u4p src = (lds_u4p)(lds + tab_off);
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+  }
+}
+
+// partial[t][j] = sum over workgroup slabs (j < D: values; D <= j < 2D+2: counts).
+// 64 output words per workgroup x 4 slab groups: every thread streams n_slabs/4 independent loads.
+__global__ __launch_bounds__(256) void kt_reduce_partials(const unsigned char* slab, int n_slabs, int T, int D, int cnt16,
+                                                         unsigned long long* partial) {
+  __shared__ unsigned long long part[4][64];
+  const int stride = partial_stride(D);
+  const size_t pitch = (lds_table_bytes(T, D, cnt16 != 0) + 15) & ~(size_t)15;
+  const int words = T * stride;
+  const int wl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int w = blockIdx.x * 64 + wl;
+  unsigned long long acc = 0;
+  if (w < words) {
+    const int t = w / stride, j = w - t * stride;
+    if (j < D) {
+      const unsigned char* base = slab + ((size_t)t * D + j) * 8;
+#pragma unroll 8
+      for (int b = g; b < n_slabs; b += 4) acc += *(const unsigned long long*)(base + b * pitch);
+    } else {
+      const size_t idx = (size_t)t * (D + 2) + (j - D);
+      const unsigned char* base = slab + (size_t)T * D * 8 + idx * (cnt16 ? 2 : 4);
+      if (cnt16) {
+#pragma unroll 8
+        for (int b = g; b < n_slabs; b += 4) acc += *(const unsigned short*)(base + b * pitch);
+      } else {
+#pragma unroll 8
+        for (int b = g; b < n_slabs; b += 4) acc += *(const unsigned int*)(base + b * pitch);
+      }
+    }
+  }
+  part[g][wl] = acc;
+  __syncthreads();
+  if (g == 0 && w < words) partial[w] = part[0][wl] + part[1][wl] + part[2][wl] + part[3][wl];
+}
+
+static inline int agg_blocks(int64_t n_rows) {
+  int64_t b = (n_rows + kBlockIx - 1) / kBlockIx;
+  return (int)(b < 1 ? 1 : b > kCUs ? kCUs : b);
+}
+
+size_t aggregate_slab_bytes(int T, int D) {
+  const size_t bytes = lds_table_bytes(T, D, false);
+  if (bytes + 2048 * 4 + 16 > (size_t)kMaxLds) return 0;
+  return (size_t)kCUs * ((bytes + 15) & ~(size_t)15);
+}
+
+void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const IndexDev& ix,
+                              bool keys, unsigned long long* partial, void* slab_, hipStream_t s) {
+  if (n_rows <= 0 || sp.T <= 0) return;
+  const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
+  unsigned char* slab = (unsigned char*)slab_;
+  const int nb = agg_blocks(n_rows);
+  const size_t ix_bytes = (size_t)ix.n_slots * sizeof(IndexSlot) + (size_t)ix.n_postings * sizeof(Posting);
+  const size_t tab32 = (lds_table_bytes(sp.T, pods.D, false) + 15) & ~(size_t)15;
+  const size_t tab16 = (lds_table_bytes(sp.T, pods.D, true) + 15) & ~(size_t)15;
+  const int64_t pods_per_block = ((n_rows + kBlockIx - 1) / kBlockIx + nb - 1) / nb * kBlockIx;
+  // mode 2: table (u16 counts) + index + a short queue, all in LDS; mode 1: table only; mode 0: global atomics
+  int mode = 0;
+  uint32_t q_cap = kQueueCap;
+  size_t tab = 0;
+  if (slab != nullptr) {
+    if (pods_per_block <= 65535 && 2048 * 4 + 16 + tab16 + ix_bytes <= (size_t)kMaxLds) mode = 2, q_cap = 2048, tab = tab16;
+    else if (kQueueCap * 4 + 16 + tab32 <= (size_t)kMaxLds) mode = 1, tab = tab32;
+    else if (2048 * 4 + 16 + tab32 <= (size_t)kMaxLds) mode = 1, q_cap = 2048, tab = tab32;
+  }
+  dim3 g_(nb), b_(kBlockIx);
+  const size_t lds_bytes = q_cap * 4 + 16 + tab + (mode == 2 ? ix_bytes : 0);
+#define KT_IX_ARGS pods, n_rows, sp, ix, partial, slab, q_cap
+  if (mode == 2) KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 2);
+  else if (mode == 1) KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 1);
+  else KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 0);
+#undef KT_IX_ARGS
+  if (mode != 0) {
+    const int words = sp.T * partial_stride(pods.D);
+    hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D,
+                       mode == 2 ? 1 : 0, partial);
+  }
+}
+
+
+}  // namespace kt

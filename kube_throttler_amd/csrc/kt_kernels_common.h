@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_pod(const PodTable& pods, int64_t p, PodReg
   r.nzmask = 0;
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
-    r.v[d] = (want_req && d < pods.D) ? pods.req[(int64_t)d * pods.cap + p] : 0;
+    r.v[d] = (want_req && d < pods.D) ? pods.req[(int64_t)p * pods.D + d] : 0;
     r.nzmask |= (r.v[d] != 0 ? 1u : 0u) << d;
   }
 }

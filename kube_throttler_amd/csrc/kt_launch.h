@@ -43,6 +43,7 @@ const char* kernel_name_check(int variant);
 const char* kernel_name_aggregate(int variant);
 
 inline int dt_bucket(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : 16; }
+inline int dt_bucket_ix(int D) { return D <= 8 ? 8 : 16; }  // indexed kernels: two instantiations
 inline int lt_bucket(int L) { return L <= 8 ? 8 : 16; }
 
 }  // namespace kt

@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ/LDS counter passes for the engine kernels (runs on the GPU box).  usage: tools/pmc_sq.sh <tag> [bench args]
+TAG=${1:-sq}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/sq_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+i=0
+for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_FLAT SQ_INSTS_BRANCH GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- $BENCH > $OUT/p$i.json 2> $OUT/p$i.err
+done
+python - <<PY
+import csv, glob, collections, re
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(kt_[a-z_]+)", r["Kernel_Name"])
+        if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt", "w") as out:
+    for k in sorted(acc):
+        if k in ("kt_ingest_pods",): continue
+        line = k + ": " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(acc[k].items()))
+        print(line); out.write(line + "\n")
+PY
