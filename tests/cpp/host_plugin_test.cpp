@@ -1,0 +1,191 @@
+// host_plugin_test — drives the C++ plugin mirror (kube_throttler_amd/host) through the reference's own
+// scenarios: example/ walk-through (BASELINE configs[0], README.md:275-374) and the integration specs of
+// test/integration/throttle_test.go / clusterthrottle_test.go, including the FailedScheduling reason strings
+// (plugin.go:182-214) and the Reserve/Unreserve bookkeeping (plugin.go:217-257).
+// Needs a GPU (the engine has no CPU fallback).  Exit code 0 = all expectations held.
+#include <cstdio>
+#include <string>
+
+#include "kt_host.hpp"
+
+using namespace kth;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                         \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      ++g_fail;                                                              \
+      fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);        \
+    }                                                                        \
+  } while (0)
+
+static const char* NOW = "2026-01-01T00:00:00Z";
+
+static Pod MakePod(const std::string& ns, const std::string& name, const std::string& cpu, const Labels& labels,
+                   const std::string& memory = "") {
+  Pod p;
+  p.ns = ns;
+  p.name = name;
+  p.labels = labels;
+  p.schedulerName = "my-scheduler";
+  p.phase = "Pending";
+  Container c;
+  if (!cpu.empty()) c.requests["cpu"] = cpu;
+  if (!memory.empty()) c.requests["memory"] = memory;
+  p.containers.push_back(c);
+  return p;
+}
+static void Schedule(KubeThrottler& k, Pod& p) {  // binding: nodeName set, phase Running
+  p.nodeName = "node-1";
+  p.phase = "Running";
+  std::string err;
+  EXPECT(k.OnPodAdd(p, &err));
+}
+static Throttle MakeThrottle(const std::string& ns, const std::string& name, const std::string& key, const std::string& val,
+                             int pod_threshold, const std::string& cpu) {
+  Throttle t;
+  t.ns = ns;
+  t.name = name;
+  t.throttlerName = "kube-throttler";
+  if (pod_threshold >= 0) t.threshold.hasCounts = true, t.threshold.pod = pod_threshold;
+  if (!cpu.empty()) t.threshold.requests["cpu"] = cpu;
+  SelectorTerm term;
+  term.podSelector.matchLabels[key] = val;
+  t.selectorTerms.push_back(term);
+  return t;
+}
+static std::unique_ptr<KubeThrottler> Fresh() {
+  PluginArgs a;
+  a.name = "kube-throttler";
+  a.targetSchedulerName = "my-scheduler";
+  a.podCapacity = 256;
+  a.throttleCapacity = 16;
+  a.namespaceCapacity = 8;
+  std::string err;
+  auto k = NewPlugin(a, &err);
+  if (!k) {
+    fprintf(stderr, "NewPlugin failed: %s\n", err.c_str());
+    exit(3);
+  }
+  Namespace ns;
+  ns.name = "default";
+  ns.labels["kubernetes.io/metadata.name"] = "default";
+  EXPECT(k->OnNamespaceAdd(ns, &err));
+  return k;
+}
+
+// BASELINE configs[0]: example/throttle.yaml (pod 5, cpu 200m, memory 1Gi) + pod1 (200m) / pod2, pod3 (300m) / pod1m (512Mi)
+static void TestExampleWalkthrough() {
+  auto k = Fresh();
+  std::string err;
+  Throttle t1 = MakeThrottle("default", "t1", "throttle", "t1", 5, "200m");
+  t1.threshold.requests["memory"] = "1Gi";
+  EXPECT(k->OnThrottleAdd(t1, &err));
+  Pod pod1 = MakePod("default", "pod1", "200m", {{"throttle", "t1"}});
+  Pod pod2 = MakePod("default", "pod2", "300m", {{"throttle", "t1"}});
+  Pod pod1m = MakePod("default", "pod1m", "", {{"throttle", "t1"}}, "512Mi");
+  EXPECT(k->PreFilter(pod1).IsSuccess());  // 200m > 200m is false
+  EXPECT(k->LastStatusOf("default/t1") == "not-throttled");
+  Status s2 = k->PreFilter(pod2);          // 300m > 200m at step 1, in any snapshot
+  EXPECT(s2.code == UnschedulableAndUnresolvable);
+  EXPECT(s2.reasons.size() == 1 && s2.reasons[0] == "throttle[pod-requests-exceeds-threshold]=default/t1");
+  Schedule(*k, pod1);
+  std::map<std::string, ThrottleStatus> st;
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(st["default/t1"].usedHasCounts && st["default/t1"].usedPod == 1);
+  EXPECT(FormatDecimalSI(st["default/t1"].used["cpu"]) == "200m");
+  EXPECT(st["default/t1"].throttledRequests["cpu"] == true && st["default/t1"].throttledRequests["memory"] == false);
+  EXPECT(!st["default/t1"].throttledPod);
+  // cpu is throttled, but pod1m requests only memory => admitted (README.md:287-309)
+  EXPECT(k->PreFilter(pod1m).IsSuccess());
+}
+
+// test/integration/throttle_test.go:77-164 (threshold pod=2, cpu=1)
+static void TestThrottleScenarios() {
+  {  // ResourceCount: two 100m pods counted => third is "active"
+    auto k = Fresh();
+    std::string err;
+    EXPECT(k->OnThrottleAdd(MakeThrottle("default", "test-throttle", "throttle", "test-throttle", 2, "1"), &err));
+    Pod a = MakePod("default", "pod1", "100m", {{"throttle", "test-throttle"}});
+    Pod b = MakePod("default", "pod2", "100m", {{"throttle", "test-throttle"}});
+    Pod c = MakePod("default", "pod3", "100m", {{"throttle", "test-throttle"}});
+    Schedule(*k, a);
+    Schedule(*k, b);
+    std::map<std::string, ThrottleStatus> st;
+    EXPECT(k->ReconcileAll(NOW, &st, &err));
+    EXPECT(st["default/test-throttle"].usedPod == 2 && FormatDecimalSI(st["default/test-throttle"].used["cpu"]) == "200m");
+    EXPECT(st["default/test-throttle"].throttledPod && !st["default/test-throttle"].throttledRequests["cpu"]);
+    Status s = k->PreFilter(c);
+    EXPECT(s.code == UnschedulableAndUnresolvable && s.reasons.size() == 1 && s.reasons[0] == "throttle[active]=default/test-throttle");
+  }
+  {  // ResourceRequest (insufficient): 900m counted, 500m pending
+    auto k = Fresh();
+    std::string err;
+    EXPECT(k->OnThrottleAdd(MakeThrottle("default", "test-throttle", "throttle", "test-throttle", 2, "1"), &err));
+    Pod a = MakePod("default", "pod1", "900m", {{"throttle", "test-throttle"}});
+    Pod b = MakePod("default", "pod2", "500m", {{"throttle", "test-throttle"}});
+    Schedule(*k, a);
+    EXPECT(k->ReconcileAll(NOW, nullptr, &err));
+    Status s = k->PreFilter(b);
+    EXPECT(s.code == UnschedulableAndUnresolvable && s.reasons.size() == 1 && s.reasons[0] == "throttle[insufficient]=default/test-throttle");
+  }
+  {  // 20 x 50m == "1" exactly => cpu throttled, 21st is active (throttle_test.go:167-197)
+    auto k = Fresh();
+    std::string err;
+    EXPECT(k->OnThrottleAdd(MakeThrottle("default", "test-throttle", "throttle", "test-throttle", -1, "1"), &err));
+    for (int i = 0; i < 20; ++i) {
+      Pod p = MakePod("default", "pod-" + std::to_string(i), "50m", {{"throttle", "test-throttle"}});
+      Schedule(*k, p);
+    }
+    std::map<std::string, ThrottleStatus> st;
+    EXPECT(k->ReconcileAll(NOW, &st, &err));
+    EXPECT(st["default/test-throttle"].usedPod == 20 && FormatDecimalSI(st["default/test-throttle"].used["cpu"]) == "1");
+    EXPECT(st["default/test-throttle"].throttledRequests["cpu"] && !st["default/test-throttle"].throttledPod);
+    Pod p = MakePod("default", "pod-20", "50m", {{"throttle", "test-throttle"}});
+    EXPECT(k->PreFilter(p).reasons == std::vector<std::string>{"throttle[active]=default/test-throttle"});
+  }
+}
+
+// ClusterThrottle renders as "/name" and is listed before Throttles (plugin.go:182-214, 289-295);
+// Reserve makes the NEXT PreFilter see the reserved amount before any reconcile (plugin.go:217-238)
+static void TestClusterThrottleAndReserve() {
+  auto k = Fresh();
+  std::string err;
+  Throttle t = MakeThrottle("default", "t", "app", "x", 2, "1");
+  Throttle ct = MakeThrottle("", "ct", "app", "x", 2, "1");
+  ct.cluster = true;
+  ct.selectorTerms[0].namespaceSelector.matchLabels["kubernetes.io/metadata.name"] = "default";
+  EXPECT(k->OnThrottleAdd(t, &err));
+  EXPECT(k->OnThrottleAdd(ct, &err));
+  Pod p1 = MakePod("default", "pod1", "100m", {{"app", "x"}});
+  Pod p2 = MakePod("default", "pod2", "100m", {{"app", "x"}});
+  Pod p3 = MakePod("default", "pod3", "100m", {{"app", "x"}});
+  EXPECT(k->PreFilter(p1).IsSuccess());
+  EXPECT(k->Reserve(p1).IsSuccess());
+  EXPECT(k->PreFilter(p2).IsSuccess());
+  EXPECT(k->Reserve(p2).IsSuccess());
+  // used{} + reserved{pod 2}: Throttle step 3 is >= (2 >= 2 => active), ClusterThrottle step 3 is > (=> insufficient)
+  Status s = k->PreFilter(p3);
+  EXPECT(s.code == UnschedulableAndUnresolvable);
+  EXPECT((s.reasons == std::vector<std::string>{"throttle[active]=default/t", "clusterthrottle[insufficient]=/ct"}));
+  k->Unreserve(p2);
+  EXPECT(k->PreFilter(p3).IsSuccess());
+  // unknown namespace => framework.Error from the ClusterThrottle path (clusterthrottle_controller.go:273-276)
+  Pod lost = MakePod("nowhere", "pod", "100m", {{"app", "x"}});
+  EXPECT(k->PreFilter(lost).code == Error);
+  // plugin args validation (plugin_args.go:46-51)
+  PluginArgs bad;
+  EXPECT(NewPlugin(bad, &err) == nullptr && err == "Name must not be empty");
+}
+
+int main() {
+  TestExampleWalkthrough();
+  TestThrottleScenarios();
+  TestClusterThrottleAndReserve();
+  if (g_fail) {
+    fprintf(stderr, "%d expectation(s) failed\n", g_fail);
+    return 1;
+  }
+  printf("host_plugin_test: all expectations held\n");
+  return 0;
+}
