@@ -104,6 +104,116 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     out.slots[h] = IndexSlot{k, (uint32_t)out.postings.size(), (uint32_t)l.size()};
     out.postings.insert(out.postings.end(), l.begin(), l.end());
   }
+  // ---- bitmap form (all indexed terms; see kt_index.h).  Built when it can live in LDS next to the
+  //      kernel's working buffers; otherwise the kernels use the postings above.
+  {
+    struct BT {
+      uint32_t g, t, pair2, flags;
+      std::vector<uint32_t> atoms;  // anchor atoms (empty => universal)
+      std::vector<uint32_t> adm;    // namespace admission set as words
+    };
+    std::vector<BT> bts;
+    const uint32_t nsw = (n_ns + 31) / 32;
+    for (size_t t = 0; t < T; ++t) {
+      const ThrInfo ti = thr_info((uint32_t)t);
+      if (!ti.live) continue;
+      if (std::find(out.slow_thr.begin(), out.slow_thr.end(), (uint32_t)t) != out.slow_thr.end()) continue;
+      for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
+        if (ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID)) continue;
+        if (!ti.cluster && ti.ns >= n_ns) continue;
+        BT b;
+        b.g = g, b.t = (uint32_t)t, b.pair2 = 0, b.flags = 0;
+        b.adm.assign(nsw, 0u);
+        bool any_ns = false;
+        for (uint32_t n = 0; n < n_ns; ++n)
+          if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) b.adm[n >> 5] |= 1u << (n & 31), any_ns = true;
+        if (!any_ns) continue;  // admitted nowhere: can never match
+        if (thr_term_off[t + 1] - thr_term_off[t] > 1) b.flags |= kPostMulti;
+        int64_t best = -1;
+        size_t best_cost = ~(size_t)0;
+        for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
+          size_t cost;
+          if (req_op[r] == KT_OP_IN) cost = req_val_off[r + 1] - req_val_off[r];
+          else if (req_op[r] == KT_OP_EXISTS) cost = 1u << 20;
+          else continue;
+          if (cost < best_cost) best_cost = cost, best = r;
+        }
+        const uint32_t n_req = term_req_off[g + 1] - term_req_off[g];
+        if (best < 0) {
+          if (n_req != 0) b.flags |= kPostComplex;  // only negative requirements
+        } else {
+          bool simple = n_req <= 2 && req_op[best] == KT_OP_IN;
+          uint32_t other = 0;
+          for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1] && simple; ++r) {
+            if (req_op[r] != KT_OP_IN || req_val_off[r + 1] - req_val_off[r] != 1) simple = false;
+            else if ((int64_t)r != best) other = req_val[req_val_off[r]];
+          }
+          if (!simple) b.flags |= kPostComplex;
+          else if (n_req == 2) b.flags |= kPostPair2, b.pair2 = other;
+          if (req_op[best] == KT_OP_IN) {
+            b.atoms.assign(req_val.begin() + req_val_off[best], req_val.begin() + req_val_off[best + 1]);
+            std::sort(b.atoms.begin(), b.atoms.end());
+            b.atoms.erase(std::unique(b.atoms.begin(), b.atoms.end()), b.atoms.end());
+            if (b.atoms.empty()) continue;  // In with no values: never matches
+          } else {
+            b.atoms.push_back(kKeyAtom | req_key[best]);
+          }
+        }
+        bts.push_back(std::move(b));
+      }
+    }
+    // terms with the same admission set become contiguous
+    std::stable_sort(bts.begin(), bts.end(), [](const BT& a, const BT& b) { return a.adm < b.adm; });
+    const uint32_t G2 = (uint32_t)bts.size();
+    if (G2 > 0) {
+      const uint32_t W = (G2 + 31) / 32;
+      out.bm_words = W;
+      out.bm_stride = W | 1u;
+      std::unordered_map<uint32_t, uint32_t> row_of;
+      for (auto& b : bts)
+        for (uint32_t a : b.atoms) row_of.emplace(a, 0u);
+      std::vector<uint32_t> atoms;
+      for (auto& kv : row_of) atoms.push_back(kv.first);
+      std::sort(atoms.begin(), atoms.end());
+      for (uint32_t i = 0; i < atoms.size(); ++i) row_of[atoms[i]] = i + 2;
+      out.bm_rows = (uint32_t)atoms.size() + 2;
+      out.bm_row_bits.assign((size_t)out.bm_rows * out.bm_stride, 0u);
+      out.bm_nsrows.assign((size_t)n_ns * out.bm_stride, 0u);
+      out.bm_trec.resize(G2);
+      for (uint32_t c = 0; c < G2; ++c) {
+        const BT& b = bts[c];
+        out.bm_trec[c] = TermRec{b.g, b.t, b.pair2, b.flags};
+        if (b.atoms.empty()) out.bm_row_bits[c >> 5] |= 1u << (c & 31);
+        for (uint32_t a : b.atoms) out.bm_row_bits[(size_t)row_of[a] * out.bm_stride + (c >> 5)] |= 1u << (c & 31);
+        for (uint32_t n = 0; n < n_ns; ++n)
+          if ((b.adm[n >> 5] >> (n & 31)) & 1u) out.bm_nsrows[(size_t)n * out.bm_stride + (c >> 5)] |= 1u << (c & 31);
+      }
+      out.bm_nswords_off.assign((size_t)n_ns + 1, 0u);
+      for (uint32_t n = 0; n < n_ns; ++n) {
+        for (uint32_t w = 0; w < W; ++w)
+          if (out.bm_nsrows[(size_t)n * out.bm_stride + w]) out.bm_nswords.push_back(w);
+        out.bm_nswords_off[n + 1] = (uint32_t)out.bm_nswords.size();
+      }
+      // atoms -> rows in 4-entry buckets; grow until no bucket overflows
+      size_t nb = 4;
+      while (nb * 2 < atoms.size()) nb <<= 1;
+      for (;;) {
+        out.bm_buckets.assign(nb, AtomBucket{{0, 0, 0, 0}, {1, 1, 1, 1}});
+        bool ok = true;
+        for (uint32_t a : atoms) {
+          AtomBucket& bk = out.bm_buckets[atom_bucket(a, (uint32_t)nb - 1)];
+          int k = 0;
+          while (k < 4 && bk.atom[k] != 0) ++k;
+          if (k == 4) { ok = false; break; }
+          bk.atom[k] = a;
+          bk.row[k] = row_of[a];
+        }
+        if (ok) break;
+        nb <<= 1;
+      }
+      out.bm_bucket_mask = (uint32_t)nb - 1;
+    }
+  }
   out.uni_ns_off.assign((size_t)n_ns + 1, 0);
   for (uint32_t n = 0; n < n_ns; ++n) {
     out.uni_ns.insert(out.uni_ns.end(), uni_ns[n].begin(), uni_ns[n].end());
@@ -143,6 +253,19 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.n_cluster_postings = 0;
   for (const IndexSlot& sl : h.slots)
     if (sl.key != 0 && (sl.key >> 32) == 0) d.n_cluster_postings += sl.count;
+  if ((e = up(d.bm_row_bits, d.cap_bm_row_bits, h.bm_row_bits, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_nsrows, d.cap_bm_nsrows, h.bm_nsrows, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_nswords_off, d.cap_bm_nswords_off, h.bm_nswords_off, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_nswords, d.cap_bm_nswords, h.bm_nswords, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_buckets, d.cap_bm_buckets, h.bm_buckets, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_trec, d.cap_bm_trec, h.bm_trec, s)) != hipSuccess) return e;
+  d.bm_words = h.bm_words;
+  d.bm_stride = h.bm_stride;
+  d.bm_rows = h.bm_rows;
+  d.bm_bucket_mask = h.bm_bucket_mask;
+  d.bm_n_trec = (uint32_t)h.bm_trec.size();
+  d.bm_n_ns = h.bm_stride ? (uint32_t)(h.bm_nsrows.size() / h.bm_stride) : 0u;
+  d.bm_n_nswords = (uint32_t)h.bm_nswords.size();
   return hipSuccess;
 }
 
@@ -153,6 +276,12 @@ void release_index(IndexDev& d) {
   if (d.uni_ns) (void)hipFree(d.uni_ns);
   if (d.uni_cluster) (void)hipFree(d.uni_cluster);
   if (d.slow_thr) (void)hipFree(d.slow_thr);
+  if (d.bm_row_bits) (void)hipFree(d.bm_row_bits);
+  if (d.bm_nsrows) (void)hipFree(d.bm_nsrows);
+  if (d.bm_nswords_off) (void)hipFree(d.bm_nswords_off);
+  if (d.bm_nswords) (void)hipFree(d.bm_nswords);
+  if (d.bm_buckets) (void)hipFree(d.bm_buckets);
+  if (d.bm_trec) (void)hipFree(d.bm_trec);
   d = IndexDev();
 }
 

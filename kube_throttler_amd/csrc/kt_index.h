@@ -56,6 +56,21 @@ __host__ __device__ inline uint32_t index_hash(uint64_t key, uint32_t mask) {
   return (uint32_t)h & mask;
 }
 
+// ---- bitmap form of the whole selector side (small-T regime) ----------------------------------------
+// Every indexed term gets a number c; terms with the same namespace-admission set are numbered
+// contiguously, so a namespace only ever touches a few 32-bit words of any bitmap:
+//     candidates(pod)[w] = (rows[0][w] | OR_l rows[row_of(label_l)][w]) & nsrows[ns][w]   for w in nswords[ns]
+// rows[0] = terms without a positive requirement, rows[1] = all zero (unknown atoms).  Atoms are found in
+// 4-entry buckets (branch-free probe).  TermRec carries what a visit needs (same flags as Posting).
+struct alignas(16) TermRec {
+  uint32_t g, t, pair2, flags;
+};
+struct alignas(16) AtomBucket {
+  uint32_t atom[4];  // 0 = empty
+  uint32_t row[4];
+};
+__host__ __device__ inline uint32_t atom_bucket(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 9) & mask; }
+
 struct ThrInfo {
   bool live;
   bool cluster;
@@ -71,6 +86,17 @@ struct HostIndex {
   std::vector<uint32_t> uni_cluster;
   std::vector<uint32_t> slow_thr;
   bool has_key_atoms = false;
+  // bitmap form (valid when bm_words != 0)
+  uint32_t bm_words = 0;   // W: words per bitmap row
+  uint32_t bm_stride = 0;  // row stride in words (odd: column reads spread over LDS banks)
+  uint32_t bm_rows = 0;
+  uint32_t bm_bucket_mask = 0;
+  std::vector<uint32_t> bm_row_bits;    // [bm_rows][bm_stride]
+  std::vector<uint32_t> bm_nsrows;      // [n_ns][bm_stride]
+  std::vector<uint32_t> bm_nswords_off; // [n_ns + 1]
+  std::vector<uint32_t> bm_nswords;     // word indices a namespace can touch
+  std::vector<AtomBucket> bm_buckets;
+  std::vector<TermRec> bm_trec;
 };
 
 struct IndexDev {
@@ -84,6 +110,14 @@ struct IndexDev {
   uint32_t has_key_atoms = 0;
   uint32_t n_slots = 0, n_postings = 0;
   uint32_t n_cluster_postings = 0;  // postings filed under scope 0 come first in the array
+  uint32_t bm_words = 0, bm_stride = 0, bm_rows = 0, bm_bucket_mask = 0, bm_n_trec = 0, bm_n_ns = 0, bm_n_nswords = 0;
+  uint32_t* bm_row_bits = nullptr;
+  uint32_t* bm_nsrows = nullptr;
+  uint32_t* bm_nswords_off = nullptr;
+  uint32_t* bm_nswords = nullptr;
+  AtomBucket* bm_buckets = nullptr;
+  TermRec* bm_trec = nullptr;
+  size_t cap_bm_row_bits = 0, cap_bm_nsrows = 0, cap_bm_nswords_off = 0, cap_bm_nswords = 0, cap_bm_buckets = 0, cap_bm_trec = 0;
   size_t cap_slots = 0, cap_postings = 0, cap_uni_ns_off = 0, cap_uni_ns = 0, cap_uni_cluster = 0, cap_slow = 0;
 };
 

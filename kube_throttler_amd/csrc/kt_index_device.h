@@ -193,6 +193,25 @@ __device__ __forceinline__ void walk_slow(const SelProgram& sp, int t, const uin
 
 extern __shared__ __attribute__((aligned(16))) unsigned char kt_smem[];
 
+__device__ __forceinline__ void lds_stage(KT_LDS unsigned char* dst, const void* src, uint32_t bytes) {
+  const u32x4* s = (const u32x4*)src;
+  KT_LDS u32x4* d = (KT_LDS u32x4*)dst;
+  for (uint32_t i = threadIdx.x; i < (bytes + 15u) / 16u; i += kBlockIx) d[i] = s[i];
+}
+
+// branch-free 4-way bucket probe: bitmap row of `atom`, or row 1 (all zero) when no selector mentions it
+__device__ __forceinline__ uint32_t atom_row(lds_u4p buckets, uint32_t mask, uint32_t atom) {
+  const uint32_t b = atom_bucket(atom, mask);
+  const u32x4 a = buckets[2 * b], r = buckets[2 * b + 1];
+  uint32_t row = 1u;
+  row = a.x == atom ? r.x : row;
+  row = a.y == atom ? r.y : row;
+  row = a.z == atom ? r.z : row;
+  row = a.w == atom ? r.w : row;
+  return atom ? row : 1u;
+}
+
+
 #define KT_IX_CASE(NAME, DT_, LT_, KEYS_, FLAG_)                                                                 \
   {                                                                                                             \
     auto kfn = NAME<DT_, LT_, KEYS_, FLAG_>;                                                                    \

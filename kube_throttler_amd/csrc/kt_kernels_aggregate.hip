@@ -152,6 +152,180 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kt_aggregate_bitmap — kt_aggregate_indexed for selector programs whose bitmap form fits in LDS next to the
+// per-workgroup `used` table (packed u16 counts).  Phase 1 is the sparse-word bitmap enumeration of
+// kt_check_bitmap restricted to counted pods; phase 2 folds (match, dimension) lanes into the LDS table.
+// ---------------------------------------------------------------------------------------------------
+struct AggBitmapLds {
+  uint32_t q, q_count, tab, rows, nsrows, nswords_off, nswords, buckets, trec, total, tab_bytes;
+};
+constexpr uint32_t kAggQueueCap = 2048;
+__host__ __device__ inline AggBitmapLds agg_bitmap_lds_layout(const IndexDev& ix, int T, int D) {
+  AggBitmapLds L;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
+  L.q = take(kAggQueueCap * 4);
+  L.q_count = take(16);
+  L.tab_bytes = (uint32_t)((lds_table_bytes(T, D, true) + 15) & ~(size_t)15);
+  L.tab = take(L.tab_bytes);
+  L.rows = take(ix.bm_rows * ix.bm_stride * 4);
+  L.nsrows = take(ix.bm_n_ns * ix.bm_stride * 4);
+  L.nswords_off = take((ix.bm_n_ns + 1) * 4);
+  L.nswords = take(ix.bm_n_nswords * 4);
+  L.buckets = take((ix.bm_bucket_mask + 1) * 32);
+  L.trec = take(ix.bm_n_trec * 16);
+  L.total = o;
+  return L;
+}
+
+template <int DT, int LT, bool KEYS>
+__global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(PodTable pods, int64_t n_rows, SelProgram sp,
+                                                               IndexDev ix, unsigned char* slab) {
+  const int D = pods.D, T = sp.T;
+  const AggBitmapLds L = agg_bitmap_lds_layout(ix, T, D);
+  KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
+  lds_u32wp q = (lds_u32wp)(lds + L.q);
+  lds_u32wp q_count = (lds_u32wp)(lds + L.q_count);
+  lds_u64wp tv = (lds_u64wp)(lds + L.tab);
+  lds_u32wp tc = (lds_u32wp)(lds + L.tab + (uint32_t)T * D * 8);
+  lds_u32p l_rows = (lds_u32p)(lds + L.rows);
+  lds_u32p l_nsrows = (lds_u32p)(lds + L.nsrows);
+  lds_u32p l_nsw_off = (lds_u32p)(lds + L.nswords_off);
+  lds_u32p l_nsw = (lds_u32p)(lds + L.nswords);
+  lds_u4p l_buckets = (lds_u4p)(lds + L.buckets);
+  lds_u4p l_trec = (lds_u4p)(lds + L.trec);
+  for (uint32_t i = threadIdx.x; i < L.tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + L.tab))[i] = 0u;
+  lds_stage(lds + L.rows, ix.bm_row_bits, ix.bm_rows * ix.bm_stride * 4);
+  lds_stage(lds + L.nsrows, ix.bm_nsrows, ix.bm_n_ns * ix.bm_stride * 4);
+  lds_stage(lds + L.nswords_off, ix.bm_nswords_off, (ix.bm_n_ns + 1) * 4);
+  lds_stage(lds + L.nswords, ix.bm_nswords, ix.bm_n_nswords * 4);
+  lds_stage(lds + L.buckets, ix.bm_buckets, (ix.bm_bucket_mask + 1) * 32);
+  lds_stage(lds + L.trec, ix.bm_trec, ix.bm_n_trec * 16);
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t stride = ix.bm_stride;
+  auto cnt_add = [&](uint32_t t, uint32_t j) {  // packed u16 counts[t][j] += 1
+    const uint32_t idx = t * (uint32_t)(D + 2) + j;
+    lds_add(tc + (idx >> 1), 1u << ((idx & 1u) * 16u));
+  };
+  auto add_pod = [&](uint32_t t, int64_t p) {  // lane-serial fold (queue overflow path)
+    const uint32_t present = pods.flags[p] >> kPresentShift;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      if (d < D && ((present >> d) & 1u)) {
+        const int64_t v = pods.req[(int64_t)p * D + d];
+        if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
+        cnt_add(t, (uint32_t)d);
+      }
+    cnt_add(t, (uint32_t)D);
+  };
+  const int64_t n_tiles = (n_rows + kBlockIx - 1) / kBlockIx;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t p = tile * kBlockIx + threadIdx.x;
+    if (threadIdx.x == 0) *q_count = 0u;
+    __syncthreads();
+    // ---- phase 1: lane = pod: enumerate matches of counted pods
+    const uint32_t fl = p < n_rows ? pods.flags[p] : 0u;
+    // shouldCountIn (throttle_controller.go:217-219)
+    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    const bool not_finished = !(fl & kPodFinished);  // isNotFinished (pod_util.go:26-28)
+    if (countable && (not_finished || ix.n_slow != 0)) {  // terminated pods only matter for error detection
+      uint32_t lp[LT], lk[LT];
+      const uint32_t ns = pods.ns[p];
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
+        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
+      }
+      const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
+      auto emit = [&](uint32_t t) {
+        if (!not_finished) return;  // matched but not counted
+        const uint64_t mask = __ballot(true);
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (base < kAggQueueCap) q[base] = (uint32_t)threadIdx.x << 20 | t;
+        else add_pod(t, p);
+      };
+      if (not_finished) {
+        uint32_t rp[LT], rk[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+          rp[l] = atom_row(l_buckets, ix.bm_bucket_mask, lp[l]) * stride;
+          rk[l] = KEYS ? atom_row(l_buckets, ix.bm_bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
+        }
+        const uint32_t k1 = l_nsw_off[ns + 1];
+        for (uint32_t k = l_nsw_off[ns]; k < k1; ++k) {
+          const uint32_t w = l_nsw[k];
+          uint32_t x = l_rows[w];
+#pragma unroll
+          for (int l = 0; l < LT; ++l) {
+            x |= l_rows[rp[l] + w];
+            if (KEYS) x |= l_rows[rk[l] + w];
+          }
+          x &= l_nsrows[ns * stride + w];
+          while (x) {
+            const uint32_t c = w * 32u + (uint32_t)__ffs((int)x) - 1u;
+            x &= x - 1u;
+            const u32x4 tr = l_trec[c];  // {g, t, pair2, flags}
+            bool ok = true;
+            if (tr.w & kPostPair2) {
+              bool has = false;
+#pragma unroll
+              for (int l = 0; l < LT; ++l) has |= lp[l] == tr.z;
+              ok = has;
+            }
+            if (ok && (tr.w & (kPostComplex | kPostMulti))) ok = m.rare(tr.x, tr.y, tr.w);
+            if (ok) emit(tr.y);
+          }
+        }
+      }
+      for (uint32_t k = 0; k < ix.n_slow; ++k) {
+        bool matched, err;
+        const int t = (int)ix.slow_thr[k];
+        walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
+        if (err) cnt_add((uint32_t)t, (uint32_t)D + 1u);
+        if (matched) emit((uint32_t)t);
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (match, dimension): fold the pod's amount into the table
+    const uint32_t qn = min(*q_count, kAggQueueCap);
+    {
+      constexpr int MPW = kWave / DT;
+      const uint32_t d = lane % DT, ml = lane / DT;
+      const uint32_t wave = threadIdx.x / kWave;
+      for (uint32_t base = wave * MPW; base < qn; base += (kBlockIx / kWave) * MPW) {
+        const uint32_t j = base + ml;
+        if (j >= qn) continue;
+        const uint32_t e = q[j];
+        const uint32_t t = e & 0xFFFFFu;
+        const int64_t mp = tile * kBlockIx + (e >> 20);
+        const uint32_t present = pods.flags[mp] >> kPresentShift;
+        if ((int)d < D && ((present >> d) & 1u)) {
+          const int64_t v = pods.req[(int64_t)mp * D + d];
+          if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
+          cnt_add(t, d);
+        }
+        if (d == 0) cnt_add(t, (uint32_t)D);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  u32x4* dst = (u32x4*)(slab + (size_t)blockIdx.x * L.tab_bytes);
+  lds_u4p src = (lds_u4p)(lds + L.tab);
+  for (uint32_t i = threadIdx.x; i < L.tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+}
+
+#define KT_AGG_BM_CASE(DT_, LT_, KEYS_)                                                                        \
+  {                                                                                                           \
+    auto kfn = kt_aggregate_bitmap<DT_, LT_, KEYS_>;                                                          \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, pods, n_rows, sp, ix, slab);                                   \
+  }
+
 // partial[t][j] = sum over workgroup slabs (j < D: values; D <= j < 2D+2: counts).
 // 64 output words per workgroup x 4 slab groups: every thread streams n_slabs/4 independent loads.
 __global__ __launch_bounds__(256) void kt_reduce_partials(const unsigned char* slab, int n_slabs, int T, int D, int cnt16,
@@ -217,6 +391,24 @@ void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelPro
     else if (2048 * 4 + 16 + tab32 <= (size_t)kMaxLds) mode = 1, q_cap = 2048, tab = tab32;
   }
   dim3 g_(nb), b_(kBlockIx);
+  // small-T regime: LDS table + the whole selector program as LDS-resident bitmaps
+  if (slab != nullptr && ix.bm_words != 0 && pods_per_block <= 65535) {
+    const AggBitmapLds LB = agg_bitmap_lds_layout(ix, sp.T, pods.D);
+    if (LB.total <= (uint32_t)kMaxLds) {
+      const size_t lds_bm = LB.total;
+#ifdef KT_FAST_BUILD
+      KT_AGG_BM_CASE(8, 8, false)
+#else
+      if (DT <= 8 && LT == 8) { if (keys) KT_AGG_BM_CASE(8, 8, true) else KT_AGG_BM_CASE(8, 8, false) }
+      else if (DT <= 8) { if (keys) KT_AGG_BM_CASE(8, 16, true) else KT_AGG_BM_CASE(8, 16, false) }
+      else if (LT == 8) { if (keys) KT_AGG_BM_CASE(16, 8, true) else KT_AGG_BM_CASE(16, 8, false) }
+      else { if (keys) KT_AGG_BM_CASE(16, 16, true) else KT_AGG_BM_CASE(16, 16, false) }
+#endif
+      const int words = sp.T * partial_stride(pods.D);
+      hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D, 1, partial);
+      return;
+    }
+  }
   const size_t lds_bytes = q_cap * 4 + 16 + tab + (mode == 2 ? ix_bytes : 0);
 #define KT_IX_ARGS pods, n_rows, sp, ix, partial, slab, q_cap
   if (mode == 2) KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 2);

@@ -149,6 +149,224 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kt_check_bitmap — same contract as kt_check_indexed, for selector programs whose bitmap form
+// (kt_index.h) fits in LDS (the small-T regime: up to a few thousand terms).
+//   phase 1, lane = pod:  8 branch-free bucket probes give the bitmap rows of the pod's labels; for each
+//            word its namespace can touch (~6):  x = (rows[0] | OR_l rows[r_l])[w] & nsrows[ns][w];
+//            every surviving bit is a candidate term: one TermRec read decides it.  Per-lane state is
+//            ~40 registers and there is no hash-chain / posting walk.
+//   phase 2, lane = (match, dimension): request rows come from the LDS tile the pods parked in phase 1.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kQueueCapBm = 4096;  // tile match queue (16 KB); beyond that a lane classifies in place
+
+struct BitmapLds {  // byte offsets into dynamic LDS (all multiples of 16)
+  uint32_t cnt, q, q_count, req, rows, nsrows, nswords_off, nswords, buckets, trec, total;
+};
+__host__ __device__ inline BitmapLds bitmap_lds_layout(const IndexDev& ix, int D) {
+  BitmapLds L;
+  uint32_t o = 0;
+  auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
+  L.cnt = take(kBlockIx * 8);
+  L.q = take(kQueueCapBm * 4);
+  L.q_count = take(16);
+  L.req = take(kBlockIx * D * 8);
+  L.rows = take(ix.bm_rows * ix.bm_stride * 4);
+  L.nsrows = take(ix.bm_n_ns * ix.bm_stride * 4);
+  L.nswords_off = take((ix.bm_n_ns + 1) * 4);
+  L.nswords = take(ix.bm_n_nswords * 4);
+  L.buckets = take((ix.bm_bucket_mask + 1) * 32);
+  L.trec = take(ix.bm_n_trec * 16);
+  L.total = o;
+  return L;
+}
+
+template <int DT, int LT, bool KEYS>
+__global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64_t n, const int64_t* rows,
+                                                           SelProgram sp, IndexDev ix, const void* recs_,
+                                                           uint64_t* summary, uint8_t* status, int dbg) {
+  const CheckRec<DT>* recs = (const CheckRec<DT>*)recs_;
+  const BitmapLds L = bitmap_lds_layout(ix, pods.D);
+  KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
+  lds_u64wp cnt = (lds_u64wp)(lds + L.cnt);
+  lds_u32wp q = (lds_u32wp)(lds + L.q);
+  lds_u32wp q_count = (lds_u32wp)(lds + L.q_count);
+  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + L.req);
+  lds_u32p l_rows = (lds_u32p)(lds + L.rows);
+  lds_u32p l_nsrows = (lds_u32p)(lds + L.nsrows);
+  lds_u32p l_nsw_off = (lds_u32p)(lds + L.nswords_off);
+  lds_u32p l_nsw = (lds_u32p)(lds + L.nswords);
+  lds_u4p l_buckets = (lds_u4p)(lds + L.buckets);
+  lds_u4p l_trec = (lds_u4p)(lds + L.trec);
+  lds_stage(lds + L.rows, ix.bm_row_bits, ix.bm_rows * ix.bm_stride * 4);
+  lds_stage(lds + L.nsrows, ix.bm_nsrows, ix.bm_n_ns * ix.bm_stride * 4);
+  lds_stage(lds + L.nswords_off, ix.bm_nswords_off, (ix.bm_n_ns + 1) * 4);
+  lds_stage(lds + L.nswords, ix.bm_nswords, ix.bm_n_nswords * 4);
+  lds_stage(lds + L.buckets, ix.bm_buckets, (ix.bm_bucket_mask + 1) * 32);
+  lds_stage(lds + L.trec, ix.bm_trec, ix.bm_n_trec * 16);
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t stride = ix.bm_stride;
+  const int64_t n_tiles = (n + kBlockIx - 1) / kBlockIx;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t i = tile * kBlockIx + threadIdx.x;
+    cnt[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) *q_count = 0u;
+    __syncthreads();
+    // ---- phase 1: lane = pod
+    const bool in = i < n;
+    const int64_t p = in ? (rows ? rows[i] : i) : 0;
+    const uint32_t fl = in ? pods.flags[p] : 0u;
+    const bool on = (fl & kPodValid) != 0;
+    // park this pod's request row in LDS (coalesced 8*D bytes per lane) for phase 2
+    {
+      int64_t myreq[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) myreq[d] = (on && d < pods.D) ? pods.req[(int64_t)p * pods.D + d] : 0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        if (d < pods.D) l_req[threadIdx.x * pods.D + d] = myreq[d];
+    }
+    bool pod_err = false;
+    if (on) {
+      uint32_t lp[LT], lk[LT];
+      const uint32_t ns = pods.ns[p];
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
+        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
+      }
+      // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
+      pod_err = !sp.ns_valid[ns];
+      const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
+      auto classify_now = [&](uint32_t t) {  // tile queue full (pathological match counts)
+        int64_t v[DT];
+        uint32_t nz = 0;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          v[d] = d < pods.D ? pods.req[(int64_t)p * pods.D + d] : 0;
+          nz |= (v[d] != 0 ? 1u : 0u) << d;
+        }
+        const uint32_t st = classify<DT>(recs + t, v, nz);
+        if (st != 1u) lds_add64(cnt + threadIdx.x, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
+        if (status) status[i * sp.T + t] = (uint8_t)st;
+      };
+      auto emit = [&](uint32_t t) {  // wave-aggregated push into the tile queue
+        const uint64_t mask = __ballot(true);
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (base < kQueueCapBm) q[base] = (uint32_t)threadIdx.x << 20 | t;
+        else classify_now(t);
+      };
+      uint32_t rp[LT], rk[LT];  // word offsets of the label rows
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        rp[l] = atom_row(l_buckets, ix.bm_bucket_mask, lp[l]) * stride;
+        rk[l] = KEYS ? atom_row(l_buckets, ix.bm_bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
+      }
+      const uint32_t k1 = l_nsw_off[ns + 1];
+      for (uint32_t k = l_nsw_off[ns]; k < k1; ++k) {
+        const uint32_t w = l_nsw[k];
+        uint32_t x = l_rows[w];  // row 0: terms without a positive requirement
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+          x |= l_rows[rp[l] + w];
+          if (KEYS) x |= l_rows[rk[l] + w];
+        }
+        x &= l_nsrows[ns * stride + w];
+        while (x) {
+          const uint32_t c = w * 32u + (uint32_t)__ffs((int)x) - 1u;
+          x &= x - 1u;
+          const u32x4 tr = l_trec[c];  // {g, t, pair2, flags}
+          bool ok = true;
+          if (tr.w & kPostPair2) {
+            bool has = false;
+#pragma unroll
+            for (int l = 0; l < LT; ++l) has |= lp[l] == tr.z;
+            ok = has;
+          }
+          if (ok && (tr.w & (kPostComplex | kPostMulti))) ok = m.rare(tr.x, tr.y, tr.w);
+          if (ok && dbg != 2) emit(tr.y);
+        }
+      }
+      // throttles with an unconvertible podSelector term: in-order walk (error semantics depend on term order)
+      for (uint32_t k = 0; k < ix.n_slow; ++k) {
+        bool matched, err;
+        const int t = (int)ix.slow_thr[k];
+        walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
+        pod_err |= err;
+        if (matched) emit((uint32_t)t);
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: lane = (match, dimension): the pod's request row (LDS) and the throttle's thr[] / head[]
+    // rows are each ONE transaction per match
+    const uint32_t qn = dbg == 1 ? 0u : min(*q_count, kQueueCapBm);
+    {
+      constexpr int MPW = kWave / DT;  // matches per wave per iteration
+      const uint32_t d = lane % DT, ml = lane / DT;
+      const uint32_t wave = threadIdx.x / kWave;
+      const uint64_t gmask = (DT == 64 ? ~0ull : ((1ull << DT) - 1ull)) << (ml * DT);
+      constexpr uint32_t kStep = (kBlockIx / kWave) * MPW;
+      constexpr int U = 2;
+      const bool dd = (int)d < pods.D;
+      for (uint32_t base = wave * MPW; base < qn; base += U * kStep) {
+        bool vv[U];
+        uint32_t pl[U], tt[U], am[U], ff[U];
+        int64_t xx[U], th[U], hd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = base + u * kStep + ml;
+          vv[u] = j < qn;
+          const uint32_t e = vv[u] ? q[j] : 0u;
+          pl[u] = e >> 20;
+          tt[u] = e & 0xFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const CheckRec<DT>* rc = recs + tt[u];
+          th[u] = rc->thr[d];
+          hd[u] = rc->head[d];
+          am[u] = rc->active_mask;
+          ff[u] = rc->flags;
+          xx[u] = (vv[u] && dd) ? l_req[pl[u] * pods.D + d] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool nz = vv[u] && xx[u] != 0;
+          const uint64_t be = __ballot(nz && xx[u] > th[u]), bi = __ballot(nz && xx[u] > hd[u]),
+                         ba = __ballot(nz && ((am[u] >> d) & 1u));
+          if (d == 0 && vv[u]) {
+            const bool exc = (ff[u] & kRecExceedsByCount) || (be & gmask);
+            const bool act = (ff[u] & kRecActiveByCount) || (ba & gmask);
+            const bool ins = (ff[u] & kRecInsufficientByCount) || (bi & gmask);
+            const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
+            if (st != 1u) lds_add64(cnt + pl[u], st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
+            if (status) status[(tile * kBlockIx + pl[u]) * sp.T + tt[u]] = (uint8_t)st;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: lane = pod
+    if (in) {
+      const unsigned long long c = cnt[threadIdx.x];
+      summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
+      if (status && pod_err)
+        for (int t = 0; t < sp.T; ++t) status[i * sp.T + t] = 255;
+    }
+    __syncthreads();
+  }
+}
+
+#define KT_BM_CASE(DT_, LT_, KEYS_)                                                                            \
+  {                                                                                                           \
+    auto kfn = kt_check_bitmap<DT_, LT_, KEYS_>;                                                              \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, pods, n, rows_dev, sp, ix, recs, summary, status, dbg);     \
+  }
+
 void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const IndexDev& ix, bool keys, const void* recs, uint64_t* summary, uint8_t* status,
                           hipStream_t s) {
@@ -159,6 +377,22 @@ void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_d
   if (nb > kCUs) nb = kCUs;
   dim3 g_((unsigned)nb), b_(kBlockIx);
   static const int dbg = getenv("KT_DEBUG_MODE") ? atoi(getenv("KT_DEBUG_MODE")) : 0;
+  // small-T regime: the whole selector program as LDS-resident bitmaps
+  if (ix.bm_words != 0 && dbg != 3) {
+    const BitmapLds L = bitmap_lds_layout(ix, pods.D);
+    if (L.total <= (uint32_t)kMaxLds) {
+      const size_t lds_bytes = L.total;
+#ifdef KT_FAST_BUILD
+      KT_BM_CASE(8, 8, false)
+#else
+      if (DT <= 8 && LT == 8) { if (keys) KT_BM_CASE(8, 8, true) else KT_BM_CASE(8, 8, false) }
+      else if (DT <= 8) { if (keys) KT_BM_CASE(8, 16, true) else KT_BM_CASE(8, 16, false) }
+      else if (LT == 8) { if (keys) KT_BM_CASE(16, 8, true) else KT_BM_CASE(16, 8, false) }
+      else { if (keys) KT_BM_CASE(16, 16, true) else KT_BM_CASE(16, 16, false) }
+#endif
+      return;
+    }
+  }
   const size_t ix_bytes = (size_t)ix.n_slots * sizeof(IndexSlot) + (size_t)ix.n_postings * sizeof(Posting);
   const size_t fixed_bytes = kBlockIx * 8 + kQueueCap * 4 + 16;
   const bool lds_ix = ix_bytes + fixed_bytes <= (size_t)kMaxLds && n >= 4 * kBlockIx;
