@@ -153,6 +153,7 @@ struct kt_engine {
   DevBuf<uint32_t> d_thr_term_off, d_term_thr, d_term_req_off, d_req_key, d_req_val_off, d_req_val, d_ns_term_ok;
   DevBuf<uint8_t> d_term_flags, d_req_op, d_ns_valid;
   kt::SelProgram sp{};
+  DevBuf<kt::SelProgram> d_sp;  // device copy (kernels that touch the program only on rare paths take a pointer)
   bool uses_keys = false;
   kt::HostIndex hindex;
   kt::IndexDev dindex;
@@ -485,6 +486,9 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   e->sp.T = (int32_t)T;
   e->sp.G = (int32_t)G;
   e->sp.n_ns = (int32_t)NS;
+  KT_HIP(e, e->d_sp.reserve(1));
+  KT_HIP(e, hipMemcpyAsync(e->d_sp.p, &e->sp, sizeof(kt::SelProgram), hipMemcpyHostToDevice, s));
+  KT_HIP(e, hipStreamSynchronize(s));
   e->program_dirty = false;
   return KT_OK;
 }
@@ -634,6 +638,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
   e->d_partial.release();
+  e->d_sp.release();
   AmountDev* ams[] = {&e->d_spec, &e->d_calc, &e->d_used, &e->d_reserved, &e->d_ovr_thr, &e->d_out_used, &e->d_out_calc};
   for (auto* a : ams) a->release();
   kt::release_index(e->dindex);
@@ -959,7 +964,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     if (e->cfg.kernel_variant == 1)
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s);
     else
-      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
+      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;
@@ -1099,7 +1104,7 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
       kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->d_recs.p,
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
     else
-      kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->dindex, e->uses_keys,
+      kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
   }
   KT_HIP(e, hipGetLastError());

@@ -187,9 +187,10 @@ __device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, i
   return as != bs ? (as < bs ? -1 : 1) : (an != bn ? (an < bn ? -1 : 1) : 0);
 }
 
-__global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
+template <int DT>
+__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
                                                      int64_t now_s, int32_t now_ns, int apply, ReconcileOut out) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
+  const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   const int stride = partial_stride(D);
   const uint32_t fl = tt.flags[t];
@@ -197,13 +198,13 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
   const bool live = (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
   const bool error = live && prow[2 * D + 1] != 0;
   // ---- stored status (returned unchanged for rows that are not reconciled)
-  int64_t s_calc_v[16];
+  int64_t s_calc_v[DT];
   const uint32_t s_calc_p = tt.calc.present[t];
   const bool s_calc_hc = tt.calc.has_count[t] != 0;
   const int64_t s_calc_c = tt.calc.count[t];
-  for (int d = 0; d < D; ++d) s_calc_v[d] = tt.calc.v[(size_t)t * D + d];
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) s_calc_v[d] = tt.calc.v[(size_t)t * D + d];
   if (!live || error) {
-    for (int d = 0; d < D; ++d) {
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
       out.used.v[(size_t)t * D + d] = tt.used.v[(size_t)t * D + d];
       out.calc.v[(size_t)t * D + d] = s_calc_v[d];
     }
@@ -221,21 +222,21 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
-  int64_t u_v[16];
+  int64_t u_v[DT];
   uint32_t u_p = 0;
   const int64_t u_c = (int64_t)prow[2 * D];
   const bool u_hc = u_c > 0;
-  for (int d = 0; d < D; ++d) {
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
     const bool pr = prow[D + d] != 0;
     u_p |= (pr ? 1u : 0u) << d;
     u_v[d] = pr ? (int64_t)prow[d] : 0;
   }
   // ---- CalculateThreshold(now)
-  int64_t c_v[16];
+  int64_t c_v[DT];
   uint32_t c_p = 0;
   bool c_hc = false, active_found = false, any_err = false;
   int64_t c_c = 0;
-  for (int d = 0; d < D; ++d) c_v[d] = 0;
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = 0;
   for (uint32_t o = tt.ovr_off[t]; o < tt.ovr_off[t + 1]; ++o) {
     if (tt.ovr_flags[o] & kOvrParseError) {
       any_err = true;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
       c_c = tt.ovr_thr.count[o];
     }
     const uint32_t op = tt.ovr_thr.present[o];
-    for (int d = 0; d < D; ++d)
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
       if (((op >> d) & 1u) && !((c_p >> d) & 1u)) {
         c_p |= 1u << d;
         c_v[d] = tt.ovr_thr.v[(size_t)o * D + d];
@@ -261,27 +262,27 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
     c_p = tt.spec.present[t];
     c_hc = tt.spec.has_count[t] != 0;
     c_c = tt.spec.count[t];
-    for (int d = 0; d < D; ++d) c_v[d] = ((c_p >> d) & 1u) ? tt.spec.v[(size_t)t * D + d] : 0;
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = ((c_p >> d) & 1u) ? tt.spec.v[(size_t)t * D + d] : 0;
   }
   const uint64_t c_fp = any_err ? tt.spec_msgs_fp[t] : 0ull;
   // ---- replace the stored calculatedThreshold only if threshold or messages differ by value
   bool same = (c_hc == s_calc_hc) && (!c_hc || c_c == s_calc_c) && (c_p == s_calc_p);
-  for (int d = 0; d < D; ++d)
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
     if ((c_p >> d) & 1u) same &= c_v[d] == s_calc_v[d];
   const bool replace = !same || tt.status_msgs_fp[t] != c_fp;
   if (!replace) {
     c_p = s_calc_p;
     c_hc = s_calc_hc;
     c_c = s_calc_c;
-    for (int d = 0; d < D; ++d) c_v[d] = s_calc_v[d];
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = s_calc_v[d];
   }
   // ---- throttled = calculatedThreshold.IsThrottled(used, onEqual = true)
   const bool th_pod = c_hc && u_hc && u_c >= c_c;
   uint32_t th_flag = 0;
-  for (int d = 0; d < D; ++d)
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
     if (((c_p >> d) & 1u) && ((u_p >> d) & 1u) && u_v[d] >= c_v[d]) th_flag |= 1u << d;
   // ---- outputs
-  for (int d = 0; d < D; ++d) {
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
     out.used.v[(size_t)t * D + d] = u_v[d];
     out.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
   }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
   out.thrl_pod[t] = th_pod;
   out.error[t] = 0;
   if (apply) {  // UpdateStatus: the result becomes the stored status the next check reads
-    for (int d = 0; d < D; ++d) {
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
       tt.used.v[(size_t)t * D + d] = u_v[d];
       if (replace) tt.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
     }
@@ -322,8 +323,11 @@ __global__ __launch_bounds__(kBlock) void kt_finalize(ThrTables tt, int T, int D
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, hipStream_t s) {
   if (sp.T <= 0) return;
-  hipLaunchKernelGGL(kt_finalize, dim3((sp.T + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tt, sp.T, D, partial, now_s,
-                     now_ns, apply ? 1 : 0, out);
+  // one wave per 64 throttles (T is small: spread over as many CUs as possible; everything is latency)
+  const dim3 g((sp.T + 63) / 64), b(64);
+  if (D <= 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
+  else if (D <= 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -333,8 +337,8 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const uns
 __device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
 
 template <int DT>
-__global__ __launch_bounds__(kBlock) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   const uint32_t fl = tt.flags[t];
   // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void kt_prepare_check(ThrTables tt, int T, 
 
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s) {
   if (T <= 0) return;
-  dim3 g((T + kBlock - 1) / kBlock), b(kBlock);
+  dim3 g((T + 63) / 64), b(64);
   if (DT == 4) hipLaunchKernelGGL(kt_prepare_check<4>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<4>*)recs);
   else if (DT == 8) hipLaunchKernelGGL(kt_prepare_check<8>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<8>*)recs);
   else hipLaunchKernelGGL(kt_prepare_check<16>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<16>*)recs);

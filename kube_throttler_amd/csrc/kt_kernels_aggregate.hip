@@ -371,8 +371,8 @@ size_t aggregate_slab_bytes(int T, int D) {
   return (size_t)kCUs * ((bytes + 15) & ~(size_t)15);
 }
 
-void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const IndexDev& ix,
-                              bool keys, unsigned long long* partial, void* slab_, hipStream_t s) {
+void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
+                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab_, hipStream_t s) {
   if (n_rows <= 0 || sp.T <= 0) return;
   const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
   unsigned char* slab = (unsigned char*)slab_;

@@ -160,52 +160,79 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kQueueCapBm = 4096;  // tile match queue (16 KB); beyond that a lane classifies in place
 
-struct BitmapLds {  // byte offsets into dynamic LDS (all multiples of 16)
-  uint32_t cnt, q, q_count, req, rows, nsrows, nswords_off, nswords, buckets, trec, total;
+// Everything the kernel needs, and nothing else: a compact argument block keeps the scalar register file
+// free of the (large) generic table descriptors, which are reached through `sp` only on rare paths.
+struct BmCheckArgs {
+  const uint32_t* ns;     // pod planes
+  const uint32_t* flags;
+  const int64_t* req;
+  const uint32_t* lpair;
+  const uint32_t* lkey;
+  int64_t cap;
+  int64_t n;
+  const int64_t* rows;
+  const void* recs;
+  uint64_t* summary;
+  uint8_t* status;
+  const SelProgram* sp;   // device copy (rare term shapes, slow throttles)
+  const uint8_t* ns_valid;
+  const uint32_t* slow_thr;
+  const void* src[6];     // LDS staging sources: rows, nsrows, nswords_off, nswords, buckets, trec
+  uint32_t bytes[6];
+  uint32_t off[6];        // ... and their byte offsets in LDS
+  uint32_t off_cnt, off_q, off_qcount, off_req;
+  uint32_t stride, bucket_mask, n_slow;
+  int32_t D, L, T, dbg;
 };
-__host__ __device__ inline BitmapLds bitmap_lds_layout(const IndexDev& ix, int D) {
-  BitmapLds L;
+
+static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
+                                      const SelProgram* sp_dev, const IndexDev& ix, const void* recs,
+                                      uint64_t* summary, uint8_t* status, int dbg, uint32_t* total) {
+  BmCheckArgs a{};
+  a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
+  a.cap = pods.cap, a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
+  a.sp = sp_dev, a.ns_valid = sp.ns_valid, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow;
+  a.D = pods.D, a.L = pods.L, a.T = sp.T, a.dbg = dbg;
+  a.stride = ix.bm_stride, a.bucket_mask = ix.bm_bucket_mask;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
-  L.cnt = take(kBlockIx * 8);
-  L.q = take(kQueueCapBm * 4);
-  L.q_count = take(16);
-  L.req = take(kBlockIx * D * 8);
-  L.rows = take(ix.bm_rows * ix.bm_stride * 4);
-  L.nsrows = take(ix.bm_n_ns * ix.bm_stride * 4);
-  L.nswords_off = take((ix.bm_n_ns + 1) * 4);
-  L.nswords = take(ix.bm_n_nswords * 4);
-  L.buckets = take((ix.bm_bucket_mask + 1) * 32);
-  L.trec = take(ix.bm_n_trec * 16);
-  L.total = o;
-  return L;
+  a.off_cnt = take(kBlockIx * 8);
+  a.off_q = take(kQueueCapBm * 4);
+  a.off_qcount = take(16);
+  a.off_req = take(kBlockIx * pods.D * 8);
+  const void* src[6] = {ix.bm_row_bits, ix.bm_nsrows, ix.bm_nswords_off, ix.bm_nswords, ix.bm_buckets, ix.bm_trec};
+  const uint32_t bytes[6] = {ix.bm_rows * ix.bm_stride * 4, ix.bm_n_ns * ix.bm_stride * 4, (ix.bm_n_ns + 1) * 4,
+                             ix.bm_n_nswords * 4, (ix.bm_bucket_mask + 1) * 32, ix.bm_n_trec * 16};
+  for (int k = 0; k < 6; ++k) a.src[k] = src[k], a.bytes[k] = bytes[k], a.off[k] = take(bytes[k]);
+  *total = o;
+  return a;
 }
 
 template <int DT, int LT, bool KEYS>
-__global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64_t n, const int64_t* rows,
-                                                           SelProgram sp, IndexDev ix, const void* recs_,
-                                                           uint64_t* summary, uint8_t* status, int dbg) {
-  const CheckRec<DT>* recs = (const CheckRec<DT>*)recs_;
-  const BitmapLds L = bitmap_lds_layout(ix, pods.D);
+__global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
+  const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u64wp cnt = (lds_u64wp)(lds + L.cnt);
-  lds_u32wp q = (lds_u32wp)(lds + L.q);
-  lds_u32wp q_count = (lds_u32wp)(lds + L.q_count);
-  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + L.req);
-  lds_u32p l_rows = (lds_u32p)(lds + L.rows);
-  lds_u32p l_nsrows = (lds_u32p)(lds + L.nsrows);
-  lds_u32p l_nsw_off = (lds_u32p)(lds + L.nswords_off);
-  lds_u32p l_nsw = (lds_u32p)(lds + L.nswords);
-  lds_u4p l_buckets = (lds_u4p)(lds + L.buckets);
-  lds_u4p l_trec = (lds_u4p)(lds + L.trec);
-  lds_stage(lds + L.rows, ix.bm_row_bits, ix.bm_rows * ix.bm_stride * 4);
-  lds_stage(lds + L.nsrows, ix.bm_nsrows, ix.bm_n_ns * ix.bm_stride * 4);
-  lds_stage(lds + L.nswords_off, ix.bm_nswords_off, (ix.bm_n_ns + 1) * 4);
-  lds_stage(lds + L.nswords, ix.bm_nswords, ix.bm_n_nswords * 4);
-  lds_stage(lds + L.buckets, ix.bm_buckets, (ix.bm_bucket_mask + 1) * 32);
-  lds_stage(lds + L.trec, ix.bm_trec, ix.bm_n_trec * 16);
+  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt);
+  lds_u32wp q = (lds_u32wp)(lds + a.off_q);
+  lds_u32wp q_count = (lds_u32wp)(lds + a.off_qcount);
+  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + a.off_req);
+  lds_u32p l_rows = (lds_u32p)(lds + a.off[0]);
+  lds_u32p l_nsrows = (lds_u32p)(lds + a.off[1]);
+  lds_u32p l_nsw_off = (lds_u32p)(lds + a.off[2]);
+  lds_u32p l_nsw = (lds_u32p)(lds + a.off[3]);
+  lds_u4p l_buckets = (lds_u4p)(lds + a.off[4]);
+  lds_u4p l_trec = (lds_u4p)(lds + a.off[5]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) lds_stage(lds + a.off[k], a.src[k], a.bytes[k]);
+  const int64_t n = a.n;
+  const int64_t* rows = a.rows;
+  uint64_t* summary = a.summary;
+  uint8_t* status = a.status;
+  const int dbg = a.dbg;
+  const int D = a.D, L = a.L, T = a.T;
+  const int64_t cap = a.cap;
   const uint32_t lane = threadIdx.x & (kWave - 1);
-  const uint32_t stride = ix.bm_stride;
+  const uint32_t stride = a.stride;
   const int64_t n_tiles = (n + kBlockIx - 1) / kBlockIx;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t i = tile * kBlockIx + threadIdx.x;
@@ -215,55 +242,57 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
     // ---- phase 1: lane = pod
     const bool in = i < n;
     const int64_t p = in ? (rows ? rows[i] : i) : 0;
-    const uint32_t fl = in ? pods.flags[p] : 0u;
-    const bool on = (fl & kPodValid) != 0;
-    // park this pod's request row in LDS (coalesced 8*D bytes per lane) for phase 2
-    {
+    // every load of the pod's record is issued up front (one HBM round trip per tile, not three)
+    const uint32_t fl = in ? a.flags[p] : 0u;
+    const uint32_t ns = in ? a.ns[p] : 0u;
+    uint32_t lp[LT], lk[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      lp[l] = (in && l < L) ? a.lpair[(int64_t)l * cap + p] : 0u;
+      lk[l] = (KEYS && in && l < L) ? a.lkey[(int64_t)l * cap + p] : 0u;
+    }
+    {  // park this pod's request row in LDS (coalesced 8*D bytes per lane) for phase 2
       int64_t myreq[DT];
 #pragma unroll
-      for (int d = 0; d < DT; ++d) myreq[d] = (on && d < pods.D) ? pods.req[(int64_t)p * pods.D + d] : 0;
+      for (int d = 0; d < DT; ++d) myreq[d] = (in && d < D) ? a.req[(int64_t)p * D + d] : 0;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        if (d < pods.D) l_req[threadIdx.x * pods.D + d] = myreq[d];
+        if (d < D) l_req[threadIdx.x * D + d] = myreq[d];
     }
+    const bool on = (fl & kPodValid) != 0;
     bool pod_err = false;
     if (on) {
-      uint32_t lp[LT], lk[LT];
-      const uint32_t ns = pods.ns[p];
-#pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
-      }
       // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
-      pod_err = !sp.ns_valid[ns];
+      pod_err = !a.ns_valid[ns];
+      const SelProgram& sp = *a.sp;
       const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
       auto classify_now = [&](uint32_t t) {  // tile queue full (pathological match counts)
         int64_t v[DT];
         uint32_t nz = 0;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          v[d] = d < pods.D ? pods.req[(int64_t)p * pods.D + d] : 0;
+          v[d] = d < D ? a.req[(int64_t)p * D + d] : 0;
           nz |= (v[d] != 0 ? 1u : 0u) << d;
         }
         const uint32_t st = classify<DT>(recs + t, v, nz);
         if (st != 1u) lds_add64(cnt + threadIdx.x, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-        if (status) status[i * sp.T + t] = (uint8_t)st;
+        if (status) status[i * T + t] = (uint8_t)st;
       };
       auto emit = [&](uint32_t t) {  // wave-aggregated push into the tile queue
         const uint64_t mask = __ballot(true);
         const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
         uint32_t base = 0;
         if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) +
+               __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (base < kQueueCapBm) q[base] = (uint32_t)threadIdx.x << 20 | t;
         else classify_now(t);
       };
       uint32_t rp[LT], rk[LT];  // word offsets of the label rows
 #pragma unroll
       for (int l = 0; l < LT; ++l) {
-        rp[l] = atom_row(l_buckets, ix.bm_bucket_mask, lp[l]) * stride;
-        rk[l] = KEYS ? atom_row(l_buckets, ix.bm_bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
+        rp[l] = atom_row(l_buckets, a.bucket_mask, lp[l]) * stride;
+        rk[l] = KEYS ? atom_row(l_buckets, a.bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
       }
       const uint32_t k1 = l_nsw_off[ns + 1];
       for (uint32_t k = l_nsw_off[ns]; k < k1; ++k) {
@@ -291,9 +320,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
         }
       }
       // throttles with an unconvertible podSelector term: in-order walk (error semantics depend on term order)
-      for (uint32_t k = 0; k < ix.n_slow; ++k) {
+      for (uint32_t k = 0; k < a.n_slow; ++k) {
         bool matched, err;
-        const int t = (int)ix.slow_thr[k];
+        const int t = (int)a.slow_thr[k];
         walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
         pod_err |= err;
         if (matched) emit((uint32_t)t);
@@ -309,8 +338,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
       const uint32_t wave = threadIdx.x / kWave;
       const uint64_t gmask = (DT == 64 ? ~0ull : ((1ull << DT) - 1ull)) << (ml * DT);
       constexpr uint32_t kStep = (kBlockIx / kWave) * MPW;
-      constexpr int U = 2;
-      const bool dd = (int)d < pods.D;
+      constexpr int U = 4;
+      const bool dd = (int)d < D;
       for (uint32_t base = wave * MPW; base < qn; base += U * kStep) {
         bool vv[U];
         uint32_t pl[U], tt[U], am[U], ff[U];
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
           hd[u] = rc->head[d];
           am[u] = rc->active_mask;
           ff[u] = rc->flags;
-          xx[u] = (vv[u] && dd) ? l_req[pl[u] * pods.D + d] : 0;
+          xx[u] = (vv[u] && dd) ? l_req[pl[u] * D + d] : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
             const bool ins = (ff[u] & kRecInsufficientByCount) || (bi & gmask);
             const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
             if (st != 1u) lds_add64(cnt + pl[u], st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-            if (status) status[(tile * kBlockIx + pl[u]) * sp.T + tt[u]] = (uint8_t)st;
+            if (status) status[(tile * kBlockIx + pl[u]) * T + tt[u]] = (uint8_t)st;
           }
         }
       }
@@ -354,7 +383,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
       const unsigned long long c = cnt[threadIdx.x];
       summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
       if (status && pod_err)
-        for (int t = 0; t < sp.T; ++t) status[i * sp.T + t] = 255;
+        for (int t = 0; t < T; ++t) status[i * T + t] = 255;
     }
     __syncthreads();
   }
@@ -364,12 +393,12 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(PodTable pods, int64
   {                                                                                                           \
     auto kfn = kt_check_bitmap<DT_, LT_, KEYS_>;                                                              \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, pods, n, rows_dev, sp, ix, recs, summary, status, dbg);     \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                   \
   }
 
 void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
-                          const IndexDev& ix, bool keys, const void* recs, uint64_t* summary, uint8_t* status,
-                          hipStream_t s) {
+                          const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
+                          uint8_t* status, hipStream_t s) {
   if (n <= 0) return;
   const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -379,9 +408,10 @@ void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_d
   static const int dbg = getenv("KT_DEBUG_MODE") ? atoi(getenv("KT_DEBUG_MODE")) : 0;
   // small-T regime: the whole selector program as LDS-resident bitmaps
   if (ix.bm_words != 0 && dbg != 3) {
-    const BitmapLds L = bitmap_lds_layout(ix, pods.D);
-    if (L.total <= (uint32_t)kMaxLds) {
-      const size_t lds_bytes = L.total;
+    uint32_t bm_total = 0;
+    const BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, dbg, &bm_total);
+    if (bm_total <= (uint32_t)kMaxLds) {
+      const size_t lds_bytes = bm_total;
 #ifdef KT_FAST_BUILD
       KT_BM_CASE(8, 8, false)
 #else
