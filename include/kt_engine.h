@@ -158,7 +158,7 @@ int32_t kt_timing_enable(kt_engine* e, int32_t on);
 int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* launches);
 int32_t kt_timing_reset(kt_engine* e);
 int32_t kt_synchronize(kt_engine* e, void* stream);
-/* name of the HIP kernel symbol behind a family (to match rocprofv3 kernel-trace rows) */
+/* symbol of the HIP kernel LAST dispatched for a family (to match rocprofv3 kernel-trace rows) */
 const char* kt_kernel_name(kt_engine* e, int32_t kernel);
 
 #ifdef __cplusplus

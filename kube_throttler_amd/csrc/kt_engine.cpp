@@ -191,6 +191,8 @@ struct kt_engine {
   // ---- staging
   DevBuf<uint8_t> d_stage;
 
+  const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check"};
+
   // ---- timing
   bool timing = false;
   TimingFamily fam[KT_KERNEL_COUNT];
@@ -962,9 +964,10 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
     if (e->cfg.kernel_variant == 1)
-      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s);
+      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
+          e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else
-      kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
+      e->last_kernel[KT_KERNEL_AGGREGATE] = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;
@@ -1102,9 +1105,10 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
     TimedLaunch tl(e, KT_KERNEL_CHECK, s);
     if (e->cfg.kernel_variant == 1)
       kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->d_recs.p,
-                             e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+                             e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
+          e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else
-      kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
+      e->last_kernel[KT_KERNEL_CHECK] = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
   }
   KT_HIP(e, hipGetLastError());
@@ -1215,14 +1219,8 @@ int32_t kt_synchronize(kt_engine* e, void* stream) {
 }
 
 const char* kt_kernel_name(kt_engine* e, int32_t kernel) {
-  const int v = e ? e->cfg.kernel_variant : 0;
-  switch (kernel) {
-    case KT_KERNEL_CHECK: return kt::kernel_name_check(v);
-    case KT_KERNEL_AGGREGATE: return kt::kernel_name_aggregate(v);
-    case KT_KERNEL_FINALIZE: return "kt_finalize";
-    case KT_KERNEL_PREPARE: return "kt_prepare_check";
-    default: return "";
-  }
+  if (!e || kernel < 0 || kernel >= KT_KERNEL_COUNT) return "";
+  return e->last_kernel[kernel];  // symbol of the kernel last dispatched for this family
 }
 
 }  // extern "C"

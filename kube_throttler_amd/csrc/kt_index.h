@@ -134,10 +134,10 @@ struct PodTable;
 struct SelProgram;
 // slab: scratch for the per-block LDS tables of the aggregate kernel (nullptr => global atomics only)
 size_t aggregate_slab_bytes(int T, int D);
-// sp_dev: device-resident copy of sp
-void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
+// sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched.
+const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, bool keys, unsigned long long* partial, void* slab, hipStream_t s);
-void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
+const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s);
 

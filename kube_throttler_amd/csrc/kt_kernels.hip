@@ -466,7 +466,4 @@ void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev
               status);
 }
 
-const char* kernel_name_check(int variant) { return variant == 1 ? "kt_check_dense" : "kt_check_indexed"; }
-const char* kernel_name_aggregate(int variant) { return variant == 1 ? "kt_aggregate_dense" : "kt_aggregate_indexed"; }
-
 }  // namespace kt

@@ -371,9 +371,9 @@ size_t aggregate_slab_bytes(int T, int D) {
   return (size_t)kCUs * ((bytes + 15) & ~(size_t)15);
 }
 
-void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
+const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, bool keys, unsigned long long* partial, void* slab_, hipStream_t s) {
-  if (n_rows <= 0 || sp.T <= 0) return;
+  if (n_rows <= 0 || sp.T <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
   unsigned char* slab = (unsigned char*)slab_;
   const int nb = agg_blocks(n_rows);
@@ -406,7 +406,7 @@ void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelPro
 #endif
       const int words = sp.T * partial_stride(pods.D);
       hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D, 1, partial);
-      return;
+      return "kt_aggregate_bitmap";
     }
   }
   const size_t lds_bytes = q_cap * 4 + 16 + tab + (mode == 2 ? ix_bytes : 0);
@@ -420,6 +420,7 @@ void launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelPro
     hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D,
                        mode == 2 ? 1 : 0, partial);
   }
+  return "kt_aggregate_indexed";
 }
 
 

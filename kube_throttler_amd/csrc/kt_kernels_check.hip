@@ -396,10 +396,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
     hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                   \
   }
 
-void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
+const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s) {
-  if (n <= 0) return;
+  if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
@@ -420,7 +420,7 @@ void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_d
       else if (LT == 8) { if (keys) KT_BM_CASE(16, 8, true) else KT_BM_CASE(16, 8, false) }
       else { if (keys) KT_BM_CASE(16, 16, true) else KT_BM_CASE(16, 16, false) }
 #endif
-      return;
+      return "kt_check_bitmap";
     }
   }
   const size_t ix_bytes = (size_t)ix.n_slots * sizeof(IndexSlot) + (size_t)ix.n_postings * sizeof(Posting);
@@ -431,6 +431,7 @@ void launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_d
   if (lds_ix) KT_IX_DISPATCH2(kt_check_indexed, DT, LT, keys, true);
   else KT_IX_DISPATCH2(kt_check_indexed, DT, LT, keys, false);
 #undef KT_IX_ARGS
+  return "kt_check_indexed";
 }
 
 }  // namespace kt

@@ -39,9 +39,6 @@ void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equ
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
                         const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s);
 
-const char* kernel_name_check(int variant);
-const char* kernel_name_aggregate(int variant);
-
 inline int dt_bucket(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : 16; }
 inline int dt_bucket_ix(int D) { return D <= 8 ? 8 : 16; }  // indexed kernels: two instantiations
 inline int lt_bucket(int L) { return L <= 8 ? 8 : 16; }
