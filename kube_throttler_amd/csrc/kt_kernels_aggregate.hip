@@ -154,20 +154,25 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
 
 // ---------------------------------------------------------------------------------------------------
 // kt_aggregate_bitmap — kt_aggregate_indexed for selector programs whose bitmap form fits in LDS next to the
-// per-workgroup `used` table (packed u16 counts).  Phase 1 is the sparse-word bitmap enumeration of
-// kt_check_bitmap restricted to counted pods; phase 2 folds (match, dimension) lanes into the LDS table.
+// per-workgroup `used` table.  WAVE-AUTONOMOUS like kt_check_bitmap: after staging, every wave walks its own
+// 64-pod tiles without workgroup barriers; phase 1 parks matches in private LDS columns, a convergent
+// compaction makes them dense, phase 2 folds (match, dimension) lanes into the workgroup's LDS table:
+//     int64 v[T][D] (ds_add_u64) | uint32 present[T] (ds_or_b32 of the pod's key mask) | uint32 pods[T]
+// Key presence travels as a mask here and is expanded to 0/1 contributor counts by kt_reduce_bitmap_slabs
+// (sum > 0 <=> some workgroup saw the key), so the all-reduced buffer keeps the [T][2D+2] layout.
 // ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kAggColSlots = 4, kAggWaveOvf = 64;
 struct AggBitmapLds {
-  uint32_t q, q_count, tab, rows, nsrows, nswords_off, nswords, buckets, trec, total, tab_bytes;
+  uint32_t col, ovq, tab, rows, nsrows, nswords_off, nswords, buckets, trec, total, tab_bytes;
 };
-constexpr uint32_t kAggQueueCap = 2048;
+__host__ __device__ inline uint32_t agg_bitmap_tab_bytes(int T, int D) { return (uint32_t)(((size_t)T * D * 8 + (size_t)T * 8 + 15) & ~(size_t)15); }
 __host__ __device__ inline AggBitmapLds agg_bitmap_lds_layout(const IndexDev& ix, int T, int D) {
   AggBitmapLds L;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
-  L.q = take(kAggQueueCap * 4);
-  L.q_count = take(16);
-  L.tab_bytes = (uint32_t)((lds_table_bytes(T, D, true) + 15) & ~(size_t)15);
+  L.col = take(kBlockIx * kAggColSlots * 4);
+  L.ovq = take((kBlockIx / kWave) * (kAggWaveOvf + 4) * 4);
+  L.tab_bytes = agg_bitmap_tab_bytes(T, D);
   L.tab = take(L.tab_bytes);
   L.rows = take(ix.bm_rows * ix.bm_stride * 4);
   L.nsrows = take(ix.bm_n_ns * ix.bm_stride * 4);
@@ -181,14 +186,14 @@ __host__ __device__ inline AggBitmapLds agg_bitmap_lds_layout(const IndexDev& ix
 
 template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(PodTable pods, int64_t n_rows, SelProgram sp,
-                                                               IndexDev ix, unsigned char* slab) {
-  const int D = pods.D, T = sp.T;
+                                                               IndexDev ix, unsigned long long* partial,
+                                                               unsigned char* slab, int dbg) {
+  const int D = pods.D, T = sp.T, pstride = partial_stride(D);
   const AggBitmapLds L = agg_bitmap_lds_layout(ix, T, D);
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u32wp q = (lds_u32wp)(lds + L.q);
-  lds_u32wp q_count = (lds_u32wp)(lds + L.q_count);
   lds_u64wp tv = (lds_u64wp)(lds + L.tab);
-  lds_u32wp tc = (lds_u32wp)(lds + L.tab + (uint32_t)T * D * 8);
+  lds_u32wp tpres = (lds_u32wp)(lds + L.tab + (uint32_t)T * D * 8);
+  lds_u32wp tpods = tpres + T;
   lds_u32p l_rows = (lds_u32p)(lds + L.rows);
   lds_u32p l_nsrows = (lds_u32p)(lds + L.nsrows);
   lds_u32p l_nsw_off = (lds_u32p)(lds + L.nswords_off);
@@ -202,51 +207,54 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(PodTable pods, i
   lds_stage(lds + L.nswords, ix.bm_nswords, ix.bm_n_nswords * 4);
   lds_stage(lds + L.buckets, ix.bm_buckets, (ix.bm_bucket_mask + 1) * 32);
   lds_stage(lds + L.trec, ix.bm_trec, ix.bm_n_trec * 16);
-  const uint32_t lane = threadIdx.x & (kWave - 1);
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const uint32_t stride = ix.bm_stride;
-  auto cnt_add = [&](uint32_t t, uint32_t j) {  // packed u16 counts[t][j] += 1
-    const uint32_t idx = t * (uint32_t)(D + 2) + j;
-    lds_add(tc + (idx >> 1), 1u << ((idx & 1u) * 16u));
-  };
-  auto add_pod = [&](uint32_t t, int64_t p) {  // lane-serial fold (queue overflow path)
-    const uint32_t present = pods.flags[p] >> kPresentShift;
+  lds_u32wp col = (lds_u32wp)(lds + L.col) + wave * kWave * kAggColSlots;
+  lds_u32wp ovq = (lds_u32wp)(lds + L.ovq) + wave * (kAggWaveOvf + 4);
+  auto add_pod = [&](uint32_t t, int64_t p, uint32_t present) {  // lane-serial fold (overflow path)
 #pragma unroll
     for (int d = 0; d < DT; ++d)
       if (d < D && ((present >> d) & 1u)) {
         const int64_t v = pods.req[(int64_t)p * D + d];
         if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
-        cnt_add(t, (uint32_t)d);
       }
-    cnt_add(t, (uint32_t)D);
+    (void)__hip_atomic_fetch_or(tpres + t, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_add(tpods + t, 1u);
   };
-  const int64_t n_tiles = (n_rows + kBlockIx - 1) / kBlockIx;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t p = tile * kBlockIx + threadIdx.x;
-    if (threadIdx.x == 0) *q_count = 0u;
-    __syncthreads();
-    // ---- phase 1: lane = pod: enumerate matches of counted pods
-    const uint32_t fl = p < n_rows ? pods.flags[p] : 0u;
-    // shouldCountIn (throttle_controller.go:217-219)
-    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
-    const bool not_finished = !(fl & kPodFinished);  // isNotFinished (pod_util.go:26-28)
-    if (countable && (not_finished || ix.n_slow != 0)) {  // terminated pods only matter for error detection
-      uint32_t lp[LT], lk[LT];
-      const uint32_t ns = pods.ns[p];
+  const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
+  const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
+  for (int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
+    const int64_t p = wt * kWave + lane;
+    const bool in = p < n_rows;
+    // ---- phase 1: lane = pod
+    const uint32_t fl = in ? pods.flags[p] : 0u;
+    const uint32_t ns = in ? pods.ns[p] : 0u;
+    uint32_t lp[LT], lk[LT];
 #pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
-      }
+    for (int l = 0; l < LT; ++l) {
+      lp[l] = (in && l < pods.L) ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
+      lk[l] = (KEYS && in && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
+    }
+    if (lane == 0) ovq[0] = 0u;
+    // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
+    // (isNotFinished, pod_util.go:26-28) and only matter for error detection
+    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    const bool not_finished = !(fl & kPodFinished);
+    const uint32_t present = fl >> kPresentShift;
+    uint32_t n_m = 0;
+    if (countable && dbg != 2 && (not_finished || ix.n_slow != 0)) {
       const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
       auto emit = [&](uint32_t t) {
-        if (!not_finished) return;  // matched but not counted
-        const uint64_t mask = __ballot(true);
-        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader) + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (base < kAggQueueCap) q[base] = (uint32_t)threadIdx.x << 20 | t;
-        else add_pod(t, p);
+        if (!not_finished) return;
+        if (n_m < kAggColSlots) {
+          col[n_m * kWave + lane] = t;  // private slot: fire and forget
+        } else {
+          const uint32_t pos = lds_add(ovq, 1u);
+          if (pos < kAggWaveOvf) ovq[4 + pos] = lane << 20 | t;
+          else add_pod(t, p, present);
+        }
+        ++n_m;
       };
       if (not_finished) {
         uint32_t rp[LT], rk[LT];
@@ -285,45 +293,95 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(PodTable pods, i
         bool matched, err;
         const int t = (int)ix.slow_thr[k];
         walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
-        if (err) cnt_add((uint32_t)t, (uint32_t)D + 1u);
+        if (err) atomicAdd(partial + (size_t)t * pstride + 2 * D + 1, 1ull);  // rare: straight to the result buffer
         if (matched) emit((uint32_t)t);
       }
     }
-    __syncthreads();
+    // ---- compaction (convergent): dense (pod << 20 | throttle) entries, in place
+    uint32_t n_dense = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kAggColSlots; ++k) {
+      const bool has = k < n_m;
+      const uint64_t mask = __ballot(has);
+      const uint32_t t = has ? col[k * kWave + lane] : 0u;
+      const uint32_t pos = n_dense + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (has) col[pos] = lane << 20 | t;
+      n_dense += (uint32_t)__popcll(mask);
+    }
     // ---- phase 2: lane = (match, dimension): fold the pod's amount into the table
-    const uint32_t qn = min(*q_count, kAggQueueCap);
-    {
+    if (dbg != 1) {
       constexpr int MPW = kWave / DT;
       const uint32_t d = lane % DT, ml = lane / DT;
-      const uint32_t wave = threadIdx.x / kWave;
-      for (uint32_t base = wave * MPW; base < qn; base += (kBlockIx / kWave) * MPW) {
+      const uint32_t n_items = n_dense + min(ovq[0], kAggWaveOvf);
+      for (uint32_t base = 0; base < n_items; base += MPW) {
         const uint32_t j = base + ml;
-        if (j >= qn) continue;
-        const uint32_t e = q[j];
+        if (j >= n_items) continue;
+        const uint32_t e = j < n_dense ? col[j] : ovq[4 + j - n_dense];
         const uint32_t t = e & 0xFFFFFu;
-        const int64_t mp = tile * kBlockIx + (e >> 20);
-        const uint32_t present = pods.flags[mp] >> kPresentShift;
-        if ((int)d < D && ((present >> d) & 1u)) {
+        const int64_t mp = wt * kWave + (e >> 20);
+        const uint32_t pres = pods.flags[mp] >> kPresentShift;
+        if ((int)d < D && ((pres >> d) & 1u)) {
           const int64_t v = pods.req[(int64_t)mp * D + d];
           if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
-          cnt_add(t, d);
         }
-        if (d == 0) cnt_add(t, (uint32_t)D);
+        if (d == 0) {
+          (void)__hip_atomic_fetch_or(tpres + t, pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          lds_add(tpods + t, 1u);
+        }
       }
     }
-    __syncthreads();
   }
-  __syncthreads();
+  __syncthreads();  // spill this workgroup's table (coalesced 16-byte stores); kt_reduce_bitmap_slabs sums the slabs
   u32x4* dst = (u32x4*)(slab + (size_t)blockIdx.x * L.tab_bytes);
   lds_u4p src = (lds_u4p)(lds + L.tab);
   for (uint32_t i = threadIdx.x; i < L.tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+}
+
+// partial[t][j] = sum over slabs: j < D values; D <= j < 2D: key seen by the slab (0/1); j == 2D: pods.
+// The error word (2D+1) is written by the scan kernel itself and left alone.
+__global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned char* slab, int n_slabs, int T, int D,
+                                                              unsigned long long* partial) {
+  constexpr int G = 16;  // slab groups: every thread streams n_slabs / 16 independent loads
+  __shared__ unsigned long long part[G][64];
+  const int stride = partial_stride(D);
+  const size_t pitch = agg_bitmap_tab_bytes(T, D);
+  const int words = T * stride;
+  const int wl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int w = blockIdx.x * 64 + wl;
+  unsigned long long acc = 0;
+  int j = 0;
+  if (w < words) {
+    const int t = w / stride;
+    j = w - t * stride;
+    if (j < D) {
+      const unsigned char* base = slab + ((size_t)t * D + j) * 8;
+#pragma unroll 16
+      for (int b = g; b < n_slabs; b += G) acc += *(const unsigned long long*)(base + b * pitch);
+    } else if (j < 2 * D) {
+      const unsigned char* base = slab + (size_t)T * D * 8 + (size_t)t * 4;
+#pragma unroll 16
+      for (int b = g; b < n_slabs; b += G) acc += (*(const unsigned int*)(base + b * pitch) >> (j - D)) & 1u;
+    } else if (j == 2 * D) {
+      const unsigned char* base = slab + (size_t)T * D * 8 + (size_t)T * 4 + (size_t)t * 4;
+#pragma unroll 16
+      for (int b = g; b < n_slabs; b += G) acc += *(const unsigned int*)(base + b * pitch);
+    }
+  }
+  part[g][wl] = acc;
+  __syncthreads();
+  if (g == 0 && w < words && j != 2 * D + 1) {
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) sum += part[k][wl];
+    partial[w] = sum;
+  }
 }
 
 #define KT_AGG_BM_CASE(DT_, LT_, KEYS_)                                                                        \
   {                                                                                                           \
     auto kfn = kt_aggregate_bitmap<DT_, LT_, KEYS_>;                                                          \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, pods, n_rows, sp, ix, slab);                                   \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, pods, n_rows, sp, ix, partial, slab, dbg);                                   \
   }
 
 // partial[t][j] = sum over workgroup slabs (j < D: values; D <= j < 2D+2: counts).
@@ -391,8 +449,9 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
     else if (2048 * 4 + 16 + tab32 <= (size_t)kMaxLds) mode = 1, q_cap = 2048, tab = tab32;
   }
   dim3 g_(nb), b_(kBlockIx);
+  static const int dbg = getenv("KT_DEBUG_MODE") ? atoi(getenv("KT_DEBUG_MODE")) : 0;
   // small-T regime: LDS table + the whole selector program as LDS-resident bitmaps
-  if (slab != nullptr && ix.bm_words != 0 && pods_per_block <= 65535) {
+  if (slab != nullptr && ix.bm_words != 0) {
     const AggBitmapLds LB = agg_bitmap_lds_layout(ix, sp.T, pods.D);
     if (LB.total <= (uint32_t)kMaxLds) {
       const size_t lds_bm = LB.total;
@@ -405,7 +464,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
       else { if (keys) KT_AGG_BM_CASE(16, 16, true) else KT_AGG_BM_CASE(16, 16, false) }
 #endif
       const int words = sp.T * partial_stride(pods.D);
-      hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D, 1, partial);
+      hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((words + 63) / 64), dim3(1024), 0, s, slab, nb, sp.T, pods.D, partial);
       return "kt_aggregate_bitmap";
     }
   }

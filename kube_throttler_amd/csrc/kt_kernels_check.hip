@@ -158,10 +158,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
 //            ~40 registers and there is no hash-chain / posting walk.
 //   phase 2, lane = (match, dimension): request rows come from the LDS tile the pods parked in phase 1.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kQueueCapBm = 4096;  // tile match queue (16 KB); beyond that a lane classifies in place
 
 // Everything the kernel needs, and nothing else: a compact argument block keeps the scalar register file
 // free of the (large) generic table descriptors, which are reached through `sp` only on rare paths.
+constexpr uint32_t kColSlots = 4;   // private match slots per pod (LDS column, plain stores)
+constexpr uint32_t kWaveOvf = 64;   // shared overflow entries per wave for pods with more matches
 struct BmCheckArgs {
   const uint32_t* ns;     // pod planes
   const uint32_t* flags;
@@ -180,7 +181,7 @@ struct BmCheckArgs {
   const void* src[6];     // LDS staging sources: rows, nsrows, nswords_off, nswords, buckets, trec
   uint32_t bytes[6];
   uint32_t off[6];        // ... and their byte offsets in LDS
-  uint32_t off_cnt, off_q, off_qcount, off_req;
+  uint32_t off_cnt, off_col, off_ovq, off_req;
   uint32_t stride, bucket_mask, n_slow;
   int32_t D, L, T, dbg;
 };
@@ -197,8 +198,8 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
-  a.off_q = take(kQueueCapBm * 4);
-  a.off_qcount = take(16);
+  a.off_col = take(kBlockIx * kColSlots * 4);
+  a.off_ovq = take((kBlockIx / kWave) * (kWaveOvf + 4) * 4);
   a.off_req = take(kBlockIx * pods.D * 8);
   const void* src[6] = {ix.bm_row_bits, ix.bm_nsrows, ix.bm_nswords_off, ix.bm_nswords, ix.bm_buckets, ix.bm_trec};
   const uint32_t bytes[6] = {ix.bm_rows * ix.bm_stride * 4, ix.bm_n_ns * ix.bm_stride * 4, (ix.bm_n_ns + 1) * 4,
@@ -208,14 +209,22 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   return a;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kt_check_bitmap — same contract as kt_check_indexed, for selector programs whose bitmap form
+// (kt_index.h) fits in LDS (the small-T regime: up to a few thousand terms).
+// WAVE-AUTONOMOUS: after the one-time staging of the tables, every wave walks its own 64-pod tiles and
+// never meets a workgroup barrier again — all of a tile's state (class counters, match column, request
+// rows) belongs to the wave that owns the 64 pods.
+//   phase 1, lane = pod:  8 branch-free bucket probes give the bitmap rows of the pod's labels; for each
+//            word its namespace can touch (~6):  x = (rows[0] | OR_l rows[r_l])[w] & nsrows[ns][w];
+//            every surviving bit is a candidate term: one TermRec read decides it; a match is a plain
+//            store into the pod's private LDS column (no atomics, no cross-lane traffic).
+//   phase 2, lane = (match, dimension): request rows come from the wave's LDS tile.
+// ---------------------------------------------------------------------------------------------------
 template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt);
-  lds_u32wp q = (lds_u32wp)(lds + a.off_q);
-  lds_u32wp q_count = (lds_u32wp)(lds + a.off_qcount);
-  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + a.off_req);
   lds_u32p l_rows = (lds_u32p)(lds + a.off[0]);
   lds_u32p l_nsrows = (lds_u32p)(lds + a.off[1]);
   lds_u32p l_nsw_off = (lds_u32p)(lds + a.off[2]);
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
   lds_u4p l_trec = (lds_u4p)(lds + a.off[5]);
 #pragma unroll
   for (int k = 0; k < 6; ++k) lds_stage(lds + a.off[k], a.src[k], a.bytes[k]);
+  __syncthreads();  // the only workgroup barrier
   const int64_t n = a.n;
   const int64_t* rows = a.rows;
   uint64_t* summary = a.summary;
@@ -231,18 +241,21 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
   const int dbg = a.dbg;
   const int D = a.D, L = a.L, T = a.T;
   const int64_t cap = a.cap;
-  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const uint32_t stride = a.stride;
-  const int64_t n_tiles = (n + kBlockIx - 1) / kBlockIx;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t i = tile * kBlockIx + threadIdx.x;
-    cnt[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) *q_count = 0u;
-    __syncthreads();
+  // this wave's private LDS areas
+  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;                 // [64] class counters
+  lds_u32wp col = (lds_u32wp)(lds + a.off_col) + wave * kWave * kColSlots;     // [kColSlots][64] matches
+  lds_u32wp ovq = (lds_u32wp)(lds + a.off_ovq) + wave * (kWaveOvf + 4);        // [0] = length, then entries
+  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + a.off_req) + (size_t)wave * kWave * D;  // [64][D]
+  const int64_t n_wtiles = (n + kWave - 1) / kWave;
+  const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
+  for (int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
+    const int64_t i = wt * kWave + lane;
     // ---- phase 1: lane = pod
     const bool in = i < n;
     const int64_t p = in ? (rows ? rows[i] : i) : 0;
-    // every load of the pod's record is issued up front (one HBM round trip per tile, not three)
+    // every load of the pod's record is issued up front (one HBM round trip per tile)
     const uint32_t fl = in ? a.flags[p] : 0u;
     const uint32_t ns = in ? a.ns[p] : 0u;
     uint32_t lp[LT], lk[LT];
@@ -257,16 +270,19 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
       for (int d = 0; d < DT; ++d) myreq[d] = (in && d < D) ? a.req[(int64_t)p * D + d] : 0;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        if (d < D) l_req[threadIdx.x * D + d] = myreq[d];
+        if (d < D) l_req[lane * D + d] = myreq[d];
     }
+    cnt[lane] = 0ull;
+    if (lane == 0) ovq[0] = 0u;
     const bool on = (fl & kPodValid) != 0;
     bool pod_err = false;
+    uint32_t n_m = 0;
     if (on) {
       // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
       pod_err = !a.ns_valid[ns];
       const SelProgram& sp = *a.sp;
       const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
-      auto classify_now = [&](uint32_t t) {  // tile queue full (pathological match counts)
+      auto classify_now = [&](uint32_t t) {  // overflow queue full (pathological match counts)
         int64_t v[DT];
         uint32_t nz = 0;
 #pragma unroll
@@ -275,18 +291,19 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
           nz |= (v[d] != 0 ? 1u : 0u) << d;
         }
         const uint32_t st = classify<DT>(recs + t, v, nz);
-        if (st != 1u) lds_add64(cnt + threadIdx.x, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
+        if (st != 1u) lds_add64(cnt + lane, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
         if (status) status[i * T + t] = (uint8_t)st;
       };
-      auto emit = [&](uint32_t t) {  // wave-aggregated push into the tile queue
-        const uint64_t mask = __ballot(true);
-        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)mask) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = lds_add(q_count, (uint32_t)__popcll(mask));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) +
-               __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (base < kQueueCapBm) q[base] = (uint32_t)threadIdx.x << 20 | t;
-        else classify_now(t);
+      auto emit = [&](uint32_t t) {
+        if (dbg == 2) return;
+        if (n_m < kColSlots) {
+          col[n_m * kWave + lane] = t;  // private slot: fire and forget
+        } else {                        // beyond the private slots: this wave's shared overflow queue
+          const uint32_t pos = lds_add(ovq, 1u);
+          if (pos < kWaveOvf) ovq[4 + pos] = lane << 20 | t;
+          else classify_now(t);
+        }
+        ++n_m;
       };
       uint32_t rp[LT], rk[LT];  // word offsets of the label rows
 #pragma unroll
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
             ok = has;
           }
           if (ok && (tr.w & (kPostComplex | kPostMulti))) ok = m.rare(tr.x, tr.y, tr.w);
-          if (ok && dbg != 2) emit(tr.y);
+          if (ok) emit(tr.y);
         }
       }
       // throttles with an unconvertible podSelector term: in-order walk (error semantics depend on term order)
@@ -328,64 +345,77 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         if (matched) emit((uint32_t)t);
       }
     }
-    __syncthreads();
-    // ---- phase 2: lane = (match, dimension): the pod's request row (LDS) and the throttle's thr[] / head[]
-    // rows are each ONE transaction per match
-    const uint32_t qn = dbg == 1 ? 0u : min(*q_count, kQueueCapBm);
-    {
-      constexpr int MPW = kWave / DT;  // matches per wave per iteration
-      const uint32_t d = lane % DT, ml = lane / DT;
-      const uint32_t wave = threadIdx.x / kWave;
-      const uint64_t gmask = (DT == 64 ? ~0ull : ((1ull << DT) - 1ull)) << (ml * DT);
-      constexpr uint32_t kStep = (kBlockIx / kWave) * MPW;
-      constexpr int U = 4;
-      const bool dd = (int)d < D;
-      for (uint32_t base = wave * MPW; base < qn; base += U * kStep) {
+    // ---- compaction (convergent code: bases live in scalar registers, no atomics): the parked matches of
+    // row k are gathered, in place, behind those of rows < k as (pod << 20 | throttle) entries
+    uint32_t n_dense = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kColSlots; ++k) {
+      const bool has = k < n_m;
+      const uint64_t mask = __ballot(has);
+      const uint32_t t = has ? col[k * kWave + lane] : 0u;
+      const uint32_t pos = n_dense + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (has) col[pos] = lane << 20 | t;
+      n_dense += (uint32_t)__popcll(mask);
+    }
+    // ---- phase 2: lane = (match, dimension pair) over the dense entries, then the overflow entries.
+    // The pod's request row (LDS) and the throttle's thr[] / head[] rows are read as 16-byte pieces.
+    if (dbg != 1) {
+      constexpr int LPM = DT / 2;        // lanes per match, two dimensions each
+      constexpr int MPW = kWave / LPM;   // matches per iteration
+      const uint32_t dp = lane % LPM, ml = lane / LPM;
+      const uint64_t gmask = ((1ull << LPM) - 1ull) << (ml * LPM);
+      const uint32_t n_ovf = min(ovq[0], kWaveOvf);
+      const uint32_t n_items = n_dense + n_ovf;
+      constexpr int U = 2;
+      for (uint32_t base = 0; base < n_items; base += U * MPW) {
         bool vv[U];
-        uint32_t pl[U], tt[U], am[U], ff[U];
-        int64_t xx[U], th[U], hd[U];
+        uint32_t pl[U], tt[U];
+        u32x2 fa[U];
+        longlong2 xx[U], th[U], hd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t j = base + u * kStep + ml;
-          vv[u] = j < qn;
-          const uint32_t e = vv[u] ? q[j] : 0u;
+          const uint32_t j = base + u * MPW + ml;
+          vv[u] = j < n_items;
+          const uint32_t e = !vv[u] ? 0u : j < n_dense ? col[j] : ovq[4 + j - n_dense];
           pl[u] = e >> 20;
           tt[u] = e & 0xFFFFFu;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const CheckRec<DT>* rc = recs + tt[u];
-          th[u] = rc->thr[d];
-          hd[u] = rc->head[d];
-          am[u] = rc->active_mask;
-          ff[u] = rc->flags;
-          xx[u] = (vv[u] && dd) ? l_req[pl[u] * D + d] : 0;
+          th[u] = *(const longlong2*)(rc->thr + 2 * dp);
+          hd[u] = *(const longlong2*)(rc->head + 2 * dp);
+          fa[u] = *(const u32x2*)&rc->flags;  // {flags, active_mask}
+          const KT_LDS int64_t* rr = l_req + pl[u] * D + 2 * dp;
+          xx[u].x = (vv[u] && (int)(2 * dp) < D) ? rr[0] : 0;
+          xx[u].y = (vv[u] && (int)(2 * dp + 1) < D) ? rr[1] : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const bool nz = vv[u] && xx[u] != 0;
-          const uint64_t be = __ballot(nz && xx[u] > th[u]), bi = __ballot(nz && xx[u] > hd[u]),
-                         ba = __ballot(nz && ((am[u] >> d) & 1u));
-          if (d == 0 && vv[u]) {
-            const bool exc = (ff[u] & kRecExceedsByCount) || (be & gmask);
-            const bool act = (ff[u] & kRecActiveByCount) || (ba & gmask);
-            const bool ins = (ff[u] & kRecInsufficientByCount) || (bi & gmask);
+          const bool nz0 = vv[u] && xx[u].x != 0, nz1 = vv[u] && xx[u].y != 0;
+          const uint32_t am = fa[u].y >> (2 * dp);
+          const uint64_t be = __ballot((nz0 && xx[u].x > th[u].x) || (nz1 && xx[u].y > th[u].y));
+          const uint64_t bi = __ballot((nz0 && xx[u].x > hd[u].x) || (nz1 && xx[u].y > hd[u].y));
+          const uint64_t ba = __ballot((nz0 && (am & 1u)) || (nz1 && (am & 2u)));
+          if (dp == 0 && vv[u]) {
+            const uint32_t ff = fa[u].x;
+            const bool exc = (ff & kRecExceedsByCount) || (be & gmask);
+            const bool act = (ff & kRecActiveByCount) || (ba & gmask);
+            const bool ins = (ff & kRecInsufficientByCount) || (bi & gmask);
             const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
             if (st != 1u) lds_add64(cnt + pl[u], st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-            if (status) status[(tile * kBlockIx + pl[u]) * T + tt[u]] = (uint8_t)st;
+            if (status) status[(wt * kWave + pl[u]) * T + tt[u]] = (uint8_t)st;
           }
         }
       }
     }
-    __syncthreads();
     // ---- phase 3: lane = pod
     if (in) {
-      const unsigned long long c = cnt[threadIdx.x];
+      const unsigned long long c = cnt[lane];
       summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
       if (status && pod_err)
         for (int t = 0; t < T; ++t) status[i * T + t] = 255;
     }
-    __syncthreads();
   }
 }
 
