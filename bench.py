@@ -137,8 +137,8 @@ def main():
     eng.timing_enable(False)
 
     k_ms = {}
-    for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("finalize", E.KERNEL_FINALIZE),
-                      ("prepare", E.KERNEL_PREPARE)):
+    for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("reduce", E.KERNEL_REDUCE),
+                      ("finalize", E.KERNEL_FINALIZE), ("prepare", E.KERNEL_PREPARE)):
         tot, n = eng.timing_read(fam)
         k_ms[name] = tot / max(n, 1)
 

@@ -152,7 +152,8 @@ int32_t kt_fetch_pod_requests(kt_engine* e, int64_t n, const int64_t* pod_rows, 
 #define KT_KERNEL_AGGREGATE 1
 #define KT_KERNEL_FINALIZE 2
 #define KT_KERNEL_PREPARE 3
-#define KT_KERNEL_COUNT 4
+#define KT_KERNEL_REDUCE 4 /* slab reduction that follows the aggregate scan kernel (when it privatises in LDS) */
+#define KT_KERNEL_COUNT 5
 int32_t kt_timing_enable(kt_engine* e, int32_t on);
 /* Sum of durations (ms) and launch count since the last reset for one kernel family; synchronises. */
 int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* launches);

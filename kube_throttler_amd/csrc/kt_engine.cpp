@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -191,7 +192,7 @@ struct kt_engine {
   // ---- staging
   DevBuf<uint8_t> d_stage;
 
-  const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check"};
+  const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check", "kt_reduce_partials"};
 
   // ---- timing
   bool timing = false;
@@ -235,9 +236,11 @@ struct TimedLaunch {
     (void)hipEventRecord(pr.first, s);
     stop = pr.second;
   }
-  ~TimedLaunch() {
+  void stop_now() {
     if (stop) (void)hipEventRecord(stop, s);
+    stop = nullptr;
   }
+  ~TimedLaunch() { stop_now(); }
 };
 
 // ---- host-side label selector evaluation (namespace selectors only; pods are matched on device) -----
@@ -963,11 +966,16 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   if (words) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
+    std::unique_ptr<TimedLaunch> tr;
+    auto after_scan = [&]() {  // the slab reduction is its own kernel: time it as its own family
+      tl.stop_now();
+      tr.reset(new TimedLaunch(e, KT_KERNEL_REDUCE, s));
+    };
     if (e->cfg.kernel_variant == 1)
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else
-      e->last_kernel[KT_KERNEL_AGGREGATE] = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s);
+      e->last_kernel[KT_KERNEL_AGGREGATE] = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;

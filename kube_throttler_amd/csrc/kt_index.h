@@ -135,8 +135,11 @@ struct SelProgram;
 // slab: scratch for the per-block LDS tables of the aggregate kernel (nullptr => global atomics only)
 size_t aggregate_slab_bytes(int T, int D);
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched.
+// after_scan (nullable) is invoked on the host right after the scan kernel is enqueued and before the slab
+// reduction kernel (if any) — the engine uses it to bracket the two kernels with separate timing events.
 const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
-                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab, hipStream_t s);
+                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab, hipStream_t s,
+                              const std::function<void()>& after_scan = nullptr);
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s);

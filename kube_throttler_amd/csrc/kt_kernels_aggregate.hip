@@ -430,7 +430,8 @@ size_t aggregate_slab_bytes(int T, int D) {
 }
 
 const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
-                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab_, hipStream_t s) {
+                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab_, hipStream_t s,
+                              const std::function<void()>& after_scan) {
   if (n_rows <= 0 || sp.T <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
   unsigned char* slab = (unsigned char*)slab_;
@@ -464,6 +465,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
       else { if (keys) KT_AGG_BM_CASE(16, 16, true) else KT_AGG_BM_CASE(16, 16, false) }
 #endif
       const int words = sp.T * partial_stride(pods.D);
+      if (after_scan) after_scan();
       hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((words + 63) / 64), dim3(1024), 0, s, slab, nb, sp.T, pods.D, partial);
       return "kt_aggregate_bitmap";
     }
@@ -474,6 +476,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
   else if (mode == 1) KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 1);
   else KT_IX_DISPATCH2(kt_aggregate_indexed, DT, LT, keys, 0);
 #undef KT_IX_ARGS
+  if (after_scan) after_scan();
   if (mode != 0) {
     const int words = sp.T * partial_stride(pods.D);
     hipLaunchKernelGGL(kt_reduce_partials, dim3((words + 63) / 64), dim3(256), 0, s, slab, nb, sp.T, pods.D,

@@ -368,14 +368,14 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
       const uint32_t n_items = n_dense + n_ovf;
       constexpr int U = 2;
       for (uint32_t base = 0; base < n_items; base += U * MPW) {
-        bool vv[U];
+        uint32_t vv[U];  // (a bool array ends up in scratch memory)
         uint32_t pl[U], tt[U];
         u32x2 fa[U];
         longlong2 xx[U], th[U], hd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + u * MPW + ml;
-          vv[u] = j < n_items;
+          vv[u] = j < n_items ? 1u : 0u;
           const uint32_t e = !vv[u] ? 0u : j < n_dense ? col[j] : ovq[4 + j - n_dense];
           pl[u] = e >> 20;
           tt[u] = e & 0xFFFFFu;
