@@ -20,18 +20,23 @@ constexpr uint8_t kOpIn = 0, kOpNotIn = 1, kOpExists = 2, kOpDoesNotExist = 3;
 constexpr uint8_t kOvrParseError = 0x1u;
 constexpr int64_t kZeroTimeS = -62135596800LL;
 
-// Pod state.  Selector-side fields are planes (pod row fastest: lane = pod => coalesced loads); the
-// request vector is one contiguous row per pod, because it is only ever GATHERED by (pod, throttle)
-// match — D lanes read one pod's row as a single 64-byte (D = 8) transaction.
+// Pod state: one 16-byte-aligned ROW per pod in each table.  lane = pod reads its label row with LS/4 and
+// its request row with DS/2 128-bit loads (a wave covers one contiguous 64 x row span: fully coalesced,
+// no per-element address math, no per-element predicates); the request row is also what the
+// (pod, throttle)-match lanes gather (D lanes read one pod's row as a single 64-byte transaction at D = 8).
+// Unused label slots hold 0 ("no label"), padding dimensions hold 0 ("not requested").
 struct PodTable {
   uint32_t* ns;     // [cap]
   uint32_t* flags;  // [cap]
-  int64_t* req;     // [cap][D]   effective request (ResourceAmountOfPod), 0 where absent
-  uint32_t* lpair;  // [L][cap]   (key,value) pair ids, 0 = empty slot
-  uint32_t* lkey;   // [L][cap]   key ids
+  int64_t* req;     // [cap][DS]  effective request (ResourceAmountOfPod), 0 where absent
+  uint32_t* lpair;  // [cap][LS]  (key,value) pair ids, 0 = empty slot
+  uint32_t* lkey;   // [cap][LS]  key ids
   int64_t cap;
   int32_t D, L;
+  int32_t DS, LS;   // row strides: DS = D rounded up to even, LS = 4 / 8 / 16 >= L
 };
+inline int req_stride(int D) { return (D + 1) & ~1; }
+inline int label_stride(int L) { return L <= 4 ? 4 : L <= 8 ? 8 : 16; }
 
 // ResourceAmount rows, row-major [n][D] like kt_amounts.
 struct AmountTab {

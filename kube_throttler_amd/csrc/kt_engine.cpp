@@ -577,7 +577,7 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   }
   *out = nullptr;
   if (cfg->n_dims < 1 || cfg->n_dims > KT_MAX_DIMS || cfg->max_labels < 1 || cfg->max_labels > KT_MAX_LABELS ||
-      cfg->pod_capacity < 1 || cfg->throttle_capacity < 1 || cfg->throttle_capacity >= (1 << 20) ||
+      cfg->pod_capacity < 1 || cfg->pod_capacity > (1ll << 31) || cfg->throttle_capacity < 1 || cfg->throttle_capacity >= (1 << 20) ||
       cfg->namespace_capacity < 1) {
     g_create_error = "invalid kt_config";
     return KT_ERR_INVALID_ARGUMENT;
@@ -606,11 +606,13 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   e->pods.cap = cfg->pod_capacity;
   e->pods.D = e->D;
   e->pods.L = e->L;
+  e->pods.DS = kt::req_stride(e->D);
+  e->pods.LS = kt::label_stride(e->L);
   if (r == hipSuccess) r = hipMalloc((void**)&e->pods.ns, cap * 4);
   if (r == hipSuccess) r = hipMalloc((void**)&e->pods.flags, cap * 4);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.req, cap * 8 * e->D);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lpair, cap * 4 * e->L);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lkey, cap * 4 * e->L);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.req, cap * 8 * e->pods.DS);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lpair, cap * 4 * e->pods.LS);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lkey, cap * 4 * e->pods.LS);
   if (r == hipSuccess) r = hipMemsetAsync(e->pods.flags, 0, cap * 4, e->own_stream);
   if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
   if (r != hipSuccess) {

@@ -2,6 +2,7 @@
 #include "kt_index.h"
 
 #include <algorithm>
+#include <cstring>
 #include <unordered_map>
 
 #include "../../include/kt_snapshot.h"
@@ -253,19 +254,26 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.n_cluster_postings = 0;
   for (const IndexSlot& sl : h.slots)
     if (sl.key != 0 && (sl.key >> 32) == 0) d.n_cluster_postings += sl.count;
-  if ((e = up(d.bm_row_bits, d.cap_bm_row_bits, h.bm_row_bits, s)) != hipSuccess) return e;
-  if ((e = up(d.bm_nsrows, d.cap_bm_nsrows, h.bm_nsrows, s)) != hipSuccess) return e;
-  if ((e = up(d.bm_nswords_off, d.cap_bm_nswords_off, h.bm_nswords_off, s)) != hipSuccess) return e;
-  if ((e = up(d.bm_nswords, d.cap_bm_nswords, h.bm_nswords, s)) != hipSuccess) return e;
-  if ((e = up(d.bm_buckets, d.cap_bm_buckets, h.bm_buckets, s)) != hipSuccess) return e;
-  if ((e = up(d.bm_trec, d.cap_bm_trec, h.bm_trec, s)) != hipSuccess) return e;
   d.bm_words = h.bm_words;
   d.bm_stride = h.bm_stride;
-  d.bm_rows = h.bm_rows;
   d.bm_bucket_mask = h.bm_bucket_mask;
-  d.bm_n_trec = (uint32_t)h.bm_trec.size();
-  d.bm_n_ns = h.bm_stride ? (uint32_t)(h.bm_nsrows.size() / h.bm_stride) : 0u;
-  d.bm_n_nswords = (uint32_t)h.bm_nswords.size();
+  d.bm_blob_bytes = 0;
+  if (h.bm_words != 0) {
+    // pack the bitmap tables into one blob (the LDS image)
+    const void* src[6] = {h.bm_row_bits.data(), h.bm_nsrows.data(), h.bm_nswords_off.data(),
+                          h.bm_nswords.data(), h.bm_buckets.data(), h.bm_trec.data()};
+    const size_t bytes[6] = {h.bm_row_bits.size() * 4, h.bm_nsrows.size() * 4, h.bm_nswords_off.size() * 4,
+                             h.bm_nswords.size() * 4, h.bm_buckets.size() * sizeof(AtomBucket),
+                             h.bm_trec.size() * sizeof(TermRec)};
+    size_t o = 0;
+    for (int k = 0; k < 6; ++k) d.bm_off[k] = (uint32_t)o, o += (bytes[k] + 15) & ~(size_t)15;
+    std::vector<unsigned char> blob(o + 16, 0);
+    for (int k = 0; k < 6; ++k)
+      if (bytes[k]) memcpy(blob.data() + d.bm_off[k], src[k], bytes[k]);
+    if ((e = up(d.bm_blob, d.cap_bm_blob, blob, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;  // `blob` is a temporary
+    d.bm_blob_bytes = (uint32_t)o;
+  }
   return hipSuccess;
 }
 
@@ -276,12 +284,7 @@ void release_index(IndexDev& d) {
   if (d.uni_ns) (void)hipFree(d.uni_ns);
   if (d.uni_cluster) (void)hipFree(d.uni_cluster);
   if (d.slow_thr) (void)hipFree(d.slow_thr);
-  if (d.bm_row_bits) (void)hipFree(d.bm_row_bits);
-  if (d.bm_nsrows) (void)hipFree(d.bm_nsrows);
-  if (d.bm_nswords_off) (void)hipFree(d.bm_nswords_off);
-  if (d.bm_nswords) (void)hipFree(d.bm_nswords);
-  if (d.bm_buckets) (void)hipFree(d.bm_buckets);
-  if (d.bm_trec) (void)hipFree(d.bm_trec);
+  if (d.bm_blob) (void)hipFree(d.bm_blob);
   d = IndexDev();
 }
 

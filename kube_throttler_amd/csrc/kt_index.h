@@ -110,14 +110,13 @@ struct IndexDev {
   uint32_t has_key_atoms = 0;
   uint32_t n_slots = 0, n_postings = 0;
   uint32_t n_cluster_postings = 0;  // postings filed under scope 0 come first in the array
-  uint32_t bm_words = 0, bm_stride = 0, bm_rows = 0, bm_bucket_mask = 0, bm_n_trec = 0, bm_n_ns = 0, bm_n_nswords = 0;
-  uint32_t* bm_row_bits = nullptr;
-  uint32_t* bm_nsrows = nullptr;
-  uint32_t* bm_nswords_off = nullptr;
-  uint32_t* bm_nswords = nullptr;
-  AtomBucket* bm_buckets = nullptr;
-  TermRec* bm_trec = nullptr;
-  size_t cap_bm_row_bits = 0, cap_bm_nsrows = 0, cap_bm_nswords_off = 0, cap_bm_nswords = 0, cap_bm_buckets = 0, cap_bm_trec = 0;
+  // bitmap form: ONE device blob holding the six tables back to back (16-byte aligned pieces, in the order
+  // rows, nsrows, nswords_off, nswords, buckets, trec) — the kernels copy it to LDS with one streaming loop
+  uint32_t bm_words = 0, bm_stride = 0, bm_bucket_mask = 0;
+  unsigned char* bm_blob = nullptr;
+  uint32_t bm_blob_bytes = 0;
+  uint32_t bm_off[6] = {0, 0, 0, 0, 0, 0};  // byte offsets of the tables inside the blob
+  size_t cap_bm_blob = 0;
   size_t cap_slots = 0, cap_postings = 0, cap_uni_ns_off = 0, cap_uni_ns = 0, cap_uni_cluster = 0, cap_slow = 0;
 };
 

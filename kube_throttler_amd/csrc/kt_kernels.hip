@@ -56,14 +56,14 @@ __global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatch
         if ((op >> d) & 1u) c[d] += b.ovh[i * D + d];
       cp |= op & 0xFFFFu;
     }
-    for (int d = 0; d < D; ++d) pods.req[(int64_t)row * pods.D + d] = ((cp >> d) & 1u) ? c[d] : 0;
+    for (int d = 0; d < pods.DS; ++d) pods.req[(int64_t)row * pods.DS + d] = (d < D && ((cp >> d) & 1u)) ? c[d] : 0;
     pods.ns[row] = b.ns[i];
     pods.flags[row] = (b.flags[i] & 0xFu) | (cp << kPresentShift);
     const uint32_t l0 = b.label_off[i] - b.label_base, l1 = b.label_off[i + 1] - b.label_base;
-    for (int l = 0; l < L; ++l) {
-      const bool have = l0 + l < l1;
-      pods.lpair[(int64_t)l * pods.cap + row] = have ? b.label_pair[l0 + l] : 0u;
-      pods.lkey[(int64_t)l * pods.cap + row] = have ? b.label_key[l0 + l] : 0u;
+    for (int l = 0; l < pods.LS; ++l) {
+      const bool have = l < L && l0 + l < l1;
+      pods.lpair[(int64_t)row * pods.LS + l] = have ? b.label_pair[l0 + l] : 0u;
+      pods.lkey[(int64_t)row * pods.LS + l] = have ? b.label_key[l0 + l] : 0u;
     }
   }
 }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void kt_gather_pod_requests(PodTable pods, 
                                                                 int64_t* out_v, uint32_t* out_present) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const int64_t row = rows ? rows[i] : i;
-    for (int d = 0; d < pods.D; ++d) out_v[i * pods.D + d] = pods.req[(int64_t)row * pods.D + d];
+    for (int d = 0; d < pods.D; ++d) out_v[i * pods.D + d] = pods.req[(int64_t)row * pods.DS + d];
     out_present[i] = pods.flags[row] >> kPresentShift;
   }
 }

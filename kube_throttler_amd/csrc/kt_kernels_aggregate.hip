@@ -1,5 +1,5 @@
 // kt_kernels_aggregate.hip — kt_aggregate_indexed + kt_reduce_partials: per-throttle `used` through the index.
-#include "kt_index_device.h"
+#include "kt_bitmap_scan.h"
 
 namespace kt {
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
 #pragma unroll
     for (int d = 0; d < DT; ++d)
       if (d < D && ((present >> d) & 1u)) {
-        const int64_t v = pods.req[(int64_t)p * D + d];
+        const int64_t v = pods.req[(int64_t)p * pods.DS + d];
         if (LDSTAB) {
           if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
           cnt_add(t, (uint32_t)d);
@@ -79,11 +79,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
     if (countable && (not_finished || ix.n_slow != 0)) {  // terminated pods only matter for error detection
       uint32_t lp[LT], lk[LT];
       const uint32_t ns = pods.ns[p];
-#pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
-      }
+      load_labels<LT, KEYS>(pods.lpair, pods.lkey, pods.LS, p, lp, lk);
       auto on_match = [&](uint32_t t) {
         if (!not_finished) return;  // matched but not counted
         // wave-aggregated push (one LDS atomic per wave); a full queue folds the pod in directly
@@ -127,7 +123,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
         const int64_t mp = tile * kBlockIx + (e >> 20);
         const uint32_t present = pods.flags[mp] >> kPresentShift;
         if ((int)d < D && ((present >> d) & 1u)) {
-          const int64_t v = pods.req[(int64_t)mp * D + d];
+          const int64_t v = pods.req[(int64_t)mp * pods.DS + d];
           if (LDSTAB) {
             if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
             cnt_add(t, d);
@@ -161,180 +157,121 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
 // Key presence travels as a mask here and is expanded to 0/1 contributor counts by kt_reduce_bitmap_slabs
 // (sum > 0 <=> some workgroup saw the key), so the all-reduced buffer keeps the [T][2D+2] layout.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kAggColSlots = 4, kAggWaveOvf = 64;
-struct AggBitmapLds {
-  uint32_t col, ovq, tab, rows, nsrows, nswords_off, nswords, buckets, trec, total, tab_bytes;
-};
 __host__ __device__ inline uint32_t agg_bitmap_tab_bytes(int T, int D) { return (uint32_t)(((size_t)T * D * 8 + (size_t)T * 8 + 15) & ~(size_t)15); }
-__host__ __device__ inline AggBitmapLds agg_bitmap_lds_layout(const IndexDev& ix, int T, int D) {
-  AggBitmapLds L;
+
+// compact argument block (see BmCheckArgs): the scalar register file only holds what the tile loop uses
+struct BmAggArgs {
+  const uint32_t* ns;  // pod tables
+  const uint32_t* flags;
+  const int64_t* req;
+  const uint32_t* lpair;
+  const uint32_t* lkey;
+  const SelProgram* sp;
+  const uint32_t* slow_thr;
+  unsigned long long* partial;
+  unsigned char* slab;
+  int64_t n_rows;
+  BmIndexArgs ix;
+  uint32_t off_list, off_tab, tab_bytes;
+  uint32_t n_slow;
+  int32_t D, DS, LS, T;
+};
+
+static BmAggArgs make_bm_agg_args(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
+                                  const IndexDev& ix, unsigned long long* partial, unsigned char* slab, uint32_t* total) {
+  BmAggArgs a{};
+  a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
+  a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab, a.n_rows = n_rows;
+  a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
-  L.col = take(kBlockIx * kAggColSlots * 4);
-  L.ovq = take((kBlockIx / kWave) * (kAggWaveOvf + 4) * 4);
-  L.tab_bytes = agg_bitmap_tab_bytes(T, D);
-  L.tab = take(L.tab_bytes);
-  L.rows = take(ix.bm_rows * ix.bm_stride * 4);
-  L.nsrows = take(ix.bm_n_ns * ix.bm_stride * 4);
-  L.nswords_off = take((ix.bm_n_ns + 1) * 4);
-  L.nswords = take(ix.bm_n_nswords * 4);
-  L.buckets = take((ix.bm_bucket_mask + 1) * 32);
-  L.trec = take(ix.bm_n_trec * 16);
-  L.total = o;
-  return L;
+  a.off_list = take((kBlockIx / kWave) * kListCap * 4);
+  a.tab_bytes = agg_bitmap_tab_bytes(sp.T, pods.D);
+  a.off_tab = take(a.tab_bytes);
+  plan_bitmap_index(ix, a.ix, take);
+  *total = o;
+  return a;
 }
 
+// kt_aggregate_bitmap — `used` partials of this GPU's pod rows (reconcile aggregation,
+// throttle_controller.go:116-133) for selector programs whose bitmap form fits in LDS.
+// Wave-autonomous like kt_check_bitmap: lane = pod finds the tile's (pod, throttle) matches
+// (bitmap_scan_tile), lane = (match, dimension pair) folds ResourceAmountOfPod into the workgroup's LDS
+// table  tv i64[T][D] | tpres u32[T] (request-key presence mask) | tpods u32[T];  the table is spilled to
+// this workgroup's slab at the end and kt_reduce_bitmap_slabs sums the slabs.
 template <int DT, int LT, bool KEYS>
-__global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(PodTable pods, int64_t n_rows, SelProgram sp,
-                                                               IndexDev ix, unsigned long long* partial,
-                                                               unsigned char* slab, int dbg) {
-  const int D = pods.D, T = sp.T, pstride = partial_stride(D);
-  const AggBitmapLds L = agg_bitmap_lds_layout(ix, T, D);
+__global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
+  const int D = a.D, DS = a.DS, T = a.T;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u64wp tv = (lds_u64wp)(lds + L.tab);
-  lds_u32wp tpres = (lds_u32wp)(lds + L.tab + (uint32_t)T * D * 8);
+  lds_u64wp tv = (lds_u64wp)(lds + a.off_tab);
+  lds_u32wp tpres = (lds_u32wp)(lds + a.off_tab + (uint32_t)T * D * 8);
   lds_u32wp tpods = tpres + T;
-  lds_u32p l_rows = (lds_u32p)(lds + L.rows);
-  lds_u32p l_nsrows = (lds_u32p)(lds + L.nsrows);
-  lds_u32p l_nsw_off = (lds_u32p)(lds + L.nswords_off);
-  lds_u32p l_nsw = (lds_u32p)(lds + L.nswords);
-  lds_u4p l_buckets = (lds_u4p)(lds + L.buckets);
-  lds_u4p l_trec = (lds_u4p)(lds + L.trec);
-  for (uint32_t i = threadIdx.x; i < L.tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + L.tab))[i] = 0u;
-  lds_stage(lds + L.rows, ix.bm_row_bits, ix.bm_rows * ix.bm_stride * 4);
-  lds_stage(lds + L.nsrows, ix.bm_nsrows, ix.bm_n_ns * ix.bm_stride * 4);
-  lds_stage(lds + L.nswords_off, ix.bm_nswords_off, (ix.bm_n_ns + 1) * 4);
-  lds_stage(lds + L.nswords, ix.bm_nswords, ix.bm_n_nswords * 4);
-  lds_stage(lds + L.buckets, ix.bm_buckets, (ix.bm_bucket_mask + 1) * 32);
-  lds_stage(lds + L.trec, ix.bm_trec, ix.bm_n_trec * 16);
+  for (uint32_t i = threadIdx.x; i < a.tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
+  const BmView bm = stage_bitmap_index(lds, a.ix);
   __syncthreads();
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const uint32_t stride = ix.bm_stride;
-  lds_u32wp col = (lds_u32wp)(lds + L.col) + wave * kWave * kAggColSlots;
-  lds_u32wp ovq = (lds_u32wp)(lds + L.ovq) + wave * (kAggWaveOvf + 4);
-  auto add_pod = [&](uint32_t t, int64_t p, uint32_t present) {  // lane-serial fold (overflow path)
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-      if (d < D && ((present >> d) & 1u)) {
-        const int64_t v = pods.req[(int64_t)p * D + d];
-        if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
-      }
-    (void)__hip_atomic_fetch_or(tpres + t, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    lds_add(tpods + t, 1u);
-  };
+  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;
+  constexpr int LPM = DT / 2, MPW = kWave / LPM;
+  const uint32_t dp = lane % LPM, ml = lane / LPM;
+  const bool dp_in = (int)(2 * dp) < DS;
+  const uint32_t dpo = dp_in ? 2 * dp : 0u;
+  const int64_t n_rows = a.n_rows;
   const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
   for (int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
-    const int64_t p = wt * kWave + lane;
-    const bool in = p < n_rows;
-    // ---- phase 1: lane = pod
-    const uint32_t fl = in ? pods.flags[p] : 0u;
-    const uint32_t ns = in ? pods.ns[p] : 0u;
+    // ---- phase 1: lane = pod (lanes past the end re-read the last row and are switched off)
+    const int64_t i = wt * kWave + lane;
+    const bool in = i < n_rows;
+    const int64_t p = in ? i : n_rows - 1;
+    const uint32_t fl = a.flags[p];
+    const uint32_t ns_raw = a.ns[p];
     uint32_t lp[LT], lk[LT];
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      lp[l] = (in && l < pods.L) ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-      lk[l] = (KEYS && in && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
+    load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, lp, lk);
+    (void)*(const volatile uint32_t*)(a.req + p * DS);  // phase 2 gathers the row: have it L2-resident by then
+    {  // next tile's records: start their trip from HBM now
+      const int64_t pn = min(i + wstep * kWave, n_rows - 1);
+      (void)*(const volatile uint32_t*)(a.lpair + pn * a.LS);
+      if (KEYS) (void)*(const volatile uint32_t*)(a.lkey + pn * a.LS);
+      if (lane < 4) {
+        const int64_t pb = min((wt + wstep) * kWave + (lane & 1) * 32, n_rows - 1);
+        (void)*(const volatile uint32_t*)((lane & 2 ? a.flags : a.ns) + pb);
+      }
     }
-    if (lane == 0) ovq[0] = 0u;
     // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
     // (isNotFinished, pod_util.go:26-28) and only matter for error detection
-    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    const bool countable = in && (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
     const bool not_finished = !(fl & kPodFinished);
-    const uint32_t present = fl >> kPresentShift;
-    uint32_t n_m = 0;
-    if (countable && dbg != 2 && (not_finished || ix.n_slow != 0)) {
-      const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
-      auto emit = [&](uint32_t t) {
-        if (!not_finished) return;
-        if (n_m < kAggColSlots) {
-          col[n_m * kWave + lane] = t;  // private slot: fire and forget
-        } else {
-          const uint32_t pos = lds_add(ovq, 1u);
-          if (pos < kAggWaveOvf) ovq[4 + pos] = lane << 20 | t;
-          else add_pod(t, p, present);
-        }
-        ++n_m;
-      };
-      if (not_finished) {
-        uint32_t rp[LT], rk[LT];
-#pragma unroll
-        for (int l = 0; l < LT; ++l) {
-          rp[l] = atom_row(l_buckets, ix.bm_bucket_mask, lp[l]) * stride;
-          rk[l] = KEYS ? atom_row(l_buckets, ix.bm_bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
-        }
-        const uint32_t k1 = l_nsw_off[ns + 1];
-        for (uint32_t k = l_nsw_off[ns]; k < k1; ++k) {
-          const uint32_t w = l_nsw[k];
-          uint32_t x = l_rows[w];
-#pragma unroll
-          for (int l = 0; l < LT; ++l) {
-            x |= l_rows[rp[l] + w];
-            if (KEYS) x |= l_rows[rk[l] + w];
-          }
-          x &= l_nsrows[ns * stride + w];
-          while (x) {
-            const uint32_t c = w * 32u + (uint32_t)__ffs((int)x) - 1u;
-            x &= x - 1u;
-            const u32x4 tr = l_trec[c];  // {g, t, pair2, flags}
-            bool ok = true;
-            if (tr.w & kPostPair2) {
-              bool has = false;
-#pragma unroll
-              for (int l = 0; l < LT; ++l) has |= lp[l] == tr.z;
-              ok = has;
-            }
-            if (ok && (tr.w & (kPostComplex | kPostMulti))) ok = m.rare(tr.x, tr.y, tr.w);
-            if (ok) emit(tr.y);
-          }
-        }
-      }
-      for (uint32_t k = 0; k < ix.n_slow; ++k) {
-        bool matched, err;
-        const int t = (int)ix.slow_thr[k];
-        walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
-        if (err) atomicAdd(partial + (size_t)t * pstride + 2 * D + 1, 1ull);  // rare: straight to the result buffer
-        if (matched) emit((uint32_t)t);
-      }
-    }
-    // ---- compaction (convergent): dense (pod << 20 | throttle) entries, in place
-    uint32_t n_dense = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kAggColSlots; ++k) {
-      const bool has = k < n_m;
-      const uint64_t mask = __ballot(has);
-      const uint32_t t = has ? col[k * kWave + lane] : 0u;
-      const uint32_t pos = n_dense + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (has) col[pos] = lane << 20 | t;
-      n_dense += (uint32_t)__popcll(mask);
-    }
-    // ---- phase 2: lane = (match, dimension): fold the pod's amount into the table
-    if (dbg != 1) {
-      constexpr int MPW = kWave / DT;
-      const uint32_t d = lane % DT, ml = lane / DT;
-      const uint32_t n_items = n_dense + min(ovq[0], kAggWaveOvf);
+    const uint32_t ns = countable ? ns_raw : 0u;
+
+    auto drain = [&](uint32_t n_items) {
+      // ---- phase 2: lane = (match, dimension pair): fold the pod's amount into the table
       for (uint32_t base = 0; base < n_items; base += MPW) {
         const uint32_t j = base + ml;
-        if (j >= n_items) continue;
-        const uint32_t e = j < n_dense ? col[j] : ovq[4 + j - n_dense];
+        const bool vv = j < n_items;
+        const uint32_t e = list[vv ? j : 0u];
         const uint32_t t = e & 0xFFFFFu;
-        const int64_t mp = wt * kWave + (e >> 20);
-        const uint32_t pres = pods.flags[mp] >> kPresentShift;
-        if ((int)d < D && ((pres >> d) & 1u)) {
-          const int64_t v = pods.req[(int64_t)mp * D + d];
-          if (v != 0) lds_add64(tv + t * (uint32_t)D + d, (unsigned long long)v);
-        }
-        if (d == 0) {
-          (void)__hip_atomic_fetch_or(tpres + t, pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          lds_add(tpods + t, 1u);
+        const uint32_t mp = (uint32_t)(wt * kWave) + (e >> 20);  // pod_capacity <= 2^31
+        const kt_i64x2 x = *(const kt_i64x2*)(a.req + (uint64_t)mp * (uint32_t)DS + dpo);
+        const uint32_t pres = a.flags[mp] >> kPresentShift;
+        if (vv && dp_in) {
+          if (x.x != 0) lds_add64(tv + t * (uint32_t)D + 2 * dp, (unsigned long long)x.x);
+          if (x.y != 0) lds_add64(tv + t * (uint32_t)D + 2 * dp + 1, (unsigned long long)x.y);  // padding dimension is 0
+          if (dp == 0) {
+            (void)__hip_atomic_fetch_or(tpres + t, pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add(tpods + t, 1u);
+          }
         }
       }
-    }
+    };
+    bitmap_scan_tile<LT, KEYS>(bm, a.sp, a.slow_thr, a.n_slow, countable && not_finished, countable, ns, lp, lk, list, lane,
+                               drain, [&](uint32_t t) {  // rare: straight to the result buffer
+                                 atomicAdd(a.partial + (size_t)t * partial_stride(D) + 2 * D + 1, 1ull);
+                               });
   }
   __syncthreads();  // spill this workgroup's table (coalesced 16-byte stores); kt_reduce_bitmap_slabs sums the slabs
-  u32x4* dst = (u32x4*)(slab + (size_t)blockIdx.x * L.tab_bytes);
-  lds_u4p src = (lds_u4p)(lds + L.tab);
-  for (uint32_t i = threadIdx.x; i < L.tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+  u32x4* dst = (u32x4*)(a.slab + (size_t)blockIdx.x * a.tab_bytes);
+  lds_u4p src = (lds_u4p)(lds + a.off_tab);
+  for (uint32_t i = threadIdx.x; i < a.tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
 }
 
 // partial[t][j] = sum over slabs: j < D values; D <= j < 2D: key seen by the slab (0/1); j == 2D: pods.
@@ -381,7 +318,7 @@ __global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned ch
   {                                                                                                           \
     auto kfn = kt_aggregate_bitmap<DT_, LT_, KEYS_>;                                                          \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, pods, n_rows, sp, ix, partial, slab, dbg);                                   \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                      \
   }
 
 // partial[t][j] = sum over workgroup slabs (j < D: values; D <= j < 2D+2: counts).
@@ -450,12 +387,12 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
     else if (2048 * 4 + 16 + tab32 <= (size_t)kMaxLds) mode = 1, q_cap = 2048, tab = tab32;
   }
   dim3 g_(nb), b_(kBlockIx);
-  static const int dbg = getenv("KT_DEBUG_MODE") ? atoi(getenv("KT_DEBUG_MODE")) : 0;
   // small-T regime: LDS table + the whole selector program as LDS-resident bitmaps
   if (slab != nullptr && ix.bm_words != 0) {
-    const AggBitmapLds LB = agg_bitmap_lds_layout(ix, sp.T, pods.D);
-    if (LB.total <= (uint32_t)kMaxLds) {
-      const size_t lds_bm = LB.total;
+    uint32_t bm_total = 0;
+    const BmAggArgs bm_args = make_bm_agg_args(pods, n_rows, sp, sp_dev, ix, partial, slab, &bm_total);
+    if (bm_total <= (uint32_t)kMaxLds) {
+      const size_t lds_bm = bm_total;
 #ifdef KT_FAST_BUILD
       KT_AGG_BM_CASE(8, 8, false)
 #else

@@ -1,5 +1,5 @@
 // kt_kernels_check.hip — kt_check_indexed: PreFilter for n pods through the label-atom index (gfx950).
-#include "kt_index_device.h"
+#include "kt_bitmap_scan.h"
 
 namespace kt {
 
@@ -67,11 +67,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
     if (on) {
       uint32_t lp[LT], lk[LT];
       const uint32_t ns = pods.ns[p];
-#pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-        lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
-      }
+      load_labels<LT, KEYS>(pods.lpair, pods.lkey, pods.LS, p, lp, lk);
       // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
       pod_err = !sp.ns_valid[ns];
       auto on_match = [&](uint32_t t) {
@@ -81,7 +77,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
         uint32_t nz = 0;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          v[d] = d < pods.D ? pods.req[(int64_t)p * pods.D + d] : 0;
+          v[d] = d < pods.D ? pods.req[(int64_t)p * pods.DS + d] : 0;
           nz |= (v[d] != 0 ? 1u : 0u) << d;
         }
         const uint32_t st = classify<DT>(recs + t, v, nz);
@@ -119,7 +115,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
         const int64_t mi = tile * kBlockIx + pl;
         const int64_t mp = rows ? rows[valid ? mi : 0] : mi;
         const CheckRec<DT>* rc = recs + t;
-        const int64_t v = (valid && (int)d < pods.D) ? pods.req[(int64_t)mp * pods.D + d] : 0;
+        const int64_t v = (valid && (int)d < pods.D) ? pods.req[(int64_t)mp * pods.DS + d] : 0;
         const bool nz = v != 0;
         const uint32_t amask = rc->active_mask;
         const bool exc_d = valid && nz && v > rc->thr[d];
@@ -152,270 +148,172 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
 // ---------------------------------------------------------------------------------------------------
 // kt_check_bitmap — same contract as kt_check_indexed, for selector programs whose bitmap form
 // (kt_index.h) fits in LDS (the small-T regime: up to a few thousand terms).
-//   phase 1, lane = pod:  8 branch-free bucket probes give the bitmap rows of the pod's labels; for each
-//            word its namespace can touch (~6):  x = (rows[0] | OR_l rows[r_l])[w] & nsrows[ns][w];
-//            every surviving bit is a candidate term: one TermRec read decides it.  Per-lane state is
-//            ~40 registers and there is no hash-chain / posting walk.
-//   phase 2, lane = (match, dimension): request rows come from the LDS tile the pods parked in phase 1.
+// WAVE-AUTONOMOUS: after the one-time staging of the tables, every wave walks its own 64-pod tiles and
+// never meets a workgroup barrier again — all of a tile's state (class counters, match list, request
+// rows) belongs to the wave that owns the 64 pods.
+//   phase 1, lane = pod: the pod's record arrives as 128-bit row loads (2 for 8 labels, 4 for 8 request
+//            dimensions) issued back to back; bitmap_scan_tile (kt_bitmap_scan.h) turns it into the
+//            tile's dense match list.
+//   phase 2, lane = (match, dimension pair): CheckThrottledFor through the CheckRec algebra; the pod's
+//            request row comes from the wave's LDS tile, thr[] / head[] as 16-byte pieces from L2.
+//   phase 3, lane = pod: the 8-byte summary word.
 // ---------------------------------------------------------------------------------------------------
 
 // Everything the kernel needs, and nothing else: a compact argument block keeps the scalar register file
 // free of the (large) generic table descriptors, which are reached through `sp` only on rare paths.
-constexpr uint32_t kColSlots = 4;   // private match slots per pod (LDS column, plain stores)
-constexpr uint32_t kWaveOvf = 64;   // shared overflow entries per wave for pods with more matches
 struct BmCheckArgs {
-  const uint32_t* ns;     // pod planes
+  const uint32_t* ns;  // pod tables
   const uint32_t* flags;
   const int64_t* req;
   const uint32_t* lpair;
   const uint32_t* lkey;
-  int64_t cap;
-  int64_t n;
   const int64_t* rows;
   const void* recs;
   uint64_t* summary;
   uint8_t* status;
-  const SelProgram* sp;   // device copy (rare term shapes, slow throttles)
+  const SelProgram* sp;  // device copy (rare term shapes, slow throttles)
   const uint8_t* ns_valid;
   const uint32_t* slow_thr;
-  const void* src[6];     // LDS staging sources: rows, nsrows, nswords_off, nswords, buckets, trec
-  uint32_t bytes[6];
-  uint32_t off[6];        // ... and their byte offsets in LDS
-  uint32_t off_cnt, off_col, off_ovq, off_req;
-  uint32_t stride, bucket_mask, n_slow;
-  int32_t D, L, T, dbg;
+  int64_t n;
+  BmIndexArgs ix;
+  uint32_t off_cnt, off_list, off_prow;
+  uint32_t n_slow;
+  int32_t DS, LS, T;
 };
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
                                       const SelProgram* sp_dev, const IndexDev& ix, const void* recs,
-                                      uint64_t* summary, uint8_t* status, int dbg, uint32_t* total) {
+                                      uint64_t* summary, uint8_t* status, uint32_t* total) {
   BmCheckArgs a{};
   a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
-  a.cap = pods.cap, a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
+  a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
   a.sp = sp_dev, a.ns_valid = sp.ns_valid, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow;
-  a.D = pods.D, a.L = pods.L, a.T = sp.T, a.dbg = dbg;
-  a.stride = ix.bm_stride, a.bucket_mask = ix.bm_bucket_mask;
+  a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
-  a.off_col = take(kBlockIx * kColSlots * 4);
-  a.off_ovq = take((kBlockIx / kWave) * (kWaveOvf + 4) * 4);
-  a.off_req = take(kBlockIx * pods.D * 8);
-  const void* src[6] = {ix.bm_row_bits, ix.bm_nsrows, ix.bm_nswords_off, ix.bm_nswords, ix.bm_buckets, ix.bm_trec};
-  const uint32_t bytes[6] = {ix.bm_rows * ix.bm_stride * 4, ix.bm_n_ns * ix.bm_stride * 4, (ix.bm_n_ns + 1) * 4,
-                             ix.bm_n_nswords * 4, (ix.bm_bucket_mask + 1) * 32, ix.bm_n_trec * 16};
-  for (int k = 0; k < 6; ++k) a.src[k] = src[k], a.bytes[k] = bytes[k], a.off[k] = take(bytes[k]);
+  a.off_list = take((kBlockIx / kWave) * kListCap * 4);
+  a.off_prow = take(kBlockIx * 4);
+  plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// kt_check_bitmap — same contract as kt_check_indexed, for selector programs whose bitmap form
-// (kt_index.h) fits in LDS (the small-T regime: up to a few thousand terms).
-// WAVE-AUTONOMOUS: after the one-time staging of the tables, every wave walks its own 64-pod tiles and
-// never meets a workgroup barrier again — all of a tile's state (class counters, match column, request
-// rows) belongs to the wave that owns the 64 pods.
-//   phase 1, lane = pod:  8 branch-free bucket probes give the bitmap rows of the pod's labels; for each
-//            word its namespace can touch (~6):  x = (rows[0] | OR_l rows[r_l])[w] & nsrows[ns][w];
-//            every surviving bit is a candidate term: one TermRec read decides it; a match is a plain
-//            store into the pod's private LDS column (no atomics, no cross-lane traffic).
-//   phase 2, lane = (match, dimension): request rows come from the wave's LDS tile.
-// ---------------------------------------------------------------------------------------------------
+// OR over the LPM consecutive lanes of a match group (LPM = 4 or 8): data-parallel primitives, no LDS traffic
+template <int LPM>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  if (LPM == 8) v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  return v;
+}
+
 template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
-  const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u32p l_rows = (lds_u32p)(lds + a.off[0]);
-  lds_u32p l_nsrows = (lds_u32p)(lds + a.off[1]);
-  lds_u32p l_nsw_off = (lds_u32p)(lds + a.off[2]);
-  lds_u32p l_nsw = (lds_u32p)(lds + a.off[3]);
-  lds_u4p l_buckets = (lds_u4p)(lds + a.off[4]);
-  lds_u4p l_trec = (lds_u4p)(lds + a.off[5]);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) lds_stage(lds + a.off[k], a.src[k], a.bytes[k]);
+  const BmView bm = stage_bitmap_index(lds, a.ix);
   __syncthreads();  // the only workgroup barrier
+  const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const int64_t n = a.n;
-  const int64_t* rows = a.rows;
-  uint64_t* summary = a.summary;
-  uint8_t* status = a.status;
-  const int dbg = a.dbg;
-  const int D = a.D, L = a.L, T = a.T;
-  const int64_t cap = a.cap;
+  const int DS = a.DS;
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const uint32_t stride = a.stride;
   // this wave's private LDS areas
-  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;                 // [64] class counters
-  lds_u32wp col = (lds_u32wp)(lds + a.off_col) + wave * kWave * kColSlots;     // [kColSlots][64] matches
-  lds_u32wp ovq = (lds_u32wp)(lds + a.off_ovq) + wave * (kWaveOvf + 4);        // [0] = length, then entries
-  KT_LDS int64_t* l_req = (KT_LDS int64_t*)(lds + a.off_req) + (size_t)wave * kWave * D;  // [64][D]
+  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;         // [64] class counters
+  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;    // match list
+  lds_u32wp prow = (lds_u32wp)(lds + a.off_prow) + wave * kWave;       // [64] pod table rows of the tile
+  // phase-2 lane mapping: LPM lanes per match, two dimensions each
+  constexpr int LPM = DT / 2, MPW = kWave / LPM;
+  const uint32_t dp = lane % LPM, ml = lane / LPM;
+  const bool dp_in = (int)(2 * dp) < DS;
+  const uint32_t dpo = dp_in ? 2 * dp : 0u;
   const int64_t n_wtiles = (n + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
-  for (int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
-    const int64_t i = wt * kWave + lane;
-    // ---- phase 1: lane = pod
-    const bool in = i < n;
-    const int64_t p = in ? (rows ? rows[i] : i) : 0;
-    // every load of the pod's record is issued up front (one HBM round trip per tile)
-    const uint32_t fl = in ? a.flags[p] : 0u;
-    const uint32_t ns = in ? a.ns[p] : 0u;
+
+  // A tile's pod records: 2 + LT/4 (+ LT/4) loads per lane, always from valid addresses (lanes past the end
+  // re-read the last pod and are switched off by `on`).  The request row is only touched: phase 2 gathers it
+  // from L2.  Tiles are loaded ONE ROUND AHEAD, so a round never starts by waiting for HBM.
+  struct Tile {
+    uint32_t fl, ns, p;
     uint32_t lp[LT], lk[LT];
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      lp[l] = (in && l < L) ? a.lpair[(int64_t)l * cap + p] : 0u;
-      lk[l] = (KEYS && in && l < L) ? a.lkey[(int64_t)l * cap + p] : 0u;
-    }
-    {  // park this pod's request row in LDS (coalesced 8*D bytes per lane) for phase 2
-      int64_t myreq[DT];
-#pragma unroll
-      for (int d = 0; d < DT; ++d) myreq[d] = (in && d < D) ? a.req[(int64_t)p * D + d] : 0;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-        if (d < D) l_req[lane * D + d] = myreq[d];
-    }
+  };
+  auto load_tile = [&](int64_t wt, Tile& t) {
+    const int64_t i = min(wt * kWave + lane, n - 1);
+    const int64_t p = a.rows ? a.rows[i] : i;
+    t.p = (uint32_t)p;  // pod_capacity <= 2^31
+    t.fl = a.flags[p];
+    t.ns = a.ns[p];
+    load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
+    (void)*(const volatile uint32_t*)(a.req + p * DS);
+  };
+  int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+  Tile cur;
+  if (wt < n_wtiles) load_tile(wt, cur);
+  for (; wt < n_wtiles; wt += wstep) {
+    Tile nxt;
+    load_tile(min(wt + wstep, n_wtiles - 1), nxt);
+    // ---- phase 1: lane = pod
+    const int64_t i = wt * kWave + lane;
+    const bool in = i < n;
     cnt[lane] = 0ull;
-    if (lane == 0) ovq[0] = 0u;
-    const bool on = (fl & kPodValid) != 0;
-    bool pod_err = false;
-    uint32_t n_m = 0;
-    if (on) {
-      // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
-      pod_err = !a.ns_valid[ns];
-      const SelProgram& sp = *a.sp;
-      const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
-      auto classify_now = [&](uint32_t t) {  // overflow queue full (pathological match counts)
-        int64_t v[DT];
-        uint32_t nz = 0;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          v[d] = d < D ? a.req[(int64_t)p * D + d] : 0;
-          nz |= (v[d] != 0 ? 1u : 0u) << d;
-        }
-        const uint32_t st = classify<DT>(recs + t, v, nz);
-        if (st != 1u) lds_add64(cnt + lane, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-        if (status) status[i * T + t] = (uint8_t)st;
+    prow[lane] = cur.p;
+    const bool on = in && (cur.fl & kPodValid) != 0;
+    const uint32_t ns = on ? cur.ns : 0u;
+    // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
+    bool pod_err = on & (a.ns_valid[ns] == 0);
+
+    auto drain = [&](uint32_t n_items) {
+      // ---- phase 2: lane = (match, dimension pair); operands are fetched one step ahead of their use
+      struct Ops {
+        uint32_t vv, pl, tt;
+        u32x2 fa;
+        kt_i64x2 xx, th, hd;
       };
-      auto emit = [&](uint32_t t) {
-        if (dbg == 2) return;
-        if (n_m < kColSlots) {
-          col[n_m * kWave + lane] = t;  // private slot: fire and forget
-        } else {                        // beyond the private slots: this wave's shared overflow queue
-          const uint32_t pos = lds_add(ovq, 1u);
-          if (pos < kWaveOvf) ovq[4 + pos] = lane << 20 | t;
-          else classify_now(t);
-        }
-        ++n_m;
+      auto fetch = [&](uint32_t base, Ops& o) {
+        const uint32_t j = base + ml;
+        o.vv = j < n_items ? 1u : 0u;
+        const uint32_t e = list[o.vv ? j : 0u];
+        o.pl = e >> 20;
+        o.tt = e & 0xFFFFFu;
+        const CheckRec<DT>* rc = recs + o.tt;
+        o.th = *(const kt_i64x2*)(rc->thr + 2 * dp);
+        o.hd = *(const kt_i64x2*)(rc->head + 2 * dp);
+        o.fa = *(const u32x2*)&rc->flags;  // {flags, active_mask}
+        o.xx = *(const kt_i64x2*)(a.req + (uint64_t)prow[o.pl] * (uint32_t)DS + dpo);
       };
-      uint32_t rp[LT], rk[LT];  // word offsets of the label rows
-#pragma unroll
-      for (int l = 0; l < LT; ++l) {
-        rp[l] = atom_row(l_buckets, a.bucket_mask, lp[l]) * stride;
-        rk[l] = KEYS ? atom_row(l_buckets, a.bucket_mask, lk[l] ? (kKeyAtom | lk[l]) : 0u) * stride : stride;
+      Ops c;
+      fetch(0, c);
+      for (uint32_t base = 0; base < n_items; base += MPW) {
+        Ops nx;
+        fetch(base + MPW, nx);
+        const bool live = c.vv && dp_in;
+        const bool nz0 = live && c.xx.x != 0, nz1 = live && c.xx.y != 0;
+        const uint32_t am = c.fa.y >> (2 * dp);
+        uint32_t bits = ((nz0 && c.xx.x > c.th.x) || (nz1 && c.xx.y > c.th.y)) ? 1u : 0u;  // exceeds
+        bits |= ((nz0 && (am & 1u)) || (nz1 && (am & 2u))) ? 2u : 0u;                       // active
+        bits |= ((nz0 && c.xx.x > c.hd.x) || (nz1 && c.xx.y > c.hd.y)) ? 4u : 0u;          // insufficient
+        bits = group_or<LPM>(bits);
+        const uint32_t ff = c.fa.x;
+        const bool exc = (ff & kRecExceedsByCount) || (bits & 1u);
+        const bool act = (ff & kRecActiveByCount) || (bits & 2u);
+        const bool ins = (ff & kRecInsufficientByCount) || (bits & 4u);
+        const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
+        if (dp == 0 && c.vv) {
+          if (st != 1u) lds_add64(cnt + c.pl, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
+          if (a.status) a.status[(wt * kWave + c.pl) * a.T + c.tt] = (uint8_t)st;
+        }
+        c = nx;
       }
-      const uint32_t k1 = l_nsw_off[ns + 1];
-      for (uint32_t k = l_nsw_off[ns]; k < k1; ++k) {
-        const uint32_t w = l_nsw[k];
-        uint32_t x = l_rows[w];  // row 0: terms without a positive requirement
-#pragma unroll
-        for (int l = 0; l < LT; ++l) {
-          x |= l_rows[rp[l] + w];
-          if (KEYS) x |= l_rows[rk[l] + w];
-        }
-        x &= l_nsrows[ns * stride + w];
-        while (x) {
-          const uint32_t c = w * 32u + (uint32_t)__ffs((int)x) - 1u;
-          x &= x - 1u;
-          const u32x4 tr = l_trec[c];  // {g, t, pair2, flags}
-          bool ok = true;
-          if (tr.w & kPostPair2) {
-            bool has = false;
-#pragma unroll
-            for (int l = 0; l < LT; ++l) has |= lp[l] == tr.z;
-            ok = has;
-          }
-          if (ok && (tr.w & (kPostComplex | kPostMulti))) ok = m.rare(tr.x, tr.y, tr.w);
-          if (ok) emit(tr.y);
-        }
-      }
-      // throttles with an unconvertible podSelector term: in-order walk (error semantics depend on term order)
-      for (uint32_t k = 0; k < a.n_slow; ++k) {
-        bool matched, err;
-        const int t = (int)a.slow_thr[k];
-        walk_slow<LT, KEYS>(sp, t, m.ns_row, true, lp, lk, matched, err);
-        pod_err |= err;
-        if (matched) emit((uint32_t)t);
-      }
-    }
-    // ---- compaction (convergent code: bases live in scalar registers, no atomics): the parked matches of
-    // row k are gathered, in place, behind those of rows < k as (pod << 20 | throttle) entries
-    uint32_t n_dense = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kColSlots; ++k) {
-      const bool has = k < n_m;
-      const uint64_t mask = __ballot(has);
-      const uint32_t t = has ? col[k * kWave + lane] : 0u;
-      const uint32_t pos = n_dense + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (has) col[pos] = lane << 20 | t;
-      n_dense += (uint32_t)__popcll(mask);
-    }
-    // ---- phase 2: lane = (match, dimension pair) over the dense entries, then the overflow entries.
-    // The pod's request row (LDS) and the throttle's thr[] / head[] rows are read as 16-byte pieces.
-    if (dbg != 1) {
-      constexpr int LPM = DT / 2;        // lanes per match, two dimensions each
-      constexpr int MPW = kWave / LPM;   // matches per iteration
-      const uint32_t dp = lane % LPM, ml = lane / LPM;
-      const uint64_t gmask = ((1ull << LPM) - 1ull) << (ml * LPM);
-      const uint32_t n_ovf = min(ovq[0], kWaveOvf);
-      const uint32_t n_items = n_dense + n_ovf;
-      constexpr int U = 2;
-      for (uint32_t base = 0; base < n_items; base += U * MPW) {
-        uint32_t vv[U];  // (a bool array ends up in scratch memory)
-        uint32_t pl[U], tt[U];
-        u32x2 fa[U];
-        longlong2 xx[U], th[U], hd[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t j = base + u * MPW + ml;
-          vv[u] = j < n_items ? 1u : 0u;
-          const uint32_t e = !vv[u] ? 0u : j < n_dense ? col[j] : ovq[4 + j - n_dense];
-          pl[u] = e >> 20;
-          tt[u] = e & 0xFFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const CheckRec<DT>* rc = recs + tt[u];
-          th[u] = *(const longlong2*)(rc->thr + 2 * dp);
-          hd[u] = *(const longlong2*)(rc->head + 2 * dp);
-          fa[u] = *(const u32x2*)&rc->flags;  // {flags, active_mask}
-          const KT_LDS int64_t* rr = l_req + pl[u] * D + 2 * dp;
-          xx[u].x = (vv[u] && (int)(2 * dp) < D) ? rr[0] : 0;
-          xx[u].y = (vv[u] && (int)(2 * dp + 1) < D) ? rr[1] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool nz0 = vv[u] && xx[u].x != 0, nz1 = vv[u] && xx[u].y != 0;
-          const uint32_t am = fa[u].y >> (2 * dp);
-          const uint64_t be = __ballot((nz0 && xx[u].x > th[u].x) || (nz1 && xx[u].y > th[u].y));
-          const uint64_t bi = __ballot((nz0 && xx[u].x > hd[u].x) || (nz1 && xx[u].y > hd[u].y));
-          const uint64_t ba = __ballot((nz0 && (am & 1u)) || (nz1 && (am & 2u)));
-          if (dp == 0 && vv[u]) {
-            const uint32_t ff = fa[u].x;
-            const bool exc = (ff & kRecExceedsByCount) || (be & gmask);
-            const bool act = (ff & kRecActiveByCount) || (ba & gmask);
-            const bool ins = (ff & kRecInsufficientByCount) || (bi & gmask);
-            const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
-            if (st != 1u) lds_add64(cnt + pl[u], st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-            if (status) status[(wt * kWave + pl[u]) * T + tt[u]] = (uint8_t)st;
-          }
-        }
-      }
-    }
+    };
+    bitmap_scan_tile<LT, KEYS>(bm, a.sp, a.slow_thr, a.n_slow, on, on, ns, cur.lp, cur.lk, list, lane, drain,
+                               [&](uint32_t) { pod_err = true; });
     // ---- phase 3: lane = pod
     if (in) {
       const unsigned long long c = cnt[lane];
-      summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
-      if (status && pod_err)
-        for (int t = 0; t < T; ++t) status[i * T + t] = 255;
+      a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
+      if (a.status && pod_err)
+        for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
     }
+    cur = nxt;
   }
 }
 
@@ -439,7 +337,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   // small-T regime: the whole selector program as LDS-resident bitmaps
   if (ix.bm_words != 0 && dbg != 3) {
     uint32_t bm_total = 0;
-    const BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, dbg, &bm_total);
+    const BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, &bm_total);
     if (bm_total <= (uint32_t)kMaxLds) {
       const size_t lds_bytes = bm_total;
 #ifdef KT_FAST_BUILD

@@ -65,20 +65,66 @@ struct PodRegs {
   int64_t v[DT];
 };
 
+typedef uint32_t kt_u32x4 __attribute__((ext_vector_type(4)));
+typedef long long kt_i64x2 __attribute__((ext_vector_type(2)));
+
+// A pod's label row (PodTable::lpair / lkey, stride LS in {4, 8, 16}) as LT >= LS registers.  Every 128-bit
+// load is issued unconditionally from an address inside the row (chunks past the row re-read chunk 0 and are
+// zeroed afterwards), so the loads of a tile go out back to back with no control flow between them.
+template <int LT, bool KEYS>
+__device__ __forceinline__ void load_labels(const uint32_t* lpair, const uint32_t* lkey, int LS, int64_t p,
+                                            uint32_t (&lp)[LT], uint32_t (&lk)[LT]) {
+  const kt_u32x4* a = (const kt_u32x4*)(lpair + p * LS);
+  const kt_u32x4* k = (const kt_u32x4*)(lkey + p * LS);
+  kt_u32x4 v[LT / 4], w[LT / 4];
+#pragma unroll
+  for (int q = 0; q < LT / 4; ++q) {
+    const int qq = 4 * q < LS ? q : 0;
+    v[q] = a[qq];
+    if (KEYS) w[q] = k[qq];
+  }
+#pragma unroll
+  for (int q = 0; q < LT / 4; ++q) {
+    const uint32_t keep = 4 * q < LS ? ~0u : 0u;
+    lp[4 * q] = v[q].x & keep, lp[4 * q + 1] = v[q].y & keep, lp[4 * q + 2] = v[q].z & keep, lp[4 * q + 3] = v[q].w & keep;
+    if (KEYS) lk[4 * q] = w[q].x & keep, lk[4 * q + 1] = w[q].y & keep, lk[4 * q + 2] = w[q].z & keep, lk[4 * q + 3] = w[q].w & keep;
+    else lk[4 * q] = lk[4 * q + 1] = lk[4 * q + 2] = lk[4 * q + 3] = 0u;
+  }
+}
+
+// A pod's request row (stride DS, even) as DT/2 two-dimension pieces, same discipline.
+template <int DT>
+__device__ __forceinline__ void load_request_pieces(const int64_t* req, int DS, int64_t p, kt_i64x2 (&x)[DT / 2]) {
+  const kt_i64x2* a = (const kt_i64x2*)(req + p * DS);
+#pragma unroll
+  for (int q = 0; q < DT / 2; ++q) x[q] = a[2 * q < DS ? q : 0];
+#pragma unroll
+  for (int q = 0; q < DT / 2; ++q) {
+    const long long keep = 2 * q < DS ? -1ll : 0ll;
+    x[q].x &= keep, x[q].y &= keep;
+  }
+}
+template <int DT>
+__device__ __forceinline__ void load_requests(const int64_t* req, int DS, int64_t p, int64_t (&v)[DT]) {
+  kt_i64x2 x[DT / 2];
+  load_request_pieces<DT>(req, DS, p, x);
+#pragma unroll
+  for (int q = 0; q < DT / 2; ++q) v[2 * q] = x[q].x, v[2 * q + 1] = x[q].y;
+}
+
 template <int DT, int LT, bool KEYS>
 __device__ __forceinline__ void load_pod(const PodTable& pods, int64_t p, PodRegs<DT, LT, KEYS>& r, bool want_req) {
   r.ns = pods.ns[p];
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    r.lp[l] = l < pods.L ? pods.lpair[(int64_t)l * pods.cap + p] : 0u;
-    r.lk[l] = (KEYS && l < pods.L) ? pods.lkey[(int64_t)l * pods.cap + p] : 0u;
-  }
+  load_labels<LT, KEYS>(pods.lpair, pods.lkey, pods.LS, p, r.lp, r.lk);
   r.nzmask = 0;
+  if (want_req) {
+    load_requests<DT>(pods.req, pods.DS, p, r.v);
+  } else {
 #pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    r.v[d] = (want_req && d < pods.D) ? pods.req[(int64_t)p * pods.D + d] : 0;
-    r.nzmask |= (r.v[d] != 0 ? 1u : 0u) << d;
+    for (int d = 0; d < DT; ++d) r.v[d] = 0;
   }
+#pragma unroll
+  for (int d = 0; d < DT; ++d) r.nzmask |= (r.v[d] != 0 ? 1u : 0u) << d;
 }
 
 __device__ __forceinline__ uint64_t pack_summary(uint32_t n_exc, uint32_t n_act, uint32_t n_ins, bool err) {
