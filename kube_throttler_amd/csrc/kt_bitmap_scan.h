@@ -3,7 +3,7 @@
 // The bitmap form of the selector program (kt_index.h) lives in LDS.  One wave owns a tile of 64 pods
 // (lane = pod) and produces the tile's (pod, throttle) matches as a dense list in its private LDS area:
 //
-//   advance : every lane that still has words takes the next word w its namespace can touch and forms
+//   advance : every lane that still has words takes the next 64-bit word w its namespace can touch and forms
 //                 x = (rows[0] | OR_l rows[row(label_l)])[w] & nsrows[ns][w]          (candidate terms)
 //   peel    : while any lane holds candidate bits, each such lane takes its lowest bit, reads the
 //             16-byte TermRec and decides the term; the matches of the step are appended to the list
@@ -20,7 +20,6 @@
 
 namespace kt {
 
-constexpr uint32_t kListCap = 256;  // match-list entries per wave (1 KB); a step appends at most 64
 
 // LDS staging plan of the bitmap tables: the index keeps them as one blob (IndexDev::bm_blob, the LDS image)
 struct BmIndexArgs {
@@ -39,8 +38,10 @@ static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, Take&& 
   a.stride = ix.bm_stride, a.bucket_mask = ix.bm_bucket_mask;
 }
 
+typedef KT_LDS const uint64_t* lds_u64p;
 struct BmView {
-  lds_u32p rows, nsrows, nsw_off, nsw;
+  lds_u64p rows, nsrows;  // 64-bit bitmap words
+  lds_u32p nsw_off, nsw;
   lds_u4p buckets, trec;
   uint32_t stride, bucket_mask;
 };
@@ -62,8 +63,8 @@ __device__ __forceinline__ BmView stage_bitmap_index(KT_LDS unsigned char* lds, 
   }
   KT_LDS unsigned char* base = lds + a.lds_off;
   BmView v;
-  v.rows = (lds_u32p)(base + a.off[0]);
-  v.nsrows = (lds_u32p)(base + a.off[1]);
+  v.rows = (lds_u64p)(base + a.off[0]);
+  v.nsrows = (lds_u64p)(base + a.off[1]);
   v.nsw_off = (lds_u32p)(base + a.off[2]);
   v.nsw = (lds_u32p)(base + a.off[3]);
   v.buckets = (lds_u4p)(base + a.off[4]);
@@ -81,7 +82,8 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 //   lane_slow  : the lane's pod is walked against throttles with an unconvertible podSelector term
 //   drain(n)   : consume list[0..n)   entries = lane << 20 | throttle row
 //   slow_err(t): the walk of slow throttle t hit the bad term before a match (lane-divergent call)
-template <int LT, bool KEYS, class Drain, class SlowErr>
+//   CAP        : capacity of `list` (entries); a step appends at most 64, the list is drained above CAP - 64
+template <int LT, bool KEYS, uint32_t CAP, class Drain, class SlowErr>
 __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgram* sp_dev, const uint32_t* slow_thr,
                                                  uint32_t n_slow, bool lane_match, bool lane_slow, uint32_t ns,
                                                  const uint32_t (&lp)[LT], const uint32_t (&lk)[LT], lds_u32wp list,
@@ -95,7 +97,8 @@ __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgr
   uint32_t k = b.nsw_off[ns];
   const uint32_t k1 = lane_match ? b.nsw_off[ns + 1] : k;
   const uint32_t nsbase = ns * b.stride;
-  uint32_t x = 0, w = 0;
+  uint64_t x = 0;
+  uint32_t w = 0;
   uint32_t ks = 0, n_list = 0;  // wave-uniform
   bool more = true;
   // decides candidate term c for this lane's pod (c = 0 with has = false for idle lanes)
@@ -114,12 +117,12 @@ __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgr
     return ok;
   };
   do {
-    while (n_list <= kListCap - kWave) {
+    while (n_list <= CAP - kWave) {
       if (__ballot(x != 0) != 0ull) {
         // ---- peel: one candidate term per lane that has any
         const bool has = x != 0;
-        const uint32_t c = has ? w * 32u + (uint32_t)__ffs((int)x) - 1u : 0u;
-        x &= x - 1u;
+        const uint32_t c = has ? w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u : 0u;
+        x &= x - 1ull;
         uint32_t t = 0;
         const bool ok = decide(has, c, t);
         const uint64_t mk = __ballot(ok);
@@ -141,14 +144,14 @@ __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgr
         // ---- advance: next word of every lane that still has one
         const bool adv = k < k1;
         w = b.nsw[adv ? k : 0u];
-        uint32_t xx = b.rows[w];  // row 0: terms without a positive requirement
+        uint64_t xx = b.rows[w];  // row 0: terms without a positive requirement
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
           xx |= b.rows[rp[l] + w];
           if (KEYS) xx |= b.rows[rk[l] + w];
         }
         xx &= b.nsrows[nsbase + w];
-        x = adv ? xx : 0u;
+        x = adv ? xx : 0ull;
         k += adv ? 1u : 0u;
       } else {
         more = false;

@@ -100,14 +100,22 @@ struct ReconcileOut {
 // so that CheckThrottledFor's steps 1 and 4 become  nz(pod,d) && pod[d] > thr[d] / head[d]
 // and steps 2+3 collapse into one bitmask (see DESIGN.md "Check algebra").
 constexpr uint32_t kRecExceedsByCount = 0x1u, kRecActiveByCount = 0x2u, kRecInsufficientByCount = 0x4u;
+// thr[] and head[] of a throttle share one 128-byte line at DT = 8 (the (match, dimension) lanes of the check
+// kernels gather them as 16-byte pieces); {flags, active_mask} is ALSO kept as a compact array behind the
+// records (rec_flags()), small enough to be staged in LDS.
 template <int DT>
-struct alignas(16) CheckRec {
+struct alignas(128) CheckRec {
   int64_t thr[DT];
   int64_t head[DT];
   uint32_t flags;
   uint32_t active_mask;
-  uint32_t pad[2];
 };
+struct RecFlags {
+  uint32_t flags, active_mask;
+};
+template <int DT>
+__host__ __device__ inline RecFlags* rec_flags(void* recs, int T) { return (RecFlags*)((CheckRec<DT>*)recs + T); }
+inline size_t recs_bytes(int T) { return (size_t)(T + 1) * (sizeof(CheckRec<16>) + sizeof(RecFlags)); }
 
 // layout of one throttle's row in the partial-used buffer (int64 words): v[D], present_count[D], pods, errors
 __host__ __device__ inline int partial_stride(int D) { return 2 * D + 2; }

@@ -459,7 +459,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_out_error.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_flag.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_has.reserve(T + 1));
-  KT_HIP(e, e->d_recs.reserve((T + 1) * sizeof(kt::CheckRec<16>)));
+  KT_HIP(e, e->d_recs.reserve(kt::recs_bytes((int)T)));
   // index for the work ~ (pods + matches) kernels
   kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val,
                   [&](uint32_t t) {

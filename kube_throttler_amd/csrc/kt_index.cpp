@@ -165,9 +165,20 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     // terms with the same admission set become contiguous
     std::stable_sort(bts.begin(), bts.end(), [](const BT& a, const BT& b) { return a.adm < b.adm; });
-    const uint32_t G2 = (uint32_t)bts.size();
+    // term numbers: a class never straddles a 64-bit word unless it is larger than one
+    std::vector<uint32_t> num(bts.size());
+    uint32_t pos = 0;
+    for (size_t i = 0; i < bts.size();) {
+      size_t j = i;
+      while (j < bts.size() && bts[j].adm == bts[i].adm) ++j;
+      const uint32_t sz = (uint32_t)(j - i);
+      if ((pos & 63u) != 0 && ((pos & 63u) + sz > 64u)) pos = (pos + 63u) & ~63u;
+      for (size_t q = i; q < j; ++q) num[q] = pos++;
+      i = j;
+    }
+    const uint32_t G2 = pos;
     if (G2 > 0) {
-      const uint32_t W = (G2 + 31) / 32;
+      const uint32_t W = (G2 + 63) / 64;
       out.bm_words = W;
       out.bm_stride = W | 1u;
       std::unordered_map<uint32_t, uint32_t> row_of;
@@ -178,16 +189,18 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       std::sort(atoms.begin(), atoms.end());
       for (uint32_t i = 0; i < atoms.size(); ++i) row_of[atoms[i]] = i + 2;
       out.bm_rows = (uint32_t)atoms.size() + 2;
-      out.bm_row_bits.assign((size_t)out.bm_rows * out.bm_stride, 0u);
-      out.bm_nsrows.assign((size_t)n_ns * out.bm_stride, 0u);
-      out.bm_trec.resize(G2);
-      for (uint32_t c = 0; c < G2; ++c) {
-        const BT& b = bts[c];
+      out.bm_row_bits.assign((size_t)out.bm_rows * out.bm_stride, 0ull);
+      out.bm_nsrows.assign((size_t)n_ns * out.bm_stride, 0ull);
+      out.bm_trec.assign(G2, TermRec{0, 0, 0, 0});
+      for (size_t q = 0; q < bts.size(); ++q) {
+        const BT& b = bts[q];
+        const uint32_t c = num[q];
+        const uint64_t bit = 1ull << (c & 63);
         out.bm_trec[c] = TermRec{b.g, b.t, b.pair2, b.flags};
-        if (b.atoms.empty()) out.bm_row_bits[c >> 5] |= 1u << (c & 31);
-        for (uint32_t a : b.atoms) out.bm_row_bits[(size_t)row_of[a] * out.bm_stride + (c >> 5)] |= 1u << (c & 31);
+        if (b.atoms.empty()) out.bm_row_bits[c >> 6] |= bit;
+        for (uint32_t a : b.atoms) out.bm_row_bits[(size_t)row_of[a] * out.bm_stride + (c >> 6)] |= bit;
         for (uint32_t n = 0; n < n_ns; ++n)
-          if ((b.adm[n >> 5] >> (n & 31)) & 1u) out.bm_nsrows[(size_t)n * out.bm_stride + (c >> 5)] |= 1u << (c & 31);
+          if ((b.adm[n >> 5] >> (n & 31)) & 1u) out.bm_nsrows[(size_t)n * out.bm_stride + (c >> 6)] |= bit;
       }
       out.bm_nswords_off.assign((size_t)n_ns + 1, 0u);
       for (uint32_t n = 0; n < n_ns; ++n) {
@@ -262,7 +275,7 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
     // pack the bitmap tables into one blob (the LDS image)
     const void* src[6] = {h.bm_row_bits.data(), h.bm_nsrows.data(), h.bm_nswords_off.data(),
                           h.bm_nswords.data(), h.bm_buckets.data(), h.bm_trec.data()};
-    const size_t bytes[6] = {h.bm_row_bits.size() * 4, h.bm_nsrows.size() * 4, h.bm_nswords_off.size() * 4,
+    const size_t bytes[6] = {h.bm_row_bits.size() * 8, h.bm_nsrows.size() * 8, h.bm_nswords_off.size() * 4,
                              h.bm_nswords.size() * 4, h.bm_buckets.size() * sizeof(AtomBucket),
                              h.bm_trec.size() * sizeof(TermRec)};
     size_t o = 0;

@@ -57,8 +57,9 @@ __host__ __device__ inline uint32_t index_hash(uint64_t key, uint32_t mask) {
 }
 
 // ---- bitmap form of the whole selector side (small-T regime) ----------------------------------------
-// Every indexed term gets a number c; terms with the same namespace-admission set are numbered
-// contiguously, so a namespace only ever touches a few 32-bit words of any bitmap:
+// Every indexed term gets a number c; terms with the same namespace-admission set (a "class") are numbered
+// contiguously and a class of <= 64 terms never straddles a 64-bit word (larger classes start on a word
+// boundary; unused numbers are padding), so a namespace only ever touches a few 64-bit words of any bitmap:
 //     candidates(pod)[w] = (rows[0][w] | OR_l rows[row_of(label_l)][w]) & nsrows[ns][w]   for w in nswords[ns]
 // rows[0] = terms without a positive requirement, rows[1] = all zero (unknown atoms).  Atoms are found in
 // 4-entry buckets (branch-free probe).  TermRec carries what a visit needs (same flags as Posting).
@@ -87,12 +88,12 @@ struct HostIndex {
   std::vector<uint32_t> slow_thr;
   bool has_key_atoms = false;
   // bitmap form (valid when bm_words != 0)
-  uint32_t bm_words = 0;   // W: words per bitmap row
-  uint32_t bm_stride = 0;  // row stride in words (odd: column reads spread over LDS banks)
+  uint32_t bm_words = 0;   // W: 64-bit words per bitmap row
+  uint32_t bm_stride = 0;  // row stride in 64-bit words (odd: column reads spread over LDS banks)
   uint32_t bm_rows = 0;
   uint32_t bm_bucket_mask = 0;
-  std::vector<uint32_t> bm_row_bits;    // [bm_rows][bm_stride]
-  std::vector<uint32_t> bm_nsrows;      // [n_ns][bm_stride]
+  std::vector<uint64_t> bm_row_bits;    // [bm_rows][bm_stride]
+  std::vector<uint64_t> bm_nsrows;      // [n_ns][bm_stride]
   std::vector<uint32_t> bm_nswords_off; // [n_ns + 1]
   std::vector<uint32_t> bm_nswords;     // word indices a namespace can touch
   std::vector<AtomBucket> bm_buckets;

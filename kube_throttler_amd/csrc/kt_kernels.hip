@@ -379,8 +379,8 @@ __global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int 
   if (act_pod) f |= kRecActiveByCount;
   rec.flags = f;
   rec.active_mask = act_mask;
-  rec.pad[0] = rec.pad[1] = 0;
   recs[t] = rec;
+  rec_flags<DT>(recs, T)[t] = RecFlags{f, act_mask};
 }
 
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s) {

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_indexed(PodTable pods, 
 __host__ __device__ inline uint32_t agg_bitmap_tab_bytes(int T, int D) { return (uint32_t)(((size_t)T * D * 8 + (size_t)T * 8 + 15) & ~(size_t)15); }
 
 // compact argument block (see BmCheckArgs): the scalar register file only holds what the tile loop uses
+constexpr uint32_t kAggListCap = 128;  // match-list entries per wave (512 B): the used-table needs the LDS
 struct BmAggArgs {
   const uint32_t* ns;  // pod tables
   const uint32_t* flags;
@@ -172,7 +173,7 @@ struct BmAggArgs {
   unsigned char* slab;
   int64_t n_rows;
   BmIndexArgs ix;
-  uint32_t off_list, off_tab, tab_bytes;
+  uint32_t off_list, off_pres, off_tab, tab_bytes;
   uint32_t n_slow;
   int32_t D, DS, LS, T;
 };
@@ -185,7 +186,8 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, int64_t n_rows, const Se
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
-  a.off_list = take((kBlockIx / kWave) * kListCap * 4);
+  a.off_list = take((kBlockIx / kWave) * kAggListCap * 4);
+  a.off_pres = take(kBlockIx * 4);
   a.tab_bytes = agg_bitmap_tab_bytes(sp.T, pods.D);
   a.off_tab = take(a.tab_bytes);
   plan_bitmap_index(ix, a.ix, take);
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const BmView bm = stage_bitmap_index(lds, a.ix);
   __syncthreads();
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;
+  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kAggListCap;
+  lds_u32wp l_pres = (lds_u32wp)(lds + a.off_pres) + wave * kWave;  // [64] request-key presence masks of the tile
   constexpr int LPM = DT / 2, MPW = kWave / LPM;
   const uint32_t dp = lane % LPM, ml = lane / LPM;
   const bool dp_in = (int)(2 * dp) < DS;
@@ -218,55 +221,72 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const int64_t n_rows = a.n_rows;
   const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
-  for (int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
-    // ---- phase 1: lane = pod (lanes past the end re-read the last row and are switched off)
-    const int64_t i = wt * kWave + lane;
-    const bool in = i < n_rows;
-    const int64_t p = in ? i : n_rows - 1;
-    const uint32_t fl = a.flags[p];
-    const uint32_t ns_raw = a.ns[p];
+  // A tile's selector-side records, always from valid addresses (lanes past the end re-read the last row and are
+  // switched off), loaded ONE ROUND AHEAD; the request row is only touched (L2 prefetch for phase 2).
+  struct Tile {
+    uint32_t fl, ns;
     uint32_t lp[LT], lk[LT];
-    load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, lp, lk);
-    (void)*(const volatile uint32_t*)(a.req + p * DS);  // phase 2 gathers the row: have it L2-resident by then
-    {  // next tile's records: start their trip from HBM now
-      const int64_t pn = min(i + wstep * kWave, n_rows - 1);
-      (void)*(const volatile uint32_t*)(a.lpair + pn * a.LS);
-      if (KEYS) (void)*(const volatile uint32_t*)(a.lkey + pn * a.LS);
-      if (lane < 4) {
-        const int64_t pb = min((wt + wstep) * kWave + (lane & 1) * 32, n_rows - 1);
-        (void)*(const volatile uint32_t*)((lane & 2 ? a.flags : a.ns) + pb);
-      }
-    }
+  };
+  auto load_tile = [&](int64_t wt, Tile& t) {
+    const int64_t p = min(wt * kWave + lane, n_rows - 1);
+    t.fl = a.flags[p];
+    t.ns = a.ns[p];
+    load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
+    (void)*(const volatile uint32_t*)(a.req + p * DS);
+  };
+  int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+  Tile cur;
+  if (wt < n_wtiles) load_tile(wt, cur);
+  for (; wt < n_wtiles; wt += wstep) {
+    Tile nxt;
+    load_tile(min(wt + wstep, n_wtiles - 1), nxt);
+    // ---- phase 1: lane = pod
+    const bool in = wt * kWave + lane < n_rows;
+    const uint32_t fl = cur.fl;
     // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
     // (isNotFinished, pod_util.go:26-28) and only matter for error detection
     const bool countable = in && (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
     const bool not_finished = !(fl & kPodFinished);
-    const uint32_t ns = countable ? ns_raw : 0u;
+    const uint32_t ns = countable ? cur.ns : 0u;
+    l_pres[lane] = fl >> kPresentShift;
 
     auto drain = [&](uint32_t n_items) {
-      // ---- phase 2: lane = (match, dimension pair): fold the pod's amount into the table
-      for (uint32_t base = 0; base < n_items; base += MPW) {
+      // ---- phase 2: lane = (match, dimension pair): fold the pod's amount into the table; operands are
+      // fetched one step ahead of their use
+      struct Ops {
+        uint32_t vv, t, pres;
+        kt_i64x2 x;
+      };
+      auto fetch = [&](uint32_t base, Ops& o) {
         const uint32_t j = base + ml;
-        const bool vv = j < n_items;
-        const uint32_t e = list[vv ? j : 0u];
-        const uint32_t t = e & 0xFFFFFu;
+        o.vv = j < n_items ? 1u : 0u;
+        const uint32_t e = list[o.vv ? j : 0u];
+        o.t = e & 0xFFFFFu;
         const uint32_t mp = (uint32_t)(wt * kWave) + (e >> 20);  // pod_capacity <= 2^31
-        const kt_i64x2 x = *(const kt_i64x2*)(a.req + (uint64_t)mp * (uint32_t)DS + dpo);
-        const uint32_t pres = a.flags[mp] >> kPresentShift;
-        if (vv && dp_in) {
-          if (x.x != 0) lds_add64(tv + t * (uint32_t)D + 2 * dp, (unsigned long long)x.x);
-          if (x.y != 0) lds_add64(tv + t * (uint32_t)D + 2 * dp + 1, (unsigned long long)x.y);  // padding dimension is 0
+        o.x = *(const kt_i64x2*)(a.req + (uint64_t)mp * (uint32_t)DS + dpo);
+        o.pres = l_pres[e >> 20];
+      };
+      Ops c;
+      fetch(0, c);
+      for (uint32_t base = 0; base < n_items; base += MPW) {
+        Ops nx;
+        fetch(base + MPW, nx);
+        if (c.vv && dp_in) {
+          if (c.x.x != 0) lds_add64(tv + c.t * (uint32_t)D + 2 * dp, (unsigned long long)c.x.x);
+          if (c.x.y != 0) lds_add64(tv + c.t * (uint32_t)D + 2 * dp + 1, (unsigned long long)c.x.y);  // padding dimension is 0
           if (dp == 0) {
-            (void)__hip_atomic_fetch_or(tpres + t, pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            lds_add(tpods + t, 1u);
+            (void)__hip_atomic_fetch_or(tpres + c.t, c.pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add(tpods + c.t, 1u);
           }
         }
+        c = nx;
       }
     };
-    bitmap_scan_tile<LT, KEYS>(bm, a.sp, a.slow_thr, a.n_slow, countable && not_finished, countable, ns, lp, lk, list, lane,
-                               drain, [&](uint32_t t) {  // rare: straight to the result buffer
-                                 atomicAdd(a.partial + (size_t)t * partial_stride(D) + 2 * D + 1, 1ull);
-                               });
+    bitmap_scan_tile<LT, KEYS, kAggListCap>(bm, a.sp, a.slow_thr, a.n_slow, countable && not_finished, countable, ns, cur.lp,
+                                            cur.lk, list, lane, drain, [&](uint32_t t) {  // rare: straight to the result buffer
+                                              atomicAdd(a.partial + (size_t)t * partial_stride(D) + 2 * D + 1, 1ull);
+                                            });
+    cur = nxt;
   }
   __syncthreads();  // spill this workgroup's table (coalesced 16-byte stores); kt_reduce_bitmap_slabs sums the slabs
   u32x4* dst = (u32x4*)(a.slab + (size_t)blockIdx.x * a.tab_bytes);

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_indexed(PodTable pods, int6
 
 // Everything the kernel needs, and nothing else: a compact argument block keeps the scalar register file
 // free of the (large) generic table descriptors, which are reached through `sp` only on rare paths.
+constexpr uint32_t kListCap = 256;  // match-list entries per wave (1 KB)
 struct BmCheckArgs {
   const uint32_t* ns;  // pod tables
   const uint32_t* flags;
@@ -176,7 +177,7 @@ struct BmCheckArgs {
   const uint32_t* slow_thr;
   int64_t n;
   BmIndexArgs ix;
-  uint32_t off_cnt, off_list, off_prow;
+  uint32_t off_cnt, off_list, off_req, off_rflags;
   uint32_t n_slow;
   int32_t DS, LS, T;
 };
@@ -193,7 +194,8 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
   a.off_list = take((kBlockIx / kWave) * kListCap * 4);
-  a.off_prow = take(kBlockIx * 4);
+  a.off_req = take(kBlockIx * 4);
+  a.off_rflags = take((uint32_t)sp.T * 8);
   plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
@@ -212,15 +214,21 @@ template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const BmView bm = stage_bitmap_index(lds, a.ix);
-  __syncthreads();  // the only workgroup barrier
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
+  {  // {flags, active_mask} of every throttle: 8 bytes each, rewritten by every kt_prepare_check
+    const u32x2* src = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
+    KT_LDS u32x2* dst = (KT_LDS u32x2*)(lds + a.off_rflags);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)a.T; i += kBlockIx) dst[i] = src[i];
+  }
+  __syncthreads();  // the only workgroup barrier
+  const KT_LDS u32x2* l_rflags = (const KT_LDS u32x2*)(lds + a.off_rflags);
   const int64_t n = a.n;
   const int DS = a.DS;
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   // this wave's private LDS areas
   lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;         // [64] class counters
   lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;    // match list
-  lds_u32wp prow = (lds_u32wp)(lds + a.off_prow) + wave * kWave;       // [64] pod table rows of the tile
+  lds_u32wp prow = (lds_u32wp)(lds + a.off_req) + wave * kWave;       // [64] pod table rows of the tile
   // phase-2 lane mapping: LPM lanes per match, two dimensions each
   constexpr int LPM = DT / 2, MPW = kWave / LPM;
   const uint32_t dp = lane % LPM, ml = lane / LPM;
@@ -229,9 +237,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
   const int64_t n_wtiles = (n + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
 
-  // A tile's pod records: 2 + LT/4 (+ LT/4) loads per lane, always from valid addresses (lanes past the end
-  // re-read the last pod and are switched off by `on`).  The request row is only touched: phase 2 gathers it
-  // from L2.  Tiles are loaded ONE ROUND AHEAD, so a round never starts by waiting for HBM.
+  // A tile's selector-side records: 2 + LT/4 (+ LT/4) loads per lane, always from valid addresses (lanes past
+  // the end re-read the last pod and are switched off by `on`), loaded ONE ROUND AHEAD so that a round never
+  // starts by waiting for HBM.  The request row of the next round is only touched (L2 prefetch): it is loaded
+  // at the start of its own round and parked in the wave's LDS tile for phase 2.
   struct Tile {
     uint32_t fl, ns, p;
     uint32_t lp[LT], lk[LT];
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         const CheckRec<DT>* rc = recs + o.tt;
         o.th = *(const kt_i64x2*)(rc->thr + 2 * dp);
         o.hd = *(const kt_i64x2*)(rc->head + 2 * dp);
-        o.fa = *(const u32x2*)&rc->flags;  // {flags, active_mask}
+        o.fa = l_rflags[o.tt];  // {flags, active_mask}
         o.xx = *(const kt_i64x2*)(a.req + (uint64_t)prow[o.pl] * (uint32_t)DS + dpo);
       };
       Ops c;
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         c = nx;
       }
     };
-    bitmap_scan_tile<LT, KEYS>(bm, a.sp, a.slow_thr, a.n_slow, on, on, ns, cur.lp, cur.lk, list, lane, drain,
+    bitmap_scan_tile<LT, KEYS, kListCap>(bm, a.sp, a.slow_thr, a.n_slow, on, on, ns, cur.lp, cur.lk, list, lane, drain,
                                [&](uint32_t) { pod_err = true; });
     // ---- phase 3: lane = pod
     if (in) {
