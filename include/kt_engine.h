@@ -36,6 +36,7 @@ extern "C" {
 #define KT_ERR_OVERFLOW_RISK (-4)  /* a per-dimension sum could leave the exact int64 range: rescale the dimension */
 #define KT_ERR_NOT_READY (-5)      /* fetch without a preceding launch */
 #define KT_ERR_NO_DEVICE (-6)      /* no gfx950 device visible: there is NO CPU fallback */
+#define KT_ERR_UNSUPPORTED (-7)    /* the request exceeds what this entry point supports (message says what) */
 
 /* per (pod, throttle) status — v1alpha1.CheckThrottleStatus (throttle_types.go:119-126) + not-affected / error */
 #define KT_STATUS_NOT_AFFECTED 0
@@ -140,6 +141,22 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
 /* out_summary [n] ; out_status [n][n_throttle_rows] (nullable; needs KT_CHECK_STATUS_MATRIX), where
  * n_throttle_rows = 1 + highest throttle row ever upserted (kt_throttle_rows). Synchronises. */
 int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status);
+/* ---- sequential admission with reservation: for i = 0..n-1 IN ORDER,
+ *      PreFilter(pod_rows[i]) (plugin.go:148-215) and, on Success, Reserve(pod_rows[i]) (plugin.go:217-239 ->
+ *      [Cluster]ThrottleController.Reserve, throttle_controller.go:271-300 -> reservedResourceAmounts.addPod,
+ *      reserved_resource_amounts.go:66-77): ResourceAmountOfPod(pod) is added to the reserved amount of every
+ *      throttle that affects the pod, and the following pods of the queue are checked against it.  One launch
+ *      replaces n PreFilter + Reserve round trips.  Results are read with kt_check_fetch: out_summary[i] /
+ *      out_status[i][*] are what PreFilter returned for pod i AT ITS TURN.
+ *      flags: KT_ADMIT_COMMIT keeps the resulting reserved amounts in the engine (as if Reserve had been called
+ *      for every admitted pod; read them back with kt_fetch_reserved); without it the call is a dry run.
+ *      Limits: n x throttle_rows <= 2^31; the reserved amounts of all throttles must fit in LDS
+ *      (throttle_rows x (8 x n_dims + 16) <= ~156 KB), else KT_ERR_UNSUPPORTED. ------------------------------------- */
+#define KT_ADMIT_COMMIT 0x1u
+int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
+                        void* stream);
+/* Current reserved amounts of n throttle rows (after kt_set_reserved / kt_admit_launch(KT_ADMIT_COMMIT)). */
+int32_t kt_fetch_reserved(kt_engine* e, int32_t n, const int32_t* throttle_rows, const kt_amounts* out);
 int32_t kt_throttle_rows(kt_engine* e, int32_t* out_rows);
 /* Device pointer of the per-pod summary words of the last check (stays valid until the next check). */
 int32_t kt_check_device_summary(kt_engine* e, void** device_ptr);

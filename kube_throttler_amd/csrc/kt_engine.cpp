@@ -148,6 +148,7 @@ struct kt_engine {
   int32_t thr_rows_hi = 0;
   bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
   bool status_host_dirty = true;  // host status/reserved rows newer than device
+  bool reserved_dev_newer = false;  // device reserved rows newer than the host mirrors (admit with commit)
   bool status_dev_newer = false;  // device status newer than host (after reconcile with APPLY)
 
   // ---- compiled program (device)
@@ -293,11 +294,21 @@ int32_t download_amounts(kt_engine* e, const AmountDev& d, AmountHostFlat& h, si
 
 // Pull the device-resident status back into the host mirrors (after a reconcile with APPLY).
 int32_t sync_status_to_host(kt_engine* e) {
-  if (!e->status_dev_newer) return KT_OK;
+  if (!e->status_dev_newer && !e->reserved_dev_newer) return KT_OK;
   const size_t T = (size_t)e->thr_rows_hi;
   const int D = e->D;
   hipStream_t s = e->own_stream;
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  if (e->reserved_dev_newer) {  // kt_admit_launch(KT_ADMIT_COMMIT) advanced the reserved amounts on the device
+    AmountHostFlat res;
+    int32_t rc0;
+    if ((rc0 = download_amounts(e, e->d_reserved, res, T, D, s)) != KT_OK) return rc0;
+    KT_HIP(e, hipStreamSynchronize(s));
+    for (size_t t = 0; t < T; ++t)
+      if (e->thr[t].flags & KT_THR_VALID) res.get(t, D, e->thr[t].reserved);
+    e->reserved_dev_newer = false;
+  }
+  if (!e->status_dev_newer) return KT_OK;
   AmountHostFlat used, calc;
   std::vector<uint32_t> flags(T), tf(T), th(T);
   std::vector<uint64_t> fp(T);
@@ -537,6 +548,13 @@ void amount_from_table(const kt_amounts& a, size_t i, int D, HostAmount& h) {
   for (int d = 0; d < D; ++d) h.v[d] = ((h.present >> d) & 1u) ? a.v[i * D + d] : 0;
   h.has_count = a.has_count ? (a.has_count[i] != 0) : 0;
   h.count = h.has_count ? a.count[i] : 0;
+}
+
+void amount_to_table(const HostAmount& h, const kt_amounts& a, size_t i, int D) {
+  if (a.present) a.present[i] = h.present;
+  for (int d = 0; d < D; ++d) a.v[i * D + d] = ((h.present >> d) & 1u) ? h.v[d] : 0;
+  if (a.has_count) a.has_count[i] = h.has_count;
+  if (a.count) a.count[i] = h.has_count ? h.count : 0;
 }
 
 constexpr unsigned __int128 kSumBound = (unsigned __int128)1 << 60;
@@ -894,6 +912,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   e->ns_rows_hi = 0;
   e->thr_rows_hi = 0;
   e->status_dev_newer = false;
+  e->reserved_dev_newer = false;
   e->program_dirty = true;
   e->status_host_dirty = true;
   e->reconcile_ready = e->check_ready = false;
@@ -1078,11 +1097,8 @@ int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
 // ---------------------------------------------------------------------------------------------------
 // check
 // ---------------------------------------------------------------------------------------------------
-int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
-  if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
-  KT_HIP(e, hipSetDevice(e->device));
-  hipStream_t s = pick_stream(e, stream);
+static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
+                                   hipStream_t s) {
   if (pod_rows) {
     for (int64_t i = 0; i < n; ++i)
       if (pod_rows[i] < 0 || pod_rows[i] >= e->cfg.pod_capacity)
@@ -1094,11 +1110,11 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   if (rc != KT_OK) return rc;
   const bool want_status = (flags & KT_CHECK_STATUS_MATRIX) != 0;
   const size_t T = (size_t)e->thr_rows_hi;
-  if (e->d_summary.cap < (size_t)n + 1 || (want_status && e->d_status.cap < (size_t)n * T + 1) ||
+  if (e->d_summary.cap < (size_t)n + 1 || (want_status && e->d_status.cap < (size_t)n * T + 64) ||
       (pod_rows && e->d_rows.cap < (size_t)n + 1)) {
     if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));  // buffers may still be in use
     KT_HIP(e, e->d_summary.reserve((size_t)n + 1));
-    if (want_status) KT_HIP(e, e->d_status.reserve((size_t)n * T + 1));
+    if (want_status) KT_HIP(e, e->d_status.reserve((size_t)n * T + 64));  // slack: kt_admit_sequential reads rows 16 bytes at a time
     if (pod_rows) KT_HIP(e, e->d_rows.reserve((size_t)n + 1));
   }
   if (pod_rows && n) {
@@ -1126,6 +1142,49 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   e->check_has_status = want_status;
   e->check_ready = true;
   e->last_stream = s;
+  return KT_OK;
+}
+
+int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
+  if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  return check_launch_locked(e, n, pod_rows, on_equal, flags, pick_stream(e, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sequential admission with reservation
+// ---------------------------------------------------------------------------------------------------
+int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
+  if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = pick_stream(e, stream);
+  if ((double)n * (double)e->thr_rows_hi > 2147483648.0)
+    return e->fail(KT_ERR_OUT_OF_RANGE, "admit queue: n x throttle_rows = %lld x %d exceeds 2^31 matrix bytes", (long long)n, e->thr_rows_hi);
+  if (kt::admit_lds_bytes(e->thr_rows_hi, e->D) > (size_t)160 * 1024)
+    return e->fail(KT_ERR_UNSUPPORTED, "admit queue: reserved amounts of %d throttles x %d dimensions do not fit in LDS", e->thr_rows_hi, e->D);
+  // (a) who affects whom, for the whole queue in parallel (statuses against the current reserved amounts)
+  int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, KT_CHECK_STATUS_MATRIX, s);
+  if (rc != KT_OK || n == 0 || e->thr_rows_hi == 0) return rc;
+  // (b) the queue in order, one wave, reserved amounts in LDS
+  const bool commit = (flags & KT_ADMIT_COMMIT) != 0;
+  kt::launch_admit(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->tt, e->thr_rows_hi, e->D, on_equal != 0, commit,
+                   e->d_status.p, e->d_summary.p, s);
+  KT_HIP(e, hipGetLastError());
+  if (commit) e->reserved_dev_newer = true;
+  return KT_OK;
+}
+
+int32_t kt_fetch_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt_amounts* out) {
+  if (!e || !out || n < 0 || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  for (int32_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
+  int32_t rc = sync_status_to_host(e);
+  if (rc != KT_OK) return rc;
+  for (int32_t i = 0; i < n; ++i) amount_to_table(e->thr[(size_t)rows[i]].reserved, *out, (size_t)i, e->D);
   return KT_OK;
 }
 

@@ -19,8 +19,9 @@ _LIB = None
 
 KT_OK = 0
 ERR_NAMES = {-1: "KT_ERR_INVALID_ARGUMENT", -2: "KT_ERR_OUT_OF_RANGE", -3: "KT_ERR_DEVICE", -4: "KT_ERR_OVERFLOW_RISK",
-             -5: "KT_ERR_NOT_READY", -6: "KT_ERR_NO_DEVICE"}
+             -5: "KT_ERR_NOT_READY", -6: "KT_ERR_NO_DEVICE", -7: "KT_ERR_UNSUPPORTED"}
 RECONCILE_APPLY = 0x1
+ADMIT_COMMIT = 0x1
 CHECK_STATUS_MATRIX = 0x1
 KERNEL_CHECK, KERNEL_AGGREGATE, KERNEL_FINALIZE, KERNEL_PREPARE, KERNEL_REDUCE = 0, 1, 2, 3, 4
 VARIANT_INDEXED, VARIANT_DENSE = 0, 1
@@ -31,7 +32,7 @@ EXPORTS = [
     "kt_set_reserved", "kt_set_status", "kt_reconcile_launch", "kt_aggregate_launch", "kt_partial_used_buffer",
     "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
-    "kt_synchronize", "kt_kernel_name",
+    "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved",
 ]
 
 
@@ -100,6 +101,8 @@ def lib():
         L.kt_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.kt_timing_reset.argtypes = [C.c_void_p]
         L.kt_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        L.kt_admit_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_fetch_reserved.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(S.KtAmounts)]
         _LIB = L
     return _LIB
 
@@ -266,6 +269,21 @@ class Engine:
         n = len(rows) if rows is not None else n
         self.check_launch(n, rows, on_equal, want_status)
         return self.check_fetch(n, want_status)
+
+    # ---- sequential admission with reservation (N1): results are read like a check's
+    def admit(self, rows=None, n=None, on_equal=False, commit=False, want_status=True):
+        a, p = self._rows(rows, np.int64)
+        n = len(a) if a is not None else n
+        self._ck(lib().kt_admit_launch(self._h, n, p, int(on_equal), ADMIT_COMMIT if commit else 0, None))
+        return self.check_fetch(n, want_status)
+
+    def fetch_reserved(self, rows=None) -> S.Amounts:
+        rows = np.arange(self.throttle_rows(), dtype=np.int32) if rows is None else rows
+        a, p = self._rows(rows, np.int32)
+        out = S.Amounts(len(a), self.D)
+        st = out.as_struct()
+        self._ck(lib().kt_fetch_reserved(self._h, len(a), p, C.byref(st)))
+        return out
 
     def check_device_summary(self) -> int:
         ptr = C.c_void_p()

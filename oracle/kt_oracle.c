@@ -542,7 +542,8 @@ static volatile int64_t g_log_sink; /* keeps the eager-log-argument work from be
 
 /* One controller's CheckThrottled — throttle_controller.go:349-397 / clusterthrottle_controller.go:378-425.
  * Writes statuses into row[] (size n_thr); returns false on error. */
-static bool check_throttled(kto_ctx* c, pod_t pod, bool cluster, bool on_equal, uint8_t* row, int mimic_log_args) {
+static bool check_throttled(kto_ctx* c, pod_t pod, bool cluster, bool on_equal, uint8_t* row, int mimic_log_args,
+                            const ra_t* reserved_now /* nullable: per-throttle totals that replace the snapshot's */) {
   const kt_snapshot* s = c->s;
   const uint32_t ns = s->pod_ns[pod.row];
   const int32_t* cand;
@@ -576,7 +577,7 @@ static bool check_throttled(kto_ctx* c, pod_t pod, bool cluster, bool on_equal, 
   for (int32_t i = 0; i < ncand; ++i) {
     int32_t t = cand[i];
     if (row[t] != KTO_NOT_THROTTLED) continue;
-    ra_t reserved = reserved_resource_amount(s, t);
+    ra_t reserved = reserved_now ? reserved_now[t] : reserved_resource_amount(s, t);
     row[t] = (uint8_t)check_throttled_for(s, t, pod, &reserved, on_equal);
     if (mimic_log_args) {
       /* klog.V(3).InfoS arguments are evaluated even when V(3) is off (throttle_controller.go:376-386):
@@ -626,9 +627,9 @@ int kto_check(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t*
       bool error = false;
       if (prow >= 0 && prow < s->n_pods && (s->pod_flags[prow] & KT_POD_VALID)) {
         pod_t pod = {s, prow};
-        if (!check_throttled(c, pod, false, on_equal != 0, row, mimic_log_args))
+        if (!check_throttled(c, pod, false, on_equal != 0, row, mimic_log_args, NULL))
           error = true; /* plugin.go:154-156 */
-        else if (!check_throttled(c, pod, true, on_equal != 0, row, mimic_log_args))
+        else if (!check_throttled(c, pod, true, on_equal != 0, row, mimic_log_args, NULL))
           error = true; /* plugin.go:166-168 */
       }
       if (error) memset(row, KTO_ERROR, (size_t)T);
@@ -636,6 +637,52 @@ int kto_check(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t*
     }
     free(scratch);
   }
+  return 0;
+}
+
+static void ra_to_row(const ra_t* a, const kt_amounts* t, int64_t row, int D, bool* overflow);
+
+/* A scheduling pass over a queue of pending pods, one at a time and in order:
+ *   KubeThrottler.PreFilter (plugin.go:148-215); on Success KubeThrottler.Reserve (plugin.go:217-239) ->
+ *   [Cluster]ThrottleController.Reserve (throttle_controller.go:271-300, clusterthrottle_controller.go:300-329):
+ *   for every affected throttle cache.addPod (reserved_resource_amounts.go:66-77) stores
+ *   ResourceAmountOfPod(pod) under the pod's name; the throttle's reserved total is the fold of Add over that
+ *   map (reserved_resource_amounts.go:148-156), which the NEXT pod's CheckThrottledFor reads.
+ * The snapshot's thr_reserved rows are the totals before the pass.  out_status[i] / out_summary[i] are what
+ * PreFilter returned for pod i at its turn; out_reserved (nullable, n_thr rows) the totals after the pass. */
+int kto_admit(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t* out_status, uint64_t* out_summary,
+              const kt_amounts* out_reserved) {
+  const kt_snapshot* s = c->s;
+  const int32_t T = s->n_thr;
+  ra_t* res = (ra_t*)malloc(sizeof(ra_t) * (size_t)(T > 0 ? T : 1));
+  uint8_t* scratch = (uint8_t*)malloc((size_t)(T > 0 ? T : 1));
+  for (int32_t t = 0; t < T; ++t) res[t] = reserved_resource_amount(s, t);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t prow = rows ? rows[i] : i;
+    uint8_t* row = out_status ? out_status + i * T : scratch;
+    memset(row, KTO_NOT_AFFECTED, (size_t)T);
+    bool error = false, valid = false;
+    pod_t pod = {s, prow};
+    if (prow >= 0 && prow < s->n_pods && (s->pod_flags[prow] & KT_POD_VALID)) {
+      valid = true;
+      if (!check_throttled(c, pod, false, on_equal != 0, row, 0, res)) error = true;
+      else if (!check_throttled(c, pod, true, on_equal != 0, row, 0, res)) error = true;
+    }
+    if (error) memset(row, KTO_ERROR, (size_t)T);
+    uint64_t sum = summarize(row, T, error);
+    if (out_summary) out_summary[i] = sum;
+    if (valid && !error && (sum & 3u) == KTO_VERDICT_ALLOW) {
+      ra_t pa = resource_amount_of_pod(pod);
+      for (int32_t t = 0; t < T; ++t)
+        if (row[t] != KTO_NOT_AFFECTED) res[t] = ra_add(res[t], &pa);
+    }
+  }
+  if (out_reserved) {
+    bool ovf = false;
+    for (int32_t t = 0; t < T; ++t) ra_to_row(&res[t], out_reserved, t, s->D, &ovf);
+  }
+  free(scratch);
+  free(res);
   return 0;
 }
 

@@ -56,6 +56,11 @@ int kto_pod_requests(kto_ctx* c, int64_t n, const int64_t* rows, int64_t* out_v,
 int kto_check(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t* out_status,
               uint64_t* out_summary, int nthreads, int mimic_log_args);
 
+/* One scheduling pass over a queue, in order: PreFilter, and on Success Reserve (which the next pods see).
+ * out_reserved: nullable, n_thr rows — reserved totals after the pass. */
+int kto_admit(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t* out_status, uint64_t* out_summary,
+              const kt_amounts* out_reserved);
+
 typedef struct kto_reconcile_out {
   kt_amounts used;       /* new status.used                                   [n][D] ... */
   kt_amounts calc;       /* new status.calculatedThreshold.threshold                      */

@@ -40,6 +40,7 @@ def lib():
         _LIB.kto_create.argtypes = [C.POINTER(S.KtSnapshot)]
         _LIB.kto_destroy.argtypes = [C.c_void_p]
         _LIB.kto_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _LIB.kto_admit.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S.KtAmounts)]
         _LIB.kto_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.kto_reconcile.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(_ReconcileOut), C.c_int]
@@ -94,6 +95,19 @@ class Oracle:
                         None if status is None else status.ctypes.data, summary.ctypes.data, nthreads,
                         int(mimic_log_args))
         return (None if status is None else status[:n, :T]), summary[:n]
+
+    def admit(self, rows=None, on_equal=False):
+        """One in-order scheduling pass: PreFilter, and on Success Reserve.  -> (status, summary, reserved totals)."""
+        n = self.snap.n_pods if rows is None else len(rows)
+        rows_a = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+        T = self.snap.n_thr
+        status = np.zeros((max(n, 1), max(T, 1)), np.uint8)
+        summary = np.zeros(max(n, 1), np.uint64)
+        reserved = S.Amounts(T, self.snap.D)
+        st = reserved.as_struct()
+        lib().kto_admit(self._ctx, n, None if rows_a is None else rows_a.ctypes.data, int(on_equal),
+                        status.ctypes.data, summary.ctypes.data, C.byref(st))
+        return status[:n, :T], summary[:n], reserved
 
     def reconcile(self, now=(0, 0), rows=None, nthreads=1) -> ReconcileResult:
         n = self.snap.n_thr if rows is None else len(rows)

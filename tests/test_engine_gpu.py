@@ -253,6 +253,87 @@ def test_set_status_and_reserved(oracle_mod):
         eng.close()
 
 
+def _stored_status(snap, oracle_mod):
+    """Reconcile on the oracle and store the result as the snapshot's status (what UpdateStatus persists)."""
+    o = oracle_mod.Oracle(snap)
+    rows = responsible_rows(snap)
+    want = o.reconcile(NOW, rows=rows)
+    snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod,
+                      want.error, rows=rows)
+
+
+@pytest.mark.parametrize("seed,on_equal", [(52, False), (54, True), (53, False)])
+def test_admit_queue_matches_sequential_prefilter_reserve(seed, on_equal, oracle_mod):
+    """kt_admit_launch == for each pod in order: PreFilter, on Success Reserve."""
+    snap = W.generate(W.small(seed=seed, n_pods=4000, n_thr=64, n_cluster=32, n_invalid_pod_sel=1 if seed == 53 else 0,
+                              n_missing_ns=1 if seed == 53 else 0))
+    # head-room on every throttle (the generator calibrates a third of them as already throttled): the queue then
+    # fills them up on the way
+    T = snap.n_thr
+    snap.thr_spec.v[:T] = snap.thr_spec.v[:T] * 2 + 1
+    snap.thr_spec.count[:T] = snap.thr_spec.count[:T] * 2 + 3
+    snap.thr_ovr_off[:] = 0  # no overrides: the spec threshold is the effective one
+    _stored_status(snap, oracle_mod)
+    o = oracle_mod.Oracle(snap)
+    fl = snap.pod_flags[:snap.n_pods]
+    pending = np.nonzero(((fl & S.POD_VALID) != 0) & ((fl & S.POD_SCHEDULED) == 0))[0]
+    rng = np.random.default_rng(seed)
+    queue = rng.permutation(pending)[:1500].astype(np.int64)
+    st_w, sm_w, res_w = o.admit(queue, on_equal=on_equal)
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        # dry run first: same answers, reserved amounts untouched
+        st_d, sm_d = eng.admit(queue, on_equal=on_equal, commit=False)
+        np.testing.assert_array_equal(st_d, st_w)
+        np.testing.assert_array_equal(sm_d, sm_w)
+        res0 = eng.fetch_reserved()
+        for f in ("v", "present", "count", "has_count"):
+            np.testing.assert_array_equal(getattr(res0, f)[:T], getattr(snap.thr_reserved, f)[:T], err_msg=f)
+        # committed run
+        st_g, sm_g = eng.admit(queue, on_equal=on_equal, commit=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+        res_g = eng.fetch_reserved()
+        resp = responsible_rows(snap)
+        for f in ("v", "present", "count", "has_count"):
+            np.testing.assert_array_equal(getattr(res_g, f)[resp], getattr(res_w, f)[resp], err_msg=f)
+        # the reservations made on the way matter: a plain (unordered) check of the same pods answers differently
+        st_c, sm_c = o.check(queue, on_equal=on_equal)
+        assert (sm_w != sm_c).any()
+        verdict = S.summary_fields(sm_w)[0]
+        assert (verdict == S.VERDICT_ALLOW).any() and (verdict == S.VERDICT_BLOCK).any()
+        # and the engine now checks against the advanced reserved amounts
+        for f in ("v", "present", "count", "has_count"):
+            getattr(snap.thr_reserved, f)[:T] = getattr(res_w, f)[:T]
+        st2_w, sm2_w = o.check(queue[:500], on_equal=on_equal)
+        st2_g, sm2_g = eng.check(queue[:500], on_equal=on_equal, want_status=True)
+        np.testing.assert_array_equal(st2_g, st2_w)
+        np.testing.assert_array_equal(sm2_g, sm2_w)
+    finally:
+        eng.close()
+
+
+def test_admit_golden_prefix(oracle_mod):
+    """Integration spec G1(ii)/G2(ii) as ONE queue (see tests/test_oracle_admit.py for the oracle side)."""
+    from test_oracle_admit import build_prefix_case, EXPECTED_PREFIX
+    built = build_prefix_case()
+    snap = built.snapshot
+    o = oracle_mod.Oracle(snap)
+    st_w, sm_w, res_w = o.admit(None)
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        st_g, sm_g = eng.admit(n=snap.n_pods, commit=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+        t_row, c_row = built.thr_names.index("default/t"), built.thr_names.index("/c")
+        assert [(int(st_g[i, t_row]), int(st_g[i, c_row])) for i in range(6)] == EXPECTED_PREFIX
+        res_g = eng.fetch_reserved()
+        for f in ("v", "present", "count", "has_count"):
+            np.testing.assert_array_equal(getattr(res_g, f), getattr(res_w, f)[:snap.n_thr], err_msg=f)
+    finally:
+        eng.close()
+
+
 def test_overflow_guard():
     """A dimension whose worst-case sum could leave int64 is refused at ingest, never wrapped."""
     snap = W.generate(W.small(seed=41, n_pods=4, n_thr=2, n_cluster=0, D=2))
