@@ -142,6 +142,10 @@ class KubeThrottler {
   Status Reserve(const Pod& pod);
   void Unreserve(const Pod& pod);
 
+  // ---- one scheduling pass over a queue of pending pods (by Key(), fed through OnPodAdd) in order: PreFilter and,
+  // on Success, Reserve — ONE engine launch (kt_admit_launch) instead of 2 x n calls; same reserved bookkeeping
+  std::vector<Status> AdmitQueue(const std::vector<std::string>& pod_keys);
+
   // ---- reconcile of every responsible throttle at `now` (RFC3339); fills per-throttle status by Key()
   bool ReconcileAll(const std::string& now_rfc3339, std::map<std::string, ThrottleStatus>* out, std::string* err);
 

@@ -178,10 +178,47 @@ static void TestClusterThrottleAndReserve() {
   EXPECT(NewPlugin(bad, &err) == nullptr && err == "Name must not be empty");
 }
 
+// The same prefix as ONE queue (kt_admit_launch): three pending pods against pod=2 on a Throttle and on a
+// ClusterThrottle, nothing reconciled — two admitted + reserved, the third `active` / `insufficient`
+// (throttle_types.go:143 vs clusterthrottle_types.go:45); Unreserve of an admitted pod frees its slot.
+static void TestAdmitQueue() {
+  auto k = Fresh();
+  std::string err;
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "t", "grp", "a", 2, "1"), &err));
+  Throttle c = MakeThrottle("", "c", "grp", "b", 2, "1");
+  c.cluster = true;
+  c.selectorTerms[0].namespaceSelector.matchLabels["kubernetes.io/metadata.name"] = "default";
+  EXPECT(k->OnThrottleAdd(c, &err));
+  std::vector<Pod> pods;
+  std::vector<std::string> keys;
+  for (const char* g : {"a", "b"})
+    for (int i = 0; i < 3; ++i) {
+      pods.push_back(MakePod("default", std::string(g) + std::to_string(i), "100m", {{"grp", g}}));
+      EXPECT(k->OnPodAdd(pods.back(), &err));
+      keys.push_back(pods.back().Key());
+    }
+  std::vector<Status> st = k->AdmitQueue(keys);
+  EXPECT(st.size() == 6);
+  EXPECT(st[0].IsSuccess() && st[1].IsSuccess() && st[3].IsSuccess() && st[4].IsSuccess());
+  EXPECT(st[2].code == UnschedulableAndUnresolvable && st[2].reasons.size() == 1 &&
+         st[2].reasons[0] == "throttle[active]=default/t");
+  EXPECT(st[5].code == UnschedulableAndUnresolvable && st[5].reasons.size() == 1 &&
+         st[5].reasons[0] == "clusterthrottle[insufficient]=/c");
+  // the reservations are in the plugin's cache: the blocked pods stay blocked on a plain PreFilter ...
+  EXPECT(k->PreFilter(pods[2]).code == UnschedulableAndUnresolvable);
+  EXPECT(k->PreFilter(pods[5]).code == UnschedulableAndUnresolvable);
+  // ... until an admitted pod of their group is un-reserved
+  k->Unreserve(pods[0]);
+  EXPECT(k->PreFilter(pods[2]).IsSuccess());
+  k->Unreserve(pods[4]);
+  EXPECT(k->PreFilter(pods[5]).IsSuccess());
+}
+
 int main() {
   TestExampleWalkthrough();
   TestThrottleScenarios();
   TestClusterThrottleAndReserve();
+  TestAdmitQueue();
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;
