@@ -171,7 +171,7 @@ struct kt_engine {
 
   // ---- reconcile state
   DevBuf<unsigned long long> d_partial;
-  DevBuf<uint8_t> d_slab;  // per-block LDS table spill area of kt_aggregate_indexed
+  DevBuf<uint8_t> d_slab;  // per-workgroup LDS table spill area of kt_aggregate_bitmap
   unsigned long long* ext_partial = nullptr;  // caller-owned partial buffer (kt_use_partial_buffer)
   int64_t ext_partial_words = 0;
   unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
@@ -193,7 +193,7 @@ struct kt_engine {
   // ---- staging
   DevBuf<uint8_t> d_stage;
 
-  const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check", "kt_reduce_partials"};
+  const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check", "kt_reduce_bitmap_slabs"};
 
   // ---- timing
   bool timing = false;
@@ -1133,9 +1133,12 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
       kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->d_recs.p,
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
-    else
-      e->last_kernel[KT_KERNEL_CHECK] = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
-                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+    else {
+      const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
+                                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+      if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
+      e->last_kernel[KT_KERNEL_CHECK] = k;
+    }
   }
   KT_HIP(e, hipGetLastError());
   e->check_n = n;

@@ -2,6 +2,8 @@
 #include "kt_index.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -17,119 +19,47 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw) {
   out = HostIndex();
   const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
-  std::unordered_map<uint64_t, std::vector<Posting>> lists;
-  std::vector<std::vector<uint32_t>> uni_ns(n_ns);
-
+  // a reachable unconvertible podSelector makes term ORDER matter: these throttles are walked term by term
   for (size_t t = 0; t < T; ++t) {
     const ThrInfo ti = thr_info((uint32_t)t);
     if (!ti.live) continue;
-    // a reachable unconvertible podSelector makes term ORDER matter: walk this throttle densely
-    bool slow = false;
     for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
-      if ((term_flags[g] & KT_TERM_POD_SEL_INVALID) && !(ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID))) slow = true;
-    if (slow) {
-      out.slow_thr.push_back((uint32_t)t);
-      continue;
-    }
-    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
-      if (ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID)) continue;  // never matches any namespace
-      if (!ti.cluster && ti.ns >= n_ns) continue;
-      // anchor: the In requirement with the fewest values, else an Exists requirement
-      int64_t best = -1;
-      size_t best_cost = ~(size_t)0;
-      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
-        size_t cost;
-        if (req_op[r] == KT_OP_IN) cost = req_val_off[r + 1] - req_val_off[r];
-        else if (req_op[r] == KT_OP_EXISTS) cost = 1u << 20;
-        else continue;
-        if (cost < best_cost) best_cost = cost, best = r;
+      if ((term_flags[g] & KT_TERM_POD_SEL_INVALID) && !(ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID))) {
+        out.slow_thr.push_back((uint32_t)t);
+        break;
       }
-      const uint64_t scope = ti.cluster ? 0ull : (uint64_t)(ti.ns + 1);
-      if (best < 0) {
-        if (ti.cluster) out.uni_cluster.push_back(g);
-        else uni_ns[ti.ns].push_back(g);
-        continue;
-      }
-      // inline description of the term for the posting fast path
-      Posting base{};
-      base.g = g;
-      base.t = (uint32_t)t;
-      if (thr_term_off[t + 1] - thr_term_off[t] > 1) base.flags |= kPostMulti;
-      if (ti.cluster) {
-        if (n_ns <= 64) {
-          base.flags |= kPostNsMask;
-          for (uint32_t n = 0; n < n_ns; ++n)
-            if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) base.nsmask |= 1ull << n;
-        } else {
-          base.flags |= kPostNsBitmap;
-        }
-      }
-      const uint32_t n_req = term_req_off[g + 1] - term_req_off[g];
-      bool simple = n_req <= 2 && req_op[best] == KT_OP_IN;
-      uint32_t other_pair = 0;
-      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1] && simple; ++r) {
-        if (req_op[r] != KT_OP_IN || req_val_off[r + 1] - req_val_off[r] != 1) simple = false;
-        else if ((int64_t)r != best) other_pair = req_val[req_val_off[r]];
-      }
-      if (!simple) base.flags |= kPostComplex;
-      else if (n_req == 2) {
-        base.flags |= kPostPair2;
-        base.pair2 = other_pair;
-      }
-      if (req_op[best] == KT_OP_IN) {
-        std::vector<uint32_t> vals(req_val.begin() + req_val_off[best], req_val.begin() + req_val_off[best + 1]);
-        std::sort(vals.begin(), vals.end());
-        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        for (uint32_t v : vals) {
-          lists[scope << 32 | v].push_back(base);  // an empty value set files nothing: never matches
-        }
-      } else {
-        lists[scope << 32 | (kKeyAtom | req_key[best])].push_back(base);
-        out.has_key_atoms = true;
-      }
-    }
   }
-  size_t n_slots = 16;
-  while (n_slots < lists.size() * 2 + 1) n_slots <<= 1;
-  out.slots.assign(n_slots, IndexSlot{0, 0, 0});
-  out.mask = (uint32_t)(n_slots - 1);
-  // deterministic order: sort keys
-  std::vector<uint64_t> keys;
-  keys.reserve(lists.size());
-  for (auto& kv : lists) keys.push_back(kv.first);
-  std::sort(keys.begin(), keys.end());
-  for (uint64_t k : keys) {
-    const std::vector<Posting>& l = lists[k];
-    uint32_t h = index_hash(k, out.mask);
-    while (out.slots[h].key != 0) h = (h + 1) & out.mask;
-    out.slots[h] = IndexSlot{k, (uint32_t)out.postings.size(), (uint32_t)l.size()};
-    out.postings.insert(out.postings.end(), l.begin(), l.end());
-  }
-  // ---- bitmap form (all indexed terms; see kt_index.h).  Built when it can live in LDS next to the
-  //      kernel's working buffers; otherwise the kernels use the postings above.
+  // ---- bitmap form (all indexed terms; see kt_index.h): LDS-resident when it fits, else read through L2.
   {
     struct BT {
       uint32_t g, t, pair2, flags;
       std::vector<uint32_t> atoms;  // anchor atoms (empty => universal)
       std::vector<uint32_t> adm;    // namespace admission set as words
+      TermX x;                      // inline extra requirements (kPostInline)
     };
     std::vector<BT> bts;
+    std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
     const uint32_t nsw = (n_ns + 31) / 32;
+    const TermX no_extras = {{{0xFFu, kNoAtom, kNoAtom, kNoAtom}, {0xFFu, kNoAtom, kNoAtom, kNoAtom}}};
     for (size_t t = 0; t < T; ++t) {
       const ThrInfo ti = thr_info((uint32_t)t);
       if (!ti.live) continue;
       if (std::find(out.slow_thr.begin(), out.slow_thr.end(), (uint32_t)t) != out.slow_thr.end()) continue;
+      const size_t first = bts.size();
       for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
         if (ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID)) continue;
         if (!ti.cluster && ti.ns >= n_ns) continue;
         BT b;
-        b.g = g, b.t = (uint32_t)t, b.pair2 = 0, b.flags = 0;
+        b.g = g, b.t = (uint32_t)t, b.pair2 = 0, b.flags = 0, b.x = no_extras;
         b.adm.assign(nsw, 0u);
         bool any_ns = false;
         for (uint32_t n = 0; n < n_ns; ++n)
           if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) b.adm[n >> 5] |= 1u << (n & 31), any_ns = true;
         if (!any_ns) continue;  // admitted nowhere: can never match
-        if (thr_term_off[t + 1] - thr_term_off[t] > 1) b.flags |= kPostMulti;
+        // several terms: the terms of a throttle are numbered contiguously and a lane meets its candidates in
+        // ascending number, so "reported once, by its first matching term" = drop a match that repeats the
+        // lane's previous throttle
+        if (thr_term_off[t + 1] - thr_term_off[t] > 1) b.flags |= kPostAdj;
         int64_t best = -1;
         size_t best_cost = ~(size_t)0;
         for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
@@ -140,17 +70,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
           if (cost < best_cost) best_cost = cost, best = r;
         }
         const uint32_t n_req = term_req_off[g + 1] - term_req_off[g];
-        if (best < 0) {
-          if (n_req != 0) b.flags |= kPostComplex;  // only negative requirements
-        } else {
-          bool simple = n_req <= 2 && req_op[best] == KT_OP_IN;
-          uint32_t other = 0;
-          for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1] && simple; ++r) {
-            if (req_op[r] != KT_OP_IN || req_val_off[r + 1] - req_val_off[r] != 1) simple = false;
-            else if ((int64_t)r != best) other = req_val[req_val_off[r]];
-          }
-          if (!simple) b.flags |= kPostComplex;
-          else if (n_req == 2) b.flags |= kPostPair2, b.pair2 = other;
+        if (best >= 0) {
           if (req_op[best] == KT_OP_IN) {
             b.atoms.assign(req_val.begin() + req_val_off[best], req_val.begin() + req_val_off[best + 1]);
             std::sort(b.atoms.begin(), b.atoms.end());
@@ -158,29 +78,66 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
             if (b.atoms.empty()) continue;  // In with no values: never matches
           } else {
             b.atoms.push_back(kKeyAtom | req_key[best]);
+            out.bm_has_key_rows = true;
           }
         }
+        // the other requirements: one extra single-valued In -> pair2; up to two small ones -> inline; else generic
+        std::vector<uint32_t> extras;
+        for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r)
+          if ((int64_t)r != best) extras.push_back(r);
+        if (best >= 0 && req_op[best] == KT_OP_IN && n_req == 2 && req_op[extras[0]] == KT_OP_IN &&
+            req_val_off[extras[0] + 1] - req_val_off[extras[0]] == 1) {
+          b.flags |= kPostPair2;
+          b.pair2 = req_val[req_val_off[extras[0]]];
+        } else if (!extras.empty()) {
+          bool fits = extras.size() <= 2;
+          for (size_t k = 0; k < extras.size() && fits; ++k) {
+            const uint32_t r = extras[k];
+            const uint32_t nv = req_val_off[r + 1] - req_val_off[r];
+            if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
+              if (nv > 3) fits = false;
+              else {
+                b.x.e[k][0] = req_op[r];
+                for (uint32_t j = 0; j < nv; ++j) b.x.e[k][1 + j] = req_val[req_val_off[r] + j];
+              }
+            } else {
+              b.x.e[k][0] = req_op[r];
+              b.x.e[k][1] = req_key[r];
+            }
+          }
+          if (fits) b.flags |= kPostInline;
+          else b.flags |= kPostComplex, b.x = no_extras;
+        }
+        first_of.push_back((uint32_t)first);
         bts.push_back(std::move(b));
       }
     }
-    // terms with the same admission set become contiguous
-    std::stable_sort(bts.begin(), bts.end(), [](const BT& a, const BT& b) { return a.adm < b.adm; });
-    // term numbers: a class never straddles a 64-bit word unless it is larger than one
+    // order: throttles by the admission set of their FIRST term (namespaces then touch few blocks as long as the
+    // terms of a throttle agree on it — always for namespaced Throttles), terms of a throttle contiguous
+    std::vector<uint32_t> order(bts.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return bts[first_of[a]].adm < bts[first_of[b]].adm; });
+    // term numbers: a class (run of throttles with the same first admission set) never straddles a step of the
+    // scan unless it is larger than one — 64-bit words for programs small enough for the LDS form, 128-bit blocks
+    // beyond (the L2 form reads 16 bytes per request)
+    const uint32_t gran = bts.size() <= 4096 ? 64u : 128u;
     std::vector<uint32_t> num(bts.size());
     uint32_t pos = 0;
-    for (size_t i = 0; i < bts.size();) {
+    for (size_t i = 0; i < order.size();) {
       size_t j = i;
-      while (j < bts.size() && bts[j].adm == bts[i].adm) ++j;
+      while (j < order.size() && bts[first_of[order[j]]].adm == bts[first_of[order[i]]].adm) ++j;
       const uint32_t sz = (uint32_t)(j - i);
-      if ((pos & 63u) != 0 && ((pos & 63u) + sz > 64u)) pos = (pos + 63u) & ~63u;
-      for (size_t q = i; q < j; ++q) num[q] = pos++;
+      if ((pos & (gran - 1)) != 0 && ((pos & (gran - 1)) + sz > gran)) pos = (pos + gran - 1) & ~(gran - 1);
+      for (size_t q = i; q < j; ++q) num[order[q]] = pos++;
       i = j;
     }
     const uint32_t G2 = pos;
-    if (G2 > 0) {
-      const uint32_t W = (G2 + 63) / 64;
+    {
+      const uint32_t W = G2 ? (G2 + 63) / 64 : 1u;  // 64-bit words per row (an empty program keeps one zero word)
+      const uint32_t NB = (W + 1) / 2;               // 128-bit blocks (the L2 form masks the missing half of the last)
       out.bm_words = W;
-      out.bm_stride = W | 1u;
+      out.bm_stride = W | 1u;  // odd: column reads spread over the LDS banks
       std::unordered_map<uint32_t, uint32_t> row_of;
       for (auto& b : bts)
         for (uint32_t a : b.atoms) row_of.emplace(a, 0u);
@@ -191,12 +148,16 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       out.bm_rows = (uint32_t)atoms.size() + 2;
       out.bm_row_bits.assign((size_t)out.bm_rows * out.bm_stride, 0ull);
       out.bm_nsrows.assign((size_t)n_ns * out.bm_stride, 0ull);
-      out.bm_trec.assign(G2, TermRec{0, 0, 0, 0});
+      out.bm_trec.assign(G2 ? G2 : 1u, TermRec{0, 0, 0, 0});
+      bool any_inline = false;
+      for (auto& b : bts) any_inline |= (b.flags & kPostInline) != 0;
+      if (any_inline) out.bm_trecx.assign(G2, no_extras);
       for (size_t q = 0; q < bts.size(); ++q) {
         const BT& b = bts[q];
         const uint32_t c = num[q];
         const uint64_t bit = 1ull << (c & 63);
         out.bm_trec[c] = TermRec{b.g, b.t, b.pair2, b.flags};
+        if (any_inline) out.bm_trecx[c] = b.x;
         if (b.atoms.empty()) out.bm_row_bits[c >> 6] |= bit;
         for (uint32_t a : b.atoms) out.bm_row_bits[(size_t)row_of[a] * out.bm_stride + (c >> 6)] |= bit;
         for (uint32_t n = 0; n < n_ns; ++n)
@@ -204,18 +165,28 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       }
       out.bm_nswords_off.assign((size_t)n_ns + 1, 0u);
       for (uint32_t n = 0; n < n_ns; ++n) {
-        for (uint32_t w = 0; w < W; ++w)
-          if (out.bm_nsrows[(size_t)n * out.bm_stride + w]) out.bm_nswords.push_back(w);
+        for (uint32_t blk = 0; blk < NB; ++blk) {
+          uint64_t any = out.bm_nsrows[(size_t)n * out.bm_stride + 2 * blk];
+          if (2 * blk + 1 < W) any |= out.bm_nsrows[(size_t)n * out.bm_stride + 2 * blk + 1];
+          if (any) out.bm_nswords.push_back(blk);
+        }
         out.bm_nswords_off[n + 1] = (uint32_t)out.bm_nswords.size();
       }
-      // atoms -> rows in 4-entry buckets; grow until no bucket overflows
+      out.bm_nswords64_off.assign((size_t)n_ns + 1, 0u);
+      for (uint32_t n = 0; n < n_ns; ++n) {
+        for (uint32_t w = 0; w < W; ++w)
+          if (out.bm_nsrows[(size_t)n * out.bm_stride + w]) out.bm_nswords64.push_back(w);
+        out.bm_nswords64_off[n + 1] = (uint32_t)out.bm_nswords64.size();
+      }
+      // atoms -> rows in 4-entry buckets: a few multipliers per size, then double, until no bucket overflows
       size_t nb = 4;
-      while (nb * 2 < atoms.size()) nb <<= 1;
-      for (;;) {
+      while (nb * 3 < atoms.size()) nb <<= 1;
+      uint32_t mult = 0x9E3779B1u;
+      for (int attempt = 0;; ++attempt) {
         out.bm_buckets.assign(nb, AtomBucket{{0, 0, 0, 0}, {1, 1, 1, 1}});
         bool ok = true;
         for (uint32_t a : atoms) {
-          AtomBucket& bk = out.bm_buckets[atom_bucket(a, (uint32_t)nb - 1)];
+          AtomBucket& bk = out.bm_buckets[atom_bucket(a, (uint32_t)nb - 1, mult)];
           int k = 0;
           while (k < 4 && bk.atom[k] != 0) ++k;
           if (k == 4) { ok = false; break; }
@@ -223,15 +194,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
           bk.row[k] = row_of[a];
         }
         if (ok) break;
-        nb <<= 1;
+        if (attempt % 24 == 23) nb <<= 1;
+        mult = mult * 0x01000193u + 0x9E3779B9u;
+        mult |= 1u;
       }
+      out.bm_bucket_mult = mult;
       out.bm_bucket_mask = (uint32_t)nb - 1;
     }
-  }
-  out.uni_ns_off.assign((size_t)n_ns + 1, 0);
-  for (uint32_t n = 0; n < n_ns; ++n) {
-    out.uni_ns.insert(out.uni_ns.end(), uni_ns[n].begin(), uni_ns[n].end());
-    out.uni_ns_off[n + 1] = (uint32_t)out.uni_ns.size();
   }
 }
 
@@ -252,36 +221,37 @@ static hipError_t up(T*& dev, size_t& cap, const std::vector<T>& h, hipStream_t 
 
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   hipError_t e;
-  if ((e = up(d.slots, d.cap_slots, h.slots, s)) != hipSuccess) return e;
-  if ((e = up(d.postings, d.cap_postings, h.postings, s)) != hipSuccess) return e;
-  if ((e = up(d.uni_ns_off, d.cap_uni_ns_off, h.uni_ns_off, s)) != hipSuccess) return e;
-  if ((e = up(d.uni_ns, d.cap_uni_ns, h.uni_ns, s)) != hipSuccess) return e;
-  if ((e = up(d.uni_cluster, d.cap_uni_cluster, h.uni_cluster, s)) != hipSuccess) return e;
   if ((e = up(d.slow_thr, d.cap_slow, h.slow_thr, s)) != hipSuccess) return e;
-  d.mask = h.mask;
-  d.n_uni_cluster = (uint32_t)h.uni_cluster.size();
   d.n_slow = (uint32_t)h.slow_thr.size();
-  d.has_key_atoms = h.has_key_atoms ? 1u : 0u;
-  d.n_slots = (uint32_t)h.slots.size();
-  d.n_postings = (uint32_t)h.postings.size();
-  d.n_cluster_postings = 0;
-  for (const IndexSlot& sl : h.slots)
-    if (sl.key != 0 && (sl.key >> 32) == 0) d.n_cluster_postings += sl.count;
   d.bm_words = h.bm_words;
   d.bm_stride = h.bm_stride;
   d.bm_bucket_mask = h.bm_bucket_mask;
+  d.bm_bucket_mult = h.bm_bucket_mult;
+  d.bm_has_key_rows = h.bm_has_key_rows ? 1u : 0u;
+  d.bm_has_inline = h.bm_trecx.empty() ? 0u : 1u;
   d.bm_blob_bytes = 0;
-  if (h.bm_words != 0) {
+  {
     // pack the bitmap tables into one blob (the LDS image)
-    const void* src[6] = {h.bm_row_bits.data(), h.bm_nsrows.data(), h.bm_nswords_off.data(),
-                          h.bm_nswords.data(), h.bm_buckets.data(), h.bm_trec.data()};
-    const size_t bytes[6] = {h.bm_row_bits.size() * 8, h.bm_nsrows.size() * 8, h.bm_nswords_off.size() * 4,
+    const void* src[9] = {h.bm_row_bits.data(), h.bm_nsrows.data(), h.bm_nswords_off.data(), h.bm_nswords.data(),
+                          h.bm_buckets.data(), h.bm_trec.data(), h.bm_trecx.data(), h.bm_nswords64_off.data(),
+                          h.bm_nswords64.data()};
+    const size_t bytes[9] = {h.bm_row_bits.size() * 8, h.bm_nsrows.size() * 8, h.bm_nswords_off.size() * 4,
                              h.bm_nswords.size() * 4, h.bm_buckets.size() * sizeof(AtomBucket),
-                             h.bm_trec.size() * sizeof(TermRec)};
+                             h.bm_trec.size() * sizeof(TermRec), h.bm_trecx.size() * sizeof(TermX),
+                             h.bm_nswords64_off.size() * 4, h.bm_nswords64.size() * 4};
+    // blob order: what the LDS form stages first, the block lists of the L2 form last
+    static const int kOrder[9] = {0, 1, 4, 5, 6, 7, 8, 2, 3};
     size_t o = 0;
-    for (int k = 0; k < 6; ++k) d.bm_off[k] = (uint32_t)o, o += (bytes[k] + 15) & ~(size_t)15;
+    for (int q = 0; q < 9; ++q) {
+      const int k = kOrder[q];
+      if (q == 7) d.bm_lds_bytes = (uint32_t)o;
+      d.bm_off[k] = (uint32_t)o, o += (bytes[k] + 15) & ~(size_t)15;
+    }
+    if (getenv("KT_DEBUG_LDS"))
+      fprintf(stderr, "bitmap blob: rows=%zu nsrows=%zu nsb_off=%zu nsb=%zu buckets=%zu trec=%zu trecx=%zu w64_off=%zu w64=%zu (stride %u words, %u rows)\n",
+              bytes[0], bytes[1], bytes[2], bytes[3], bytes[4], bytes[5], bytes[6], bytes[7], bytes[8], h.bm_stride, h.bm_rows);
     std::vector<unsigned char> blob(o + 16, 0);
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 9; ++k)
       if (bytes[k]) memcpy(blob.data() + d.bm_off[k], src[k], bytes[k]);
     if ((e = up(d.bm_blob, d.cap_bm_blob, blob, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;  // `blob` is a temporary
@@ -291,11 +261,6 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
 }
 
 void release_index(IndexDev& d) {
-  if (d.slots) (void)hipFree(d.slots);
-  if (d.postings) (void)hipFree(d.postings);
-  if (d.uni_ns_off) (void)hipFree(d.uni_ns_off);
-  if (d.uni_ns) (void)hipFree(d.uni_ns);
-  if (d.uni_cluster) (void)hipFree(d.uni_cluster);
   if (d.slow_thr) (void)hipFree(d.slow_thr);
   if (d.bm_blob) (void)hipFree(d.bm_blob);
   d = IndexDev();

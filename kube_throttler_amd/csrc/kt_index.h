@@ -3,16 +3,14 @@
 //
 // Every term of a live throttle (valid, responsible, no unconvertible podSelector) is filed under ONE
 // anchor requirement:
-//   In{key, values}  -> one posting per (key,value) pair id of the set        (atom = pair id)
-//   Exists{key}      -> one posting under the key                             (atom = 0x80000000 | key id)
-// scoped by namespace for namespaced Throttles (scope = ns + 1; Throttles(pod.Namespace).List is an
-// implicit namespace-equality predicate, throttle_controller.go:249) and unscoped (scope = 0) for
-// ClusterThrottles, whose namespaceSelector is pre-evaluated into SelProgram::ns_term_ok.
+//   In{key, values}  -> under every (key,value) pair id of the set            (atom = pair id)
+//   Exists{key}      -> under the key                                         (atom = 0x80000000 | key id)
 // A pod carries at most one value per key, so a matching term is reached through exactly one of the
-// pod's labels.  Terms with no positive requirement (empty selector, only NotIn/DoesNotExist) go to
-// per-namespace / cluster-wide "universal" lists; throttles that contain an unconvertible podSelector
-// term go to a "slow" list and are walked term by term in order (error semantics of
-// throttle_selector.go:30-42 depend on term order).
+// pod's labels.  Terms with no positive requirement (empty selector, only NotIn/DoesNotExist) are filed under
+// row 0 ("every pod"); throttles that contain an unconvertible podSelector term go to a "slow" list and are
+// walked term by term in order (error semantics of throttle_selector.go:30-42 depend on term order).
+// The namespace side of every term (implicit namespace equality of a Throttle, throttle_controller.go:249;
+// namespaceSelector of a ClusterThrottle) is pre-evaluated into SelProgram::ns_term_ok and enters as a bitmap.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,53 +22,39 @@
 
 namespace kt {
 
-struct alignas(16) IndexSlot {
-  uint64_t key;  // (scope << 32) | atom ; 0 = empty
-  uint32_t begin;
-  uint32_t count;
-};
-
 constexpr uint32_t kKeyAtom = 0x80000000u;
 
-// One posting = one candidate term, with everything the common case needs to decide the match inline:
-// a term whose requirements are all single-value In (matchLabels with <= 2 pairs) is fully described by
-// its anchor pair (implied by the hash key) and `pair2`; ClusterThrottle terms carry the 64-bit
-// namespace admission mask when the engine holds <= 64 namespaces.
-constexpr uint32_t kPostComplex = 0x1u;   // needs the generic requirement walk (term_match)
-constexpr uint32_t kPostMulti = 0x2u;     // owning throttle has several terms: first-matching-term dedup
-constexpr uint32_t kPostNsMask = 0x4u;    // cluster term, namespace test = bit `ns` of nsmask
-constexpr uint32_t kPostNsBitmap = 0x8u;  // cluster term, namespace test = SelProgram::ns_term_ok
-constexpr uint32_t kPostPair2 = 0x10u;    // pod must also carry `pair2`
-struct alignas(16) Posting {
-  uint32_t g;      // term
-  uint32_t t;      // owning throttle row
-  uint32_t pair2;
-  uint32_t flags;
-  uint64_t nsmask;
-  uint64_t pad;
-};
+// TermRec flags
+constexpr uint32_t kPostComplex = 0x1u;  // needs the generic requirement walk (term_match)
+constexpr uint32_t kPostMulti = 0x2u;    // (generic path) owning throttle has several terms: first-matching-term check
+constexpr uint32_t kPostPair2 = 0x10u;   // pod must also carry `pair2`
 
-__host__ __device__ inline uint32_t index_hash(uint64_t key, uint32_t mask) {
-  uint64_t h = key * 0x9E3779B97F4A7C15ull;
-  h ^= h >> 29;
-  return (uint32_t)h & mask;
-}
-
-// ---- bitmap form of the whole selector side (small-T regime) ----------------------------------------
+// ---- bitmap form of the whole selector side ----------------------------------------------------------
 // Every indexed term gets a number c; terms with the same namespace-admission set (a "class") are numbered
-// contiguously and a class of <= 64 terms never straddles a 64-bit word (larger classes start on a word
-// boundary; unused numbers are padding), so a namespace only ever touches a few 64-bit words of any bitmap:
-//     candidates(pod)[w] = (rows[0][w] | OR_l rows[row_of(label_l)][w]) & nsrows[ns][w]   for w in nswords[ns]
+// contiguously — throttles ordered by the admission set of their first term, the terms of a throttle kept
+// together — and a class of <= 128 terms never straddles a 128-bit block (larger classes start on a block
+// boundary; unused numbers are padding), so a namespace only ever touches a few blocks of any bitmap:
+//     candidates(pod)[b] = (rows[0][b] | OR_l rows[row_of(label_l)][b]) & nsrows[ns][b]   for b in nsblocks[ns]
 // rows[0] = terms without a positive requirement, rows[1] = all zero (unknown atoms).  Atoms are found in
 // 4-entry buckets (branch-free probe).  TermRec carries what a visit needs (same flags as Posting).
 struct alignas(16) TermRec {
   uint32_t g, t, pair2, flags;
 };
+// Bitmap-form extras of a term (flag kPostInline): up to two requirements besides the anchor, small enough to be
+// decided from registers.  e[k] = {op (KT_OP_*; 0xFF = none), up to three atoms (pair ids for In / NotIn, the key id
+// for Exists / DoesNotExist; kNoAtom = unused)}.
+constexpr uint32_t kPostInline = 0x20u;  // TermX holds the remaining requirements
+constexpr uint32_t kPostAdj = 0x40u;     // multi-term throttle: a match repeating the lane's previous throttle is dropped
+constexpr uint32_t kNoAtom = 0xFFFFFFFFu;
+struct alignas(16) TermX {
+  uint32_t e[2][4];
+};
 struct alignas(16) AtomBucket {
   uint32_t atom[4];  // 0 = empty
   uint32_t row[4];
 };
-__host__ __device__ inline uint32_t atom_bucket(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 9) & mask; }
+// bucket of an atom: multiplicative hash; the builder tries several odd multipliers per table size before doubling it
+__host__ __device__ inline uint32_t atom_bucket(uint32_t atom, uint32_t mask, uint32_t mult) { return ((atom * mult) >> 9) & mask; }
 
 struct ThrInfo {
   bool live;
@@ -79,46 +63,34 @@ struct ThrInfo {
 };
 
 struct HostIndex {
-  std::vector<IndexSlot> slots;
-  uint32_t mask = 0;
-  std::vector<Posting> postings;
-  std::vector<uint32_t> uni_ns_off;  // [n_ns + 1]
-  std::vector<uint32_t> uni_ns;
-  std::vector<uint32_t> uni_cluster;
   std::vector<uint32_t> slow_thr;
-  bool has_key_atoms = false;
-  // bitmap form (valid when bm_words != 0)
   uint32_t bm_words = 0;   // W: 64-bit words per bitmap row
   uint32_t bm_stride = 0;  // row stride in 64-bit words (odd: column reads spread over LDS banks)
   uint32_t bm_rows = 0;
-  uint32_t bm_bucket_mask = 0;
+  uint32_t bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u;
   std::vector<uint64_t> bm_row_bits;    // [bm_rows][bm_stride]
   std::vector<uint64_t> bm_nsrows;      // [n_ns][bm_stride]
   std::vector<uint32_t> bm_nswords_off; // [n_ns + 1]
-  std::vector<uint32_t> bm_nswords;     // word indices a namespace can touch
+  std::vector<uint32_t> bm_nswords;     // 128-bit block indices a namespace can touch (L2 form: one 16-byte read each)
+  std::vector<uint32_t> bm_nswords64_off, bm_nswords64;  // the same as 64-bit word indices (LDS form)
   std::vector<AtomBucket> bm_buckets;
   std::vector<TermRec> bm_trec;
+  std::vector<TermX> bm_trecx;   // empty when no term needs it
+  bool bm_has_key_rows = false;  // some term is anchored on an Exists requirement
 };
 
 struct IndexDev {
-  IndexSlot* slots = nullptr;
-  Posting* postings = nullptr;
-  uint32_t* uni_ns_off = nullptr;
-  uint32_t* uni_ns = nullptr;
-  uint32_t* uni_cluster = nullptr;
   uint32_t* slow_thr = nullptr;
-  uint32_t mask = 0, n_uni_cluster = 0, n_slow = 0;
-  uint32_t has_key_atoms = 0;
-  uint32_t n_slots = 0, n_postings = 0;
-  uint32_t n_cluster_postings = 0;  // postings filed under scope 0 come first in the array
+  uint32_t n_slow = 0;
   // bitmap form: ONE device blob holding the six tables back to back (16-byte aligned pieces, in the order
   // rows, nsrows, nswords_off, nswords, buckets, trec) — the kernels copy it to LDS with one streaming loop
-  uint32_t bm_words = 0, bm_stride = 0, bm_bucket_mask = 0;
+  uint32_t bm_words = 0, bm_stride = 0, bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u, bm_has_key_rows = 0;
   unsigned char* bm_blob = nullptr;
   uint32_t bm_blob_bytes = 0;
-  uint32_t bm_off[6] = {0, 0, 0, 0, 0, 0};  // byte offsets of the tables inside the blob
-  size_t cap_bm_blob = 0;
-  size_t cap_slots = 0, cap_postings = 0, cap_uni_ns_off = 0, cap_uni_ns = 0, cap_uni_cluster = 0, cap_slow = 0;
+  uint32_t bm_lds_bytes = 0;  // prefix of the blob the LDS form stages
+  uint32_t bm_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of the tables inside the blob
+  uint32_t bm_has_inline = 0;
+  size_t cap_bm_blob = 0, cap_slow = 0;
 };
 
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,

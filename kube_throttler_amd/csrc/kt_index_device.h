@@ -1,15 +1,6 @@
-// kt_index_device.h — device side of the indexed pod x throttle scans for gfx950: work ~ (pods + candidate terms).
-//
-// lane = pod.  Each lane probes the label-atom hash index (kt_index.h) with its own labels; postings carry
-// an inline description of the common term shapes, so a candidate is usually decided from one 32-byte
-// record.  Decisions still cover the full P x T matrix: every pair not enumerated is "not affected" by
-// construction of the index.
-//
-//  * kt_check_indexed     : hash slots + postings staged in LDS when they fit (one 1024-thread workgroup per
-//                           CU shares one copy; 160 KB LDS/CU), else read through L2.
-//  * kt_aggregate_indexed : per-workgroup partial-`used` table in LDS (ds_add_u64 / ds_add_u32), spilled to a
-//                           slab and summed by kt_reduce_partials; global atomics only when the table does
-//                           not fit LDS.
+// kt_index_device.h — device-side pieces shared by the index-driven kernels (gfx950): LDS pointer types, the generic
+// requirement walk for rare term shapes, the in-order walk of throttles with unconvertible selectors.
+// The scan itself is kt_bitmap_scan.h.
 #pragma once
 #include <cstdlib>
 
@@ -22,7 +13,6 @@ namespace kt {
 constexpr int kBlockIx = 1024;       // one workgroup per CU: 16 waves = 4 per SIMD
 constexpr int kMaxLds = 160 * 1024;  // gfx950 LDS per CU / per workgroup
 constexpr int kCUs = 256;
-constexpr uint32_t kQueueCap = 6 * 1024;  // tile match-queue entries (24 KB): ~6 matches per pod of a 1024-pod tile
 
 template <int LT, bool KEYS>
 struct Matcher {
@@ -51,22 +41,6 @@ struct Matcher {
     return true;
   }
 
-  // posting fast path: the anchor requirement is already satisfied (that is how the posting was reached)
-  __device__ __forceinline__ bool posting_match(const Posting& p, uint32_t ns) const {
-    const uint32_t f = p.flags;
-    bool ok = true;
-    if (f & kPostNsMask) ok = (p.nsmask >> ns) & 1ull;
-    else if (f & kPostNsBitmap) ok = ns_ok(p.g);
-    if (ok && (f & kPostPair2)) {
-      bool has = false;
-#pragma unroll
-      for (int l = 0; l < LT; ++l) has |= lp[l] == p.pair2;
-      ok = has;
-    }
-    if (ok && (f & (kPostComplex | kPostMulti))) ok = rare(p.g, p.t, f);
-    return ok;
-  }
-
   // rare term shapes (requirements beyond one extra matchLabels pair, multi-term throttles): a real call
   __device__ __forceinline__ bool rare(uint32_t g, uint32_t t, uint32_t f) const {
     if ((f & kPostComplex) && !term_match<LT, KEYS>(sp, g, lp, lk)) return false;
@@ -92,83 +66,6 @@ __device__ __forceinline__ uint32_t lds_add(lds_u32wp p, uint32_t v) {
 __device__ __forceinline__ void lds_add64(lds_u64wp p, unsigned long long v) {
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// tables are viewed as arrays of 16-byte vectors: IndexSlot = 1, TermRec = 1, Posting = 2 vectors
-__device__ __forceinline__ Posting make_posting(u32x4 a, u32x4 b) {
-  Posting p;
-  p.g = a.x, p.t = a.y, p.pair2 = a.z, p.flags = a.w;
-  p.nsmask = (uint64_t)b.x | (uint64_t)b.y << 32;
-  p.pad = 0;
-  return p;
-}
-template <class V4Ptr>
-__device__ __forceinline__ Posting load_posting(V4Ptr posts16, uint32_t idx) {
-  return make_posting(posts16[2 * idx], posts16[2 * idx + 1]);
-}
-
-// One hash lookup: (begin, count) of the posting list filed under `key` (count 0 when absent).
-template <class V4Ptr>
-__device__ __forceinline__ uint2 lookup(V4Ptr slots16, uint32_t mask, uint64_t key) {
-  uint32_t h = index_hash(key, mask);
-  const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-  for (;;) {
-    const u32x4 s = slots16[h];  // {key lo, key hi, begin, count}
-    if (s.x == klo && s.y == khi) return make_uint2(s.z, s.w);
-    if ((s.x | s.y) == 0) return make_uint2(0u, 0u);
-    h = (h + 1) & mask;
-  }
-}
-
-template <int LT, bool KEYS, class SlotPtr, class PostPtr, class F>
-__device__ __forceinline__ void enumerate_matches(const SelProgram& sp, const IndexDev& ix, SlotPtr slots,
-                                                  PostPtr posts, uint32_t ns, const uint32_t (&lp)[LT],
-                                                  const uint32_t (&lk)[LT], F&& on_match) {
-  const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
-  const uint64_t scope = (uint64_t)(ns + 1) << 32;
-  // all lookups first (independent loads in flight together), then the posting walks
-  uint2 rn[LT], rc[LT];
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    const uint32_t pair = lp[l];
-    rn[l] = pair ? lookup(slots, ix.mask, scope | pair) : make_uint2(0u, 0u);    // Throttles of the pod's namespace
-    rc[l] = pair ? lookup(slots, ix.mask, (uint64_t)pair) : make_uint2(0u, 0u);  // ClusterThrottles
-  }
-#pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    for (uint32_t k = 0; k < rn[l].y; ++k) {
-      const Posting p = load_posting(posts, rn[l].x + k);
-      if (m.posting_match(p, ns)) on_match(p.t);
-    }
-    for (uint32_t k = 0; k < rc[l].y; ++k) {
-      const Posting p = load_posting(posts, rc[l].x + k);
-      if (m.posting_match(p, ns)) on_match(p.t);
-    }
-  }
-  if (KEYS && ix.has_key_atoms) {
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-      if (lk[l] == 0) continue;
-      const uint32_t ka = kKeyAtom | lk[l];
-      const uint2 a = lookup(slots, ix.mask, scope | ka), b = lookup(slots, ix.mask, (uint64_t)ka);
-      for (uint32_t k = 0; k < a.y; ++k) {
-        const Posting p = load_posting(posts, a.x + k);
-        if (m.posting_match(p, ns)) on_match(p.t);
-      }
-      for (uint32_t k = 0; k < b.y; ++k) {
-        const Posting p = load_posting(posts, b.x + k);
-        if (m.posting_match(p, ns)) on_match(p.t);
-      }
-    }
-  }
-  for (uint32_t k = ix.uni_ns_off[ns]; k < ix.uni_ns_off[ns + 1]; ++k) {
-    uint32_t t;
-    if (m.owns_match(ix.uni_ns[k], false, t)) on_match(t);
-  }
-  for (uint32_t k = 0; k < ix.n_uni_cluster; ++k) {
-    uint32_t t;
-    if (m.owns_match(ix.uni_cluster[k], true, t)) on_match(t);
-  }
-}
-
 // Throttles with an unconvertible podSelector term: in-order walk, error when the bad term is reached
 // before a match (same semantics as the dense kernels; t is wave-uniform).
 template <int LT, bool KEYS>
@@ -192,44 +89,5 @@ __device__ __forceinline__ void walk_slow(const SelProgram& sp, int t, const uin
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char kt_smem[];
-
-__device__ __forceinline__ void lds_stage(KT_LDS unsigned char* dst, const void* src, uint32_t bytes) {
-  const u32x4* s = (const u32x4*)src;
-  KT_LDS u32x4* d = (KT_LDS u32x4*)dst;
-  for (uint32_t i = threadIdx.x; i < (bytes + 15u) / 16u; i += kBlockIx) d[i] = s[i];
-}
-
-// branch-free 4-way bucket probe: bitmap row of `atom`, or row 1 (all zero) when no selector mentions it
-__device__ __forceinline__ uint32_t atom_row(lds_u4p buckets, uint32_t mask, uint32_t atom) {
-  const uint32_t b = atom_bucket(atom, mask);
-  const u32x4 a = buckets[2 * b], r = buckets[2 * b + 1];
-  uint32_t row = 1u;
-  row = a.x == atom ? r.x : row;
-  row = a.y == atom ? r.y : row;
-  row = a.z == atom ? r.z : row;
-  row = a.w == atom ? r.w : row;
-  return atom ? row : 1u;
-}
-
-
-#define KT_IX_CASE(NAME, DT_, LT_, KEYS_, FLAG_)                                                                 \
-  {                                                                                                             \
-    auto kfn = NAME<DT_, LT_, KEYS_, FLAG_>;                                                                    \
-    if (lds_bytes > 48 * 1024)                                                                                  \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, KT_IX_ARGS);                                                  \
-  }
-#ifdef KT_FAST_BUILD
-#define KT_IX_DISPATCH2(NAME, DT_, LT_, KEYS_, FLAG_) do { KT_IX_CASE(NAME, 8, 8, false, FLAG_) } while (0)
-#else
-#define KT_IX_DISPATCH2(NAME, DT_, LT_, KEYS_, FLAG_)                                                                          \
-  do {                                                                                                                         \
-    if (DT_ <= 8 && LT_ == 8) { if (KEYS_) KT_IX_CASE(NAME, 8, 8, true, FLAG_) else KT_IX_CASE(NAME, 8, 8, false, FLAG_) } \
-    else if (DT_ <= 8) { if (KEYS_) KT_IX_CASE(NAME, 8, 16, true, FLAG_) else KT_IX_CASE(NAME, 8, 16, false, FLAG_) }           \
-    else if (LT_ == 8) { if (KEYS_) KT_IX_CASE(NAME, 16, 8, true, FLAG_) else KT_IX_CASE(NAME, 16, 8, false, FLAG_) }           \
-    else { if (KEYS_) KT_IX_CASE(NAME, 16, 16, true, FLAG_) else KT_IX_CASE(NAME, 16, 16, false, FLAG_) }                       \
-  } while (0)
-#endif
-
 
 }  // namespace kt
