@@ -227,7 +227,9 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
   const int64_t u_c = (int64_t)prow[2 * D];
   const bool u_hc = u_c > 0;
   _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-    const bool pr = prow[D + d] != 0;
+    // a key is present when some counted pod carried it: the presence count says so, and so does a non-zero sum
+    // (the L2-form aggregate skips the presence increment for positive values)
+    const bool pr = prow[D + d] != 0 || prow[d] != 0;
     u_p |= (pr ? 1u : 0u) << d;
     u_v[d] = pr ? (int64_t)prow[d] : 0;
   }

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             unsigned long long* pr = a.partial + (size_t)c.t * pstride;
             if (c.x.x != 0) atomicAdd(pr + 2 * dp, (unsigned long long)c.x.x);
             if (c.x.y != 0) atomicAdd(pr + 2 * dp + 1, (unsigned long long)c.x.y);
-            if ((c.pres >> (2 * dp)) & 1u) atomicAdd(pr + D + 2 * dp, 1ull);
-            if ((c.pres >> (2 * dp + 1)) & 1u) atomicAdd(pr + D + 2 * dp + 1, 1ull);
+            // key presence: a positive value already makes the sum non-zero unless something negative cancels it,
+            // and every non-positive contribution increments the presence word (kt_finalize: count != 0 || sum != 0)
+            if (((c.pres >> (2 * dp)) & 1u) && c.x.x <= 0) atomicAdd(pr + D + 2 * dp, 1ull);
+            if (((c.pres >> (2 * dp + 1)) & 1u) && c.x.y <= 0) atomicAdd(pr + D + 2 * dp + 1, 1ull);
             if (dp == 0) atomicAdd(pr + 2 * D, 1ull);
           }
         }

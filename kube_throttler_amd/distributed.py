@@ -32,7 +32,9 @@ def unpack_partial(buf: np.ndarray, D: int):
     buf = np.asarray(buf).reshape(-1, partial_stride(D))
     present = np.zeros(len(buf), dtype=np.uint32)
     for d in range(D):
-        present |= ((buf[:, D + d] > 0).astype(np.uint32) << np.uint32(d))
+        # present = presence count != 0 or sum != 0 (kt_finalize's rule: the L2-form aggregate skips the presence
+        # increment for positive values)
+        present |= (((buf[:, D + d] > 0) | (buf[:, d] != 0)).astype(np.uint32) << np.uint32(d))
     v = np.where(buf[:, D:2 * D] > 0, buf[:, :D], 0)
     count = buf[:, 2 * D]
     return v, present, count, count > 0, buf[:, 2 * D + 1] > 0
