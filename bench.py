@@ -102,17 +102,26 @@ def main():
     t0 = time.time()
     eng = E.Engine.for_snapshot(snap, variant, device=local_rank)
     t_load = time.time() - t0
-    stream = torch.cuda.current_stream().cuda_stream
+    # ONE explicit stream carries the whole step: the engine's kernels are enqueued on it through the C-ABI and the
+    # RCCL all-reduce is issued with it as torch's current stream, so aggregate -> all-reduce -> finalize -> check are
+    # ordered without any host synchronisation.  (The legacy null stream would NOT do: the engine substitutes its own
+    # non-blocking stream for a null handle, which the collective would not be ordered against.)
+    ts = torch.cuda.Stream()
+    stream = ts.cuda_stream
+    assert stream != 0
 
-    partial = torch.zeros(eng.partial_words(), dtype=torch.int64, device="cuda")
+    with torch.cuda.stream(ts):
+        partial = torch.zeros(eng.partial_words(), dtype=torch.int64, device="cuda")
+    ts.synchronize()
     eng.use_partial_buffer(partial.data_ptr(), partial.numel())
 
     def step():
-        eng.aggregate_launch(stream)
-        if world > 1:
-            KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
-        eng.finalize_launch(now, True, stream)
-        eng.check_launch(per_gpu, None, False, False, stream)
+        with torch.cuda.stream(ts):
+            eng.aggregate_launch(stream)
+            if world > 1:
+                KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
+            eng.finalize_launch(now, True, stream)
+            eng.check_launch(per_gpu, None, False, False, stream)
 
     def fence():
         torch.cuda.synchronize()

@@ -35,7 +35,7 @@ def unpack_partial(buf: np.ndarray, D: int):
         # present = presence count != 0 or sum != 0 (kt_finalize's rule: the L2-form aggregate skips the presence
         # increment for positive values)
         present |= (((buf[:, D + d] > 0) | (buf[:, d] != 0)).astype(np.uint32) << np.uint32(d))
-    v = np.where(buf[:, D:2 * D] > 0, buf[:, :D], 0)
+    v = np.where((buf[:, D:2 * D] > 0) | (buf[:, :D] != 0), buf[:, :D], 0)
     count = buf[:, 2 * D]
     return v, present, count, count > 0, buf[:, 2 * D + 1] > 0
 
