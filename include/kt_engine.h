@@ -128,6 +128,10 @@ int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64);
 int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out);
+/* ThrottleSpecBase.NextOverrideHappensIn(now) (throttle_types.go:37-63) of the last reconcile for throttle rows
+ * [0, n), as the INSTANT of the next override boundary (the controller's enqueueAfter delay is instant - now,
+ * throttle_controller.go:201-208); has[i] = 0 when nothing lies ahead or the row was not reconciled. Synchronises. */
+int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_s, int32_t* next_ns, uint8_t* has);
 
 /* ---- check: KubeThrottler.PreFilter (plugin.go:148-215) = ThrottleController.CheckThrottled
  *      (throttle_controller.go:349-397) + ClusterThrottleController.CheckThrottled

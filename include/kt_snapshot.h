@@ -58,6 +58,8 @@ extern "C" {
 
 /* override flags */
 #define KT_OVR_PARSE_ERROR 0x1u /* begin or end is not RFC3339 (temporary_threshold_override.go:33-55) */
+#define KT_OVR_BEGIN_PARSED 0x2u /* with PARSE_ERROR: the error is in `end`; `begin` parsed and ovr_begin_* is valid
+                                   (NextOverrideHappensIn still counts it, throttle_types.go:44-51) */
 
 /* Instants are (seconds since Unix epoch, nanoseconds); Go's zero time.Time is KT_ZERO_TIME_S, 0. */
 #define KT_ZERO_TIME_S (-62135596800LL)

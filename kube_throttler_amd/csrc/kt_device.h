@@ -17,7 +17,7 @@ constexpr uint32_t kThrValid = 0x1u, kThrCluster = 0x2u, kThrResponsible = 0x4u,
                    kThrThrottledPod = 0x10u;
 constexpr uint8_t kTermPodSelInvalid = 0x1u, kTermNsSelInvalid = 0x2u;
 constexpr uint8_t kOpIn = 0, kOpNotIn = 1, kOpExists = 2, kOpDoesNotExist = 3;
-constexpr uint8_t kOvrParseError = 0x1u;
+constexpr uint8_t kOvrParseError = 0x1u, kOvrBeginParsed = 0x2u;
 constexpr int64_t kZeroTimeS = -62135596800LL;
 
 // Pod state: one 16-byte-aligned ROW per pod in each table.  lane = pod reads its label row with LS/4 and
@@ -92,6 +92,8 @@ struct ReconcileOut {
   uint32_t* thrl_has;
   uint8_t* thrl_pod;
   uint8_t* error;
+  int64_t* next_s;   // NextOverrideHappensIn as an instant: seconds (INT64_MAX = none) ...
+  int32_t* next_ns;  // ... and nanoseconds
 };
 
 // Per-throttle record the check kernels consume (built by kt_prepare_check):

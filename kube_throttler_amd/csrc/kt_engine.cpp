@@ -177,6 +177,8 @@ struct kt_engine {
   unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
   AmountDev d_out_used, d_out_calc;
   DevBuf<uint8_t> d_out_calc_updated, d_out_thrl_pod, d_out_error;
+  DevBuf<int64_t> d_out_next_s;
+  DevBuf<int32_t> d_out_next_ns;
   DevBuf<uint32_t> d_out_thrl_flag, d_out_thrl_has;
   bool reconcile_ready = false;
 
@@ -468,6 +470,8 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_pod.reserve(T + 1));
   KT_HIP(e, e->d_out_error.reserve(T + 1));
+  KT_HIP(e, e->d_out_next_s.reserve(T + 1));
+  KT_HIP(e, e->d_out_next_ns.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_flag.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_has.reserve(T + 1));
   KT_HIP(e, e->d_recs.reserve(kt::recs_bytes((int)T)));
@@ -663,6 +667,8 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
   e->d_partial.release();
+  e->d_out_next_s.release();
+  e->d_out_next_ns.release();
   e->d_sp.release();
   AmountDev* ams[] = {&e->d_spec, &e->d_calc, &e->d_used, &e->d_reserved, &e->d_ovr_thr, &e->d_out_used, &e->d_out_calc};
   for (auto* a : ams) a->release();
@@ -1007,7 +1013,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
-                       e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p};
+                       e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p, e->d_out_next_s.p, e->d_out_next_ns.p};
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
     kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, (flags & KT_RECONCILE_APPLY) != 0, out, s);
@@ -1091,6 +1097,26 @@ int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
 #undef DL
   }
   KT_HIP(e, hipStreamSynchronize(s));
+  return KT_OK;
+}
+
+// NextOverrideHappensIn of the last reconcile, as instants (has = 0: nothing ahead / row not reconciled)
+int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_s, int32_t* next_ns, uint8_t* has) {
+  if (!e || !next_s || !next_ns || !has) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch_next_override before a reconcile launch");
+  if (n < 0 || n > e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows=%d", n, e->thr_rows_hi);
+  hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
+  if (n) {
+    KT_HIP(e, hipMemcpyAsync(next_s, e->d_out_next_s.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(next_ns, e->d_out_next_ns.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  }
+  KT_HIP(e, hipStreamSynchronize(s));
+  for (int32_t i = 0; i < n; ++i) {
+    has[i] = next_s[i] != INT64_MAX;
+    if (!has[i]) next_s[i] = 0, next_ns[i] = 0;
+  }
   return KT_OK;
 }
 

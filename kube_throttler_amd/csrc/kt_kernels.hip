@@ -219,6 +219,8 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
     out.thrl_has[t] = tt.thrl_has[t];
     out.thrl_pod[t] = (fl & kThrThrottledPod) ? 1 : 0;
     out.error[t] = error ? 1 : 0;
+    out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
+    out.next_ns[t] = 0;
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
@@ -239,11 +241,20 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
   bool c_hc = false, active_found = false, any_err = false;
   int64_t c_c = 0;
   _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = 0;
+  // NextOverrideHappensIn (throttle_types.go:37-63): earliest begin / end instant strictly after now
+  int64_t nx_s = INT64_MAX;
+  int32_t nx_ns = 0;
+  auto sooner = [&](int64_t s_, int32_t ns_) {
+    if (instant_cmp(s_, ns_, now_s, now_ns) > 0 && instant_cmp(s_, ns_, nx_s, nx_ns) < 0) nx_s = s_, nx_ns = ns_;
+  };
   for (uint32_t o = tt.ovr_off[t]; o < tt.ovr_off[t + 1]; ++o) {
     if (tt.ovr_flags[o] & kOvrParseError) {
       any_err = true;
+      if (tt.ovr_flags[o] & kOvrBeginParsed) sooner(tt.ovr_begin_s[o], tt.ovr_begin_ns[o]);  // only `end` is bad
       continue;
     }
+    sooner(tt.ovr_begin_s[o], tt.ovr_begin_ns[o]);
+    sooner(tt.ovr_end_s[o], tt.ovr_end_ns[o]);
     const bool begin = instant_cmp(tt.ovr_begin_s[o], tt.ovr_begin_ns[o], now_s, now_ns) <= 0;
     const bool end_zero = tt.ovr_end_s[o] == kZeroTimeS && tt.ovr_end_ns[o] == 0;
     const bool end = end_zero || instant_cmp(now_s, now_ns, tt.ovr_end_s[o], tt.ovr_end_ns[o]) <= 0;
@@ -299,6 +310,8 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
   out.thrl_has[t] = c_p;
   out.thrl_pod[t] = th_pod;
   out.error[t] = 0;
+  out.next_s[t] = nx_s;
+  out.next_ns[t] = nx_ns;
   if (apply) {  // UpdateStatus: the result becomes the stored status the next check reads
     _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
       tt.used.v[(size_t)t * D + d] = u_v[d];

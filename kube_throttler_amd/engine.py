@@ -32,7 +32,7 @@ EXPORTS = [
     "kt_set_reserved", "kt_set_status", "kt_reconcile_launch", "kt_aggregate_launch", "kt_partial_used_buffer",
     "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
-    "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved",
+    "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
         L.kt_timing_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.kt_timing_reset.argtypes = [C.c_void_p]
         L.kt_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        L.kt_reconcile_fetch_next_override.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kt_admit_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_fetch_reserved.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(S.KtAmounts)]
         _LIB = L
@@ -248,6 +249,13 @@ class Engine:
         st = r.as_struct()
         self._ck(lib().kt_reconcile_fetch(self._h, n, C.byref(st)))
         return r
+
+    def next_override(self, n=None):
+        """NextOverrideHappensIn of the last reconcile: (instant seconds, nanoseconds, has) per throttle row."""
+        n = self.throttle_rows() if n is None else n
+        sec, nsec, has = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint8)
+        self._ck(lib().kt_reconcile_fetch_next_override(self._h, n, sec.ctypes.data, nsec.ctypes.data, has.ctypes.data))
+        return sec[:n], nsec[:n], has[:n]
 
     def reconcile(self, now, apply=True) -> ReconcileResult:
         self.reconcile_launch(now, apply)

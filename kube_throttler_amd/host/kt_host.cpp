@@ -563,15 +563,20 @@ bool KubeThrottler::OnThrottleAdd(const Throttle& thr, std::string* err) {
   for (size_t j = 0; j < no; ++j) {
     const auto& o = thr.overrides[j];
     std::string perr;
-    bool bad = false;
+    bool bad = false, begin_ok = false;
     if (!o.begin.empty() && !ParseRFC3339(o.begin, &ob[j], &obn[j], &perr)) {
       bad = true;
       msgs.push_back("index " + std::to_string(j) + ": Failed to parse Begin: " + perr);
     } else if (!o.end.empty() && !ParseRFC3339(o.end, &oe[j], &oen[j], &perr)) {
-      bad = true;
+      bad = begin_ok = true;
       msgs.push_back("index " + std::to_string(j) + ": Failed to parse End: " + perr);
     }
-    if (bad) oflags[j] |= KT_OVR_PARSE_ERROR, ob[j] = oe[j] = KT_ZERO_TIME_S, obn[j] = oen[j] = 0;
+    if (bad) {
+      oflags[j] |= KT_OVR_PARSE_ERROR;
+      oe[j] = KT_ZERO_TIME_S, oen[j] = 0;
+      if (begin_ok) oflags[j] |= KT_OVR_BEGIN_PARSED;  // NextOverrideHappensIn still counts the begin instant
+      else ob[j] = KT_ZERO_TIME_S, obn[j] = 0;
+    }
     DenseAmount a;
     if (!p.fill_amount(o.threshold, &a, err)) return false;
     std::memcpy(&ov[j * D], a.v, sizeof(int64_t) * D);
@@ -866,6 +871,10 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
   st.error = terr.data();
   int32_t rc = kt_reconcile_launch(p.e, now_s, now_ns, KT_RECONCILE_APPLY, nullptr);
   if (rc == KT_OK) rc = kt_reconcile_fetch(p.e, T, &st);
+  std::vector<int64_t> nx_s((size_t)T + 1);
+  std::vector<int32_t> nx_ns((size_t)T + 1);
+  std::vector<uint8_t> nx_has((size_t)T + 1);
+  if (rc == KT_OK) rc = kt_reconcile_fetch_next_override(p.e, T, nx_s.data(), nx_ns.data(), nx_has.data());
   if (rc != KT_OK) {
     if (err) *err = p.engine_error(rc);
     return false;
@@ -895,6 +904,9 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
     s.throttledPod = tpod[t] != 0;
     s.calculatedThresholdUpdated = updated[t] != 0;
     s.messages = p.thr_msgs[(size_t)t];
+    s.hasNextOverride = nx_has[(size_t)t] != 0;  // NextOverrideHappensIn -> enqueueAfter (throttle_controller.go:201-208)
+    s.nextOverrideSec = nx_s[(size_t)t];
+    s.nextOverrideNsec = nx_ns[(size_t)t];
     for (int d = 0; d < D; ++d) {
       if ((upresent[t] >> d) & 1u) {
         Quantity q;

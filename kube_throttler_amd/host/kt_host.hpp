@@ -98,6 +98,10 @@ struct ThrottleStatus {
   bool calculatedThresholdUpdated = false;
   std::vector<std::string> messages;
   bool error = false;
+  // ThrottleSpecBase.NextOverrideHappensIn as an instant: when the controller must reconcile this throttle again
+  bool hasNextOverride = false;
+  int64_t nextOverrideSec = 0;
+  int32_t nextOverrideNsec = 0;
 };
 
 // framework.Code values used by the plugin

@@ -285,6 +285,8 @@ class BuiltState:
                         snap.ovr_end_s[o_i], snap.ovr_end_ns[o_i] = sec, nsec
                 if err:
                     snap.ovr_flags[o_i] |= S.OVR_PARSE_ERROR
+                    if "Failed to parse End" in err:
+                        snap.ovr_flags[o_i] |= S.OVR_BEGIN_PARSED
                     msgs.append(err)
                 self._fill_amount(snap.ovr_thr, o_i, o.get("threshold"))
                 o_i += 1

@@ -19,6 +19,7 @@ THR_VALID, THR_CLUSTER, THR_RESPONSIBLE, THR_CALC_AT_NONZERO, THR_THROTTLED_POD 
 TERM_POD_SEL_INVALID, TERM_NS_SEL_INVALID = 0x1, 0x2
 OP_IN, OP_NOT_IN, OP_EXISTS, OP_DOES_NOT_EXIST = 0, 1, 2, 3
 OVR_PARSE_ERROR = 0x1
+OVR_BEGIN_PARSED = 0x2
 ZERO_TIME_S = -62135596800
 
 # per (pod, throttle) status codes / per-pod verdicts (include/kt_engine.h)

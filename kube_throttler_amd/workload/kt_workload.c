@@ -433,6 +433,10 @@ static void gen_throttles(const kt_workload_cfg* c, kt_snapshot* s) {
           s->ovr_flags[o] |= KT_OVR_PARSE_ERROR;
           s->ovr_begin_s[o] = KT_ZERO_TIME_S;
           s->ovr_end_s[o] = KT_ZERO_TIME_S;
+          if (chance(&r, .5)) { /* only `end` is unparsable: begin is a real instant, before or after now */
+            s->ovr_flags[o] |= KT_OVR_BEGIN_PARSED;
+            s->ovr_begin_s[o] = chance(&r, .5) ? c->now_s + span_a : c->now_s - span_a;
+          }
           fp = fp * 1099511628211ull + (uint64_t)(j + 1) + ((uint64_t)t << 8) + 0x9E3779B97F4A7C15ull;
         }
         double of = between(&r, .3, 4.0);

@@ -686,6 +686,36 @@ int kto_admit(kto_ctx* c, int64_t n, const int64_t* rows, int on_equal, uint8_t*
   return 0;
 }
 
+/* ThrottleSpecBase.NextOverrideHappensIn — throttle_types.go:37-63: the earliest begin / end instant strictly after
+ * `now` over all overrides, skipping what does not parse (a bad `begin` skips the override, a bad `end` only the end).
+ * Returned as the instant itself (out_has = 0: none); the caller's enqueueAfter delay is (instant - now).
+ * No reference test covers it: parity unpinned, restated from the code. */
+int kto_next_override(kto_ctx* c, int32_t n, const int32_t* rows, int64_t now_s, int32_t now_ns, int64_t* out_s,
+                      int32_t* out_ns, uint8_t* out_has) {
+  const kt_snapshot* s = c->s;
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t t = rows ? rows[i] : i;
+    bool has = false;
+    int64_t bs = 0;
+    int32_t bn = 0;
+    for (uint32_t o = s->thr_ovr_off[t]; o < s->thr_ovr_off[t + 1]; ++o) {
+      const bool err = (s->ovr_flags[o] & KT_OVR_PARSE_ERROR) != 0;
+      if (err && !(s->ovr_flags[o] & KT_OVR_BEGIN_PARSED)) continue; /* BeginTime() failed */
+      if (instant_cmp(s->ovr_begin_s[o], s->ovr_begin_ns[o], now_s, now_ns) > 0 &&
+          (!has || instant_cmp(s->ovr_begin_s[o], s->ovr_begin_ns[o], bs, bn) < 0))
+        has = true, bs = s->ovr_begin_s[o], bn = s->ovr_begin_ns[o];
+      if (err) continue; /* EndTime() failed */
+      if (instant_cmp(s->ovr_end_s[o], s->ovr_end_ns[o], now_s, now_ns) > 0 &&
+          (!has || instant_cmp(s->ovr_end_s[o], s->ovr_end_ns[o], bs, bn) < 0))
+        has = true, bs = s->ovr_end_s[o], bn = s->ovr_end_ns[o];
+    }
+    out_has[i] = has;
+    out_s[i] = has ? bs : 0;
+    out_ns[i] = has ? bn : 0;
+  }
+  return 0;
+}
+
 int kto_pod_requests(kto_ctx* c, int64_t n, const int64_t* rows, int64_t* out_v, uint32_t* out_present) {
   const kt_snapshot* s = c->s;
   for (int64_t i = 0; i < n; ++i) {

@@ -76,6 +76,10 @@ typedef struct kto_reconcile_out {
 int kto_reconcile(kto_ctx* c, int32_t n, const int32_t* rows, int64_t now_s, int32_t now_ns,
                   kto_reconcile_out* out, int nthreads);
 
+/* ThrottleSpecBase.NextOverrideHappensIn for n throttles (rows NULL => 0..n-1), as the instant (has = 0: none). */
+int kto_next_override(kto_ctx* c, int32_t n, const int32_t* rows, int64_t now_s, int32_t now_ns, int64_t* out_s,
+                      int32_t* out_ns, uint8_t* out_has);
+
 /* Function-level entry points used to replay the reference's unit-test tables (tests/test_oracle_unit_tables.py). */
 int kto_unit_is_throttled(int D, const kt_amounts* threshold, const kt_amounts* used, int on_equal,
                           uint32_t* out_flag, uint32_t* out_has, uint8_t* out_pod);

@@ -41,6 +41,7 @@ def lib():
         _LIB.kto_destroy.argtypes = [C.c_void_p]
         _LIB.kto_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _LIB.kto_admit.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S.KtAmounts)]
+        _LIB.kto_next_override.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.kto_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.kto_reconcile.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(_ReconcileOut), C.c_int]
@@ -95,6 +96,14 @@ class Oracle:
                         None if status is None else status.ctypes.data, summary.ctypes.data, nthreads,
                         int(mimic_log_args))
         return (None if status is None else status[:n, :T]), summary[:n]
+
+    def next_override(self, now=(0, 0)):
+        """NextOverrideHappensIn of every throttle as (instant seconds, nanoseconds, has)."""
+        T = self.snap.n_thr
+        sec, nsec, has = np.zeros(max(T, 1), np.int64), np.zeros(max(T, 1), np.int32), np.zeros(max(T, 1), np.uint8)
+        lib().kto_next_override(self._ctx, T, None, int(now[0]), int(now[1]), sec.ctypes.data, nsec.ctypes.data,
+                                has.ctypes.data)
+        return sec[:T], nsec[:T], has[:T]
 
     def admit(self, rows=None, on_equal=False):
         """One in-order scheduling pass: PreFilter, and on Success Reserve.  -> (status, summary, reserved totals)."""

@@ -214,11 +214,33 @@ static void TestAdmitQueue() {
   EXPECT(k->PreFilter(pods[5]).IsSuccess());
 }
 
+// temporaryThresholdOverrides: the reconcile also says when the throttle has to be looked at again
+static void TestNextOverride() {
+  auto k = Fresh();
+  std::string err;
+  Throttle t = MakeThrottle("default", "t", "app", "x", 1, "");
+  TemporaryThresholdOverride o1, o2;
+  o1.begin = "2026-02-01T00:00:00Z", o1.end = "2026-03-01T00:00:00Z";
+  o1.threshold.hasCounts = true, o1.threshold.pod = 5;
+  o2.begin = "2025-12-01T00:00:00Z", o2.end = "2026-01-15T00:00:00Z";  // active at NOW: replaces the threshold
+  o2.threshold.hasCounts = true, o2.threshold.pod = 3;
+  t.overrides = {o1, o2};
+  EXPECT(k->OnThrottleAdd(t, &err));
+  std::map<std::string, ThrottleStatus> st;
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  int64_t sec = 0;
+  int32_t nsec = 0;
+  EXPECT(ParseRFC3339("2026-01-15T00:00:00Z", &sec, &nsec, &err));
+  EXPECT(st["default/t"].hasNextOverride && st["default/t"].nextOverrideSec == sec && st["default/t"].nextOverrideNsec == 0);
+  EXPECT(st["default/t"].calculatedThresholdUpdated);
+}
+
 int main() {
   TestExampleWalkthrough();
   TestThrottleScenarios();
   TestClusterThrottleAndReserve();
   TestAdmitQueue();
+  TestNextOverride();
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;

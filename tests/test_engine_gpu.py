@@ -88,6 +88,13 @@ def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True),
             for f in ("v", "present", "count", "has_count"):
                 getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
         assert_reconcile_equal(got, want, len(rows))
+        # NextOverrideHappensIn (the controller's enqueueAfter instant) of every reconciled throttle
+        ws, wn, wh = o.next_override(now)
+        gs, gn, gh = eng.next_override()
+        okr = rows[want.error[:len(rows)] == 0]
+        np.testing.assert_array_equal(gh[okr], wh[okr], err_msg="next override: has")
+        np.testing.assert_array_equal(gs[okr], ws[okr], err_msg="next override: seconds")
+        np.testing.assert_array_equal(gn[okr], wn[okr], err_msg="next override: nanoseconds")
         # UpdateStatus on the oracle side, then check against the stored status
         snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod,
                           want.error, rows=rows)
