@@ -1,0 +1,48 @@
+"""Prometheus export: metric names, label sets and units of the reference's recorders
+(throttle_metrics.go:34-131, clusterthrottle_metrics.go:34-128, metrics_recorder.go:28-66), fed from the per-throttle
+vectors a reconcile produces (here: the oracle's, on CPU)."""
+import numpy as np
+
+from kube_throttler_amd.metrics import MetricsRecorder
+from kube_throttler_amd.objects import ClusterState
+
+
+def test_gauges_follow_the_reference_families(oracle_mod):
+    cs = ClusterState()
+    cs.add_namespace("default", {"kubernetes.io/metadata.name": "default"})
+    spec = {"throttlerName": "kube-throttler", "threshold": {"resourceCounts": {"pod": 2},
+                                                              "resourceRequests": {"cpu": "1", "memory": "1Gi"}}}
+    cs.add({"kind": "Throttle", "metadata": {"namespace": "default", "name": "t1", "uid": "u-1"},
+            "spec": dict(spec, selector={"selectorTerms": [{"podSelector": {"matchLabels": {"throttle": "t1"}}}]})})
+    cs.add({"kind": "ClusterThrottle", "metadata": {"name": "c1", "uid": "u-2"},
+            "spec": dict(spec, selector={"selectorTerms": [{"podSelector": {"matchLabels": {"throttle": "t1"}},
+                                                            "namespaceSelector": {}}]})})
+    for i, cpu in enumerate(("500m", "600m")):
+        cs.add({"kind": "Pod", "metadata": {"namespace": "default", "name": f"p{i}", "labels": {"throttle": "t1"}},
+                "spec": {"schedulerName": "my-scheduler", "nodeName": "node-1",
+                         "containers": [{"resources": {"requests": {"cpu": cpu, "memory": "256Mi"}}}]},
+                "status": {"phase": "Running"}})
+    built = cs.build()
+    rec = oracle_mod.Oracle(built.snapshot).reconcile((1767225600, 0))
+    text = MetricsRecorder().record(built, rec).exposition()
+    samples = {line.split(" ")[0]: float(line.split(" ")[1]) for line in text.splitlines() if line and line[0] != "#"}
+
+    def s(metric, **lab):
+        key = metric + "{" + ",".join(f'{k}="{v}"' for k, v in sorted(lab.items())) + "}"
+        return samples[key]
+
+    t = dict(namespace="default", name="t1", uid="u-1")
+    assert s("throttle_spec_threshold_resourceCounts", resource="pod", **t) == 2
+    assert s("throttle_spec_threshold_resourceRequests", resource="cpu", **t) == 1000          # milli
+    assert s("throttle_spec_threshold_resourceRequests", resource="memory", **t) == 2 ** 30    # units
+    assert s("throttle_status_used_resourceCounts", resource="pod", **t) == 2
+    assert s("throttle_status_used_resourceRequests", resource="cpu", **t) == 1100
+    assert s("throttle_status_used_resourceRequests", resource="memory", **t) == 2 * 256 * 2 ** 20
+    assert s("throttle_status_throttled_resourceCounts", resource="pod", **t) == 1              # 2 >= 2
+    assert s("throttle_status_throttled_resourceRequests", resource="cpu", **t) == 1            # 1100m >= 1
+    assert s("throttle_status_throttled_resourceRequests", resource="memory", **t) == 0
+    assert s("throttle_status_calculated_threshold_resourceRequests", resource="cpu", **t) == 1000
+    c = dict(name="c1", uid="u-2")
+    assert s("clusterthrottle_status_used_resourceRequests", resource="cpu", **c) == 1100
+    assert s("clusterthrottle_status_throttled_resourceCounts", resource="pod", **c) == 1
+    assert not any(k.startswith("clusterthrottle_") and "namespace=" in k for k in samples)
