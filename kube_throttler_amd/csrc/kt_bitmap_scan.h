@@ -24,65 +24,37 @@
 
 namespace kt {
 
-// Staging plan of the bitmap tables: the index keeps them as one blob (IndexDev::bm_blob, the LDS image)
+// What the kernels need of the index (IndexDev): the chunk directory, the images, the atom buckets
 struct BmIndexArgs {
-  const unsigned char* blob;
-  uint32_t blob_bytes;  // staged prefix (LDS form), multiple of 16
-  uint32_t lds_off;     // where the blob goes in LDS (LDS-resident form)
-  uint32_t off[9];      // rows, nsrows, nsblocks_off, nsblocks, buckets, trec, trecx, nswords64_off, nswords64
-  uint32_t stride, words, bucket_mask, bucket_mult, key_rows, has_inline;  // stride / words: 64-bit words per row
+  const unsigned char* blob;   // chunk images
+  const BmChunk* chunks;
+  const u32x4* buckets;        // AtomBucket table (staged once)
+  uint32_t n_chunks, bucket_bytes;
+  uint32_t lds_buckets, lds_img;  // LDS offsets: buckets, current chunk image
+  uint32_t bucket_mask, bucket_mult, key_rows, has_inline;
 };
 
 template <class Take>
-static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, bool in_lds, Take&& take) {
-  a.blob = ix.bm_blob, a.blob_bytes = ix.bm_lds_bytes;
-  a.lds_off = in_lds ? take(ix.bm_lds_bytes) : 0u;
-  for (int k = 0; k < 9; ++k) a.off[k] = ix.bm_off[k];
-  a.stride = ix.bm_stride, a.words = ix.bm_words, a.bucket_mask = ix.bm_bucket_mask, a.bucket_mult = ix.bm_bucket_mult, a.key_rows = ix.bm_has_key_rows;
+static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, Take&& take) {
+  a.blob = ix.bm_blob, a.chunks = ix.bm_chunks, a.buckets = (const u32x4*)ix.bm_buckets;
+  a.n_chunks = ix.n_chunks, a.bucket_bytes = ix.bm_bucket_bytes;
+  a.lds_buckets = take(ix.bm_bucket_bytes);
+  a.lds_img = take(ix.bm_max_img);
+  a.bucket_mask = ix.bm_bucket_mask, a.bucket_mult = ix.bm_bucket_mult, a.key_rows = ix.bm_has_key_rows;
   a.has_inline = ix.bm_has_inline;
 }
 
-typedef unsigned long long kt_u64x2 __attribute__((ext_vector_type(2)));
-
-// The tables, in LDS (LDSIX) or in the device blob (read through L2).  The LDS form walks the bitmaps 64 bits at
-// a time (LDS reads are cheap, shorter peel loops win); the L2 form 128 bits at a time (one cache-line request per
-// 16 bytes: half the requests).
-template <bool LDSIX>
-struct BmView;
-template <>
-struct BmView<true> {
-  typedef unsigned long long word_t;  // 64-bit steps
-  static constexpr uint32_t kBits = 64;
-  KT_LDS const word_t* rows;
-  KT_LDS const word_t* nsrows;
-  lds_u32p nsb_off, nsb;  // 64-bit word indices per namespace
+// The tables of the chunk that is resident in LDS
+struct BmView {
+  KT_LDS const unsigned long long* rows;    // [rows][stride] 64-bit bitmap words of this chunk
+  KT_LDS const unsigned long long* nsrows;  // [n_ns][stride]
+  lds_u32p nsb_off, nsb;                    // chunk-local word indices a namespace can touch
   lds_u4p buckets, trec, trecx;
-  uint32_t stride, words, bucket_mask, bucket_mult, key_rows, has_inline;
-};
-template <>
-struct BmView<false> {
-  typedef kt_u64x2 word_t;  // 128-bit steps: 16-byte reads at 8-byte alignment
-  static constexpr uint32_t kBits = 128;
-  const unsigned long long* rows;
-  const unsigned long long* nsrows;
-  const uint32_t* nsb_off;  // 128-bit block indices per namespace
-  const uint32_t* nsb;
-  const u32x4* buckets;
-  const u32x4* trec;
-  const u32x4* trecx;
-  uint32_t stride, words, bucket_mask, bucket_mult, key_rows, has_inline;
+  uint32_t stride, bucket_mask, bucket_mult, key_rows, has_inline;
 };
 
-// LDS-resident form: copies the blob into LDS (all threads of the workgroup; the caller barriers afterwards):
-// four independent 16-byte loads per thread are in flight before the first store, so the whole image costs about
-// one memory round trip per 64 KB.  L2 form: just the pointers.
-template <bool LDSIX>
-__device__ __forceinline__ BmView<LDSIX> open_bitmap_index(KT_LDS unsigned char* lds, const BmIndexArgs& a);
-template <>
-__device__ __forceinline__ BmView<true> open_bitmap_index<true>(KT_LDS unsigned char* lds, const BmIndexArgs& a) {
-  const u32x4* src = (const u32x4*)a.blob;
-  KT_LDS u32x4* dst = (KT_LDS u32x4*)(lds + a.lds_off);
-  const uint32_t n16 = a.blob_bytes / 16u;
+// all threads of the workgroup: n16 16-byte pieces from src to dst, four independent loads in flight per thread
+__device__ __forceinline__ void lds_stage16(KT_LDS u32x4* dst, const u32x4* src, uint32_t n16) {
   for (uint32_t i = threadIdx.x; i < n16; i += 4 * kBlockIx) {
     u32x4 v[4];
 #pragma unroll
@@ -91,30 +63,22 @@ __device__ __forceinline__ BmView<true> open_bitmap_index<true>(KT_LDS unsigned 
     for (int k = 0; k < 4; ++k)
       if (i + k * kBlockIx < n16) dst[i + k * kBlockIx] = v[k];
   }
-  KT_LDS unsigned char* base = lds + a.lds_off;
-  BmView<true> v;
-  v.rows = (KT_LDS const unsigned long long*)(base + a.off[0]);
-  v.nsrows = (KT_LDS const unsigned long long*)(base + a.off[1]);
-  v.nsb_off = (lds_u32p)(base + a.off[7]);
-  v.nsb = (lds_u32p)(base + a.off[8]);
-  v.buckets = (lds_u4p)(base + a.off[4]);
-  v.trec = (lds_u4p)(base + a.off[5]);
-  v.trecx = (lds_u4p)(base + a.off[6]);
-  v.stride = a.stride, v.words = a.words, v.bucket_mask = a.bucket_mask, v.bucket_mult = a.bucket_mult, v.key_rows = a.key_rows, v.has_inline = a.has_inline;
-  return v;
 }
-template <>
-__device__ __forceinline__ BmView<false> open_bitmap_index<false>(KT_LDS unsigned char*, const BmIndexArgs& a) {
-  const unsigned char* base = a.blob;
-  BmView<false> v;
-  v.rows = (const unsigned long long*)(base + a.off[0]);
-  v.nsrows = (const unsigned long long*)(base + a.off[1]);
-  v.nsb_off = (const uint32_t*)(base + a.off[2]);
-  v.nsb = (const uint32_t*)(base + a.off[3]);
-  v.buckets = (const u32x4*)(base + a.off[4]);
-  v.trec = (const u32x4*)(base + a.off[5]);
-  v.trecx = (const u32x4*)(base + a.off[6]);
-  v.stride = a.stride, v.words = a.words, v.bucket_mask = a.bucket_mask, v.bucket_mult = a.bucket_mult, v.key_rows = a.key_rows, v.has_inline = a.has_inline;
+
+// Makes chunk `ch` resident (the caller barriers before — nobody still reads the previous image — and after)
+__device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const BmIndexArgs& a, const BmChunk& ch) {
+  lds_stage16((KT_LDS u32x4*)(lds + a.lds_img), (const u32x4*)(a.blob + ch.img_off), ch.img_bytes / 16u);
+  KT_LDS unsigned char* base = lds + a.lds_img;
+  BmView v;
+  v.rows = (KT_LDS const unsigned long long*)base;
+  v.nsrows = (KT_LDS const unsigned long long*)(base + ch.off_nsrows);
+  v.nsb_off = (lds_u32p)(base + ch.off_nsw_off);
+  v.nsb = (lds_u32p)(base + ch.off_nsw);
+  v.trec = (lds_u4p)(base + ch.off_trec);
+  v.trecx = (lds_u4p)(base + ch.off_trecx);
+  v.buckets = (lds_u4p)(lds + a.lds_buckets);
+  v.stride = ch.stride, v.bucket_mask = a.bucket_mask, v.bucket_mult = a.bucket_mult, v.key_rows = a.key_rows;
+  v.has_inline = a.has_inline;
   return v;
 }
 
@@ -150,30 +114,18 @@ __device__ __forceinline__ bool extra_ok(const u32x4 e, const uint32_t (&lp)[LT]
   return op == 0xFFu || (positive ? hit : !hit);
 }
 
-// one step of a bitmap row: word w (LDS form) / the 16 bytes of block b = words 2b, 2b+1 (L2 form)
-__device__ __forceinline__ unsigned long long load_step(const BmView<true>& b, KT_LDS const unsigned long long* row, uint32_t step) {
-  return row[step];
-}
-__device__ __forceinline__ kt_u64x2 load_step(const BmView<false>& b, const unsigned long long* row, uint32_t step) {
-  return *(const kt_u64x2*)(row + 2 * step);
-}
-// candidate bits of one step as a (lo, hi) pair of 64-bit halves
-__device__ __forceinline__ void split_step(const BmView<true>&, unsigned long long v, uint32_t, uint64_t& lo, uint64_t& hi) { lo = v, hi = 0; }
-__device__ __forceinline__ void split_step(const BmView<false>& b, kt_u64x2 v, uint32_t step, uint64_t& lo, uint64_t& hi) {
-  lo = v.x, hi = 2 * step + 1 < b.words ? v.y : 0ull;  // an odd word count leaves the last block half empty
-}
-
 // One 64-pod tile.  `ns` must be a valid namespace row for EVERY lane (callers pass 0 for lanes without a pod).
 //   lane_match : the lane's pod takes part in selector matching (its matches are listed)
 //   lane_slow  : the lane's pod is walked against throttles with an unconvertible podSelector term
-//   drain(n)   : consume list[0..n)   entries = lane << 20 | throttle row
+//   drain(n)   : consume list[0..n)   entries = lane << 20 | throttle row (BY_RANK: chunk-local throttle rank)
+//   slow_match(t): BY_RANK only — the pod matches slow throttle t (which has no rank): lane-divergent call
 //   slow_err(t): the walk of slow throttle t hit the bad term before a match (lane-divergent call)
 //   CAP        : capacity of `list` (entries); a step appends at most 64, the list is drained above CAP - 64
-template <int LT, bool KEYS, uint32_t CAP, class View, class Drain, class SlowErr>
-__device__ __forceinline__ void bitmap_scan_tile(const View& b, const SelProgram* sp_dev, const uint32_t* slow_thr,
+template <int LT, bool KEYS, uint32_t CAP, bool BY_RANK, class Drain, class SlowErr, class SlowMatch>
+__device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgram* sp_dev, const uint32_t* slow_thr,
                                                  uint32_t n_slow, bool lane_match, bool lane_slow, uint32_t ns,
                                                  const uint32_t (&lp)[LT], const uint32_t (&lk)[LT], lds_u32wp list,
-                                                 uint32_t lane, Drain&& drain, SlowErr&& slow_err) {
+                                                 uint32_t lane, Drain&& drain, SlowErr&& slow_err, SlowMatch&& slow_match) {
   uint32_t rp[LT], rk[LT];  // word offsets of the label rows
 #pragma unroll
   for (int l = 0; l < LT; ++l) {
@@ -184,12 +136,12 @@ __device__ __forceinline__ void bitmap_scan_tile(const View& b, const SelProgram
   uint32_t k = b.nsb_off[ns];
   const uint32_t k1 = lane_match ? b.nsb_off[ns + 1] : k;
   const uint32_t nsbase = ns * b.stride;
-  uint64_t xlo = 0, xhi = 0;
-  uint32_t blk = 0, last_t = 0xFFFFFFFFu;
+  uint64_t x = 0;
+  uint32_t w = 0, last_t = 0xFFFFFFFFu;
   uint32_t ks = 0, n_list = 0;  // wave-uniform
   bool more = true;
   // decides candidate term c for this lane's pod (c = 0 with has = false for idle lanes)
-  auto decide = [&](bool has, uint32_t c, uint32_t& t) -> bool {
+  auto decide = [&](bool has, uint32_t c, uint32_t& t, uint32_t& rank) -> bool {
     const u32x4 tr = b.trec[c];  // {g, t, pair2, flags}
     bool hasp = false;
 #pragma unroll
@@ -206,31 +158,22 @@ __device__ __forceinline__ void bitmap_scan_tile(const View& b, const SelProgram
       ok = m.rare(tr.x, tr.y, tr.w);
     }
     t = tr.y;
+    rank = tr.w >> 8;  // chunk-local throttle rank
     if ((tr.w & kPostAdj) && t == last_t) ok = false;  // an earlier term of the same throttle matched already
     if (ok) last_t = t;
     return ok;
   };
   do {
     while (n_list <= CAP - kWave) {
-      const bool has = View::kBits == 64 ? xlo != 0 : (xlo | xhi) != 0;
+      const bool has = x != 0;
       if (__ballot(has) != 0ull) {
         // ---- peel: one candidate term per lane that has any
-        uint32_t c;
-        if (View::kBits == 64) {
-          c = has ? blk * 64u + (uint32_t)__ffsll((unsigned long long)xlo) - 1u : 0u;
-          xlo &= xlo - 1ull;
-        } else {
-          const bool lo = xlo != 0;
-          uint64_t v = lo ? xlo : xhi;
-          c = has ? blk * 128u + (lo ? 0u : 64u) + (uint32_t)__ffsll((unsigned long long)v) - 1u : 0u;
-          v &= v - 1ull;
-          xlo = lo ? v : xlo;
-          xhi = lo ? xhi : v;
-        }
-        uint32_t t = 0;
-        const bool ok = decide(has, c, t);
+        const uint32_t c = has ? w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u : 0u;
+        x &= x - 1ull;
+        uint32_t t = 0, rank = 0;
+        const bool ok = decide(has, c, t, rank);
         const uint64_t mk = __ballot(ok);
-        if (ok) list[n_list + lane_rank(mk)] = lane << 20 | t;
+        if (ok) list[n_list + lane_rank(mk)] = lane << 20 | (BY_RANK ? rank : t);
         n_list += (uint32_t)__popcll(mk);
       } else if (ks < n_slow) {
         // ---- throttles with an unconvertible podSelector term: in-order walk (error semantics depend on
@@ -241,24 +184,25 @@ __device__ __forceinline__ void bitmap_scan_tile(const View& b, const SelProgram
         walk_slow<LT, KEYS>(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, lane_slow, lp, lk, matched, err);
         if (err) slow_err((uint32_t)ts);
         const bool ok = matched && lane_match;
-        const uint64_t mk = __ballot(ok);
-        if (ok) list[n_list + lane_rank(mk)] = lane << 20 | (uint32_t)ts;
-        n_list += (uint32_t)__popcll(mk);
+        if (BY_RANK) {
+          if (ok) slow_match((uint32_t)ts);
+        } else {
+          const uint64_t mk = __ballot(ok);
+          if (ok) list[n_list + lane_rank(mk)] = lane << 20 | (uint32_t)ts;
+          n_list += (uint32_t)__popcll(mk);
+        }
       } else if (__ballot(k < k1) != 0ull) {
         // ---- advance: next block of every lane that still has one
         const bool adv = k < k1;
-        blk = b.nsb[adv ? k : 0u];
-        typename View::word_t xx = load_step(b, b.rows, blk);  // row 0: terms without a positive requirement
+        w = b.nsb[adv ? k : 0u];
+        unsigned long long xx = b.rows[w];  // row 0: terms without a positive requirement
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-          xx |= load_step(b, b.rows + rp[l], blk);
-          if (key_rows) xx |= load_step(b, b.rows + rk[l], blk);
+          xx |= b.rows[rp[l] + w];
+          if (key_rows) xx |= b.rows[rk[l] + w];
         }
-        xx &= load_step(b, b.nsrows + nsbase, blk);
-        uint64_t nlo, nhi;
-        split_step(b, xx, blk, nlo, nhi);
-        xlo = adv ? nlo : 0ull;
-        xhi = adv ? nhi : 0ull;
+        xx &= b.nsrows[nsbase + w];
+        x = adv ? xx : 0ull;
         k += adv ? 1u : 0u;
       } else {
         more = false;

@@ -464,7 +464,6 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
   // result / scratch buffers sized by T
   KT_HIP(e, e->d_partial.reserve(T * kt::partial_stride(D) + 1));
-  KT_HIP(e, e->d_slab.reserve(kt::aggregate_slab_bytes((int)T, D) + 16));
   KT_HIP(e, e->d_out_used.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
@@ -486,7 +485,9 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
                     ti.ns = h.ns;
                     return ti;
                   },
-                  (uint32_t)NS, ns_term_ok, gw);
+                  (uint32_t)NS, ns_term_ok, gw, 160u * 1024u - kt::aggregate_fixed_lds(), 160u * 1024u - kt::check_fixed_lds(),
+                  (uint32_t)(8 * D + 8));
+  KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
     hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
     if (he != hipSuccess) return e->fail(KT_ERR_DEVICE, "upload_index: %s", hipGetErrorString(he));
@@ -1001,8 +1002,11 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     if (e->cfg.kernel_variant == 1)
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
-    else
-      e->last_kernel[KT_KERNEL_AGGREGATE] = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
+    else {
+      const char* k = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
+      if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
+      e->last_kernel[KT_KERNEL_AGGREGATE] = k;
+    }
   }
   KT_HIP(e, hipGetLastError());
   e->last_stream = s;

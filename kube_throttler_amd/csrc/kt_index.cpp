@@ -16,7 +16,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
-                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw) {
+                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
   out = HostIndex();
   const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
   // a reachable unconvertible podSelector makes term ORDER matter: these throttles are walked term by term
@@ -133,73 +133,161 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       i = j;
     }
     const uint32_t G2 = pos;
+    const uint32_t W = G2 ? (G2 + 63) / 64 : 1u;  // 64-bit words per full row (an empty program keeps one zero word)
+    out.bm_words = W;
+    // ---- atoms -> bitmap rows
+    std::unordered_map<uint32_t, uint32_t> row_of;
+    for (auto& b : bts)
+      for (uint32_t a : b.atoms) row_of.emplace(a, 0u);
+    std::vector<uint32_t> atoms;
+    for (auto& kv : row_of) atoms.push_back(kv.first);
+    std::sort(atoms.begin(), atoms.end());
+    for (uint32_t i = 0; i < atoms.size(); ++i) row_of[atoms[i]] = i + 2;
+    const uint32_t R = (uint32_t)atoms.size() + 2;
+    out.bm_rows = R;
+    // ---- full bitmaps (host only), dense throttle ranks in term order
+    std::vector<uint64_t> rows((size_t)R * W, 0ull), nsrows((size_t)n_ns * W, 0ull);
+    std::vector<TermRec> trec(W * 64, TermRec{0, 0, 0, 0});
+    std::vector<TermX> trecx(W * 64, no_extras);
+    std::vector<uint32_t> term_rank(W * 64, 0u);
+    std::vector<uint8_t> real(W * 64, 0);  // term number in use (not padding)
+    bool any_inline = false;
+    out.bm_rank_t.clear();
     {
-      const uint32_t W = G2 ? (G2 + 63) / 64 : 1u;  // 64-bit words per row (an empty program keeps one zero word)
-      const uint32_t NB = (W + 1) / 2;               // 128-bit blocks (the L2 form masks the missing half of the last)
-      out.bm_words = W;
-      out.bm_stride = W | 1u;  // odd: column reads spread over the LDS banks
-      std::unordered_map<uint32_t, uint32_t> row_of;
-      for (auto& b : bts)
-        for (uint32_t a : b.atoms) row_of.emplace(a, 0u);
-      std::vector<uint32_t> atoms;
-      for (auto& kv : row_of) atoms.push_back(kv.first);
-      std::sort(atoms.begin(), atoms.end());
-      for (uint32_t i = 0; i < atoms.size(); ++i) row_of[atoms[i]] = i + 2;
-      out.bm_rows = (uint32_t)atoms.size() + 2;
-      out.bm_row_bits.assign((size_t)out.bm_rows * out.bm_stride, 0ull);
-      out.bm_nsrows.assign((size_t)n_ns * out.bm_stride, 0ull);
-      out.bm_trec.assign(G2 ? G2 : 1u, TermRec{0, 0, 0, 0});
-      bool any_inline = false;
-      for (auto& b : bts) any_inline |= (b.flags & kPostInline) != 0;
-      if (any_inline) out.bm_trecx.assign(G2, no_extras);
-      for (size_t q = 0; q < bts.size(); ++q) {
-        const BT& b = bts[q];
-        const uint32_t c = num[q];
+      std::vector<uint32_t> by_num(G2, ~0u);
+      for (size_t q = 0; q < bts.size(); ++q) by_num[num[q]] = (uint32_t)q;
+      uint32_t last_t = ~0u;
+      for (uint32_t c = 0; c < G2; ++c) {
+        if (by_num[c] == ~0u) continue;  // padding
+        const BT& b = bts[by_num[c]];
+        if (b.t != last_t) out.bm_rank_t.push_back(b.t), last_t = b.t;
+        term_rank[c] = (uint32_t)out.bm_rank_t.size() - 1;
+        real[c] = 1;
         const uint64_t bit = 1ull << (c & 63);
-        out.bm_trec[c] = TermRec{b.g, b.t, b.pair2, b.flags};
-        if (any_inline) out.bm_trecx[c] = b.x;
-        if (b.atoms.empty()) out.bm_row_bits[c >> 6] |= bit;
-        for (uint32_t a : b.atoms) out.bm_row_bits[(size_t)row_of[a] * out.bm_stride + (c >> 6)] |= bit;
+        trec[c] = TermRec{b.g, b.t, b.pair2, b.flags};
+        trecx[c] = b.x;
+        any_inline |= (b.flags & kPostInline) != 0;
+        if (b.atoms.empty()) rows[c >> 6] |= bit;
+        for (uint32_t a : b.atoms) rows[(size_t)row_of[a] * W + (c >> 6)] |= bit;
         for (uint32_t n = 0; n < n_ns; ++n)
-          if ((b.adm[n >> 5] >> (n & 31)) & 1u) out.bm_nsrows[(size_t)n * out.bm_stride + (c >> 6)] |= bit;
+          if ((b.adm[n >> 5] >> (n & 31)) & 1u) nsrows[(size_t)n * W + (c >> 6)] |= bit;
       }
-      out.bm_nswords_off.assign((size_t)n_ns + 1, 0u);
-      for (uint32_t n = 0; n < n_ns; ++n) {
-        for (uint32_t blk = 0; blk < NB; ++blk) {
-          uint64_t any = out.bm_nsrows[(size_t)n * out.bm_stride + 2 * blk];
-          if (2 * blk + 1 < W) any |= out.bm_nsrows[(size_t)n * out.bm_stride + 2 * blk + 1];
-          if (any) out.bm_nswords.push_back(blk);
+    }
+    out.bm_has_inline = any_inline;
+    // ---- atoms -> rows in 4-entry buckets: a few multipliers per size, then double, until no bucket overflows
+    size_t nb = 4;
+    while (nb * 3 < atoms.size()) nb <<= 1;
+    uint32_t mult = 0x9E3779B1u;
+    for (int attempt = 0;; ++attempt) {
+      out.bm_buckets.assign(nb, AtomBucket{{0, 0, 0, 0}, {1, 1, 1, 1}});
+      bool ok = true;
+      for (uint32_t a : atoms) {
+        AtomBucket& bk = out.bm_buckets[atom_bucket(a, (uint32_t)nb - 1, mult)];
+        int k = 0;
+        while (k < 4 && bk.atom[k] != 0) ++k;
+        if (k == 4) { ok = false; break; }
+        bk.atom[k] = a;
+        bk.row[k] = row_of[a];
+      }
+      if (ok) break;
+      if (attempt % 24 == 23) nb <<= 1;
+      mult = mult * 0x01000193u + 0x9E3779B9u;
+      mult |= 1u;
+    }
+    out.bm_bucket_mult = mult;
+    out.bm_bucket_mask = (uint32_t)nb - 1;
+    // ---- chunks: word ranges whose image (rows | nsrows | word lists | TermRec | TermX) plus the aggregate table
+    //      of their throttles fits the LDS budget; a throttle's terms never straddle a chunk
+    std::vector<uint8_t> splittable(W + 1, 1);  // chunk may START at word w
+    for (uint32_t w = 1; w < W; ++w) {
+      // the last real term of word w-1 and the first real term of word w belong to different throttles?
+      int64_t a = -1, b2 = -1;
+      for (int k = 63; k >= 0 && a < 0; --k)
+        if (real[(size_t)(w - 1) * 64 + k]) a = (int64_t)(w - 1) * 64 + k;
+      for (int k = 0; k < 64 && b2 < 0; ++k)
+        if (real[(size_t)w * 64 + k]) b2 = (int64_t)w * 64 + k;
+      if (a >= 0 && b2 >= 0 && term_rank[a] == term_rank[b2]) splittable[w] = 0;
+    }
+    // LDS left for a chunk once the atom buckets are resident: image + table (aggregate), image alone (check)
+    const size_t bucket_bytes = out.bm_buckets.size() * sizeof(AtomBucket);
+    const size_t agg_room = agg_budget > bucket_bytes ? agg_budget - bucket_bytes : 0;
+    const size_t chk_room = chk_budget > bucket_bytes ? chk_budget - bucket_bytes : 0;
+    uint64_t slab_run = 0;
+    const size_t per_word = (size_t)R * 8 + (size_t)n_ns * 8 + 64 * sizeof(TermRec) + (any_inline ? 64 * sizeof(TermX) : 0);
+    out.bm_chunks.clear();
+    out.bm_images.clear();
+    out.bm_max_img = 0, out.bm_max_thr = 0, out.bm_slab_bytes = 0;
+    uint32_t w0 = 0;
+    while (w0 < W) {
+      // grow the chunk word by word while it fits; cut at the last boundary that splits no throttle
+      uint32_t w1 = 0;
+      for (uint32_t cand = w0 + 1; cand <= W; ++cand) {
+        uint32_t r_lo = ~0u, r_hi = 0;
+        for (size_t c = (size_t)w0 * 64; c < (size_t)cand * 64; ++c)
+          if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
+        const uint32_t nthr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
+        const size_t nw = cand - w0;
+        const size_t img = ((nw | 1) * ((size_t)R + n_ns)) * 8 + nw * (per_word - (size_t)R * 8 - (size_t)n_ns * 8) +
+                           ((size_t)n_ns + 1) * 4 + (size_t)n_ns * nw * 4 + 256;
+        const bool fits = img <= chk_room && img + (size_t)nthr * thr_bytes + 16 <= agg_room;
+        if (!fits && w1 != 0) break;
+        if (cand == W || splittable[cand]) {
+          w1 = cand;
+          if (!fits) break;  // a single stretch larger than the budget: the launchers notice
         }
-        out.bm_nswords_off[n + 1] = (uint32_t)out.bm_nswords.size();
       }
-      out.bm_nswords64_off.assign((size_t)n_ns + 1, 0u);
+      // ---- image of words [w0, w1)
+      BmChunk ch{};
+      ch.w0 = w0, ch.n_words = w1 - w0;
+      ch.stride = ch.n_words | 1u;
+      uint32_t r_lo = ~0u, r_hi = 0;
+      for (size_t c = (size_t)w0 * 64; c < (size_t)w1 * 64; ++c)
+        if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
+      ch.rank0 = r_lo == ~0u ? 0 : r_lo;
+      ch.n_thr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
+      std::vector<uint64_t> irows((size_t)R * ch.stride, 0ull), insrows((size_t)n_ns * ch.stride, 0ull);
+      for (uint32_t r = 0; r < R; ++r)
+        for (uint32_t w = 0; w < ch.n_words; ++w) irows[(size_t)r * ch.stride + w] = rows[(size_t)r * W + w0 + w];
+      std::vector<uint32_t> nsw_off((size_t)n_ns + 1, 0u), nsw;
       for (uint32_t n = 0; n < n_ns; ++n) {
-        for (uint32_t w = 0; w < W; ++w)
-          if (out.bm_nsrows[(size_t)n * out.bm_stride + w]) out.bm_nswords64.push_back(w);
-        out.bm_nswords64_off[n + 1] = (uint32_t)out.bm_nswords64.size();
-      }
-      // atoms -> rows in 4-entry buckets: a few multipliers per size, then double, until no bucket overflows
-      size_t nb = 4;
-      while (nb * 3 < atoms.size()) nb <<= 1;
-      uint32_t mult = 0x9E3779B1u;
-      for (int attempt = 0;; ++attempt) {
-        out.bm_buckets.assign(nb, AtomBucket{{0, 0, 0, 0}, {1, 1, 1, 1}});
-        bool ok = true;
-        for (uint32_t a : atoms) {
-          AtomBucket& bk = out.bm_buckets[atom_bucket(a, (uint32_t)nb - 1, mult)];
-          int k = 0;
-          while (k < 4 && bk.atom[k] != 0) ++k;
-          if (k == 4) { ok = false; break; }
-          bk.atom[k] = a;
-          bk.row[k] = row_of[a];
+        for (uint32_t w = 0; w < ch.n_words; ++w) {
+          insrows[(size_t)n * ch.stride + w] = nsrows[(size_t)n * W + w0 + w];
+          if (insrows[(size_t)n * ch.stride + w]) nsw.push_back(w);
         }
-        if (ok) break;
-        if (attempt % 24 == 23) nb <<= 1;
-        mult = mult * 0x01000193u + 0x9E3779B9u;
-        mult |= 1u;
+        nsw_off[n + 1] = (uint32_t)nsw.size();
       }
-      out.bm_bucket_mult = mult;
-      out.bm_bucket_mask = (uint32_t)nb - 1;
+      std::vector<TermRec> itrec((size_t)ch.n_words * 64);
+      std::vector<TermX> itrecx(any_inline ? (size_t)ch.n_words * 64 : 0);
+      for (uint32_t k = 0; k < ch.n_words * 64; ++k) {
+        TermRec tr = trec[(size_t)w0 * 64 + k];
+        if (real[(size_t)w0 * 64 + k]) tr.flags |= (term_rank[(size_t)w0 * 64 + k] - ch.rank0) << 8;  // chunk-local throttle rank
+        itrec[k] = tr;
+        if (any_inline) itrecx[k] = trecx[(size_t)w0 * 64 + k];
+      }
+      const void* src[6] = {irows.data(), insrows.data(), nsw_off.data(), nsw.data(), itrec.data(), itrecx.data()};
+      const size_t bytes[6] = {irows.size() * 8, insrows.size() * 8, nsw_off.size() * 4, nsw.size() * 4,
+                               itrec.size() * sizeof(TermRec), itrecx.size() * sizeof(TermX)};
+      uint32_t* offs[6] = {nullptr, &ch.off_nsrows, &ch.off_nsw_off, &ch.off_nsw, &ch.off_trec, &ch.off_trecx};
+      size_t o = 0;
+      const size_t img0 = out.bm_images.size();
+      for (int k = 0; k < 6; ++k) {
+        if (offs[k]) *offs[k] = (uint32_t)o;
+        o += (bytes[k] + 15) & ~(size_t)15;
+      }
+      out.bm_images.resize(img0 + o, 0);
+      size_t oo = 0;
+      for (int k = 0; k < 6; ++k) {
+        if (bytes[k]) memcpy(out.bm_images.data() + img0 + oo, src[k], bytes[k]);
+        oo += (bytes[k] + 15) & ~(size_t)15;
+      }
+      ch.img_off = (uint32_t)img0, ch.img_bytes = (uint32_t)o;
+      ch.slab_off = (uint32_t)(slab_run / 16);  // one table per (chunk, workgroup), 256 workgroups at most
+      slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull);
+      out.bm_max_img = std::max(out.bm_max_img, ch.img_bytes);
+      out.bm_max_thr = std::max(out.bm_max_thr, ch.n_thr);
+      out.bm_chunks.push_back(ch);
+      out.bm_slab_bytes = slab_run;
+      w0 = w1;
     }
   }
 }
@@ -223,46 +311,31 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   hipError_t e;
   if ((e = up(d.slow_thr, d.cap_slow, h.slow_thr, s)) != hipSuccess) return e;
   d.n_slow = (uint32_t)h.slow_thr.size();
-  d.bm_words = h.bm_words;
-  d.bm_stride = h.bm_stride;
+  if ((e = up(d.bm_blob, d.cap_bm_blob, h.bm_images, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_chunks, d.cap_bm_chunks, h.bm_chunks, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_rank_t, d.cap_bm_rank_t, h.bm_rank_t, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_buckets, d.cap_bm_buckets, h.bm_buckets, s)) != hipSuccess) return e;
+  d.h_chunks = h.bm_chunks;
+  d.n_chunks = (uint32_t)h.bm_chunks.size();
+  d.bm_max_img = h.bm_max_img, d.bm_max_thr = h.bm_max_thr;
+  d.bm_slab_bytes = h.bm_slab_bytes;
+  d.bm_bucket_bytes = (uint32_t)(h.bm_buckets.size() * sizeof(AtomBucket));
   d.bm_bucket_mask = h.bm_bucket_mask;
   d.bm_bucket_mult = h.bm_bucket_mult;
   d.bm_has_key_rows = h.bm_has_key_rows ? 1u : 0u;
-  d.bm_has_inline = h.bm_trecx.empty() ? 0u : 1u;
-  d.bm_blob_bytes = 0;
-  {
-    // pack the bitmap tables into one blob (the LDS image)
-    const void* src[9] = {h.bm_row_bits.data(), h.bm_nsrows.data(), h.bm_nswords_off.data(), h.bm_nswords.data(),
-                          h.bm_buckets.data(), h.bm_trec.data(), h.bm_trecx.data(), h.bm_nswords64_off.data(),
-                          h.bm_nswords64.data()};
-    const size_t bytes[9] = {h.bm_row_bits.size() * 8, h.bm_nsrows.size() * 8, h.bm_nswords_off.size() * 4,
-                             h.bm_nswords.size() * 4, h.bm_buckets.size() * sizeof(AtomBucket),
-                             h.bm_trec.size() * sizeof(TermRec), h.bm_trecx.size() * sizeof(TermX),
-                             h.bm_nswords64_off.size() * 4, h.bm_nswords64.size() * 4};
-    // blob order: what the LDS form stages first, the block lists of the L2 form last
-    static const int kOrder[9] = {0, 1, 4, 5, 6, 7, 8, 2, 3};
-    size_t o = 0;
-    for (int q = 0; q < 9; ++q) {
-      const int k = kOrder[q];
-      if (q == 7) d.bm_lds_bytes = (uint32_t)o;
-      d.bm_off[k] = (uint32_t)o, o += (bytes[k] + 15) & ~(size_t)15;
-    }
-    if (getenv("KT_DEBUG_LDS"))
-      fprintf(stderr, "bitmap blob: rows=%zu nsrows=%zu nsb_off=%zu nsb=%zu buckets=%zu trec=%zu trecx=%zu w64_off=%zu w64=%zu (stride %u words, %u rows)\n",
-              bytes[0], bytes[1], bytes[2], bytes[3], bytes[4], bytes[5], bytes[6], bytes[7], bytes[8], h.bm_stride, h.bm_rows);
-    std::vector<unsigned char> blob(o + 16, 0);
-    for (int k = 0; k < 9; ++k)
-      if (bytes[k]) memcpy(blob.data() + d.bm_off[k], src[k], bytes[k]);
-    if ((e = up(d.bm_blob, d.cap_bm_blob, blob, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;  // `blob` is a temporary
-    d.bm_blob_bytes = (uint32_t)o;
-  }
+  d.bm_has_inline = h.bm_has_inline ? 1u : 0u;
+  if (getenv("KT_DEBUG_LDS"))
+    fprintf(stderr, "bitmap index: %u words, %u rows, %zu chunks, largest image %u B, largest chunk %u throttles, buckets %u B\n",
+            h.bm_words, h.bm_rows, h.bm_chunks.size(), h.bm_max_img, h.bm_max_thr, d.bm_bucket_bytes);
   return hipSuccess;
 }
 
 void release_index(IndexDev& d) {
   if (d.slow_thr) (void)hipFree(d.slow_thr);
   if (d.bm_blob) (void)hipFree(d.bm_blob);
+  if (d.bm_chunks) (void)hipFree(d.bm_chunks);
+  if (d.bm_rank_t) (void)hipFree(d.bm_rank_t);
+  if (d.bm_buckets) (void)hipFree(d.bm_buckets);
   d = IndexDev();
 }
 

@@ -62,50 +62,65 @@ struct ThrInfo {
   uint32_t ns;
 };
 
+// One LDS-sized slice of the bitmap form: 64-bit words [w0, w0 + n_words) of every row, with the TermRecs of those
+// term numbers and the per-namespace lists of words that can hold candidates.  The terms of a throttle never
+// straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers —
+// TermRec::flags carries the chunk-local rank in bits 8+.
+struct BmChunk {
+  uint32_t w0, n_words;
+  uint32_t rank0, n_thr;
+  uint32_t img_off, img_bytes;  // image inside the blob (multiple of 16): rows first
+  uint32_t off_nsrows, off_nsw_off, off_nsw, off_trec, off_trecx;  // relative to the image
+  uint32_t stride;              // 64-bit words per row inside the image (odd: column reads spread over LDS banks)
+  uint32_t slab_off;            // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
+  uint32_t pad[3];
+};
+
 struct HostIndex {
   std::vector<uint32_t> slow_thr;
-  uint32_t bm_words = 0;   // W: 64-bit words per bitmap row
-  uint32_t bm_stride = 0;  // row stride in 64-bit words (odd: column reads spread over LDS banks)
+  uint32_t bm_words = 0;  // W: 64-bit words per full bitmap row
   uint32_t bm_rows = 0;
   uint32_t bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u;
-  std::vector<uint64_t> bm_row_bits;    // [bm_rows][bm_stride]
-  std::vector<uint64_t> bm_nsrows;      // [n_ns][bm_stride]
-  std::vector<uint32_t> bm_nswords_off; // [n_ns + 1]
-  std::vector<uint32_t> bm_nswords;     // 128-bit block indices a namespace can touch (L2 form: one 16-byte read each)
-  std::vector<uint32_t> bm_nswords64_off, bm_nswords64;  // the same as 64-bit word indices (LDS form)
+  std::vector<BmChunk> bm_chunks;
+  std::vector<unsigned char> bm_images;  // chunk images back to back
+  std::vector<uint32_t> bm_rank_t;       // dense throttle rank (term order) -> throttle row
   std::vector<AtomBucket> bm_buckets;
-  std::vector<TermRec> bm_trec;
-  std::vector<TermX> bm_trecx;   // empty when no term needs it
+  uint32_t bm_max_img = 0, bm_max_thr = 0;
+  uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
   bool bm_has_key_rows = false;  // some term is anchored on an Exists requirement
+  bool bm_has_inline = false;    // some term carries TermX
 };
 
 struct IndexDev {
   uint32_t* slow_thr = nullptr;
   uint32_t n_slow = 0;
-  // bitmap form: ONE device blob holding the six tables back to back (16-byte aligned pieces, in the order
-  // rows, nsrows, nswords_off, nswords, buckets, trec) — the kernels copy it to LDS with one streaming loop
-  uint32_t bm_words = 0, bm_stride = 0, bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u, bm_has_key_rows = 0;
-  unsigned char* bm_blob = nullptr;
-  uint32_t bm_blob_bytes = 0;
-  uint32_t bm_lds_bytes = 0;  // prefix of the blob the LDS form stages
-  uint32_t bm_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of the tables inside the blob
-  uint32_t bm_has_inline = 0;
-  size_t cap_bm_blob = 0, cap_slow = 0;
+  unsigned char* bm_blob = nullptr;  // chunk images
+  BmChunk* bm_chunks = nullptr;
+  uint32_t* bm_rank_t = nullptr;
+  AtomBucket* bm_buckets = nullptr;
+  std::vector<BmChunk> h_chunks;     // host copy (launch planning)
+  uint32_t n_chunks = 0, bm_max_img = 0, bm_max_thr = 0, bm_bucket_bytes = 0;
+  uint64_t bm_slab_bytes = 0;
+  uint32_t bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u, bm_has_key_rows = 0, bm_has_inline = 0;
+  size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_buckets = 0, cap_slow = 0;
 };
 
+// agg_budget / chk_budget: LDS bytes left for (atom buckets + chunk image + table of the chunk's throttles, thr_bytes
+// each) in kt_aggregate_bitmap and for (atom buckets + chunk image) in kt_check_bitmap
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
-                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw);
+                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
 struct PodTable;
 struct SelProgram;
-// slab: scratch for the per-block LDS tables of the aggregate kernel (nullptr => global atomics only)
-size_t aggregate_slab_bytes(int T, int D);
+// LDS the two scan kernels need beside the atom buckets, the chunk image and (aggregate) the chunk's table
+uint32_t aggregate_fixed_lds();
+uint32_t check_fixed_lds();
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched.
 // after_scan (nullable) is invoked on the host right after the scan kernel is enqueued and before the slab
 // reduction kernel (if any) — the engine uses it to bracket the two kernels with separate timing events.

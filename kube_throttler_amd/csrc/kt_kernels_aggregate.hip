@@ -5,7 +5,10 @@
 
 namespace kt {
 
-__host__ __device__ inline uint32_t agg_bitmap_tab_bytes(int T, int D) { return (uint32_t)(((size_t)T * D * 8 + (size_t)T * 8 + 15) & ~(size_t)15); }
+// LDS table of one chunk: tv i64[n_thr][D] | tpres u32[n_thr] | tpods u32[n_thr], 16-byte granules
+__host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D) {
+  return (uint32_t)(((size_t)n_thr * D * 8 + (size_t)n_thr * 8 + 15) & ~(size_t)15);
+}
 
 // compact argument block (see BmCheckArgs): the scalar register file only holds what the tile loop uses
 constexpr uint32_t kAggListCap = 128;  // match-list entries per wave (512 B): the used-table needs the LDS
@@ -21,14 +24,13 @@ struct BmAggArgs {
   unsigned char* slab;
   int64_t n_rows;
   BmIndexArgs ix;
-  uint32_t off_list, off_pres, off_tab, tab_bytes;
+  uint32_t off_list, off_pres, off_tab;
   uint32_t n_slow;
   int32_t D, DS, LS, T;
 };
 
 static BmAggArgs make_bm_agg_args(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
-                                  const IndexDev& ix, unsigned long long* partial, unsigned char* slab, bool in_lds,
-                                  uint32_t* total) {
+                                  const IndexDev& ix, unsigned long long* partial, unsigned char* slab, uint32_t* total) {
   BmAggArgs a{};
   a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab, a.n_rows = n_rows;
@@ -37,32 +39,26 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, int64_t n_rows, const Se
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_list = take((kBlockIx / kWave) * kAggListCap * 4);
   a.off_pres = take(kBlockIx * 2);
-  a.tab_bytes = in_lds ? agg_bitmap_tab_bytes(sp.T, pods.D) : 0u;  // L2 form: no LDS table either (global atomics)
-  a.off_tab = take(a.tab_bytes);
-  plan_bitmap_index(ix, a.ix, in_lds, take);
+  a.off_tab = take(agg_tab_bytes(ix.bm_max_thr, pods.D));
+  plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
 }
 
 // kt_aggregate_bitmap — `used` partials of this GPU's pod rows: affectedPods + fold Add for all throttles
 // (throttle_controller.go:116-119,221-246; clusterthrottle_controller.go:119-122,224-270).
-// INLDS: the bitmap index AND the workgroup's partial table live in LDS (small-T regime); otherwise the index is
-// read through L2 and the amounts go straight to the partial buffer with global atomics.
-// Wave-autonomous like kt_check_bitmap: lane = pod finds the tile's (pod, throttle) matches
-// (bitmap_scan_tile), lane = (match, dimension pair) folds ResourceAmountOfPod into the workgroup's LDS
-// table  tv i64[T][D] | tpres u32[T] (request-key presence mask) | tpods u32[T];  the table is spilled to
-// this workgroup's slab at the end and kt_reduce_bitmap_slabs sums the slabs.
-template <int DT, int LT, bool KEYS, bool INLDS>
+// The workgroup walks the chunks of the index: chunk image in, table of the chunk's throttles zeroed, every tile of
+// the workgroup scanned against it — wave-autonomous like kt_check_bitmap: lane = pod finds the tile's
+// (pod, throttle) matches (bitmap_scan_tile), lane = (match, dimension pair) folds ResourceAmountOfPod into the
+// LDS table  tv i64[n_thr][D] | tpres u32[n_thr] (request-key presence mask) | tpods u32[n_thr] — then the table is
+// spilled to this (chunk, workgroup)'s slab; kt_reduce_bitmap_slabs sums the slabs into the partial buffer.
+// No global atomics except for throttles with unconvertible selectors (the "slow" list).
+template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
-  const int D = a.D, DS = a.DS, T = a.T;
+  const int D = a.D, DS = a.DS;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  lds_u64wp tv = (lds_u64wp)(lds + a.off_tab);
-  lds_u32wp tpres = (lds_u32wp)(lds + a.off_tab + (uint32_t)T * D * 8);
-  lds_u32wp tpods = tpres + T;
-  for (uint32_t i = threadIdx.x; i < a.tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
-  const BmView<INLDS> bm = open_bitmap_index<INLDS>(lds, a.ix);
   const int pstride = partial_stride(D);
-  __syncthreads();
+  lds_stage16((KT_LDS u32x4*)(lds + a.ix.lds_buckets), a.ix.buckets, a.ix.bucket_bytes / 16u);
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kAggListCap;
   KT_LDS uint16_t* l_pres = (KT_LDS uint16_t*)(lds + a.off_pres) + wave * kWave;  // [64] request-key presence masks of the tile
@@ -86,105 +82,124 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
     (void)*(const volatile uint32_t*)(a.req + p * DS);
   };
-  int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-  Tile cur;
-  if (wt < n_wtiles) load_tile(wt, cur);
-  for (; wt < n_wtiles; wt += wstep) {
-    Tile nxt;
-    load_tile(min(wt + wstep, n_wtiles - 1), nxt);
-    // ---- phase 1: lane = pod
-    const bool in = wt * kWave + lane < n_rows;
-    const uint32_t fl = cur.fl;
-    // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
-    // (isNotFinished, pod_util.go:26-28) and only matter for error detection
-    const bool countable = in && (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
-    const bool not_finished = !(fl & kPodFinished);
-    const uint32_t ns = countable ? cur.ns : 0u;
-    l_pres[lane] = (uint16_t)(fl >> kPresentShift);
+  for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
+    const BmChunk ch = a.ix.chunks[ci];
+    const uint32_t n_thr = ch.n_thr;
+    const uint32_t tab_bytes = agg_tab_bytes(n_thr, D);
+    lds_u64wp tv = (lds_u64wp)(lds + a.off_tab);
+    lds_u32wp tpres = (lds_u32wp)(lds + a.off_tab + n_thr * (uint32_t)D * 8);
+    lds_u32wp tpods = tpres + n_thr;
+    __syncthreads();  // nobody reads the previous image / table any more
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
+    const BmView bm = open_chunk(lds, a.ix, ch);
+    __syncthreads();
+    int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+    Tile cur;
+    if (wt < n_wtiles) load_tile(wt, cur);
+    for (; wt < n_wtiles; wt += wstep) {
+      Tile nxt;
+      load_tile(min(wt + wstep, n_wtiles - 1), nxt);
+      // ---- phase 1: lane = pod
+      const bool in = wt * kWave + lane < n_rows;
+      const uint32_t fl = cur.fl;
+      // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
+      // (isNotFinished, pod_util.go:26-28) and only matter for error detection
+      const bool countable = in && (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+      const bool not_finished = !(fl & kPodFinished);
+      const uint32_t ns = countable ? cur.ns : 0u;
+      const uint32_t present = fl >> kPresentShift;
+      l_pres[lane] = (uint16_t)present;
+      const uint32_t mp_lane = (uint32_t)(wt * kWave) + lane;  // pod_capacity <= 2^31
 
-    auto drain = [&](uint32_t n_items) {
-      // ---- phase 2: lane = (match, dimension pair): fold the pod's amount into the table; operands are
-      // fetched one step ahead of their use
-      struct Ops {
-        uint32_t vv, t, pres;
-        kt_i64x2 x;
-      };
-      auto fetch = [&](uint32_t base, Ops& o) {
-        const uint32_t j = base + ml;
-        o.vv = j < n_items ? 1u : 0u;
-        const uint32_t e = list[o.vv ? j : 0u];
-        o.t = e & 0xFFFFFu;
-        const uint32_t mp = (uint32_t)(wt * kWave) + (e >> 20);  // pod_capacity <= 2^31
-        o.x = *(const kt_i64x2*)(a.req + (uint64_t)mp * (uint32_t)DS + dpo);
-        o.pres = l_pres[e >> 20];
-      };
-      Ops c;
-      fetch(0, c);
-      for (uint32_t base = 0; base < n_items; base += MPW) {
-        Ops nx;
-        fetch(base + MPW, nx);
-        if (c.vv && dp_in) {
-          if (INLDS) {
-            if (c.x.x != 0) lds_add64(tv + c.t * (uint32_t)D + 2 * dp, (unsigned long long)c.x.x);
-            if (c.x.y != 0) lds_add64(tv + c.t * (uint32_t)D + 2 * dp + 1, (unsigned long long)c.x.y);  // padding dimension is 0
+      auto drain = [&](uint32_t n_items) {
+        // ---- phase 2: lane = (match, dimension pair): fold the pod's amount into the table; operands are
+        // fetched one step ahead of their use
+        struct Ops {
+          uint32_t vv, r, pres;
+          kt_i64x2 x;
+        };
+        auto fetch = [&](uint32_t base, Ops& o) {
+          const uint32_t j = base + ml;
+          o.vv = j < n_items ? 1u : 0u;
+          const uint32_t e = list[o.vv ? j : 0u];
+          o.r = e & 0xFFFFFu;  // chunk-local throttle rank
+          const uint32_t mp = (uint32_t)(wt * kWave) + (e >> 20);
+          o.x = *(const kt_i64x2*)(a.req + (uint64_t)mp * (uint32_t)DS + dpo);
+          o.pres = l_pres[e >> 20];
+        };
+        Ops c;
+        fetch(0, c);
+        for (uint32_t base = 0; base < n_items; base += MPW) {
+          Ops nx;
+          fetch(base + MPW, nx);
+          if (c.vv && dp_in) {
+            if (c.x.x != 0) lds_add64(tv + c.r * (uint32_t)D + 2 * dp, (unsigned long long)c.x.x);
+            if (c.x.y != 0) lds_add64(tv + c.r * (uint32_t)D + 2 * dp + 1, (unsigned long long)c.x.y);  // padding dimension is 0
             if (dp == 0) {
-              (void)__hip_atomic_fetch_or(tpres + c.t, c.pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              lds_add(tpods + c.t, 1u);
+              (void)__hip_atomic_fetch_or(tpres + c.r, c.pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              lds_add(tpods + c.r, 1u);
             }
-          } else {  // partial[t] = values[D] | presence counts[D] | pods | errors
-            unsigned long long* pr = a.partial + (size_t)c.t * pstride;
-            if (c.x.x != 0) atomicAdd(pr + 2 * dp, (unsigned long long)c.x.x);
-            if (c.x.y != 0) atomicAdd(pr + 2 * dp + 1, (unsigned long long)c.x.y);
-            // key presence: a positive value already makes the sum non-zero unless something negative cancels it,
-            // and every non-positive contribution increments the presence word (kt_finalize: count != 0 || sum != 0)
-            if (((c.pres >> (2 * dp)) & 1u) && c.x.x <= 0) atomicAdd(pr + D + 2 * dp, 1ull);
-            if (((c.pres >> (2 * dp + 1)) & 1u) && c.x.y <= 0) atomicAdd(pr + D + 2 * dp + 1, 1ull);
-            if (dp == 0) atomicAdd(pr + 2 * D, 1ull);
           }
+          c = nx;
         }
-        c = nx;
-      }
-    };
-    bitmap_scan_tile<LT, KEYS, kAggListCap>(bm, a.sp, a.slow_thr, a.n_slow, countable && not_finished, countable, ns, cur.lp,
-                                            cur.lk, list, lane, drain, [&](uint32_t t) {  // rare: straight to the result buffer
-                                              atomicAdd(a.partial + (size_t)t * pstride + 2 * D + 1, 1ull);
-                                            });
-    cur = nxt;
-  }
-  if (INLDS) {
-    __syncthreads();  // spill this workgroup's table (coalesced 16-byte stores); kt_reduce_bitmap_slabs sums the slabs
-    u32x4* dst = (u32x4*)(a.slab + (size_t)blockIdx.x * a.tab_bytes);
+      };
+      // throttles with unconvertible selectors have no rank: walked once (with the first chunk), straight to the
+      // result buffer
+      bitmap_scan_tile<LT, KEYS, kAggListCap, true>(
+          bm, a.sp, a.slow_thr, ci == 0 ? a.n_slow : 0u, countable && not_finished, countable, ns, cur.lp, cur.lk, list,
+          lane, drain,
+          [&](uint32_t t) { atomicAdd(a.partial + (size_t)t * pstride + 2 * D + 1, 1ull); },
+          [&](uint32_t t) {
+            unsigned long long* pr = a.partial + (size_t)t * pstride;
+            for (int d = 0; d < D; ++d)
+              if ((present >> d) & 1u) {
+                const int64_t v = a.req[(uint64_t)mp_lane * (uint32_t)DS + d];
+                if (v != 0) atomicAdd(pr + d, (unsigned long long)v);
+                atomicAdd(pr + D + d, 1ull);
+              }
+            atomicAdd(pr + 2 * D, 1ull);
+          });
+      cur = nxt;
+    }
+    __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
+    u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
     lds_u4p src = (lds_u4p)(lds + a.off_tab);
-    for (uint32_t i = threadIdx.x; i < a.tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
   }
 }
 
-// partial[t][j] = sum over slabs: j < D values; D <= j < 2D: key seen by the slab (0/1); j == 2D: pods.
-// The error word (2D+1) is written by the scan kernel itself and left alone.
-__global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned char* slab, int n_slabs, int T, int D,
+// partial[t][j] += sum over the workgroups' slabs of t's chunk: j < D values; D <= j < 2D: key seen by the slab
+// (0/1); j == 2D: pods.  "+=": throttles of the slow list were written by the scan kernel with atomics, and so was
+// every error word (2D+1), which is left alone.  grid = (word groups, chunks).
+__global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned char* slab, const BmChunk* chunks,
+                                                              const uint32_t* rank_t, int n_slabs, int D,
                                                               unsigned long long* partial) {
   constexpr int G = 16;  // slab groups: every thread streams n_slabs / 16 independent loads
   __shared__ unsigned long long part[G][64];
+  const BmChunk ch = chunks[blockIdx.y];
+  const int n_thr = (int)ch.n_thr;
   const int stride = partial_stride(D);
-  const size_t pitch = agg_bitmap_tab_bytes(T, D);
-  const int words = T * stride;
+  const size_t pitch = agg_tab_bytes(ch.n_thr, D);
+  const unsigned char* base0 = slab + (size_t)ch.slab_off * 16;
+  const int words = n_thr * stride;
+  if ((int)blockIdx.x * 64 >= words) return;
   const int wl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int w = blockIdx.x * 64 + wl;
   unsigned long long acc = 0;
-  int j = 0;
+  int j = 0, r = 0;
   if (w < words) {
-    const int t = w / stride;
-    j = w - t * stride;
+    r = w / stride;
+    j = w - r * stride;
     if (j < D) {
-      const unsigned char* base = slab + ((size_t)t * D + j) * 8;
+      const unsigned char* base = base0 + ((size_t)r * D + j) * 8;
 #pragma unroll 16
       for (int b = g; b < n_slabs; b += G) acc += *(const unsigned long long*)(base + b * pitch);
     } else if (j < 2 * D) {
-      const unsigned char* base = slab + (size_t)T * D * 8 + (size_t)t * 4;
+      const unsigned char* base = base0 + (size_t)n_thr * D * 8 + (size_t)r * 4;
 #pragma unroll 16
       for (int b = g; b < n_slabs; b += G) acc += (*(const unsigned int*)(base + b * pitch) >> (j - D)) & 1u;
     } else if (j == 2 * D) {
-      const unsigned char* base = slab + (size_t)T * D * 8 + (size_t)T * 4 + (size_t)t * 4;
+      const unsigned char* base = base0 + (size_t)n_thr * D * 8 + (size_t)n_thr * 4 + (size_t)r * 4;
 #pragma unroll 16
       for (int b = g; b < n_slabs; b += G) acc += *(const unsigned int*)(base + b * pitch);
     }
@@ -195,13 +210,13 @@ __global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned ch
     unsigned long long sum = 0;
 #pragma unroll
     for (int k = 0; k < G; ++k) sum += part[k][wl];
-    partial[w] = sum;
+    partial[(size_t)rank_t[ch.rank0 + r] * stride + j] += sum;
   }
 }
 
 #define KT_AGG_BM_CASE(DT_, LT_, KEYS_)                                                                        \
   {                                                                                                           \
-    auto kfn = in_lds ? kt_aggregate_bitmap<DT_, LT_, KEYS_, true> : kt_aggregate_bitmap<DT_, LT_, KEYS_, false>; \
+    auto kfn = kt_aggregate_bitmap<DT_, LT_, KEYS_>;                                                          \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
     hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                      \
   }
@@ -211,14 +226,10 @@ static inline int agg_blocks(int64_t n_rows) {
   return (int)(b < 1 ? 1 : b > kCUs ? kCUs : b);
 }
 
-// slab scratch for the LDS-table form (0 when the table cannot live in LDS at all)
-size_t aggregate_slab_bytes(int T, int D) {
-  const size_t bytes = agg_bitmap_tab_bytes(T, D);
-  if (bytes + 16 * 1024 > (size_t)kMaxLds) return 0;
-  return (size_t)kCUs * bytes;
-}
+uint32_t aggregate_fixed_lds() { return (kBlockIx / kWave) * kAggListCap * 4 + kBlockIx * 2 + 64; }
 
-// `partial` must be zeroed by the caller.  Returns the dispatched scan kernel's symbol.
+// `partial` must be zeroed by the caller.  Returns the dispatched scan kernel's symbol, nullptr when a chunk of the
+// index does not fit the workgroup's LDS.
 const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, bool keys, unsigned long long* partial, void* slab_, hipStream_t s,
                               const std::function<void()>& after_scan) {
@@ -228,15 +239,11 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
   const int nb = agg_blocks(n_rows);
   dim3 g_(nb), b_(kBlockIx);
   uint32_t bm_total = 0;
-  bool in_lds = slab != nullptr && aggregate_slab_bytes(sp.T, pods.D) != 0;
-  BmAggArgs bm_args = make_bm_agg_args(pods, n_rows, sp, sp_dev, ix, partial, slab, in_lds, &bm_total);
-  if (in_lds && bm_total > (uint32_t)kMaxLds) {
-    in_lds = false;
-    bm_args = make_bm_agg_args(pods, n_rows, sp, sp_dev, ix, partial, slab, false, &bm_total);
-  }
+  const BmAggArgs bm_args = make_bm_agg_args(pods, n_rows, sp, sp_dev, ix, partial, slab, &bm_total);
+  if (bm_total > (uint32_t)kMaxLds) return nullptr;
   const size_t lds_bm = bm_total;
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
-  if (dbg_lds) fprintf(stderr, "kt_aggregate_bitmap: in_lds=%d lds=%u blob=%u tab=%u T=%d\n", (int)in_lds, bm_total, ix.bm_blob_bytes, bm_args.tab_bytes, sp.T);
+  if (dbg_lds) fprintf(stderr, "kt_aggregate_bitmap: lds=%u chunks=%u max image=%u max thr=%u T=%d\n", bm_total, ix.n_chunks, ix.bm_max_img, ix.bm_max_thr, sp.T);
 #ifdef KT_FAST_BUILD
   KT_AGG_BM_CASE(8, 8, false)
 #else
@@ -246,11 +253,11 @@ const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const
   else { if (keys) KT_AGG_BM_CASE(16, 16, true) else KT_AGG_BM_CASE(16, 16, false) }
 #endif
   if (after_scan) after_scan();
-  if (in_lds) {
-    const int words = sp.T * partial_stride(pods.D);
-    hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((words + 63) / 64), dim3(1024), 0, s, slab, nb, sp.T, pods.D, partial);
-  }
-  return in_lds ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_l2";
+  const int max_words = (int)ix.bm_max_thr * partial_stride(pods.D);
+  if (max_words > 0)
+    hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_words + 63) / 64, ix.n_chunks), dim3(1024), 0, s, slab, ix.bm_chunks,
+                       ix.bm_rank_t, nb, pods.D, partial);
+  return ix.n_chunks == 1 ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_chunked";
 }
 
 }  // namespace kt

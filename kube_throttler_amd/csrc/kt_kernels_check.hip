@@ -43,7 +43,7 @@ struct BmCheckArgs {
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
                                       const SelProgram* sp_dev, const IndexDev& ix, const void* recs,
-                                      uint64_t* summary, uint8_t* status, bool ix_in_lds, uint32_t* total) {
+                                      uint64_t* summary, uint8_t* status, bool one_chunk, uint32_t* total) {
   BmCheckArgs a{};
   a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
@@ -54,8 +54,8 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   a.off_cnt = take(kBlockIx * 8);
   a.off_list = take((kBlockIx / kWave) * kListCap * 4);
   a.off_req = take(kBlockIx * 4);
-  a.off_rflags = ix_in_lds ? take((uint32_t)sp.T * 8) : 0u;  // L2 form: the flags are read through L2 as well
-  plan_bitmap_index(ix, a.ix, ix_in_lds, take);
+  a.off_rflags = one_chunk ? take((uint32_t)sp.T * 8) : 0u;  // several chunks: the flags are read through L2
+  plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
 }
@@ -69,17 +69,19 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return v;
 }
 
-template <int DT, int LT, bool KEYS, bool LDSIX>
+// ONE: the whole program is one chunk (the small-T regime): throttle flags live in LDS and the summary is written
+// once.  Otherwise the kernel walks the chunks: chunk image in, every tile of the workgroup scanned against it, the
+// per-pod class counters carried from chunk to chunk in the summary words (finished by the last chunk).
+template <int DT, int LT, bool KEYS, bool ONE>
 __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  const BmView<LDSIX> bm = open_bitmap_index<LDSIX>(lds, a.ix);
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
-  if (LDSIX) {  // {flags, active_mask} of every throttle: 8 bytes each, rewritten by every kt_prepare_check
+  lds_stage16((KT_LDS u32x4*)(lds + a.ix.lds_buckets), a.ix.buckets, a.ix.bucket_bytes / 16u);
+  if (ONE) {  // {flags, active_mask} of every throttle: 8 bytes each, rewritten by every kt_prepare_check
     KT_LDS u32x2* dst = (KT_LDS u32x2*)(lds + a.off_rflags);
     for (uint32_t i = threadIdx.x; i < (uint32_t)a.T; i += kBlockIx) dst[i] = g_rflags[i];
   }
-  __syncthreads();  // the only workgroup barrier
   const KT_LDS u32x2* l_rflags = (const KT_LDS u32x2*)(lds + a.off_rflags);
   const int64_t n = a.n;
   const int DS = a.DS;
@@ -113,6 +115,12 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
     load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
     (void)*(const volatile uint32_t*)(a.req + p * DS);
   };
+  const uint32_t n_chunks = ONE ? 1u : a.ix.n_chunks;
+  for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+  const bool first = ci == 0, last = ci + 1 == n_chunks;
+  __syncthreads();  // nobody reads the previous image any more
+  const BmView bm = open_chunk(lds, a.ix, a.ix.chunks[ci]);
+  __syncthreads();
   int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
   Tile cur;
   if (wt < n_wtiles) load_tile(wt, cur);
@@ -122,12 +130,15 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
     // ---- phase 1: lane = pod
     const int64_t i = wt * kWave + lane;
     const bool in = i < n;
-    cnt[lane] = 0ull;
+    // class counters so far (bit 1 = error) ride in the summary word between chunks
+    const unsigned long long carried =
+        (!ONE && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    cnt[lane] = carried & ~3ull;
     prow[lane] = cur.p;
     const bool on = in && (cur.fl & kPodValid) != 0;
     const uint32_t ns = on ? cur.ns : 0u;
     // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
-    bool pod_err = on & (a.ns_valid[ns] == 0);
+    bool pod_err = (carried & 2ull) != 0 || (on & (a.ns_valid[ns] == 0));
 
     auto drain = [&](uint32_t n_items) {
       // ---- phase 2: lane = (match, dimension pair); operands are fetched one step ahead of their use
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         const CheckRec<DT>* rc = recs + o.tt;
         o.th = *(const kt_i64x2*)(rc->thr + 2 * dp);
         o.hd = *(const kt_i64x2*)(rc->head + 2 * dp);
-        o.fa = LDSIX ? l_rflags[o.tt] : g_rflags[o.tt];  // {flags, active_mask}
+        o.fa = ONE ? l_rflags[o.tt] : g_rflags[o.tt];  // {flags, active_mask}
         o.xx = *(const kt_i64x2*)(a.req + (uint64_t)prow[o.pl] * (uint32_t)DS + dpo);
       };
       Ops c;
@@ -172,28 +183,36 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         c = nx;
       }
     };
-    bitmap_scan_tile<LT, KEYS, kListCap>(bm, a.sp, a.slow_thr, a.n_slow, on, on, ns, cur.lp, cur.lk, list, lane, drain,
-                               [&](uint32_t) { pod_err = true; });
+    // throttles with unconvertible selectors are walked once, with the first chunk
+    bitmap_scan_tile<LT, KEYS, kListCap, false>(bm, a.sp, a.slow_thr, first ? a.n_slow : 0u, on, on, ns, cur.lp, cur.lk,
+                                                list, lane, drain, [&](uint32_t) { pod_err = true; }, [](uint32_t) {});
     // ---- phase 3: lane = pod
     if (in) {
       const unsigned long long c = cnt[lane];
-      a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
-      if (a.status && pod_err)
-        for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
+      if (last) {
+        a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
+        if (a.status && pod_err)
+          for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
+      } else {
+        a.summary[i] = c | (pod_err ? 2ull : 0ull);
+      }
     }
     cur = nxt;
   }
+  }
 }
+
+uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + kBlockIx * 4 + 64; }
 
 #define KT_BM_CASE(DT_, LT_, KEYS_)                                                                            \
   {                                                                                                           \
-    auto kfn = in_lds ? kt_check_bitmap<DT_, LT_, KEYS_, true> : kt_check_bitmap<DT_, LT_, KEYS_, false>;       \
+    auto kfn = one ? kt_check_bitmap<DT_, LT_, KEYS_, true> : kt_check_bitmap<DT_, LT_, KEYS_, false>;         \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
     hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                   \
   }
 
-// returns the dispatched kernel's symbol, or nullptr when even the L2 form does not fit the workgroup's LDS
-// (throttle_rows x 8 bytes of flags beside the working buffers)
+// returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
+// beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s) {
@@ -204,13 +223,13 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   if (nb > kCUs) nb = kCUs;
   dim3 g_((unsigned)nb), b_(kBlockIx);
   uint32_t bm_total = 0;
-  bool in_lds = true;
-  BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, true, &bm_total);
-  if (bm_total > (uint32_t)kMaxLds) {
-    in_lds = false;
+  bool one = ix.n_chunks == 1;
+  BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, one, &bm_total);
+  if (one && bm_total > (uint32_t)kMaxLds) {  // the flags of all throttles do not fit beside the image
+    one = false;
     bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, false, &bm_total);
-    if (bm_total > (uint32_t)kMaxLds) return nullptr;
   }
+  if (bm_total > (uint32_t)kMaxLds) return nullptr;
   const size_t lds_bytes = bm_total;
 #ifdef KT_FAST_BUILD
   KT_BM_CASE(8, 8, false)
@@ -220,7 +239,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   else if (LT == 8) { if (keys) KT_BM_CASE(16, 8, true) else KT_BM_CASE(16, 8, false) }
   else { if (keys) KT_BM_CASE(16, 16, true) else KT_BM_CASE(16, 16, false) }
 #endif
-  return in_lds ? "kt_check_bitmap" : "kt_check_bitmap_l2";
+  return one ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
 }
 
 }  // namespace kt
