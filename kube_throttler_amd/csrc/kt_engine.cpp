@@ -485,7 +485,11 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
                     ti.ns = h.ns;
                     return ti;
                   },
-                  (uint32_t)NS, ns_term_ok, gw, 160u * 1024u - kt::aggregate_fixed_lds(), 160u * 1024u - kt::check_fixed_lds(),
+                  (uint32_t)NS, ns_term_ok, gw,
+                  // KT_CHUNK_BUDGET (bytes): test hook that forces small chunks so that tiny programs exercise the
+                  // multi-chunk path too
+                  getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::aggregate_fixed_lds(),
+                  getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::check_fixed_lds(),
                   (uint32_t)(8 * D + 8));
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {

@@ -260,6 +260,20 @@ def test_set_status_and_reserved(oracle_mod):
         eng.close()
 
 
+@pytest.mark.parametrize("budget", [3000, 12000])
+@pytest.mark.parametrize("seed", [1, 7])
+def test_multi_chunk_index(seed, budget, oracle_mod, monkeypatch):
+    """The index walked in several LDS-sized chunks (forced small here): terms of a throttle never straddle a chunk,
+    class counters and errors carry from chunk to chunk, per-chunk `used` tables are summed per throttle."""
+    monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
+    kw = dict(n_invalid_pod_sel=1, n_invalid_ns_sel=2, n_missing_ns=1) if seed == 7 else {}
+    snap = W.generate(W.small(seed=seed, n_pods=3000, n_thr=192, n_cluster=96, **kw))
+    st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED, S.ACTIVE}
+    if seed == 7:
+        assert (S.summary_fields(sm)[0] == S.VERDICT_ERROR).any() and rec.error.any()
+
+
 def _stored_status(snap, oracle_mod):
     """Reconcile on the oracle and store the result as the snapshot's status (what UpdateStatus persists)."""
     o = oracle_mod.Oracle(snap)
