@@ -149,6 +149,9 @@ struct kt_engine {
   bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
   bool status_host_dirty = true;  // host status/reserved rows newer than device
   bool reserved_dev_newer = false;  // device reserved rows newer than the host mirrors (admit with commit)
+  bool recs_valid = false;          // d_recs matches the device status + reserved tables for (recs_eq, recs_DT)
+  bool recs_eq = false;
+  int recs_DT = 0;
   bool status_dev_newer = false;  // device status newer than host (after reconcile with APPLY)
 
   // ---- compiled program (device)
@@ -368,6 +371,7 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
   if ((rc = upload(e, e->d_status_fp, fp, s)) != KT_OK) return rc;
   KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
   e->status_host_dirty = false;
+  e->recs_valid = false;
   return KT_OK;
 }
 
@@ -1022,12 +1026,21 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   if (rc != KT_OK) return rc;
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
                        e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p, e->d_out_next_s.p, e->d_out_next_ns.p};
+  const bool apply = (flags & KT_RECONCILE_APPLY) != 0;
+  // with APPLY the stored status changes: leave the CheckRecs of the new status behind (kt_prepare_check fused in),
+  // built for the isThrottledOnEqual value the last check used (PreFilter: false)
+  const int rec_DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
-    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, (flags & KT_RECONCILE_APPLY) != 0, out, s);
+    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
+                        e->recs_eq, s);
   }
   KT_HIP(e, hipGetLastError());
-  if (flags & KT_RECONCILE_APPLY) e->status_dev_newer = true;
+  if (apply) {
+    e->status_dev_newer = true;
+    e->recs_valid = true;  // e->recs_eq unchanged
+    e->recs_DT = rec_DT;
+  }
   e->reconcile_ready = true;
   e->last_stream = s;
   return KT_OK;
@@ -1157,9 +1170,14 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   }
   // the record layout follows the scan kernel that will read it
   const int DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
-  {
+  // the CheckRecs only depend on (stored status, reserved amounts, isThrottledOnEqual): rebuilt when one of them
+  // changed since they were last built (by kt_prepare_check or by kt_finalize with APPLY)
+  if (!(e->recs_valid && e->recs_eq == (on_equal != 0) && e->recs_DT == DT)) {
     TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
     kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, s);
+    e->recs_valid = true;
+    e->recs_eq = on_equal != 0;
+    e->recs_DT = DT;
   }
   {
     TimedLaunch tl(e, KT_KERNEL_CHECK, s);
@@ -1209,7 +1227,7 @@ int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   kt::launch_admit(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->tt, e->thr_rows_hi, e->D, on_equal != 0, commit,
                    e->d_status.p, e->d_summary.p, s);
   KT_HIP(e, hipGetLastError());
-  if (commit) e->reserved_dev_newer = true;
+  if (commit) e->reserved_dev_newer = true, e->recs_valid = false;
   return KT_OK;
 }
 

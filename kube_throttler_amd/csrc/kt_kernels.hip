@@ -187,13 +187,88 @@ __device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, i
   return as != bs ? (as < bs ? -1 : 1) : (an != bn ? (an < bn ? -1 : 1) : 0);
 }
 
+__device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
+
+// Everything CheckThrottledFor needs that does not depend on the pod, folded into the throttle's CheckRec
+// (effective threshold, headroom, step-2/3 bitmask, count verdicts) — see DESIGN.md "Check algebra".
+// fl: the throttle's flags as stored AFTER this point (kThrCalcAtNonzero already decided the threshold passed in).
+template <int DT>
+__device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int T, int D, uint32_t fl, const int64_t (&th_v)[DT],
+                                                uint32_t th_p, bool th_hc, int64_t th_c, const int64_t (&u_v)[DT], uint32_t u_p,
+                                                bool u_hc, int64_t u_c_, const int64_t (&r_v)[DT], uint32_t r_p, bool r_hc,
+                                                int64_t r_c_, uint32_t thrl_flag, uint32_t thrl_has, bool eq,
+                                                CheckRec<DT>* recs) {
+  const int64_t u_c = u_hc ? u_c_ : 0, r_c = r_hc ? r_c_ : 0;
+  const bool eq3 = (fl & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
+  CheckRec<DT> rec;
+  uint32_t f = 0;
+  // step 1, counts: IsThrottled(podAmount{pod:1}, false).pod
+  if (th_hc && 1 > th_c) f |= kRecExceedsByCount;
+  // step 2: stored status.throttled ; step 3: IsThrottled(used + reserved, eq3)
+  uint32_t act_mask = thrl_flag & thrl_has;
+  bool act_pod = (fl & kThrThrottledPod) != 0;
+  if (th_hc && (u_hc || r_hc) && cmp_eq(u_c + r_c, th_c, eq3)) act_pod = true;
+  // step 4, counts: used + pod(1) + reserved always has counts
+  if (th_hc && cmp_eq(u_c + 1 + r_c, th_c, eq)) f |= kRecInsufficientByCount;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    int64_t thr = kInf, head = kInf;
+    if (d < D && ((th_p >> d) & 1u)) {
+      const int64_t tv = th_v[d];
+      const int64_t uv = ((u_p >> d) & 1u) ? u_v[d] : 0;
+      const int64_t rv = ((r_p >> d) & 1u) ? r_v[d] : 0;
+      if ((((u_p | r_p) >> d) & 1u) && cmp_eq(uv + rv, tv, eq3)) act_mask |= 1u << d;
+      thr = tv;
+      __int128 h = (__int128)tv - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
+      head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
+    }
+    rec.thr[d] = thr;
+    rec.head[d] = head;
+  }
+  if (act_pod) f |= kRecActiveByCount;
+  rec.flags = f;
+  rec.active_mask = act_mask;
+  recs[t] = rec;
+  rec_flags<DT>(recs, T)[t] = RecFlags{f, act_mask};
+}
+
+// the CheckRec of throttle t from the status as stored in the tables
+template <int DT>
+__device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int t, int T, int D, bool eq, CheckRec<DT>* recs) {
+  const uint32_t fl = tt.flags[t];
+  // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
+  const AmountTab& th = (fl & kThrCalcAtNonzero) ? tt.calc : tt.spec;
+  int64_t th_v[DT], u_v[DT], r_v[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    th_v[d] = d < D ? th.v[(size_t)t * D + d] : 0;
+    u_v[d] = d < D ? tt.used.v[(size_t)t * D + d] : 0;
+    r_v[d] = d < D ? tt.reserved.v[(size_t)t * D + d] : 0;
+  }
+  build_check_rec<DT>(tt, t, T, D, fl, th_v, th.present[t], th.has_count[t] != 0, th.count[t], u_v, tt.used.present[t],
+                      tt.used.has_count[t] != 0, tt.used.count[t], r_v, tt.reserved.present[t],
+                      tt.reserved.has_count[t] != 0, tt.reserved.count[t], tt.thrl_flag[t], tt.thrl_has[t], eq, recs);
+}
+
 template <int DT>
 __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
-                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out) {
+                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+                                                     CheckRec<DT>* recs, int rec_eq) {
+  // recs (nullable): also leave the CheckRec of every throttle for the check that follows (kt_prepare_check fused in:
+  // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   const int stride = partial_stride(D);
   const uint32_t fl = tt.flags[t];
+  // reserved amounts (only the fused CheckRec needs them): loaded with everything else, up front
+  int64_t r_v[DT];
+  uint32_t r_p = 0;
+  bool r_hc = false;
+  int64_t r_c = 0;
+  if (recs) {
+    r_p = tt.reserved.present[t], r_hc = tt.reserved.has_count[t] != 0, r_c = tt.reserved.count[t];
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) r_v[d] = d < D ? tt.reserved.v[(size_t)t * D + d] : 0;
+  }
   const unsigned long long* prow = partial + (size_t)t * stride;
   const bool live = (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
   const bool error = live && prow[2 * D + 1] != 0;
@@ -221,6 +296,7 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
     out.error[t] = error ? 1 : 0;
     out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
     out.next_ns[t] = 0;
+    if (recs) build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, recs);
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
@@ -332,70 +408,47 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
     tt.flags[t] = nf;
     tt.thrl_flag[t] = th_flag;
     tt.thrl_has[t] = c_p;
+    if (recs) {  // from the registers that were just stored (no re-read of this thread's own writes)
+      int64_t th_v[DT];
+      uint32_t th_p = c_p;
+      bool th_hc = c_hc;
+      int64_t th_c = c_c;
+      _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = d < D ? c_v[d] : 0;
+      if (!(nf & kThrCalcAtNonzero)) {  // calculatedAt still zero: spec.threshold
+        th_p = tt.spec.present[t], th_hc = tt.spec.has_count[t] != 0, th_c = tt.spec.count[t];
+        _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = d < D ? tt.spec.v[(size_t)t * D + d] : 0;
+      }
+      _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d >= D) u_v[d] = 0;
+      build_check_rec<DT>(tt, t, T, D, nf, th_v, th_p, th_hc, th_c, u_v, u_p, u_hc, u_c, r_v, r_p, r_hc, r_c, th_flag, c_p,
+                          rec_eq != 0, recs);
+    }
+  } else if (recs) {
+    build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, recs);
   }
 }
 
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
-                     int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, hipStream_t s) {
+                     int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
+                     hipStream_t s) {
   if (sp.T <= 0) return;
   // one wave per 64 throttles (T is small: spread over as many CUs as possible; everything is latency)
   const dim3 g((sp.T + 63) / 64), b(64);
-  if (D <= 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
-  else if (D <= 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
-  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out);
+  const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
+  const int eq = rec_eq ? 1 : 0;
+  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq);
+  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // kt_prepare_check — per throttle: fold everything CheckThrottledFor needs that does not depend on
 // the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
-
 template <int DT>
 __global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
-  const uint32_t fl = tt.flags[t];
-  // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
-  const AmountTab& th = (fl & kThrCalcAtNonzero) ? tt.calc : tt.spec;
-  const uint32_t th_p = th.present[t];
-  const bool th_hc = th.has_count[t] != 0;
-  const int64_t th_c = th.count[t];
-  const uint32_t u_p = tt.used.present[t], r_p = tt.reserved.present[t];
-  const bool u_hc = tt.used.has_count[t] != 0, r_hc = tt.reserved.has_count[t] != 0;
-  const int64_t u_c = u_hc ? tt.used.count[t] : 0, r_c = r_hc ? tt.reserved.count[t] : 0;
-  const bool eq = on_equal != 0;
-  const bool eq3 = (fl & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
-  CheckRec<DT> rec;
-  uint32_t f = 0;
-  // step 1, counts: IsThrottled(podAmount{pod:1}, false).pod
-  if (th_hc && 1 > th_c) f |= kRecExceedsByCount;
-  // step 2: stored status.throttled ; step 3: IsThrottled(used + reserved, eq3)
-  uint32_t act_mask = tt.thrl_flag[t] & tt.thrl_has[t];
-  bool act_pod = (fl & kThrThrottledPod) != 0;
-  if (th_hc && (u_hc || r_hc) && cmp_eq(u_c + r_c, th_c, eq3)) act_pod = true;
-  // step 4, counts: used + pod(1) + reserved always has counts
-  if (th_hc && cmp_eq(u_c + 1 + r_c, th_c, eq)) f |= kRecInsufficientByCount;
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    int64_t thr = kInf, head = kInf;
-    if (d < D && ((th_p >> d) & 1u)) {
-      const int64_t tv = th.v[(size_t)t * D + d];
-      const int64_t uv = ((u_p >> d) & 1u) ? tt.used.v[(size_t)t * D + d] : 0;
-      const int64_t rv = ((r_p >> d) & 1u) ? tt.reserved.v[(size_t)t * D + d] : 0;
-      if ((((u_p | r_p) >> d) & 1u) && cmp_eq(uv + rv, tv, eq3)) act_mask |= 1u << d;
-      thr = tv;
-      __int128 h = (__int128)tv - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
-      head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
-    }
-    rec.thr[d] = thr;
-    rec.head[d] = head;
-  }
-  if (act_pod) f |= kRecActiveByCount;
-  rec.flags = f;
-  rec.active_mask = act_mask;
-  recs[t] = rec;
-  rec_flags<DT>(recs, T)[t] = RecFlags{f, act_mask};
+  build_check_rec_stored<DT>(tt, t, T, D, on_equal != 0, recs);
 }
 
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s) {
