@@ -66,8 +66,15 @@ typedef struct kt_config {
   int32_t throttle_capacity;  /* Throttle + ClusterThrottle rows (< 2^20) */
   int32_t namespace_capacity;
   int32_t device;             /* HIP device ordinal; -1 = current device */
-  int32_t kernel_variant;     /* 0 = default (indexed); 1 = dense P x T scan (reference shape, for cross-checks) */
+  int32_t kernel_variant;     /* low byte: 0 = default (indexed); 1 = dense P x T scan (reference shape, for cross-checks);
+                                 | KT_VARIANT_INCREMENTAL: see below */
 } kt_config;
+/* Incremental event path, indexed kernels only: the engine keeps the per-throttle `used` partials of
+ * its pod rows current across kt_upsert_pods / kt_delete_pods by delta scans over just the touched rows (old content
+ * out, new content in — which also covers the label-change symmetric difference of throttle_controller.go:469-500),
+ * so that a reconcile no longer rescans every pod: kt_aggregate_launch becomes a copy.  A change of throttles or
+ * namespaces voids the partials; the next reconcile rescans once.  Results are identical to a full rescan. */
+#define KT_VARIANT_INCREMENTAL 0x100
 
 /* Library / device facts (for logs and bench JSON). */
 const char* kt_version(void);

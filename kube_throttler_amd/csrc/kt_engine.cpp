@@ -149,6 +149,9 @@ struct kt_engine {
   bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
   bool status_host_dirty = true;  // host status/reserved rows newer than device
   bool reserved_dev_newer = false;  // device reserved rows newer than the host mirrors (admit with commit)
+  bool incremental = false;         // KT_VARIANT_INCREMENTAL: `used` partials maintained by pod deltas
+  bool agg_valid = false;           // d_agg = this GPU's partials for the current pods + selector program
+  DevBuf<unsigned long long> d_agg;
   bool recs_valid = false;          // d_recs matches the device status + reserved tables for (recs_eq, recs_DT)
   bool recs_eq = false;
   int recs_DT = 0;
@@ -494,7 +497,8 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
                   // multi-chunk path too
                   getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::aggregate_fixed_lds(),
                   getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::check_fixed_lds(),
-                  (uint32_t)(8 * D + 8));
+                  (uint32_t)(e->incremental ? 12 * D + 4 : 8 * D + 8));
+  e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
     hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
@@ -631,6 +635,13 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   e->device = dev;
   e->D = cfg->n_dims;
   e->L = cfg->max_labels;
+  e->incremental = (cfg->kernel_variant & KT_VARIANT_INCREMENTAL) != 0;
+  e->cfg.kernel_variant &= 0xFF;
+  if (e->incremental && e->cfg.kernel_variant != 0) {
+    g_create_error = "KT_VARIANT_INCREMENTAL needs the indexed kernels (kernel_variant 0)";
+    delete e;
+    return KT_ERR_INVALID_ARGUMENT;
+  }
   hipError_t r = hipSetDevice(dev);
   if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   const size_t cap = (size_t)cfg->pod_capacity;
@@ -677,6 +688,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
   e->d_partial.release();
   e->d_out_next_s.release();
+  e->d_agg.release();
   e->d_out_next_ns.release();
   e->d_sp.release();
   AmountDev* ams[] = {&e->d_spec, &e->d_calc, &e->d_used, &e->d_reserved, &e->d_ovr_thr, &e->d_out_used, &e->d_out_calc};
@@ -724,6 +736,8 @@ int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* rows) {
   if (n > 0) e->program_dirty = true;
   return KT_OK;
 }
+
+static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, int sign, hipStream_t s);
 
 static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
   const int D = e->D;
@@ -805,8 +819,14 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     pb.ctr_base = kb;
     pb.ovh_present = (const uint32_t*)(st + o_op);
     pb.ovh = (const int64_t*)(st + o_ov);
+    // incremental engines: out with the old content of these rows, in with the new (a row that is not valid yet /
+    // any more contributes nothing either way)
+    if (e->incremental && e->program_dirty) e->agg_valid = false;  // selectors changed: the next reconcile rescans
+    int32_t drc = delta_scan(e, cn, pb.rows, pb.row0, -1, s);
+    if (drc != KT_OK) return drc;
     kt::launch_ingest_pods(e->pods, pb, s);
     KT_HIP(e, hipGetLastError());
+    if ((drc = delta_scan(e, cn, pb.rows, pb.row0, +1, s)) != KT_OK) return drc;
     KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
   }
   e->pod_rows_hi = hi;
@@ -831,6 +851,11 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
+  if (e->incremental && e->program_dirty) e->agg_valid = false;
+  {
+    int32_t drc = delta_scan(e, n, e->d_rows.p, 0, -1, e->own_stream);
+    if (drc != KT_OK) return drc;
+  }
   kt::launch_delete_pods(e->pods, n, e->d_rows.p, e->own_stream);
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   return KT_OK;
@@ -999,6 +1024,13 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   if (e->ext_partial && (int64_t)words > e->ext_partial_words)
     return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed",
                    (long long)e->ext_partial_words, (long long)words);
+  if (e->incremental && e->agg_valid) {
+    // the partials were kept current by the pod event path: no scan
+    if (words) KT_HIP(e, hipMemcpyAsync(e->partial(), e->d_agg.p, words * 8, hipMemcpyDeviceToDevice, s));
+    e->last_kernel[KT_KERNEL_AGGREGATE] = "(incremental: no scan)";
+    e->last_stream = s;
+    return KT_OK;
+  }
   if (words) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
@@ -1011,13 +1043,33 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else {
-      const char* k = kt::launch_aggregate_indexed(e->pods, e->pod_rows_hi, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
+      kt::AggScan sc;
+      sc.n = e->pod_rows_hi, sc.counts = e->incremental;
+      const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
       e->last_kernel[KT_KERNEL_AGGREGATE] = k;
     }
   }
   KT_HIP(e, hipGetLastError());
+  if (e->incremental) {  // baseline for the delta scans of the pod event path
+    KT_HIP(e, e->d_agg.reserve(words + 1));
+    if (words) KT_HIP(e, hipMemcpyAsync(e->d_agg.p, e->partial(), words * 8, hipMemcpyDeviceToDevice, s));
+    e->agg_valid = true;
+  }
   e->last_stream = s;
+  return KT_OK;
+}
+
+// Pod event path of an incremental engine: the contribution of `n` pod rows (device list `rows_dev`,
+// or the contiguous range row0 + [0, n)) is removed from (sign -1) or added to (+1) the maintained partials with one
+// delta scan — the symmetric difference of throttle_controller.go:469-500 falls out of "remove the old pod, add the new".
+static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, int sign, hipStream_t s) {
+  if (!e->incremental || !e->agg_valid || n <= 0 || e->thr_rows_hi == 0) return KT_OK;
+  kt::AggScan sc;
+  sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign;
+  const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->d_agg.p, e->d_slab.p, s, nullptr);
+  if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget");
+  KT_HIP(e, hipGetLastError());
   return KT_OK;
 }
 

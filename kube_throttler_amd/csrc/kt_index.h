@@ -124,7 +124,15 @@ uint32_t check_fixed_lds();
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched.
 // after_scan (nullable) is invoked on the host right after the scan kernel is enqueued and before the slab
 // reduction kernel (if any) — the engine uses it to bracket the two kernels with separate timing events.
-const char* launch_aggregate_indexed(const PodTable& pods, int64_t n_rows, const SelProgram& sp, const SelProgram* sp_dev,
+// which pods an aggregate scan covers and how they enter the target buffer
+struct AggScan {
+  int64_t n = 0;                 // pods
+  const int64_t* rows = nullptr; // device list of pod rows, or
+  int64_t row0 = 0;              // ... the contiguous range row0 + [0, n)
+  bool counts = false;           // exact per-key pod counts (incremental engines) instead of presence masks
+  int sign = 1;                  // -1: remove the scanned pods' contribution (delta scans)
+};
+const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& scan, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, bool keys, unsigned long long* partial, void* slab, hipStream_t s,
                               const std::function<void()>& after_scan = nullptr);
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,

@@ -22,6 +22,7 @@ ERR_NAMES = {-1: "KT_ERR_INVALID_ARGUMENT", -2: "KT_ERR_OUT_OF_RANGE", -3: "KT_E
              -5: "KT_ERR_NOT_READY", -6: "KT_ERR_NO_DEVICE", -7: "KT_ERR_UNSUPPORTED"}
 RECONCILE_APPLY = 0x1
 ADMIT_COMMIT = 0x1
+VARIANT_INCREMENTAL = 0x100  # | VARIANT_INDEXED: pod events keep the `used` partials current (N2)
 CHECK_STATUS_MATRIX = 0x1
 KERNEL_CHECK, KERNEL_AGGREGATE, KERNEL_FINALIZE, KERNEL_PREPARE, KERNEL_REDUCE = 0, 1, 2, 3, 4
 VARIANT_INDEXED, VARIANT_DENSE = 0, 1

@@ -202,6 +202,83 @@ def test_incremental_feed_matches_bulk(oracle_mod):
         eng.close()
 
 
+def _with_pods(base, src_rows):
+    """A copy of `base` (same namespaces / throttles) whose pod row r holds base's pod src_rows[r] (-1: row deleted)."""
+    import copy
+    src_rows = np.asarray(src_rows)
+    live = np.where(src_rows >= 0, src_rows, 0)
+    pods = _permute_pods(base, live)
+    out = copy.copy(base)
+    for f in ("n_pods", "pod_ns", "pod_flags", "pod_label_off", "pod_label_key", "pod_label_pair", "pod_ctr_off", "ctr_init",
+              "ctr_present", "ctr_req", "pod_ovh_present", "pod_ovh"):
+        setattr(out, f, getattr(pods, f))
+    out.pod_flags = out.pod_flags.copy()
+    out.pod_flags[:len(src_rows)][src_rows < 0] = 0
+    return out
+
+
+@pytest.mark.parametrize("budget", [None, 6000])
+def test_incremental_event_path(budget, oracle_mod, monkeypatch):
+    """KT_VARIANT_INCREMENTAL: pod adds / updates (labels, requests, phase) / deletes keep the `used`
+    partials current by delta scans; every reconcile equals a full rescan of the current pods (= the oracle)."""
+    if budget:
+        monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
+    base = W.generate(W.small(seed=71, n_pods=2400, n_thr=96, n_cluster=48, n_invalid_pod_sel=1))
+    P = 2000
+    rng = np.random.default_rng(71)
+    state = np.full(P, -1, dtype=np.int64)   # pod row -> which of base's pods it currently holds
+    state[:1200] = np.arange(1200)
+    eng = E.Engine(base.D, max(base.L, 1), P, max(base.n_thr, 1), max(base.n_ns, 1), -1, E.VARIANT_INDEXED | E.VARIANT_INCREMENTAL)
+    try:
+        eng.upsert_namespaces(base)
+        eng.upsert_throttles(base)
+        eng.upsert_pods(_permute_pods(base, np.arange(1200)), rows=np.arange(1200))
+
+        def check_state(expect_scan):
+            snap = _with_pods(base, state)
+            want = oracle_mod.Oracle(snap).reconcile(NOW, rows=responsible_rows(snap))
+            got_all = eng.reconcile(NOW, apply=False)
+            rows = responsible_rows(snap)
+            got = E.ReconcileResult(len(rows), snap.D)
+            for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+                getattr(got, name)[:len(rows)] = getattr(got_all, name)[rows]
+            for tab in ("used", "calc"):
+                for f in ("v", "present", "count", "has_count"):
+                    getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
+            assert_reconcile_equal(got, want, len(rows))
+            assert ("no scan" in eng.kernel_name(E.KERNEL_AGGREGATE)) == (not expect_scan)
+
+        check_state(expect_scan=True)            # first reconcile: full scan, baseline
+        check_state(expect_scan=False)           # nothing changed: a copy
+        # adds
+        add_rows = np.arange(1200, 1700)
+        state[add_rows] = np.arange(1200, 1700)
+        eng.upsert_pods(_permute_pods(base, state[add_rows]), rows=add_rows)
+        check_state(expect_scan=False)
+        # updates: the rows take the labels / requests / phase of other pods
+        upd_rows = rng.choice(1700, 400, replace=False)
+        state[upd_rows] = rng.integers(1700, 2400, 400)
+        eng.upsert_pods(_permute_pods(base, state[upd_rows]), rows=upd_rows)
+        check_state(expect_scan=False)
+        # deletes, then re-adding two of the deleted rows
+        del_rows = rng.choice(1700, 300, replace=False).astype(np.int64)
+        state[del_rows] = -1
+        eng.delete_pods(del_rows)
+        check_state(expect_scan=False)
+        back = del_rows[:2]
+        state[back] = [5, 6]
+        eng.upsert_pods(_permute_pods(base, state[back]), rows=back)
+        check_state(expect_scan=False)
+        # a throttle change voids the partials: one rescan, then incremental again
+        eng.upsert_throttles(base)
+        check_state(expect_scan=True)
+        state[7] = 2399
+        eng.upsert_pods(_permute_pods(base, state[7:8]), rows=np.array([7]))
+        check_state(expect_scan=False)
+    finally:
+        eng.close()
+
+
 def _permute_pods(snap, rows):
     """A pods-only batch holding snap's pods in the order given by rows."""
     rows = np.asarray(rows)
