@@ -161,8 +161,9 @@ int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* 
  *      out_status[i][*] are what PreFilter returned for pod i AT ITS TURN.
  *      flags: KT_ADMIT_COMMIT keeps the resulting reserved amounts in the engine (as if Reserve had been called
  *      for every admitted pod; read them back with kt_fetch_reserved); without it the call is a dry run.
- *      Limits: n x throttle_rows <= 2^31; the reserved amounts of all throttles must fit in LDS
- *      (throttle_rows x (8 x n_dims + 16) <= ~156 KB), else KT_ERR_UNSUPPORTED. ------------------------------------- */
+ *      Limit: n x throttle_rows <= 2^31 (the status matrix).  The reserved amounts of all throttles live in LDS while
+ *      they fit (throttle_rows x (8 x n_dims + 16) <= ~156 KB), beyond that in HBM (same results, L2 latency per
+ *      pod). ---------------------------------------------------------------------------------------------------- */
 #define KT_ADMIT_COMMIT 0x1u
 int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
                         void* stream);

@@ -177,6 +177,7 @@ struct kt_engine {
 
   // ---- reconcile state
   DevBuf<unsigned long long> d_partial;
+  DevBuf<uint8_t> d_admit;  // HBM-resident state of kt_admit_sequential when it does not fit LDS
   DevBuf<uint8_t> d_slab;  // per-workgroup LDS table spill area of kt_aggregate_bitmap
   unsigned long long* ext_partial = nullptr;  // caller-owned partial buffer (kt_use_partial_buffer)
   int64_t ext_partial_words = 0;
@@ -682,7 +683,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
   for (auto* b : u32s) b->release();
   DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
-                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage, &e->d_slab};
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage, &e->d_slab, &e->d_admit};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
@@ -1269,15 +1270,16 @@ int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   hipStream_t s = pick_stream(e, stream);
   if ((double)n * (double)e->thr_rows_hi > 2147483648.0)
     return e->fail(KT_ERR_OUT_OF_RANGE, "admit queue: n x throttle_rows = %lld x %d exceeds 2^31 matrix bytes", (long long)n, e->thr_rows_hi);
-  if (kt::admit_lds_bytes(e->thr_rows_hi, e->D) > (size_t)160 * 1024)
-    return e->fail(KT_ERR_UNSUPPORTED, "admit queue: reserved amounts of %d throttles x %d dimensions do not fit in LDS", e->thr_rows_hi, e->D);
   // (a) who affects whom, for the whole queue in parallel (statuses against the current reserved amounts)
   int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, KT_CHECK_STATUS_MATRIX, s);
   if (rc != KT_OK || n == 0 || e->thr_rows_hi == 0) return rc;
   // (b) the queue in order, one wave, reserved amounts in LDS
   const bool commit = (flags & KT_ADMIT_COMMIT) != 0;
-  kt::launch_admit(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->tt, e->thr_rows_hi, e->D, on_equal != 0, commit,
-                   e->d_status.p, e->d_summary.p, s);
+  KT_HIP(e, e->d_admit.reserve(kt::admit_state_bytes(e->thr_rows_hi, e->D) + 64));
+  static const bool force_global = getenv("KT_ADMIT_FORCE_GLOBAL") != nullptr;  // test hook: HBM-resident state
+  if (!kt::launch_admit(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->tt, e->thr_rows_hi, e->D, on_equal != 0, commit,
+                        e->d_status.p, e->d_summary.p, e->d_admit.p, force_global, s))
+    return e->fail(KT_ERR_UNSUPPORTED, "admit queue: %d throttle rows exceed the kernel's LDS list", e->thr_rows_hi);
   KT_HIP(e, hipGetLastError());
   if (commit) e->reserved_dev_newer = true, e->recs_valid = false;
   return KT_OK;

@@ -17,6 +17,8 @@
 //               statuses the pod actually met
 //           (4) verdict Success => reserved[t] += ResourceAmountOfPod(pod) for every affected throttle (LDS)
 //   output  per-pod summary words, the rewritten matrix, and (commit) the reserved tables in HBM.
+// When the state does not fit in LDS (thousands of throttles) it lives in an HBM scratch buffer instead (same code,
+// L2 latency per step).
 #include "kt_index_device.h"
 
 namespace kt {
@@ -27,6 +29,7 @@ struct AdmitArgs {
   const int64_t* rows;  // nullable: queue position -> pod table row
   int64_t n;
   ThrTables tt;
+  unsigned char* scratch;  // state in HBM when it does not fit LDS (nullable)
   uint8_t* status;    // [n][T] in/out
   uint64_t* summary;  // [n] out
   int32_t T, D, DS, on_equal, commit;
@@ -35,23 +38,60 @@ struct AdmitArgs {
 
 __device__ __forceinline__ bool admit_cmp(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
 
-template <int DT>
+// The mutable state (reserved amounts of all throttles) lives in LDS when it fits; otherwise in a scratch buffer in
+// HBM that only this wave touches, read and written through L2 (agent-scope atomics: never served from a stale L1 line).
+template <bool IN_LDS>
+struct AdmitState;
+template <>
+struct AdmitState<true> {
+  KT_LDS int64_t* rv;
+  KT_LDS int64_t* rc;
+  KT_LDS uint32_t* rp;
+  __device__ __forceinline__ int64_t ld_v(int i) const { return rv[i]; }
+  __device__ __forceinline__ void st_v(int i, int64_t x) const { rv[i] = x; }
+  __device__ __forceinline__ int64_t ld_c(int i) const { return rc[i]; }
+  __device__ __forceinline__ void st_c(int i, int64_t x) const { rc[i] = x; }
+  __device__ __forceinline__ uint32_t ld_p(int i) const { return rp[i]; }
+  __device__ __forceinline__ void st_p(int i, uint32_t x) const { rp[i] = x; }
+};
+template <>
+struct AdmitState<false> {
+  int64_t* rv;
+  int64_t* rc;
+  uint32_t* rp;
+  __device__ __forceinline__ int64_t ld_v(int i) const { return __hip_atomic_load(rv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ void st_v(int i, int64_t x) const { __hip_atomic_store(rv + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ int64_t ld_c(int i) const { return __hip_atomic_load(rc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ void st_c(int i, int64_t x) const { __hip_atomic_store(rc + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ uint32_t ld_p(int i) const { return __hip_atomic_load(rp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ void st_p(int i, uint32_t x) const { __hip_atomic_store(rp + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+
+template <int DT, bool IN_LDS>
 __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) {
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  KT_LDS int64_t* rv = (KT_LDS int64_t*)(lds + a.off_rv);    // [T][D] reserved requests
-  KT_LDS int64_t* rc = (KT_LDS int64_t*)(lds + a.off_rc);    // [T]    reserved pod count
-  lds_u32wp rp = (lds_u32wp)(lds + a.off_rp);                // [T]    presence mask | has_count << 31
+  AdmitState<IN_LDS> st;
+  if constexpr (IN_LDS) {
+    st.rv = (KT_LDS int64_t*)(lds + a.off_rv);    // [T][D] reserved requests
+    st.rc = (KT_LDS int64_t*)(lds + a.off_rc);    // [T]    reserved pod count
+    st.rp = (KT_LDS uint32_t*)(lds + a.off_rp);   // [T]    presence mask | has_count << 31
+  } else {
+    st.rv = (int64_t*)(a.scratch + a.off_rv);
+    st.rc = (int64_t*)(a.scratch + a.off_rc);
+    st.rp = (uint32_t*)(a.scratch + a.off_rp);
+  }
   lds_u32wp list = (lds_u32wp)(lds + a.off_list);            // affected throttles of the current pod
   const int T = a.T, D = a.D;
   const uint32_t lane = threadIdx.x;
   const ThrTables& tt = a.tt;
   for (int t = (int)lane; t < T; t += kWave) {
     const uint32_t p = tt.reserved.present[t];
-    for (int d = 0; d < D; ++d) rv[t * D + d] = ((p >> d) & 1u) ? tt.reserved.v[(size_t)t * D + d] : 0;
+    for (int d = 0; d < D; ++d) st.st_v(t * D + d, ((p >> d) & 1u) ? tt.reserved.v[(size_t)t * D + d] : 0);
     const bool hc = tt.reserved.has_count[t] != 0;
-    rc[t] = hc ? tt.reserved.count[t] : 0;
-    rp[t] = p | (hc ? 0x80000000u : 0u);
+    st.st_c(t, hc ? tt.reserved.count[t] : 0);
+    st.st_p(t, p | (hc ? 0x80000000u : 0u));
   }
+  if (!IN_LDS) __threadfence();
   constexpr int MPW = kWave / DT;
   const uint32_t d = lane % DT, ml = lane / DT;
   const bool d_in = (int)d < D;
@@ -102,13 +142,13 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
       const uint32_t tf = tt.flags[t];
       // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
       const AmountTab& th = (tf & kThrCalcAtNonzero) ? tt.calc : tt.spec;
-      const uint32_t th_p = th.present[t], u_p = tt.used.present[t], r_pw = rp[t];
+      const uint32_t th_p = th.present[t], u_p = tt.used.present[t], r_pw = st.ld_p(t);
       const bool eq3 = (tf & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
       uint32_t bits = 0;
       if (vv && d_in && ((th_p >> d) & 1u)) {
         const int64_t tv = th.v[(size_t)t * D + d];
         const int64_t uv = ((u_p >> d) & 1u) ? tt.used.v[(size_t)t * D + d] : 0;
-        const int64_t rvd = rv[t * D + d];
+        const int64_t rvd = st.ld_v(t * D + d);
         if (nz && v > tv) bits |= 1u;                                                        // step 1
         if (nz && (((u_p | r_pw) >> d) & 1u) && admit_cmp(uv + rvd, tv, eq3)) bits |= 2u;    // step 3
         if (nz && admit_cmp(uv + v + rvd, tv, eq)) bits |= 4u;                               // step 4
@@ -118,7 +158,7 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
         const bool th_hc = th.has_count[t] != 0;
         const int64_t th_c = th.count[t];
         const bool u_hc = tt.used.has_count[t] != 0, r_hc = (r_pw >> 31) != 0;
-        const int64_t u_c = u_hc ? tt.used.count[t] : 0, r_c = rc[t];
+        const int64_t u_c = u_hc ? tt.used.count[t] : 0, r_c = st.ld_c(t);
         if (th_hc && 1 > th_c) bits |= 1u;
         if ((tf & kThrThrottledPod) || (th_hc && (u_hc || r_hc) && admit_cmp(u_c + r_c, th_c, eq3))) bits |= 2u;
         if (th_hc && admit_cmp(u_c + 1 + r_c, th_c, eq)) bits |= 4u;
@@ -139,10 +179,10 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
         const uint32_t j = base + ml;
         if (j < n_aff) {
           const uint32_t t = list[j];
-          if (d_in && ((present >> d) & 1u)) rv[t * D + d] += v;
+          if (d_in && ((present >> d) & 1u)) st.st_v(t * D + d, st.ld_v(t * D + d) + v);
           if (d == 0) {
-            rc[t] += 1;
-            rp[t] |= present | 0x80000000u;
+            st.st_c(t, st.ld_c(t) + 1);
+            st.st_p(t, st.ld_p(t) | present | 0x80000000u);
           }
         }
       }
@@ -150,39 +190,44 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
   }
   if (a.commit) {
     for (int t = (int)lane; t < T; t += kWave) {
-      const uint32_t w = rp[t];
-      for (int dd = 0; dd < D; ++dd) tt.reserved.v[(size_t)t * D + dd] = rv[t * D + dd];
+      const uint32_t w = st.ld_p(t);
+      for (int dd = 0; dd < D; ++dd) tt.reserved.v[(size_t)t * D + dd] = st.ld_v(t * D + dd);
       tt.reserved.present[t] = w & 0x7FFFFFFFu;
       tt.reserved.has_count[t] = (uint8_t)(w >> 31);
-      tt.reserved.count[t] = rc[t];
+      tt.reserved.count[t] = st.ld_c(t);
     }
   }
 }
 
-size_t admit_lds_bytes(int T, int D) {
-  return ((size_t)T * D * 8 + 15) / 16 * 16 + ((size_t)T * 8 + 15) / 16 * 16 + 2 * (((size_t)T * 4 + 15) / 16 * 16);
+// LDS: state + list when the state fits, else the list alone
+size_t admit_state_bytes(int T, int D) {
+  return ((size_t)T * D * 8 + 15) / 16 * 16 + ((size_t)T * 8 + 15) / 16 * 16 + ((size_t)T * 4 + 15) / 16 * 16;
 }
 
-// returns false when the mutable state does not fit in LDS
+// scratch: admit_state_bytes(T, D) bytes of device memory, used when the state does not fit in LDS (or when forced)
 bool launch_admit(const PodTable& pods, int64_t n, const int64_t* rows_dev, const ThrTables& tt, int T, int D,
-                  bool on_equal, bool commit, uint8_t* status, uint64_t* summary, hipStream_t s) {
-  if (admit_lds_bytes(T, D) > (size_t)kMaxLds) return false;
+                  bool on_equal, bool commit, uint8_t* status, uint64_t* summary, void* scratch, bool force_global,
+                  hipStream_t s) {
+  const size_t list_bytes = ((size_t)T * 4 + 15) / 16 * 16;
+  const bool in_lds = !force_global && admit_state_bytes(T, D) + list_bytes <= (size_t)kMaxLds;
+  if (!in_lds && (!scratch || list_bytes > (size_t)kMaxLds)) return false;
   AdmitArgs a{};
   a.pod_flags = pods.flags, a.req = pods.req, a.rows = rows_dev, a.n = n, a.tt = tt;
-  a.status = status, a.summary = summary;
+  a.status = status, a.summary = summary, a.scratch = (unsigned char*)scratch;
   a.T = T, a.D = D, a.DS = pods.DS, a.on_equal = on_equal ? 1 : 0, a.commit = commit ? 1 : 0;
   uint32_t o = 0;
   auto take = [&](size_t bytes) { uint32_t r = o; o += (uint32_t)((bytes + 15) & ~(size_t)15); return r; };
-  a.off_rv = take((size_t)T * D * 8);
+  a.off_rv = take((size_t)T * D * 8);  // offsets inside LDS or inside the scratch buffer
   a.off_rc = take((size_t)T * 8);
   a.off_rp = take((size_t)T * 4);
   a.list_cap = (uint32_t)T;  // a pod can be affected by every throttle
+  if (!in_lds) o = 0;
   a.off_list = take((size_t)a.list_cap * 4);
   const int DT = dt_bucket(D);
   const size_t lds_bytes = o;
 #define KT_ADMIT_CASE(DT_)                                                                                        \
   {                                                                                                              \
-    auto kfn = kt_admit_sequential<DT_>;                                                                         \
+    auto kfn = in_lds ? kt_admit_sequential<DT_, true> : kt_admit_sequential<DT_, false>;                        \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
     hipLaunchKernelGGL(kfn, dim3(1), dim3(kWave), lds_bytes, s, a);                                              \
   }

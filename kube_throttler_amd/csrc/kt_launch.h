@@ -41,11 +41,12 @@ void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equ
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
                         const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s);
 
-// sequential admission of a pod queue with reservation (kt_kernels_admit.hip); false when the mutable state
-// (reserved amounts of all throttles) does not fit in LDS
-size_t admit_lds_bytes(int T, int D);
+// sequential admission of a pod queue with reservation (kt_kernels_admit.hip); the mutable state (reserved amounts of
+// all throttles) lives in LDS when it fits, else in `scratch` (admit_state_bytes)
+size_t admit_state_bytes(int T, int D);
 bool launch_admit(const PodTable& pods, int64_t n, const int64_t* rows_dev, const ThrTables& tt, int T, int D,
-                  bool on_equal, bool commit, uint8_t* status, uint64_t* summary, hipStream_t s);
+                  bool on_equal, bool commit, uint8_t* status, uint64_t* summary, void* scratch, bool force_global,
+                  hipStream_t s);
 
 inline int dt_bucket(int D) { return D <= 4 ? 4 : D <= 8 ? 8 : 16; }
 inline int dt_bucket_ix(int D) { return D <= 8 ? 8 : 16; }  // indexed kernels: two instantiations

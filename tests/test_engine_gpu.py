@@ -360,9 +360,20 @@ def _stored_status(snap, oracle_mod):
                       want.error, rows=rows)
 
 
+@pytest.mark.parametrize("hbm_state", [False, True], ids=["lds", "hbm"])
 @pytest.mark.parametrize("seed,on_equal", [(52, False), (54, True), (53, False)])
-def test_admit_queue_matches_sequential_prefilter_reserve(seed, on_equal, oracle_mod):
-    """kt_admit_launch == for each pod in order: PreFilter, on Success Reserve."""
+def test_admit_queue_matches_sequential_prefilter_reserve(seed, on_equal, hbm_state, oracle_mod):
+    """kt_admit_launch == for each pod in order: PreFilter, on Success Reserve; with the reserved
+    amounts in LDS and (forced, as for thousands of throttles) in HBM."""
+    if hbm_state:
+        import subprocess, sys, os
+        # the hook is read once per process: run this case in a child
+        env = dict(os.environ, KT_ADMIT_FORCE_GLOBAL="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                            f"test_admit_queue_matches_sequential_prefilter_reserve and {seed}-{on_equal}-lds"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     snap = W.generate(W.small(seed=seed, n_pods=4000, n_thr=64, n_cluster=32, n_invalid_pod_sel=1 if seed == 53 else 0,
                               n_missing_ns=1 if seed == 53 else 0))
     # head-room on every throttle (the generator calibrates a third of them as already throttled): the queue then
