@@ -90,7 +90,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     t.fl = a.flags[p];
     t.ns = a.ns[p];
     load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
-    (void)*(const volatile uint32_t*)(a.req + p * DS);
   };
   for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
     const BmChunk ch = a.ix.chunks[ci];

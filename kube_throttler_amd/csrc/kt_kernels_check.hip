@@ -113,7 +113,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
     t.fl = a.flags[p];
     t.ns = a.ns[p];
     load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
-    (void)*(const volatile uint32_t*)(a.req + p * DS);
   };
   const uint32_t n_chunks = ONE ? 1u : a.ix.n_chunks;
   for (uint32_t ci = 0; ci < n_chunks; ++ci) {
