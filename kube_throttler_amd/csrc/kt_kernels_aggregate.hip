@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
   // A tile's selector-side records, always from valid addresses (lanes past the end re-read the last row and are
-  // switched off), loaded ONE ROUND AHEAD; the request row is only touched (L2 prefetch for phase 2).
+  // switched off).  The request rows are gathered by phase 2 for matched pods only.
   struct Tile {
     uint32_t fl, ns, p;
     uint32_t lp[LT], lk[LT];
@@ -104,11 +104,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const BmView bm = open_chunk(lds, a.ix, ch);
     __syncthreads();
     int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-    Tile cur;
-    if (wt < n_wtiles) load_tile(wt, cur);
     for (; wt < n_wtiles; wt += wstep) {
-      Tile nxt;
-      load_tile(min(wt + wstep, n_wtiles - 1), nxt);
+      Tile cur;
+      load_tile(wt, cur);
       // ---- phase 1: lane = pod
       const bool in = wt * kWave + lane < n_rows;
       const uint32_t fl = cur.fl;
@@ -174,7 +172,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
               }
             atomicAdd(pr + 2 * D, (unsigned long long)(long long)a.sign);
           });
-      cur = nxt;
     }
     __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);

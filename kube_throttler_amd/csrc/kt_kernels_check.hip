@@ -98,10 +98,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
   const int64_t n_wtiles = (n + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
 
-  // A tile's selector-side records: 2 + LT/4 (+ LT/4) loads per lane, always from valid addresses (lanes past
-  // the end re-read the last pod and are switched off by `on`), loaded ONE ROUND AHEAD so that a round never
-  // starts by waiting for HBM.  The request row of the next round is only touched (L2 prefetch): it is loaded
-  // at the start of its own round and parked in the wave's LDS tile for phase 2.
+  // A tile's selector-side records: 2 + LT/4 (+ LT/4) 128-bit loads per lane, issued back to back and always from
+  // valid addresses (lanes past the end re-read the last pod and are switched off by `on`).  The request rows are
+  // gathered by phase 2, for matched pods only.  (Loading tiles a round ahead, or touching the request rows early,
+  // measurably does not help: the 16 waves of a CU already overlap each other's memory phases, and early touches
+  // are evicted from L2 before they are used.)
   struct Tile {
     uint32_t fl, ns, p;
     uint32_t lp[LT], lk[LT];
@@ -121,11 +122,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
   const BmView bm = open_chunk(lds, a.ix, a.ix.chunks[ci]);
   __syncthreads();
   int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-  Tile cur;
-  if (wt < n_wtiles) load_tile(wt, cur);
   for (; wt < n_wtiles; wt += wstep) {
-    Tile nxt;
-    load_tile(min(wt + wstep, n_wtiles - 1), nxt);
+    Tile cur;
+    load_tile(wt, cur);
     // ---- phase 1: lane = pod
     const int64_t i = wt * kWave + lane;
     const bool in = i < n;
@@ -196,7 +195,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a)
         a.summary[i] = c | (pod_err ? 2ull : 0ull);
       }
     }
-    cur = nxt;
   }
   }
 }
