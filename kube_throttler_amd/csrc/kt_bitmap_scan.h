@@ -1,12 +1,12 @@
 // kt_bitmap_scan.h — the wave-autonomous selector scan shared by kt_check_bitmap and kt_aggregate_bitmap.
 //
-// The bitmap form of the selector program (kt_index.h) lives in LDS when it fits (small-T regime), else it is
-// read through L2 from the index blob.  One wave owns a tile of 64 pods (lane = pod) and produces the tile's
-// (pod, throttle) matches as a dense list in its private LDS area:
+// The bitmap form of the selector program (kt_index.h) is cut into chunks that fit LDS; the kernels make one chunk
+// resident at a time (open_chunk) and scan every tile of the workgroup against it.  One wave owns a tile of 64 pods
+// (lane = pod) and produces the tile's (pod, throttle) matches as a dense list in its private LDS area:
 //
-//   advance : every lane that still has steps takes the next 64-bit word (LDS form) / 128-bit block (L2 form) b its
-//             namespace can touch and forms
-//                 x = (rows[0] | OR_l rows[row(label_l)])[b] & nsrows[ns][b]          (candidate terms)
+//   advance : every lane that still has words takes the next 64-bit word w its namespace can touch in this chunk
+//             and forms
+//                 x = (rows[0] | OR_l rows[row(label_l)])[w] & nsrows[ns][w]          (candidate terms)
 //   peel    : while any lane holds candidate bits, each such lane takes its lowest bit, reads the
 //             16-byte TermRec and decides the term (second matchLabels pair: 8 compares; up to two more small
 //             requirements from the 32-byte TermX; anything else: the generic requirement walk); the matches

@@ -1,6 +1,6 @@
 // kt_engine.cpp — host side of libkt_engine.so: the C-ABI of include/kt_engine.h over the HIP kernels.
 //
-// Responsibilities: own every device allocation (SoA pod planes, throttle tables, selector program,
+// Responsibilities: own every device allocation (pod row tables, throttle tables, selector program,
 // index, result buffers), validate and stage caller batches (the caller's memory is never retained),
 // compile throttles + namespaces into the device selector program, launch kernels on the caller's
 // stream, time them with HIP events.  No compute happens here: without a gfx950 device

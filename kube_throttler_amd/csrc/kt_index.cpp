@@ -118,9 +118,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t b) { return bts[first_of[a]].adm < bts[first_of[b]].adm; });
-    // term numbers: a class (run of throttles with the same first admission set) never straddles a step of the
-    // scan unless it is larger than one — 64-bit words for programs small enough for the LDS form, 128-bit blocks
-    // beyond (the L2 form reads 16 bytes per request)
+    // term numbers: a class (run of throttles with the same first admission set) never straddles a 64-bit word of
+    // the bitmaps unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
     const uint32_t gran = bts.size() <= 4096 ? 64u : 128u;
     std::vector<uint32_t> num(bts.size());
     uint32_t pos = 0;

@@ -32,13 +32,13 @@ constexpr uint32_t kPostPair2 = 0x10u;   // pod must also carry `pair2`
 // ---- bitmap form of the whole selector side ----------------------------------------------------------
 // Every indexed term gets a number c; terms with the same namespace-admission set (a "class") are numbered
 // contiguously — throttles ordered by the admission set of their first term, the terms of a throttle kept
-// together — and a class of <= 128 terms never straddles a 128-bit block (larger classes start on a block
-// boundary; unused numbers are padding), so a namespace only ever touches a few blocks of any bitmap:
-//     candidates(pod)[b] = (rows[0][b] | OR_l rows[row_of(label_l)][b]) & nsrows[ns][b]   for b in nsblocks[ns]
+// together — and a class of <= 64 terms never straddles a 64-bit word (larger classes start on a word boundary;
+// unused numbers are padding), so a namespace only ever touches a few words of any bitmap:
+//     candidates(pod)[w] = (rows[0][w] | OR_l rows[row_of(label_l)][w]) & nsrows[ns][w]   for w in nswords[ns]
 // rows[0] = terms without a positive requirement, rows[1] = all zero (unknown atoms).  Atoms are found in
-// 4-entry buckets (branch-free probe).  TermRec carries what a visit needs (same flags as Posting).
+// 4-entry buckets (branch-free probe).  TermRec carries what a visit needs.
 struct alignas(16) TermRec {
-  uint32_t g, t, pair2, flags;
+  uint32_t g, t, pair2, flags;  // flags: kPost* in the low byte, the chunk-local throttle rank above
 };
 // Bitmap-form extras of a term (flag kPostInline): up to two requirements besides the anchor, small enough to be
 // decided from registers.  e[k] = {op (KT_OP_*; 0xFF = none), up to three atoms (pair ids for In / NotIn, the key id

@@ -2,7 +2,7 @@
 // finalize / check-record preparation, and the DENSE pod x throttle scans (reference loop shape).
 // The indexed (work ~ pods + matches) scans live in kt_kernels_index.hip.
 //
-// Everything here is integer / compare work on SoA planes in HBM: no MFMA, no floating point.
+// Everything here is integer / compare work on row tables in HBM: no MFMA, no floating point.
 #include "kt_kernels_common.h"
 #include "kt_launch.h"
 
@@ -18,7 +18,7 @@ static inline int grid_for(int64_t n, int per_block = kBlock, int max_blocks = 2
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Pod ingest: staged row-major batch -> planes, computing the pod's effective request on the way.
+// Pod ingest: staged batch -> the pod tables (one row per pod), computing the pod's effective request on the way.
 // Restates resourcelist.PodRequestResourceList (pkg/resourcelist/resourcelist.go:27-46):
 //   ic = SetMax over initContainers (missing key => copy, :76-84); c = Add over containers (key created
 //   even for +0, :48-54); c.SetMax(ic); c.Add(overhead) when overhead != nil.
