@@ -86,6 +86,9 @@ bool ParseQuantity(const std::string& text, Quantity* out, std::string* err) {
     }
   }
   out->nano = neg ? -nano : nano;
+  out->format = bin >= 0 ? Format::BinarySI
+                         : (!suf.empty() && (suf[0] == 'e' || (suf[0] == 'E' && suf.size() > 1))) ? Format::DecimalExponent
+                                                                                                   : Format::DecimalSI;
   return true;
 }
 
@@ -122,6 +125,58 @@ std::string FormatDecimalSI(const Quantity& q) {
     }
   }
   return "?";
+}
+
+namespace {
+std::string digits_of(__int128 v) {
+  const bool neg = v < 0;
+  if (neg) v = -v;
+  std::string digits;
+  do { digits.insert(digits.begin(), (char)('0' + (int)(v % 10))); v /= 10; } while (v > 0);
+  return (neg ? "-" : "") + digits;
+}
+}  // namespace
+
+std::string FormatQuantity(const Quantity& q) {
+  if (q.nano == 0) return "0";
+  Format f = q.format;
+  const __int128 one = pow10_128(9);
+  if (f == Format::BinarySI) {
+    const __int128 mag = q.nano < 0 ? -q.nano : q.nano;
+    if (mag < 1024 * one || q.nano % one != 0) f = Format::DecimalSI;  // small or fractional: shown as DecimalSI
+  }
+  if (f == Format::BinarySI) {
+    static const char* kBin[] = {"", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"};
+    __int128 v = q.nano / one;
+    int e = 0;
+    while (e < 6 && v % 1024 == 0) v /= 1024, ++e;
+    return digits_of(v) + kBin[e];
+  }
+  if (f == Format::DecimalSI) return FormatDecimalSI(q);
+  // DecimalExponent: mantissa without factors of 10, then the exponent lowered to a multiple of 3
+  __int128 v = q.nano;
+  int e = -9;
+  while (v % 10 == 0) v /= 10, ++e;
+  int r = ((e % 3) + 3) % 3;
+  for (; r > 0; --r) v *= 10, --e;
+  return e == 0 ? digits_of(v) : digits_of(v) + "e" + std::to_string(e);
+}
+
+std::map<std::string, std::string> ThrottleStatus::UsedStrings() const {
+  std::map<std::string, std::string> out;
+  for (auto& kv : used) out[kv.first] = FormatQuantity(kv.second);
+  return out;
+}
+
+bool StatusSemanticEqual(const ThrottleStatus& a, const ThrottleStatus& b) {
+  if (a.usedHasCounts != b.usedHasCounts || (a.usedHasCounts && a.usedPod != b.usedPod)) return false;
+  if (a.throttledPod != b.throttledPod || a.throttledRequests != b.throttledRequests) return false;
+  if (a.used.size() != b.used.size()) return false;
+  for (auto& kv : a.used) {
+    auto it = b.used.find(kv.first);
+    if (it == b.used.end() || it->second.nano != kv.second.nano) return false;  // Format is not part of Cmp
+  }
+  return true;
 }
 
 // =====================================================================================================
@@ -268,6 +323,11 @@ struct KubeThrottler::Impl {
   kt_engine* e = nullptr;
   int D = KT_MAX_DIMS;
   std::map<std::string, std::pair<int, int>> dims;  // resource name -> (dimension, scale)
+  // resource name -> Format of the first non-zero quantity seen under that name: what a `used` sum inherits through
+  // Quantity.Add when every pod writes the resource in one suffix family (the reference's result otherwise depends on
+  // the lister's pod order)
+  std::map<std::string, Format> dim_format;
+  std::map<std::string, ThrottleStatus> written;  // thr_key -> status last handed to UpdateStatus
   std::unordered_map<std::string, uint32_t> key_ids;
   std::unordered_map<std::string, uint32_t> pair_ids;
   RowTable<std::string> ns_rows, pod_rows, thr_rows;
@@ -316,6 +376,7 @@ struct KubeThrottler::Impl {
       }
       v[dim] = x;
       *present |= 1u << dim;
+      if (q.nano != 0) dim_format.emplace(kv.first, q.format);
     }
     return true;
   }
@@ -662,6 +723,7 @@ bool KubeThrottler::OnThrottleAdd(const Throttle& thr, std::string* err) {
   p.thr_by_row[(size_t)row] = thr;
   p.thr_live[(size_t)row] = 1;
   p.thr_msgs[(size_t)row] = msgs;
+  p.written.erase(tk);
   if (!p.push_reserved(r32, err)) return false;
   return true;
 }
@@ -677,6 +739,7 @@ bool KubeThrottler::OnThrottleDelete(const std::string& key, bool cluster, std::
   p.thr_rows.release(tk);
   p.thr_live[(size_t)row] = 0;
   p.reserved.erase(r32);
+  p.written.erase(tk);
   return true;
 }
 
@@ -891,7 +954,6 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
     }
     if (changed) p.push_reserved(kv.first, nullptr);
   }
-  if (!out) return true;
   std::vector<std::string> dim_name((size_t)D);
   std::vector<int> dim_scale((size_t)D, 0);
   for (auto& kv : p.dims) dim_name[(size_t)kv.second.first] = kv.first, dim_scale[(size_t)kv.second.first] = kv.second.second;
@@ -912,11 +974,18 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
         Quantity q;
         q.nano = (__int128)uv[(size_t)t * D + d];
         for (int k = 0; k < 9 + dim_scale[d]; ++k) q.nano *= 10;
+        auto f = p.dim_format.find(dim_name[d]);
+        if (f != p.dim_format.end()) q.format = f->second;
         s.used[dim_name[d]] = q;
       }
       if ((thas[t] >> d) & 1u) s.throttledRequests[dim_name[d]] = (tflag[t] >> d) & 1u;
     }
-    (*out)[p.thr_by_row[(size_t)t].Key()] = s;
+    if (!s.error) {  // a reconcile error returns before any status is built (throttle_controller.go:103-106)
+      ThrottleStatus& prev = p.written[Impl::thr_key(p.thr_by_row[(size_t)t])];
+      s.needsUpdate = s.calculatedThresholdUpdated || !StatusSemanticEqual(prev, s);
+      prev = s;
+    }
+    if (out) (*out)[p.thr_by_row[(size_t)t].Key()] = s;
   }
   return true;
 }

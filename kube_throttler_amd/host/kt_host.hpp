@@ -26,10 +26,23 @@ namespace kth {
 
 // ---- k8s.io/apimachinery pkg/api/resource.Quantity, exact (restated) ---------------
 // value = nano * 1e-9 ; finer input is rounded away from zero at parse time.
+// Format is the suffix family the text was written in; it only steers String() (quantity.go CanonicalizeBytes) and
+// is inherited by a sum from the addend that first made it non-zero (Quantity.Add).
+enum class Format : uint8_t { DecimalSI = 0, BinarySI = 1, DecimalExponent = 2 };
 struct Quantity {
   __int128 nano = 0;
+  Format format = Format::DecimalSI;
 };
 bool ParseQuantity(const std::string& text, Quantity* out, std::string* err);
+// Quantity.String(): the canonical text the API server persists (status write-back).  BinarySI
+// falls back to DecimalSI for |value| < 1024 and for non-integers; mantissa without trailing zeros, exponent a
+// multiple of 3 (DecimalSI / DecimalExponent) or a power of 1024 (BinarySI).
+std::string FormatQuantity(const Quantity& q);
+// Quantity.Add's format rule: a zero receiver takes the addend's format.
+inline void AddQuantity(Quantity* q, const Quantity& y) {
+  if (q->nano == 0) q->format = y.format;
+  q->nano += y.nano;
+}
 // value / 10^scale as an exact integer; false when not representable (or beyond int64).
 bool ScaledValue(const Quantity& q, int scale, int64_t* out);
 std::string FormatDecimalSI(const Quantity& q);
@@ -102,7 +115,15 @@ struct ThrottleStatus {
   bool hasNextOverride = false;
   int64_t nextOverrideSec = 0;
   int32_t nextOverrideNsec = 0;
+  // !apiequality.Semantic.DeepEqual(thr.Status, *newStatus) (throttle_controller.go:157): UpdateStatus is only called
+  // when this is set; otherwise the reference logs "No need to update status"
+  bool needsUpdate = false;
+  // status.used.resourceRequests as the API server would persist it (Quantity.String())
+  std::map<std::string, std::string> UsedStrings() const;
 };
+// apiequality.Semantic.DeepEqual on the parts of ThrottleStatus a reconcile can change besides calculatedThreshold
+// (used, throttled): quantities compare by value (Cmp == 0), nil and empty maps are equal, resourceCounts nil != &{0}.
+bool StatusSemanticEqual(const ThrottleStatus& a, const ThrottleStatus& b);
 
 // framework.Code values used by the plugin
 enum Code { Success = 0, Error = 1, UnschedulableAndUnresolvable = 3 };

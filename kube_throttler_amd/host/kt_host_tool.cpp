@@ -1,6 +1,6 @@
 // kt_host_tool — tiny CLI over the host-side parsers, used by the CPU tests to cross-check them against
 // the independent Python implementations (kube_throttler_amd/quantity.py).
-//   kt_host_tool quantity <text>...   -> "<nano value>" or "error: ..."
+//   kt_host_tool quantity <text>...   -> "<nano value> <DecimalSI text> <canonical text in its own format>" or "error: ..."
 //   kt_host_tool time <rfc3339>...    -> "<sec> <nsec>" or "error: ..."
 #include <cstdio>
 #include <cstring>
@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     std::string err;
     if (!strcmp(argv[1], "quantity")) {
       kth::Quantity q;
-      if (kth::ParseQuantity(argv[i], &q, &err)) printf("%s %s\n", i128(q.nano).c_str(), kth::FormatDecimalSI(q).c_str());
+      if (kth::ParseQuantity(argv[i], &q, &err)) printf("%s %s %s\n", i128(q.nano).c_str(), kth::FormatDecimalSI(q).c_str(), kth::FormatQuantity(q).c_str());
       else printf("error: %s\n", err.c_str());
     } else {
       int64_t s;

@@ -26,6 +26,20 @@ class QuantityError(ValueError):
     pass
 
 
+DECIMAL_SI, BINARY_SI, DECIMAL_EXPONENT = "DecimalSI", "BinarySI", "DecimalExponent"
+
+
+def quantity_format(text) -> str:
+    """The Format a Quantity text parses to (its suffix family); steers only the canonical string."""
+    if isinstance(text, int):
+        return DECIMAL_SI
+    m = _RE.match(str(text).strip())
+    suf = (m.group(4) or "") if m else ""
+    if suf in _BIN:
+        return BINARY_SI
+    return DECIMAL_SI if suf in _DEC else DECIMAL_EXPONENT
+
+
 def parse_quantity(text) -> Fraction:
     """Exact value of a Quantity string (int/float-free)."""
     if isinstance(text, int):
@@ -78,6 +92,46 @@ def format_decimal_si(value: Fraction) -> str:
         if q.denominator == 1:
             return f"{int(q)}{suf}"
     raise QuantityError("finer than nano")
+
+
+def format_quantity(value: Fraction, fmt: str = DECIMAL_SI) -> str:
+    """``Quantity.String()`` for a value carrying Format ``fmt`` (apimachinery quantity.go CanonicalizeBytes, restated):
+    BinarySI is shown as DecimalSI when |value| < 1024 or the value is not an integer, else as mantissa x 1024^k with
+    every factor of 1024 moved into the suffix; DecimalSI / DecimalExponent strip the mantissa's factors of ten and then
+    lower the exponent to a multiple of three (``1500`` stays "1500", ``1100m`` stays "1100m", 20 x 50m is "1")."""
+    if value == 0:
+        return "0"
+    if fmt == BINARY_SI and (abs(value) < 1024 or value.denominator != 1):
+        fmt = DECIMAL_SI
+    if fmt == BINARY_SI:
+        v, e = int(value), 0
+        while e < 6 and v % 1024 == 0:
+            v //= 1024
+            e += 1
+        return f"{v}{['', 'Ki', 'Mi', 'Gi', 'Ti', 'Pi', 'Ei'][e]}"
+    if fmt == DECIMAL_SI:
+        return format_decimal_si(value)
+    q = value / NANO
+    if q.denominator != 1:
+        raise QuantityError("finer than nano")
+    v, e = int(q), -9
+    while v % 10 == 0:
+        v //= 10
+        e += 1
+    while e % 3:
+        v *= 10
+        e -= 1
+    return str(v) if e == 0 else f"{v}e{e}"
+
+
+def add_quantities(items):
+    """Fold ``Quantity.Add`` over (value, format) pairs: a zero receiver takes the addend's format."""
+    total, fmt = Fraction(0), DECIMAL_SI
+    for v, f in items:
+        if total == 0:
+            fmt = f
+        total += v
+    return total, fmt
 
 
 _RFC3339 = re.compile(

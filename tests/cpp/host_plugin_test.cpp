@@ -235,12 +235,38 @@ static void TestNextOverride() {
   EXPECT(st["default/t"].calculatedThresholdUpdated);
 }
 
+// status write-back: UpdateStatus only when the status changed (throttle_controller.go:157), quantities rendered as
+// the API server persists them
+static void TestStatusWriteBack() {
+  auto k = Fresh();
+  std::string err;
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "t", "app", "x", 5, "2"), &err));
+  Pod a = MakePod("default", "a", "500m", {{"app", "x"}}, "512Mi");
+  Schedule(*k, a);
+  std::map<std::string, ThrottleStatus> st;
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(st["default/t"].needsUpdate);
+  auto used = st["default/t"].UsedStrings();
+  EXPECT(used["cpu"] == "500m" && used["memory"] == "512Mi");
+  EXPECT(k->ReconcileAll(NOW, &st, &err));               // nothing happened in between: "No need to update status"
+  EXPECT(!st["default/t"].needsUpdate);
+  Pod b = MakePod("default", "b", "500m", {{"app", "x"}}, "512Mi");
+  Schedule(*k, b);
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(st["default/t"].needsUpdate);
+  used = st["default/t"].UsedStrings();
+  EXPECT(used["cpu"] == "1" && used["memory"] == "1Gi" && st["default/t"].usedPod == 2);
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(!st["default/t"].needsUpdate);
+}
+
 int main() {
   TestExampleWalkthrough();
   TestThrottleScenarios();
   TestClusterThrottleAndReserve();
   TestAdmitQueue();
   TestNextOverride();
+  TestStatusWriteBack();
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;

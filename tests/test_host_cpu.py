@@ -6,7 +6,9 @@ from fractions import Fraction
 
 import pytest
 
-from kube_throttler_amd.quantity import NANO, QuantityError, format_decimal_si, parse_quantity, parse_rfc3339
+from kube_throttler_amd.quantity import (BINARY_SI, DECIMAL_EXPONENT, DECIMAL_SI, NANO, QuantityError, add_quantities,
+                                         format_decimal_si, format_quantity, parse_quantity, parse_rfc3339,
+                                         quantity_format)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "kube_throttler_amd", "host")
@@ -23,7 +25,9 @@ def tool():
 QUANTITIES = ["0", "1", "500m", "100m", "1.1", "900m", "50m", "1m", "1Gi", "512Mi", "64Mi", "16Gi", "1Ki", "0.5Ki",
               "1.5Gi", "2Ti", "3Pi", "1Ei", "1k", "5M", "2G", "1T", "1P", "1E", "100n", "1u", "1e3", "1E3", "2e-3", "1.5e2",
               "-1", "-2", "-500m", "+3", ".5", "5.", "0.000000001", "0.0000000001", "0.0000000015", "123456789.123456789",
-              "9223372036854775807", "200m", "300m", "4000m", "1e-9", "1e-10"]
+              "9223372036854775807", "200m", "300m", "4000m", "1e-9", "1e-10", "1024Mi", "1023Ki", "2048Ki", "0.0001Ki",
+              "1500e0", "5e-1", "12e4", "1e0", "0Gi", "0e5", "-1Gi", "-1500m", "1000E", "1100m", "1000", "1500", "1000000",
+              "-1.5Gi", "-0.5Ki", "3e-9", "25e-4"]
 BAD = ["", "abc", "1Xi", "1.2.3", "1e", "--1", "1 Gi", "Ki", "1ki", "1KI"]
 
 
@@ -43,16 +47,46 @@ def test_known_values():
             parse_quantity(b)
 
 
+def test_canonical_strings():
+    """Quantity.String() per Format — the text UpdateStatus persists (throttle_controller.go:157-175).  Answers follow
+    apimachinery v0.26.4's documented canonical form (source not on disk: parity unpinned beyond the two reference
+    expectations marked below)."""
+    def canon(text):
+        return format_quantity(parse_quantity(text), quantity_format(text))
+    table = {
+        "1000m": "1",            # throttle_test.go:189: 20 x 50m is reported as "1"
+        "100m": "100m",          # clusterthrottle_stress_test.go:36,81
+        "1100m": "1100m", "1.1": "1100m", "1500": "1500", "1000": "1k", "1000000": "1M", "0.5": "500m",
+        "1Gi": "1Gi", "1024Mi": "1Gi", "1.5Gi": "1536Mi", "0.5Ki": "512", "1023Ki": "1023Ki", "1025Ki": "1025Ki",
+        "2048Ki": "2Mi", "1048576Ki": "1Gi", "0.0001Ki": "102400u",
+        "1e3": "1e3", "1E3": "1e3", "1500e0": "1500", "5e-1": "500e-3", "12e4": "120e3", "1e0": "1",
+        "0": "0", "0Gi": "0", "0e5": "0", "-1Gi": "-1Gi", "-1500m": "-1500m", "1E": "1E",
+    }
+    for text, want in table.items():
+        assert canon(text) == want, text
+    assert quantity_format("1Gi") == BINARY_SI and quantity_format("1E") == DECIMAL_SI
+    assert quantity_format("1E3") == DECIMAL_EXPONENT and quantity_format("7") == DECIMAL_SI
+    # Quantity.Add: the sum keeps the format of the addend that first made it non-zero
+    mem = [(parse_quantity(t), quantity_format(t)) for t in ("0", "512Mi", "1G", "512Mi")]
+    total, fmt = add_quantities(mem)
+    assert fmt == BINARY_SI and format_quantity(total, fmt) == str(2 ** 30 + 10 ** 9)   # no factor of 1024 left
+    total, fmt = add_quantities([(parse_quantity("512Mi"), BINARY_SI)] * 2)
+    assert format_quantity(total, fmt) == "1Gi"
+    total, fmt = add_quantities([(parse_quantity("50m"), DECIMAL_SI)] * 20)
+    assert format_quantity(total, fmt) == "1"
+
+
 def test_cpp_quantity_matches_python(tool):
     out = subprocess.check_output([tool, "quantity"] + QUANTITIES + BAD).decode().splitlines()
     assert len(out) == len(QUANTITIES) + len(BAD)
     for text, line in zip(QUANTITIES, out):
         want = parse_quantity(text) / NANO
         assert want.denominator == 1
-        nano, canon = line.split()
+        nano, canon, own = line.split()
         assert int(nano) == int(want), text
         if abs(want) < 10 ** 27:
             assert canon == format_decimal_si(parse_quantity(text)), text
+            assert own == format_quantity(parse_quantity(text), quantity_format(text)), text
     for text, line in zip(BAD, out[len(QUANTITIES):]):
         assert line.startswith("error:"), (text, line)
 
@@ -74,3 +108,11 @@ def test_cpp_rfc3339_matches_python(tool):
         assert line.startswith("error:"), text
         with pytest.raises(ValueError):
             parse_rfc3339(text)
+
+
+def test_cpp_host_unit(tool):
+    """Pure host helpers in C++ (no engine call): Quantity.Add format rule, Quantity.String(), and the
+    Semantic.DeepEqual stand-in behind ThrottleStatus.needsUpdate (tests/cpp/host_unit_test.cpp)."""
+    subprocess.check_call(["make", "-C", HOST, "host_unit_test"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "host_unit_test")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
