@@ -15,7 +15,8 @@ from fractions import Fraction
 import numpy as np
 
 from . import snapshot as S
-from .quantity import min_scale, parse_quantity, parse_rfc3339, to_scaled
+from .quantity import (DECIMAL_SI, format_quantity, min_scale, parse_quantity, parse_rfc3339, quantity_format,
+                       to_scaled)
 
 _QNAME = re.compile(r"^([A-Za-z0-9]([-A-Za-z0-9_.]*[A-Za-z0-9])?)$")
 _DNS1123_SUB = re.compile(r"^[a-z0-9]([-a-z0-9]*[a-z0-9])?(\.[a-z0-9]([-a-z0-9]*[a-z0-9])?)*$")
@@ -146,9 +147,16 @@ class BuiltState:
         # ---- resource dimensions and scales
         quantities: dict[str, list[Fraction]] = {}
 
+        # Format (suffix family) of the first non-zero quantity seen per resource name: what a `used` sum inherits
+        # through Quantity.Add when a resource is always written in one family (status write-back only)
+        self.formats: dict[str, str] = {}
+
         def see(rl):
             for name, q in (rl or {}).items():
-                quantities.setdefault(name, []).append(parse_quantity(q))
+                v = parse_quantity(q)
+                quantities.setdefault(name, []).append(v)
+                if v != 0:
+                    self.formats.setdefault(name, quantity_format(q))
 
         for p in cs.pods:
             spec = p.get("spec", {})
@@ -337,6 +345,34 @@ class BuiltState:
         if rr:
             out["resourceRequests"] = rr
         return out
+
+    def amount_to_manifest(self, amounts: S.Amounts, i) -> dict:
+        """Dense row -> the ResourceAmount as the API server persists it: ``Quantity.String()`` per resource."""
+        out = self.amount_to_dict(amounts, i)
+        if "resourceRequests" in out:
+            out["resourceRequests"] = {k: format_quantity(v, self.formats.get(k, DECIMAL_SI))
+                                       for k, v in out["resourceRequests"].items()}
+        return out
+
+    def status_manifest(self, res, i, now_text: str, previous: dict | None = None) -> dict:
+        """``status`` of throttle row ``i`` after a reconcile, as UpdateStatus would write it
+        (throttle_controller.go:116-133,157-175): ``used`` always replaced, ``calculatedThreshold`` only when the
+        engine reports it replaced (threshold or messages changed by value: ``calculatedAt`` := now), ``throttled``
+        with one key per calculated-threshold resource.  ``res`` carries used, calc, calc_updated, thrl_flag, thrl_has,
+        thrl_pod (rows = all throttles)."""
+        st = dict(previous or {})
+        st["used"] = self.amount_to_manifest(res.used, i)
+        if res.calc_updated[i]:
+            st["calculatedThreshold"] = {"threshold": self.amount_to_manifest(res.calc, i), "calculatedAt": now_text,
+                                         "messages": list(self.thr_messages[i])}
+        else:
+            st.setdefault("calculatedThreshold", {})
+        thr = {"resourceCounts": {"pod": bool(res.thrl_pod[i])}, "resourceRequests": {}}
+        for name, d in self.dims.items():
+            if int(res.thrl_has[i]) >> d & 1:
+                thr["resourceRequests"][name] = bool(int(res.thrl_flag[i]) >> d & 1)
+        st["throttled"] = thr
+        return st
 
     def reasons(self, status_row) -> list[str]:
         """PreFilter reason strings in the reference's fixed order (plugin.go:182-214)."""

@@ -17,7 +17,7 @@ import yaml
 
 from kube_throttler_amd import snapshot as S
 from kube_throttler_amd.objects import ClusterState
-from kube_throttler_amd.quantity import NANO, parse_quantity, parse_rfc3339
+from kube_throttler_amd.quantity import format_quantity, parse_quantity, parse_rfc3339, quantity_format
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _STATUS_BY_NAME = {v: k for k, v in S.STATUS_NAMES.items()}
@@ -108,36 +108,13 @@ def _expected_amount(exp: dict):
     return count, {k: parse_quantity(v) for k, v in exp.items()}
 
 
-def _quantity_text(q: Fraction) -> str:
-    n = q / NANO
-    assert n.denominator == 1
-    return f"{int(n)}n"
-
-
 def write_back_status(cs: ClusterState, built, res, now_text):
-    """UpdateStatus: persist the reconcile result into the manifests (throttle_controller.go:157-173)."""
+    """UpdateStatus: persist the reconcile result into the manifests (throttle_controller.go:157-173), in the
+    canonical text the API server would hold; the next step re-parses it like an informer update would."""
     for i, t in enumerate(cs.throttles):
         if res.error[i]:
             continue
-        st = t.setdefault("status", {})
-
-        def amt(a):
-            d = built.amount_to_dict(a, i)
-            if "resourceRequests" in d:
-                d["resourceRequests"] = {k: _quantity_text(v) for k, v in d["resourceRequests"].items()}
-            return d
-
-        st["used"] = amt(res.used)
-        ct = st.setdefault("calculatedThreshold", {})
-        if res.calc_updated[i]:
-            ct["threshold"] = amt(res.calc)
-            ct["calculatedAt"] = now_text
-            ct["messages"] = list(built.thr_messages[i])
-        thr = {"resourceCounts": {"pod": bool(res.thrl_pod[i])}, "resourceRequests": {}}
-        for name, d in built.dims.items():
-            if int(res.thrl_has[i]) >> d & 1:
-                thr["resourceRequests"][name] = bool(int(res.thrl_flag[i]) >> d & 1)
-        st["throttled"] = thr
+        t["status"] = built.status_manifest(res, i, now_text, previous=t.get("status"))
 
 
 def check_reconcile_expectation(built, res, i, exp, label):
@@ -145,6 +122,12 @@ def check_reconcile_expectation(built, res, i, exp, label):
     got = built.amount_to_dict(res.used, i)
     assert got.get("resourceCounts", {}).get("pod") == count, f"{label}: used.pod {got} != {count}"
     assert got.get("resourceRequests", {}) == reqs, f"{label}: used.requests {got} != {reqs}"
+    # the expectation is spelled the way the reference's specs spell it (e.g. "1" for 20 x 50m, "200m"): when that
+    # spelling is canonical, the written-back text has to be exactly it
+    text = built.amount_to_manifest(res.used, i).get("resourceRequests", {})
+    for name, want in (exp.get("used") or {}).items():
+        if name != "pod" and format_quantity(parse_quantity(want), quantity_format(want)) == want:
+            assert text[name] == want, f"{label}: used.{name} written as {text[name]!r}, want {want!r}"
     thr = dict(exp.get("throttled") or {})
     if "pod" in thr:
         assert bool(res.thrl_pod[i]) == thr.pop("pod"), f"{label}: throttled.pod"
