@@ -152,6 +152,12 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
 /* out_summary [n] ; out_status [n][n_throttle_rows] (nullable; needs KT_CHECK_STATUS_MATRIX), where
  * n_throttle_rows = 1 + highest throttle row ever upserted (kt_throttle_rows). Synchronises. */
 int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status);
+/* kt_check_launch + kt_check_fetch as ONE critical section on the engine's own stream (out_status nullable: no
+ * matrix is produced then).  This is the form a PreFilter shim calls when other threads use the engine concurrently
+ * (Unreserve from binding goroutines plugin.go:240-257, reconcile workers controller.go:52-122): results of a
+ * separate launch / fetch pair may be replaced by another thread's launch in between. */
+int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary,
+                 uint8_t* out_status);
 /* ---- sequential admission with reservation: for i = 0..n-1 IN ORDER,
  *      PreFilter(pod_rows[i]) (plugin.go:148-215) and, on Success, Reserve(pod_rows[i]) (plugin.go:217-239 ->
  *      [Cluster]ThrottleController.Reserve, throttle_controller.go:271-300 -> reservedResourceAmounts.addPod,

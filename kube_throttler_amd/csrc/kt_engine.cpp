@@ -1297,10 +1297,27 @@ int32_t kt_fetch_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt
   return KT_OK;
 }
 
+static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status);
+
 int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(e->mu);
   KT_HIP(e, hipSetDevice(e->device));
+  return check_fetch_locked(e, n, out_summary, out_status);
+}
+
+// launch + fetch as ONE critical section: what a caller needs when other threads use the engine at the same time
+// (Unreserve from binding goroutines, reconcile workers) — a kt_check_launch / kt_check_fetch pair can be interleaved
+int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary, uint8_t* out_status) {
+  if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, out_status ? KT_CHECK_STATUS_MATRIX : 0u, e->own_stream);
+  if (rc != KT_OK) return rc;
+  return check_fetch_locked(e, n, out_summary, out_status);
+}
+
+static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status) {
   if (!e->check_ready) return e->fail(KT_ERR_NOT_READY, "kt_check_fetch before kt_check_launch");
   if (n < 0 || n > e->check_n) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%lld, last check had %lld pods", (long long)n, (long long)e->check_n);
   if (out_status && !e->check_has_status) return e->fail(KT_ERR_NOT_READY, "status matrix was not requested at launch");

@@ -34,6 +34,7 @@ EXPORTS = [
     "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
+    "kt_check",
 ]
 
 
@@ -95,6 +96,7 @@ def lib():
         L.kt_reconcile_fetch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KtStatus)]
         L.kt_check_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_check_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.kt_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.kt_fetch_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -278,6 +280,17 @@ class Engine:
         n = len(rows) if rows is not None else n
         self.check_launch(n, rows, on_equal, want_status)
         return self.check_fetch(n, want_status)
+
+    def check_atomic(self, rows=None, n=None, on_equal=False, want_status=True):
+        """kt_check: launch + fetch under one engine lock (safe next to other threads using the engine)."""
+        a, p = self._rows(rows, np.int64)
+        n = len(a) if a is not None else n
+        T = self.throttle_rows()
+        summary = np.zeros(max(n, 1), np.uint64)
+        status = np.zeros((max(n, 1), max(T, 1)), np.uint8) if want_status else None
+        self._ck(lib().kt_check(self._h, n, p, int(on_equal), summary.ctypes.data,
+                                None if status is None else status.ctypes.data))
+        return (None if status is None else status[:n, :T]), summary[:n]
 
     # ---- sequential admission with reservation (N1): results are read like a check's
     def admit(self, rows=None, n=None, on_equal=False, commit=False, want_status=True):
