@@ -11,6 +11,15 @@ from kube_throttler_amd.objects import ClusterState
 from kube_throttler_amd.quantity import parse_quantity, parse_rfc3339
 
 
+RECORDED = None   # tests/test_unit_tables_gpu.py puts a list here to collect every ClusterState the tables build
+
+
+def _build(cs):
+    if RECORDED is not None:
+        RECORDED.append(cs)
+    return cs.build()
+
+
 def mk_pod(name, namespace, labels=None, requests=None, init_requests=None, containers=None, overhead=None):
     spec = {"schedulerName": "my-scheduler",
             "containers": containers if containers is not None else [{"name": "ctr", "resources": {"requests": dict(requests or {})}}]}
@@ -90,7 +99,7 @@ def _state_with_pods(pods, extra_dims=("r1", "r2", "r3")):
             "spec": {"throttlerName": "other", "threshold": {"resourceRequests": {d: "0" for d in extra_dims}}}})
     for p in pods:
         cs.add(p)
-    return cs.build()
+    return _build(cs)
 
 
 def test_is_throttled_for(oracle_mod):
@@ -144,6 +153,56 @@ def test_pod_request_resource_list_overhead_and_zero_keys(oracle_mod):
     assert (v[1, d["n1"]], v[1, d["n2"]], v[1, d["n3"]]) == (6, 0, 7)
 
 
+# ---------------------------------------------------------------- resourcelist_test.go:119-170 (Add), :320-366 (setMax)
+def _used_of(oracle_mod, pods, dims=("n1", "n2", "n3", "n4")):
+    """`used` of a throttle selecting every pod of the namespace: the Add fold of reconcile
+    (throttle_controller.go:116-119 -> resource_amount.go:91-110 -> resourcelist.go:48-54)."""
+    cs = ClusterState()
+    cs.add_namespace("test")
+    cs.add({"kind": "Throttle", "metadata": {"name": "all", "namespace": "test"},
+            "spec": {"throttlerName": "kube-throttler", "selector": {"selectorTerms": [{"podSelector": {}}]},
+                     "threshold": {"resourceRequests": {d: "0" for d in dims}}}})
+    for p in pods:
+        p["spec"]["nodeName"] = "node-1"
+        p["status"] = {"phase": "Running"}
+        cs.add(p)
+    b = _build(cs)
+    res = oracle_mod.Oracle(b.snapshot).reconcile(parse_rfc3339("2026-01-01T00:00:00Z"))
+    assert not res.error[0]
+    return b.amount_to_dict(res.used, 0)
+
+
+def test_resourcelist_add_merges_key_sets(oracle_mod):
+    """resourcelist_test.go:121-143: {n1:0,n2:1,n3:1} + {n2:0,n3:1,n4:2} = {n1:0,n2:1,n3:2,n4:2} — zero-valued keys
+    survive on both sides."""
+    got = _used_of(oracle_mod, [mk_pod("l", "test", requests={"n1": "0", "n2": "1", "n3": "1"}),
+                                mk_pod("r", "test", requests={"n2": "0", "n3": "1", "n4": "2"})])
+    assert got == {"resourceCounts": {"pod": 2}, "resourceRequests": {"n1": 0, "n2": 1, "n3": 2, "n4": 2}}
+
+
+def test_resourcelist_add_equal_key_sets(oracle_mod):
+    """resourcelist_test.go:146-170: {0,0,1,1} + {0,1,0,1} = {0,1,1,2}."""
+    got = _used_of(oracle_mod, [mk_pod("l", "test", requests={"n1": "0", "n2": "0", "n3": "1", "n4": "1"}),
+                                mk_pod("r", "test", requests={"n1": "0", "n2": "1", "n3": "0", "n4": "1"})])
+    assert got == {"resourceCounts": {"pod": 2}, "resourceRequests": {"n1": 0, "n2": 1, "n3": 1, "n4": 2}}
+
+
+def test_resourcelist_set_max_tables(oracle_mod):
+    """resourcelist_test.go:321-343 and :345-366 through the one place SetMax is used on the path
+    (resourcelist.go:28-38: containers' sum SetMax initContainers' max): lhs = the single container, rhs = the single
+    init container.  A key only the rhs has is merged "even if its quantity is zero"."""
+    b = _state_with_pods([
+        mk_pod("p0", "test", requests={"n1": "1", "n2": "2", "n3": "2"}, init_requests=[{"n2": "1", "n3": "2", "n4": "0"}]),
+        mk_pod("p1", "test", requests={"n1": "1", "n2": "1", "n3": "2", "n4": "2"},
+               init_requests=[{"n1": "1", "n2": "2", "n3": "1", "n4": "2"}]),
+    ], extra_dims=("n1", "n2", "n3", "n4"))
+    v, present = oracle_mod.Oracle(b.snapshot).pod_requests()
+    d = b.dims
+    every = sum(1 << d[k] for k in ("n1", "n2", "n3", "n4"))
+    assert present[0] == every and [int(v[0, d[k]]) for k in ("n1", "n2", "n3", "n4")] == [1, 2, 2, 0]
+    assert present[1] == every and [int(v[1, d[k]]) for k in ("n1", "n2", "n3", "n4")] == [1, 2, 2, 2]
+
+
 # ---------------------------------------------------------------- temporary_threshold_override_test.go:27-102
 def _override_state(overrides, threshold=None):
     cs = ClusterState()
@@ -151,7 +210,7 @@ def _override_state(overrides, threshold=None):
     cs.add({"kind": "Throttle", "metadata": {"name": "t", "namespace": "default"},
             "spec": {"throttlerName": "dummy", "threshold": threshold or {},
                      "temporaryThresholdOverrides": overrides}})
-    return cs.build()
+    return _build(cs)
 
 
 BEGIN, END = "2021-08-04T10:00:00Z", "2021-08-05T10:00:00Z"
@@ -248,7 +307,7 @@ def _selector_state(kind, terms, pods, namespaces):
     cs.add({"kind": kind, "metadata": md, "spec": {"throttlerName": "kube-throttler", "selector": {"selectorTerms": terms}}})
     for p in pods:
         cs.add(p)
-    return cs.build()
+    return _build(cs)
 
 
 def test_throttle_selector_empty_matches_nothing(oracle_mod):
