@@ -12,8 +12,8 @@ HOST = os.path.join(ROOT, "kube_throttler_amd", "host")
 
 def test_host_plugin_scenarios():
     exe = os.path.join(HOST, "host_plugin_test")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-C", HOST, "host_plugin_test"], stdout=subprocess.DEVNULL)
+    # always through make: a binary older than its sources must not be what gets tested
+    subprocess.check_call(["make", "-C", HOST, "host_plugin_test"], stdout=subprocess.DEVNULL)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all expectations held" in r.stdout
