@@ -43,3 +43,20 @@ def test_state_without_pods(oracle_mod):
     assert snap.n_pods == 0
     _, _, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED, now=parse_rfc3339("2006-01-02T15:04:05Z"), nthreads=1)
     assert rec.calc_updated[0] and not rec.used.has_count[0]
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_random_manifest_clusters_on_engine(variant, oracle_mod):
+    """The random manifest-level clusters of tests/test_manifest_model.py (where the oracle is pinned against an
+    independent manifest-level model) through the engine: snapshots built by objects.py rather than by the workload
+    generator — other label / selector / override / missing-namespace mixes, resourceCounts-only thresholds, zero
+    thresholds."""
+    from test_manifest_model import random_cluster
+    from kube_throttler_amd.quantity import parse_rfc3339
+    for seed in range(32):
+        for now_text in ("2026-01-01T00:00:00Z", "2026-01-20T00:00:00Z"):
+            snap = random_cluster(seed).build().snapshot
+            try:
+                run_full_parity(snap, oracle_mod, variant, now=parse_rfc3339(now_text), nthreads=1)
+            except AssertionError as ex:
+                raise AssertionError(f"random cluster seed {seed} at {now_text}: {ex}") from ex
