@@ -116,3 +116,14 @@ def test_cpp_host_unit(tool):
     subprocess.check_call(["make", "-C", HOST, "host_unit_test"], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(HOST, "host_unit_test")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_index_builder_against_cpu_scan_replay(tool):
+    """kt_index.cpp (the selector index the scan kernels walk) on the CPU: random programs are compiled, every chunk
+    image is decoded and the device scan is replayed on the host; matches / errors must equal the brute-force
+    evaluation of the program, from one resident chunk down to a few words per chunk and at the size of
+    BASELINE configs[4]'s shard (tests/cpp/index_sim_test.cpp)."""
+    subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "all expectations held" in out.stdout
