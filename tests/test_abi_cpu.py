@@ -51,3 +51,26 @@ def test_invalid_config_rejected(built_lib):
     cfg = E.KtConfig(0, 4, 16, 4, 2, -1, 0)
     h = C.c_void_p()
     assert E.lib().kt_engine_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_product_never_reaches_for_the_oracle():
+    """oracle/ is test infrastructure: nothing under kube_throttler_amd/ may import, load or link it, bench.py only in
+    its cpu_baseline leg, __graft_entry__ only in build() (compiling the checker) and smoke() (checking)."""
+    import ast
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|kt_oracle|libkt_oracle|oracle/", re.M)
+    for dirpath, _, files in os.walk(os.path.join(root, "kube_throttler_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".c")) or f == "Makefile":
+                with open(os.path.join(dirpath, f), errors="replace") as fh:
+                    m = pat.search(fh.read())
+                assert m is None, f"{os.path.join(dirpath, f)} refers to the oracle: {m.group(0)!r}"
+    # bench.py: every import of the oracle sits inside the `if ... not args.no_cpu_baseline` block
+    src = open(os.path.join(root, "bench.py")).read()
+    tree = ast.parse(src)
+    imports = [n for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
+    assert len(imports) == 1
+    guard = next(n for n in ast.walk(tree) if isinstance(n, ast.If) and "no_cpu_baseline" in ast.unparse(n.test))
+    assert guard.lineno < imports[0].lineno <= guard.end_lineno
+    assert not [n for n in ast.walk(tree) if isinstance(n, ast.Import) and any(a.name.startswith("oracle") for a in n.names)]
