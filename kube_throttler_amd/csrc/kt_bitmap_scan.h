@@ -153,9 +153,8 @@ __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgr
       ok = ok && (!(tr.w & kPostInline) || eok);
     }
     if (ok && (tr.w & kPostComplex)) {  // rare shapes: generic requirement walk
-      const SelProgram& sp = *sp_dev;
-      const Matcher<LT, KEYS> m{sp, sp.ns_term_ok + (size_t)ns * sp.gw, lp, lk};
-      ok = m.rare(tr.x, tr.y, tr.w);
+      const Matcher<LT, KEYS> m{*sp_dev, lp, lk};
+      ok = m.rare(tr.x);
     }
     t = tr.y;
     rank = tr.w >> 8;  // chunk-local throttle rank
@@ -180,10 +179,9 @@ __device__ __forceinline__ void bitmap_scan_tile(const BmView& b, const SelProgr
         //      term order, throttle_selector.go:30-42)
         const SelProgram& sp = *sp_dev;
         const int ts = (int)slow_thr[ks++];
-        bool matched, err;
-        walk_slow<LT, KEYS>(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, lane_slow, lp, lk, matched, err);
-        if (err) slow_err((uint32_t)ts);
-        const bool ok = matched && lane_match;
+        const uint32_t res = walk_slow<LT, KEYS>(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, lane_slow, lp, lk);
+        if (res & kSlowError) slow_err((uint32_t)ts);
+        const bool ok = (res & kSlowMatched) && lane_match;
         if (BY_RANK) {
           if (ok) slow_match((uint32_t)ts);
         } else {

@@ -26,7 +26,6 @@ constexpr uint32_t kKeyAtom = 0x80000000u;
 
 // TermRec flags
 constexpr uint32_t kPostComplex = 0x1u;  // needs the generic requirement walk (term_match)
-constexpr uint32_t kPostMulti = 0x2u;    // (generic path) owning throttle has several terms: first-matching-term check
 constexpr uint32_t kPostPair2 = 0x10u;   // pod must also carry `pair2`
 
 // ---- bitmap form of the whole selector side ----------------------------------------------------------
