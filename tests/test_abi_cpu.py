@@ -3,6 +3,7 @@ include/kt_engine.h declares, and refuses to run without a GPU (no CPU fallback)
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -74,3 +75,17 @@ def test_product_never_reaches_for_the_oracle():
     guard = next(n for n in ast.walk(tree) if isinstance(n, ast.If) and "no_cpu_baseline" in ast.unparse(n.test))
     assert guard.lineno < imports[0].lineno <= guard.end_lineno
     assert not [n for n in ast.walk(tree) if isinstance(n, ast.Import) and any(a.name.startswith("oracle") for a in n.names)]
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: include/*.h must compile as C99 on their own (cgo compiles them with a C compiler),
+    and every size the binding relies on is fixed-width."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "kt_engine.h"\n#include "kt_snapshot.h"\n'
+                   'int main(void) { kt_config c; kt_snapshot s; kt_status st; kt_amounts a;\n'
+                   '  (void)c; (void)s; (void)st; (void)a;\n'
+                   '  return (sizeof(c.pod_capacity) == 8 && sizeof(s.n_pods) == 8 && KT_OK == 0) ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{root}/include", str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
