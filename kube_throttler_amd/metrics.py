@@ -17,7 +17,6 @@ from __future__ import annotations
 import math
 from fractions import Fraction
 
-import numpy as np
 from prometheus_client import CollectorRegistry, Gauge, generate_latest
 
 from . import snapshot as S

@@ -10,9 +10,7 @@ from __future__ import annotations
 import copy
 import json
 import os
-from fractions import Fraction
 
-import numpy as np
 import yaml
 
 from kube_throttler_amd import snapshot as S

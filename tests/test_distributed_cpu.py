@@ -31,7 +31,7 @@ def _worker(rank, world, port, n_pods, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from kube_throttler_amd import workload as W, distributed as KD, snapshot as S
+    from kube_throttler_amd import workload as W, distributed as KD
     from oracle import kt_oracle as O
     full_cfg = W.small(seed=77, n_pods=n_pods, n_thr=40, n_cluster=20)
     snap = W.generate(full_cfg.shard(rank, world))

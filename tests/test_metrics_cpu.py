@@ -1,7 +1,6 @@
 """Prometheus export: metric names, label sets and units of the reference's recorders
 (throttle_metrics.go:34-131, clusterthrottle_metrics.go:34-128, metrics_recorder.go:28-66), fed from the per-throttle
 vectors a reconcile produces (here: the oracle's, on CPU)."""
-import numpy as np
 
 from kube_throttler_amd.metrics import MetricsRecorder
 from kube_throttler_amd.objects import ClusterState
