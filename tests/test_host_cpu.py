@@ -76,6 +76,36 @@ def test_canonical_strings():
     assert format_quantity(total, fmt) == "1"
 
 
+def test_canonical_strings_round_trip(tool):
+    """String() then Parse gives the value back, in every format, in both implementations; and the C++ text equals the
+    Python text (5000 random values: nano to exa, negative, binary multiples)."""
+    import random
+    r = random.Random(20260921)
+    texts = []
+    for _ in range(5000):
+        kind = r.random()
+        if kind < 0.35:
+            t = f"{r.randint(0, 10 ** r.randint(1, 12))}{r.choice(['n', 'u', 'm', '', 'k', 'M', 'G'])}"
+        elif kind < 0.6:
+            t = f"{r.randint(0, 1 << r.randint(1, 20))}{r.choice(['Ki', 'Mi', 'Gi', 'Ti'])}"
+        elif kind < 0.75:
+            t = f"{r.randint(0, 10 ** 6)}.{r.randint(0, 999999):06d}{r.choice(['', 'k', 'Mi', 'm'])}"
+        elif kind < 0.9:
+            t = f"{r.randint(0, 10 ** 9)}e{r.randint(-9, 6)}"
+        else:
+            t = f"-{r.randint(1, 10 ** 9)}{r.choice(['m', '', 'Ki', 'e3'])}"
+        texts.append(t)
+    out = subprocess.check_output([tool, "quantity"] + texts).decode().splitlines()
+    assert len(out) == len(texts)
+    for text, line in zip(texts, out):
+        v, fmt = parse_quantity(text), quantity_format(text)
+        own = format_quantity(v, fmt)
+        assert parse_quantity(own) == v, (text, own)
+        if fmt != BINARY_SI or own.endswith("i"):
+            assert quantity_format(own) in (fmt, DECIMAL_SI), (text, own)   # a bare number reads back as DecimalSI
+        assert line.split()[2] == own, (text, line, own)
+
+
 def test_cpp_quantity_matches_python(tool):
     out = subprocess.check_output([tool, "quantity"] + QUANTITIES + BAD).decode().splitlines()
     assert len(out) == len(QUANTITIES) + len(BAD)
