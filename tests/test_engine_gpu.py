@@ -393,12 +393,14 @@ def test_concurrent_callers(oracle_mod):
             eng.reconcile(NOW, apply=False)
 
     try:
-        threads = [threading.Thread(target=writer, args=(k,)) for k in range(n_writers)]
-        threads += [threading.Thread(target=checker, args=(k,)) for k in range(2)] + [threading.Thread(target=reader)]
+        threads = [threading.Thread(target=writer, args=(k,), daemon=True) for k in range(n_writers)]
+        threads += [threading.Thread(target=checker, args=(k,), daemon=True) for k in range(2)]
+        threads.append(threading.Thread(target=reader, daemon=True))
         for th in threads:
             th.start()
         for th in threads:
-            th.join()
+            th.join(timeout=240)     # a deadlock fails the test instead of hanging the box
+        assert not any(th.is_alive() for th in threads), "engine calls did not return: deadlock?"
         if errors:
             raise errors[0]
         for j, t in enumerate(rows):
