@@ -296,6 +296,32 @@ def test_calculate_threshold_override_replaces_not_overlays(oracle_mod):
     assert got == {"resourceRequests": {"memory": 5}} and not err
 
 
+def test_readme_override_example_follows_the_code(oracle_mod):
+    """README.md:157-198 (the documentation example of temporaryThresholdOverrides).  At 2019-02-16T00:00:00+09:00 both
+    overrides are active and merge first-wins: cpu "5" from [0], memory "8Gi" from [1] — as the README says.  The README
+    also keeps `resourceCounts: pod: 3` ("this is not overridden") and is silent about nvidia.com/gpu; the CODE replaces
+    the whole threshold by the merged overrides (throttle_types.go:96-98, pinned by throttle_types_test.go:101-127), so
+    neither the pod count nor the gpu limit survives while an override is active.  The engine follows the code."""
+    threshold = {"resourceCounts": {"pod": 3}, "resourceRequests": {"cpu": "200m", "memory": "1Gi", "nvidia.com/gpu": "2"}}
+    overrides = [
+        {"begin": "2019-02-01T00:00:00+09:00", "end": "2019-03-01T00:00:00+09:00", "threshold": {"resourceRequests": {"cpu": "5"}}},
+        {"begin": "2019-02-15T00:00:00+09:00", "end": "2019-03-01T00:00:00+09:00",
+         "threshold": {"resourceRequests": {"cpu": "1", "memory": "8Gi"}}}]
+    b = _override_state(overrides, threshold)
+
+    def at(text):
+        out, err = oracle_mod.unit_calculate_threshold(b.snapshot, 0, parse_rfc3339(text))
+        assert not err
+        return b.amount_to_dict(out, 0)
+
+    gi = 1 << 30
+    assert at("2019-02-16T00:00:00+09:00") == {"resourceRequests": {"cpu": 5, "memory": 8 * gi}}
+    assert at("2019-02-10T00:00:00+09:00") == {"resourceRequests": {"cpu": 5}}                 # only [0] active
+    assert at("2019-03-01T00:00:00+09:00") == {"resourceRequests": {"cpu": 5, "memory": 8 * gi}}   # end is inclusive
+    base = {"resourceCounts": {"pod": 3}, "resourceRequests": {"cpu": parse_quantity("200m"), "memory": gi, "nvidia.com/gpu": 2}}
+    assert at("2019-03-01T00:00:01+09:00") == base and at("2019-01-31T23:59:59+09:00") == base
+
+
 # ---------------------------------------------------------------- throttle_selector_test.go / clusterthrottle_selector_test.go
 def _selector_state(kind, terms, pods, namespaces):
     cs = ClusterState()
