@@ -60,3 +60,12 @@ def test_random_manifest_clusters_on_engine(variant, oracle_mod):
                 run_full_parity(snap, oracle_mod, variant, now=parse_rfc3339(now_text), nthreads=1)
             except AssertionError as ex:
                 raise AssertionError(f"random cluster seed {seed} at {now_text}: {ex}") from ex
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_override_examples_on_engine(variant):
+    """example/throttle-with-temporaryThresholdOverrides.yaml + the ClusterThrottle twin with the example pods, inside
+    and outside the override window (expected values hand-traced in tests/examples_overrides.py)."""
+    from examples_overrides import run_examples
+    from test_engine_gpu import EngineBackend
+    run_examples(EngineBackend(variant))
