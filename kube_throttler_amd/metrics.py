@@ -22,11 +22,18 @@ from prometheus_client import CollectorRegistry, Gauge, generate_latest
 from . import snapshot as S
 
 _FAMILIES = ("spec_threshold", "status_throttled", "status_used", "status_calculated_threshold")
+# help texts verbatim (throttle_metrics.go:44-97, clusterthrottle_metrics.go:44-97: both kinds say "of the throttle")
 _HELP = {
-    "spec_threshold": "threshold on specific {} of the {}",
-    "status_throttled": "{} of the {} is throttled or not on specific resource (1=throttled, 0=not throttled)",
-    "status_used": "used {} of the {}",
-    "status_calculated_threshold": "calculated threshold on specific {} of the {}",
+    ("spec_threshold", "resourceCounts"): "threshold on specific resourceCounts of the throttle",
+    ("spec_threshold", "resourceRequests"): "threshold on specific resourceRequests of the throttle",
+    ("status_throttled", "resourceCounts"):
+        "resourceCounts of the throttle is throttled or not on specific resource (1=throttled, 0=not throttled)",
+    ("status_throttled", "resourceRequests"):
+        "resourceRequests of the throttle is throttled or not on specific resource (1=throttled, 0=not throttled)",
+    ("status_used", "resourceCounts"): "used resource counts of the throttle",
+    ("status_used", "resourceRequests"): "used amount of resource requests of the throttle",
+    ("status_calculated_threshold", "resourceCounts"): "calculated threshold on specific resourceCounts of the throttle",
+    ("status_calculated_threshold", "resourceRequests"): "calculated threshold on specific resourceRequests of the throttle",
 }
 
 
@@ -45,7 +52,7 @@ class MetricsRecorder:
                                      ("ClusterThrottle", "clusterthrottle", ["name", "uid", "resource"])):
             for fam in _FAMILIES:
                 for what in ("resourceCounts", "resourceRequests"):
-                    self.g[(kind, fam, what)] = Gauge(f"{prefix}_{fam}_{what}", _HELP[fam].format(what, prefix), labels,
+                    self.g[(kind, fam, what)] = Gauge(f"{prefix}_{fam}_{what}", _HELP[(fam, what)], labels,
                                                       registry=self.registry)
 
     def _labels(self, kind, manifest, resource):

@@ -45,3 +45,14 @@ def test_gauges_follow_the_reference_families(oracle_mod):
     assert s("clusterthrottle_status_used_resourceRequests", resource="cpu", **c) == 1100
     assert s("clusterthrottle_status_throttled_resourceCounts", resource="pod", **c) == 1
     assert not any(k.startswith("clusterthrottle_") and "namespace=" in k for k in samples)
+    # help texts, verbatim from throttle_metrics.go:44-97 / clusterthrottle_metrics.go:44-97 (both say "the throttle")
+    helps = {line.split(" ", 3)[2]: line.split(" ", 3)[3] for line in text.splitlines() if line.startswith("# HELP ")}
+    for prefix in ("throttle", "clusterthrottle"):
+        assert helps[f"{prefix}_spec_threshold_resourceCounts"] == "threshold on specific resourceCounts of the throttle"
+        assert helps[f"{prefix}_status_used_resourceCounts"] == "used resource counts of the throttle"
+        assert helps[f"{prefix}_status_used_resourceRequests"] == "used amount of resource requests of the throttle"
+        assert helps[f"{prefix}_status_throttled_resourceRequests"] == \
+            "resourceRequests of the throttle is throttled or not on specific resource (1=throttled, 0=not throttled)"
+        assert helps[f"{prefix}_status_calculated_threshold_resourceRequests"] == \
+            "calculated threshold on specific resourceRequests of the throttle"
+    assert len(helps) == 16
