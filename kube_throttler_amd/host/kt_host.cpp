@@ -794,6 +794,22 @@ static std::vector<std::string> block_reasons(const KubeThrottler::Impl& p, cons
   return out;
 }
 
+// the Warning event PreFilter records when the pod's own requests exceed a threshold (plugin.go:190-202):
+// ClusterThrottle names first, then Throttle names
+static std::vector<Event> block_events(const KubeThrottler::Impl& p, const uint8_t* row, size_t n) {
+  std::string names;
+  for (int cluster = 1; cluster >= 0; --cluster)
+    for (size_t t = 0; t < n; ++t) {
+      if (!p.thr_live[t] || p.thr_by_row[t].cluster != (cluster == 1) || row[t] != KT_STATUS_POD_REQUESTS_EXCEEDS_THRESHOLD) continue;
+      if (!names.empty()) names += ",";
+      names += p.thr_by_row[t].Key();
+    }
+  if (names.empty()) return {};
+  return {Event{"Warning", "ResourceRequestsExceedsThrottleThreshold",
+                "It won't be scheduled unless decreasing resource requests or increasing ClusterThrottle/Throttle threshold "
+                "because its resource requests exceeds their thresholds: " + names}};
+}
+
 Status KubeThrottler::PreFilter(const Pod& pod) {
   auto& p = *p_;
   Status st;
@@ -812,6 +828,7 @@ Status KubeThrottler::PreFilter(const Pod& pod) {
   if (KT_SUMMARY_VERDICT(summary) == KT_VERDICT_SUCCESS) return st;  // plugin.go:177-180
   st.code = UnschedulableAndUnresolvable;
   st.reasons = block_reasons(p, p.last_status.data(), p.last_status.size());
+  st.events = block_events(p, p.last_status.data(), p.last_status.size());
   return st;
 }
 
@@ -895,6 +912,7 @@ std::vector<Status> KubeThrottler::AdmitQueue(const std::vector<std::string>& po
     } else if (v != KT_VERDICT_SUCCESS) {
       out[i].code = UnschedulableAndUnresolvable;
       out[i].reasons = block_reasons(p, row, (size_t)T);
+      out[i].events = block_events(p, row, (size_t)T);
     } else {
       DenseAmount amt;
       for (int d = 0; d < p.D; ++d) amt.v[d] = req[i * (size_t)p.D + d];

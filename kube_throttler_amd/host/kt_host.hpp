@@ -127,9 +127,14 @@ bool StatusSemanticEqual(const ThrottleStatus& a, const ThrottleStatus& b);
 
 // framework.Code values used by the plugin
 enum Code { Success = 0, Error = 1, UnschedulableAndUnresolvable = 3 };
+// what PreFilter hands to fh.EventRecorder().Eventf (plugin.go:190-202)
+struct Event {
+  std::string type, reason, message;
+};
 struct Status {
   Code code = Success;
   std::vector<std::string> reasons;
+  std::vector<Event> events;
   bool IsSuccess() const { return code == Success; }
 };
 

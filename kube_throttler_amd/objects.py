@@ -374,6 +374,17 @@ class BuiltState:
         st["throttled"] = thr
         return st
 
+    def events(self, status_row) -> list[dict]:
+        """The Warning event PreFilter records when the pod's own requests exceed a threshold (plugin.go:190-202):
+        ClusterThrottle names first, then Throttle names."""
+        names = [self.thr_names[t] for kind in ("ClusterThrottle", "Throttle") for t in range(len(self.thr_names))
+                 if self.thr_kinds[t] == kind and status_row[t] == S.EXCEEDS]
+        if not names:
+            return []
+        return [{"type": "Warning", "reason": "ResourceRequestsExceedsThrottleThreshold",
+                 "message": "It won't be scheduled unless decreasing resource requests or increasing ClusterThrottle/Throttle "
+                            "threshold because its resource requests exceeds their thresholds: " + ",".join(names)}]
+
     def reasons(self, status_row) -> list[str]:
         """PreFilter reason strings in the reference's fixed order (plugin.go:182-214)."""
         out = []

@@ -89,6 +89,10 @@ static void TestExampleWalkthrough() {
   Status s2 = k->PreFilter(pod2);          // 300m > 200m at step 1, in any snapshot
   EXPECT(s2.code == UnschedulableAndUnresolvable);
   EXPECT(s2.reasons.size() == 1 && s2.reasons[0] == "throttle[pod-requests-exceeds-threshold]=default/t1");
+  // ... and the Warning event of plugin.go:190-202
+  EXPECT(s2.events.size() == 1 && s2.events[0].type == "Warning" && s2.events[0].reason == "ResourceRequestsExceedsThrottleThreshold" &&
+         s2.events[0].message == "It won't be scheduled unless decreasing resource requests or increasing ClusterThrottle/Throttle "
+                                 "threshold because its resource requests exceeds their thresholds: default/t1");
   Schedule(*k, pod1);
   std::map<std::string, ThrottleStatus> st;
   EXPECT(k->ReconcileAll(NOW, &st, &err));

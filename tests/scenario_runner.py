@@ -175,6 +175,12 @@ def run_scenario(sc, backend):
                         f"{label}: status[{built.thr_names[t]}]={S.STATUS_NAMES[int(status[k, t])]}"
                 assert int(verdict[k]) == _VERDICT[exp["verdict"]], f"{label}: verdict"
                 assert built.reasons(status[k]) == exp["reasons"], f"{label}: reasons {built.reasons(status[k])}"
+                exceeded = [r.split("=", 1)[1] for r in exp["reasons"] if "[pod-requests-exceeds-threshold]=" in r]
+                ev = built.events(status[k])
+                assert len(ev) == (1 if exceeded else 0), f"{label}: events {ev}"
+                if exceeded:   # ClusterThrottle names first, then Throttle names — the order of the reason strings
+                    assert ev[0]["reason"] == "ResourceRequestsExceedsThrottleThreshold" and \
+                        ev[0]["message"].endswith("exceeds their thresholds: " + ",".join(exceeded)), f"{label}: {ev}"
                 row = status[k]
                 assert (n_exc[k], n_act[k], n_ins[k]) == (int((row == S.EXCEEDS).sum()), int((row == S.ACTIVE).sum()),
                                                           int((row == S.INSUFFICIENT).sum())), f"{label}: summary counts"
