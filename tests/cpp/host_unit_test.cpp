@@ -2,6 +2,7 @@
 // Quantity.Add's format rule + Quantity.String(), and the Semantic.DeepEqual stand-in that decides whether a
 // reconcile has to call UpdateStatus (throttle_controller.go:157).
 #include <cstdio>
+#include <memory>
 #include <string>
 
 #include "kt_host.hpp"
@@ -71,6 +72,20 @@ int main() {
   EXPECT(StatusSemanticEqual(a, b));
   auto text = a.UsedStrings();
   EXPECT(text.size() == 1 && text["cpu"] == "1");
+
+  // NewPlugin: DecodePluginArgs' checks come first (plugin_args.go:46-51), with the reference's messages
+  {
+    std::string err;
+    PluginArgs a;
+    EXPECT(NewPlugin(a, &err) == nullptr && err == "Name must not be empty");
+    a.name = "kube-throttler";
+    EXPECT(NewPlugin(a, &err) == nullptr && err == "TargetSchedulerName must not be empty");
+    EXPECT(std::string(PluginName) == "kube-throttler");                                    // plugin.go:45
+    // the engine has no CPU fallback: on a box without a GPU the plugin cannot be created, and says why
+    a.targetSchedulerName = "my-scheduler";
+    std::unique_ptr<KubeThrottler> k = NewPlugin(a, &err);
+    if (!k) EXPECT(err.find("kt_engine_create") != std::string::npos);
+  }
 
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
