@@ -565,6 +565,9 @@ bool KubeThrottler::OnPodDelete(const std::string& key, std::string* err) {
   auto& p = *p_;
   const int64_t row = p.pod_rows.find(key);
   if (row < 0) return true;
+  auto known = p.pods.find(key);
+  if (known != p.pods.end() && known->second.schedulerName == p.args.targetSchedulerName && !known->second.nodeName.empty())
+    Unreserve(known->second);  // "observe the deleted pod is now scheduled. controller should unreserve it."
   int32_t rc = kt_delete_pods(p.e, 1, &row);
   if (rc != KT_OK) { if (err) *err = p.engine_error(rc); return false; }
   p.pod_rows.release(key);
@@ -872,6 +875,40 @@ void KubeThrottler::Unreserve(const Pod& pod) {
   auto& p = *p_;
   for (auto& kv : p.reserved)
     if (kv.second.erase(pod.Key())) p.push_reserved(kv.first, nullptr);
+}
+
+bool KubeThrottler::OnPodUpdate(const Pod& old_pod, const Pod& new_pod, std::string* err) {
+  auto& p = *p_;
+  auto counts_in = [&](const Pod& q) { return q.schedulerName == p.args.targetSchedulerName && !q.nodeName.empty(); };
+  if (old_pod.Key() != new_pod.Key() || (!counts_in(old_pod) && !counts_in(new_pod))) return OnPodAdd(new_pod, err);
+  // affectedThrottles(oldPod) and affectedThrottles(newPod): an error on either side skips the move (:459-468)
+  std::vector<uint8_t> before, after;
+  uint64_t s_before = 0, s_after = 0;
+  std::string ignored;
+  const bool ok_before = check_one(p, old_pod, this, &before, &s_before, &ignored) && KT_SUMMARY_VERDICT(s_before) != KT_VERDICT_ERROR;
+  if (!OnPodAdd(new_pod, err)) return false;  // from here on the engine holds the new object
+  const bool ok_after = check_one(p, new_pod, this, &after, &s_after, &ignored) && KT_SUMMARY_VERDICT(s_after) != KT_VERDICT_ERROR;
+  if (!ok_before || !ok_after) return true;
+  DenseAmount amt;  // ResourceAmountOfPod(newPod), as the engine computed it
+  const int64_t prow = p.pod_rows.find(new_pod.Key());
+  int32_t rc = kt_fetch_pod_requests(p.e, 1, &prow, amt.v, &amt.present);
+  if (rc != KT_OK) { if (err) *err = p.engine_error(rc); return false; }
+  amt.has_count = 1;
+  amt.count = 1;
+  const size_t n = std::max(before.size(), after.size());
+  for (size_t t = 0; t < n; ++t) {
+    const bool was = t < before.size() && before[t] != KT_STATUS_NOT_AFFECTED;
+    const bool is = t < after.size() && after[t] != KT_STATUS_NOT_AFFECTED;
+    if (was == is) continue;  // common throttles keep whatever they hold (symmetric difference only)
+    if (was) {
+      auto it = p.reserved.find((int32_t)t);
+      if (it == p.reserved.end() || !it->second.erase(new_pod.Key())) continue;
+    } else {
+      p.reserved[(int32_t)t][new_pod.Key()] = amt;
+    }
+    if (!p.push_reserved((int32_t)t, err)) return false;
+  }
+  return true;
 }
 
 // One scheduling pass over a queue of pending pods IN ORDER: PreFilter, and on Success Reserve — a single engine

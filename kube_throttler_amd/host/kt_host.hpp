@@ -161,7 +161,13 @@ class KubeThrottler {
   // ---- informer feed
   bool OnNamespaceAdd(const Namespace& ns, std::string* err);
   bool OnNamespaceDelete(const std::string& name, std::string* err);
-  bool OnPodAdd(const Pod& pod, std::string* err);  // also Update
+  bool OnPodAdd(const Pod& pod, std::string* err);  // Add; also what the engine has to see of an Update
+  // Update handler (throttle_controller.go:451-507, clusterthrottle_controller.go:483-539): when the pod counts in
+  // (before or after) and its set of affected throttles changes, its reservation moves with it — removed from the
+  // throttles it left, ADDED to the ones it joined (reserved_resource_amounts.go:92-111), until their next reconcile
+  // counts it in `used` and un-reserves it.  Then the new object is fed to the engine like OnPodAdd.
+  bool OnPodUpdate(const Pod& old_pod, const Pod& new_pod, std::string* err);
+  // Delete handler: a scheduled pod that counts in is un-reserved first (throttle_controller.go:508-517)
   bool OnPodDelete(const std::string& key, std::string* err);
   bool OnThrottleAdd(const Throttle& thr, std::string* err);  // also Update; the stored status restarts empty until ReconcileAll
   bool OnThrottleDelete(const std::string& key, bool cluster, std::string* err);

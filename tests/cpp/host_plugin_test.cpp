@@ -264,6 +264,45 @@ static void TestStatusWriteBack() {
   EXPECT(!st["default/t"].needsUpdate);
 }
 
+// pod Update / Delete handlers: the reservation follows a counted pod whose labels move it to other throttles
+// (throttle_controller.go:451-507 -> reserved_resource_amounts.go:92-111), a deleted scheduled pod is un-reserved (:508-517)
+static void TestPodUpdateAndDeleteHandlers() {
+  auto k = Fresh();
+  std::string err;
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "ta", "grp", "a", 1, ""), &err));
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "tb", "grp", "b", 1, ""), &err));
+  Pod x = MakePod("default", "x", "100m", {{"grp", "a"}});
+  Schedule(*k, x);
+  std::map<std::string, ThrottleStatus> st;
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(st["default/ta"].usedPod == 1 && st["default/ta"].throttledPod && !st["default/tb"].usedHasCounts);
+  Pod y = MakePod("default", "y", "100m", {{"grp", "b"}});
+  Pod z = MakePod("default", "z", "100m", {{"grp", "a"}});
+  EXPECT(k->PreFilter(y).IsSuccess());
+  // x is relabelled: it leaves ta and joins tb; until tb is reconciled x sits in tb's reservations
+  Pod x2 = x;
+  x2.labels = {{"grp", "b"}};
+  EXPECT(k->OnPodUpdate(x, x2, &err));
+  Status sy = k->PreFilter(y);   // tb: used {} + reserved {pod 1} >= 1  (step 3, onEqual = true)
+  EXPECT(sy.code == UnschedulableAndUnresolvable && sy.reasons.size() == 1 && sy.reasons[0] == "throttle[active]=default/tb");
+  Status sz = k->PreFilter(z);   // ta still carries the stored throttled.pod of the last reconcile
+  EXPECT(sz.code == UnschedulableAndUnresolvable && sz.reasons.size() == 1 && sz.reasons[0] == "throttle[active]=default/ta");
+  EXPECT(k->ReconcileAll(NOW, &st, &err));   // x now counts into tb.used and is un-reserved; ta is empty again
+  EXPECT(!st["default/ta"].usedHasCounts && !st["default/ta"].throttledPod && st["default/tb"].usedPod == 1 && st["default/tb"].throttledPod);
+  EXPECT(k->PreFilter(z).IsSuccess());
+  EXPECT(k->PreFilter(y).code == UnschedulableAndUnresolvable);
+  EXPECT(k->OnPodDelete(x2.Key(), &err));
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(k->PreFilter(y).IsSuccess());
+  // a reserved pod that got bound and is deleted before any reconcile saw it: the Delete handler un-reserves it
+  Pod w = MakePod("default", "w", "100m", {{"grp", "a"}});
+  EXPECT(k->PreFilter(w).IsSuccess() && k->Reserve(w).IsSuccess());
+  EXPECT(k->PreFilter(z).code == UnschedulableAndUnresolvable);   // ta: reserved {pod 1} >= 1
+  Schedule(*k, w);
+  EXPECT(k->OnPodDelete(w.Key(), &err));
+  EXPECT(k->PreFilter(z).IsSuccess());
+}
+
 int main() {
   TestExampleWalkthrough();
   TestThrottleScenarios();
@@ -271,6 +310,7 @@ int main() {
   TestAdmitQueue();
   TestNextOverride();
   TestStatusWriteBack();
+  TestPodUpdateAndDeleteHandlers();
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;
