@@ -303,14 +303,18 @@ static void TestPodUpdateAndDeleteHandlers() {
   EXPECT(k->PreFilter(z).IsSuccess());
 }
 
-int main() {
-  TestExampleWalkthrough();
-  TestThrottleScenarios();
-  TestClusterThrottleAndReserve();
-  TestAdmitQueue();
-  TestNextOverride();
-  TestStatusWriteBack();
-  TestPodUpdateAndDeleteHandlers();
+int main(int argc, char** argv) {
+  // no argument: the reference's scenarios; "extended": status write-back and the pod Update / Delete handlers
+  if (argc > 1 && std::string(argv[1]) == "extended") {
+    TestStatusWriteBack();
+    TestPodUpdateAndDeleteHandlers();
+  } else {
+    TestExampleWalkthrough();
+    TestThrottleScenarios();
+    TestClusterThrottleAndReserve();
+    TestAdmitQueue();
+    TestNextOverride();
+  }
   if (g_fail) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;

@@ -337,89 +337,6 @@ def test_set_status_and_reserved(oracle_mod):
         eng.close()
 
 
-def test_concurrent_callers(oracle_mod):
-    """Thread safety at the C-ABI (SURVEY.md 8b "Threading"; the reference hammers its reserved cache from 2000
-    goroutines, pkg/controllers/reserved_resource_amounts_test.go:44-108): writer threads replace reservations on their
-    own throttle rows while other threads check (kt_check = launch + fetch as one critical section), read the
-    reservations back and run dry reconciles.  No call fails, every atomic check is self-consistent (summary counters
-    = its own status matrix), and the end state is the serial one: parity with the oracle."""
-    import threading
-    snap = W.generate(W.small(seed=33, n_pods=800, n_thr=40, n_cluster=20))
-    _stored_status(snap, oracle_mod)
-    eng = E.Engine.for_snapshot(snap)
-    rows = responsible_rows(snap)[:12]
-    n_writers, rounds = 4, 20
-    errors = []
-
-    def amount(j, it):
-        a = S.Amounts(1, snap.D)
-        last = it == rounds - 1
-        a.set_row(0, {0: 1000 * (j + 1) + (0 if last else it + 1), 1: (1 << 30) if last else (it + 1) << 20},
-                  count=(j % 3 + 1) if last else it + 1)
-        return a
-
-    def guarded(fn):
-        def run(*args):
-            try:
-                fn(*args)
-            except Exception as ex:  # noqa: BLE001 - collected and re-raised on the main thread
-                errors.append(ex)
-        return run
-
-    @guarded
-    def writer(k):
-        for it in range(rounds):
-            for j, t in enumerate(rows):
-                if j % n_writers == k:
-                    eng.set_reserved(np.array([t], np.int32), amount(j, it))
-
-    @guarded
-    def checker(step):
-        sample = np.arange(step, snap.n_pods, 7, dtype=np.int64)
-        for _ in range(rounds):
-            st, sm = eng.check_atomic(rows=sample, want_status=True)
-            verdict, n_exc, n_act, n_ins = S.summary_fields(sm)
-            ok = verdict != S.VERDICT_ERROR
-            np.testing.assert_array_equal(n_exc[ok], (st == S.EXCEEDS).sum(axis=1)[ok])
-            np.testing.assert_array_equal(n_act[ok], (st == S.ACTIVE).sum(axis=1)[ok])
-            np.testing.assert_array_equal(n_ins[ok], (st == S.INSUFFICIENT).sum(axis=1)[ok])
-            blocked = (n_exc + n_act + n_ins) > 0
-            np.testing.assert_array_equal(verdict[ok] == S.VERDICT_BLOCK, blocked[ok])
-
-    @guarded
-    def reader():
-        for _ in range(rounds):
-            eng.fetch_reserved()
-            eng.reconcile(NOW, apply=False)
-
-    try:
-        threads = [threading.Thread(target=writer, args=(k,), daemon=True) for k in range(n_writers)]
-        threads += [threading.Thread(target=checker, args=(k,), daemon=True) for k in range(2)]
-        threads.append(threading.Thread(target=reader, daemon=True))
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join(timeout=240)     # a deadlock fails the test instead of hanging the box
-        assert not any(th.is_alive() for th in threads), "engine calls did not return: deadlock?"
-        if errors:
-            raise errors[0]
-        for j, t in enumerate(rows):
-            a = amount(j, rounds - 1)
-            for f in ("v", "present", "count", "has_count"):
-                getattr(snap.thr_reserved, f)[t] = getattr(a, f)[0]
-        res = eng.fetch_reserved()
-        T = snap.n_thr
-        for f in ("v", "present", "count", "has_count"):
-            np.testing.assert_array_equal(getattr(res, f)[:T], getattr(snap.thr_reserved, f)[:T], err_msg=f)
-        o = oracle_mod.Oracle(snap)
-        st_w, sm_w = o.check()
-        st_g, sm_g = eng.check_atomic(n=snap.n_pods, want_status=True)
-        np.testing.assert_array_equal(st_g, st_w)
-        np.testing.assert_array_equal(sm_g, sm_w)
-    finally:
-        eng.close()
-
-
 @pytest.mark.parametrize("budget", [3000, 12000])
 @pytest.mark.parametrize("seed", [1, 7])
 def test_multi_chunk_index(seed, budget, oracle_mod, monkeypatch):

@@ -11,7 +11,7 @@ from kube_throttler_amd.objects import ClusterState
 from kube_throttler_amd.quantity import parse_quantity, parse_rfc3339
 
 
-RECORDED = None   # tests/test_unit_tables_gpu.py puts a list here to collect every ClusterState the tables build
+RECORDED = None   # tests/test_parity_extended_gpu.py puts a list here to collect every ClusterState the tables build
 
 
 def _build(cs):

@@ -1,5 +1,5 @@
 """Sanity of the unit-table replay itself (no GPU): the collector finds the states, and the oracle handles each of
-them end to end at every probed instant — so that tests/test_unit_tables_gpu.py only adds the engine side."""
+them end to end at every probed instant — so that tests/test_parity_extended_gpu.py only adds the engine side."""
 import numpy as np
 
 from kube_throttler_amd import snapshot as S

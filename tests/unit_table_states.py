@@ -1,7 +1,7 @@
 """Collects every cluster state the reference's unit-test tables build (tests/test_oracle_unit_tables.py) so that the
 same states can be replayed end to end: pod requests, reconcile, next override, check with both isThrottledOnEqual
 values, at the instants the tables probe.  The CPU suite replays them on the oracle alone (sanity of the replay
-itself), the GPU suite through the C-ABI against the oracle (tests/test_unit_tables_gpu.py)."""
+itself), the GPU suite through the C-ABI against the oracle (tests/test_parity_extended_gpu.py)."""
 import copy
 import inspect
 
