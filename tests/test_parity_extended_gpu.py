@@ -23,35 +23,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
-def test_unit_table_states_on_engine(variant, oracle_mod):
-    states = collect(oracle_mod)
-    assert len(states) >= 30
-    runs = 0
-    for label, cs in states:
-        for now in instants(cs):
-            snap = cs.build().snapshot   # fresh: run_full_parity stores the reconciled status into it
-            try:
-                run_full_parity(snap, oracle_mod, variant, now=now, nthreads=1)
-            except AssertionError as ex:
-                raise AssertionError(f"state {label} at {now}: {ex}") from ex
-            runs += 1
-    assert runs >= len(states)
-
-
-def test_state_without_pods(oracle_mod):
-    """A throttle with overrides and not a single pod in the cluster: every launch of the path has zero pod rows."""
-    from test_oracle_unit_tables import OVERRIDE1, THRESHOLD
-    from kube_throttler_amd.objects import ClusterState
-    from kube_throttler_amd.quantity import parse_rfc3339
-    cs = ClusterState()
-    cs.add_namespace("default")
-    cs.add({"kind": "Throttle", "metadata": {"name": "t", "namespace": "default"},
-            "spec": {"throttlerName": cs.throttler_name, "threshold": THRESHOLD, "temporaryThresholdOverrides": [OVERRIDE1],
-                     "selector": {"selectorTerms": [{"podSelector": {}}]}}})
-    snap = cs.build().snapshot
-    assert snap.n_pods == 0
-    _, _, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED, now=parse_rfc3339("2006-01-02T15:04:05Z"), nthreads=1)
-    assert rec.calc_updated[0] and not rec.used.has_count[0]
+def test_override_examples_on_engine(variant):
+    """example/throttle-with-temporaryThresholdOverrides.yaml + the ClusterThrottle twin with the example pods, inside
+    and outside the override window (expected values hand-traced in tests/examples_overrides.py)."""
+    from examples_overrides import run_examples
+    from test_engine_gpu import EngineBackend
+    run_examples(EngineBackend(variant))
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
@@ -72,12 +49,45 @@ def test_random_manifest_clusters_on_engine(variant, oracle_mod):
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
-def test_override_examples_on_engine(variant):
-    """example/throttle-with-temporaryThresholdOverrides.yaml + the ClusterThrottle twin with the example pods, inside
-    and outside the override window (expected values hand-traced in tests/examples_overrides.py)."""
-    from examples_overrides import run_examples
-    from test_engine_gpu import EngineBackend
-    run_examples(EngineBackend(variant))
+def test_unit_table_states_on_engine(variant, oracle_mod):
+    states = collect(oracle_mod)
+    assert len(states) >= 30
+    runs = 0
+    for label, cs in states:
+        for now in instants(cs):
+            snap = cs.build().snapshot   # fresh: run_full_parity stores the reconciled status into it
+            try:
+                run_full_parity(snap, oracle_mod, variant, now=now, nthreads=1)
+            except AssertionError as ex:
+                raise AssertionError(f"state {label} at {now}: {ex}") from ex
+            runs += 1
+    assert runs >= len(states)
+
+
+def test_host_plugin_extended_scenarios():
+    """The C++ plugin mirror's newer scenarios (tests/cpp/host_plugin_test.cpp `extended`): status write-back with
+    UpdateStatus change detection and canonical quantities, the pod Update / Delete handlers' reservation moves."""
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kube_throttler_amd", "host")
+    subprocess.check_call(["make", "-C", host, "host_plugin_test"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(host, "host_plugin_test"), "extended"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all expectations held" in r.stdout
+
+
+def test_state_without_pods(oracle_mod):
+    """A throttle with overrides and not a single pod in the cluster: every launch of the path has zero pod rows."""
+    from test_oracle_unit_tables import OVERRIDE1, THRESHOLD
+    from kube_throttler_amd.objects import ClusterState
+    from kube_throttler_amd.quantity import parse_rfc3339
+    cs = ClusterState()
+    cs.add_namespace("default")
+    cs.add({"kind": "Throttle", "metadata": {"name": "t", "namespace": "default"},
+            "spec": {"throttlerName": cs.throttler_name, "threshold": THRESHOLD, "temporaryThresholdOverrides": [OVERRIDE1],
+                     "selector": {"selectorTerms": [{"podSelector": {}}]}}})
+    snap = cs.build().snapshot
+    assert snap.n_pods == 0
+    _, _, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED, now=parse_rfc3339("2006-01-02T15:04:05Z"), nthreads=1)
+    assert rec.calc_updated[0] and not rec.used.has_count[0]
 
 
 def test_concurrent_callers(oracle_mod):
@@ -161,13 +171,3 @@ def test_concurrent_callers(oracle_mod):
         np.testing.assert_array_equal(sm_g, sm_w)
     finally:
         eng.close()
-
-
-def test_host_plugin_extended_scenarios():
-    """The C++ plugin mirror's newer scenarios (tests/cpp/host_plugin_test.cpp `extended`): status write-back with
-    UpdateStatus change detection and canonical quantities, the pod Update / Delete handlers' reservation moves."""
-    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kube_throttler_amd", "host")
-    subprocess.check_call(["make", "-C", host, "host_plugin_test"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([os.path.join(host, "host_plugin_test"), "extended"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "all expectations held" in r.stdout
