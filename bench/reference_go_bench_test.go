@@ -7,6 +7,7 @@
 //   ClusterThrottleSelector.MatchesToPod     (clusterthrottle_selector.go:44)
 //   Throttle.CheckThrottledFor               (throttle_types.go:128)
 //   ClusterThrottle.CheckThrottledFor        (clusterthrottle_types.go:30)
+//   ResourceAmountOfPod / ResourceAmount.Add / ResourceAmount.IsThrottled   (resource_amount.go:71,91,127)
 //
 // Usage: copy this file to <kube-throttler checkout>/bench/ and run
 //     go test -run xxx -bench PreFilter -benchtime 10x ./bench/
@@ -183,4 +184,66 @@ func BenchmarkPreFilter(b *testing.B) {
 	decisions := float64(b.N) * float64(nPods) * float64(nThr)
 	b.ReportMetric(decisions/b.Elapsed().Seconds(), "decisions/s")
 	_ = blocked
+}
+
+// BenchmarkReconcile: one iteration = the aggregation half of reconcile for every throttle (throttle_controller.go:116-133,
+// clusterthrottle_controller.go:119-136): scan the pods in scope, match, fold ResourceAmountOfPod with ResourceAmount.Add,
+// then IsThrottled(used, true).  Reported as pod x throttle pairs per second (P_counted x T), the unit of the engine's
+// aggregation rate.
+func BenchmarkReconcile(b *testing.B) {
+	nPods, nThr := envInt("KT_PODS", 20000), envInt("KT_THROTTLES", 1000)
+	pods := makePods(nPods)
+	for i, p := range pods { // 60 % bound and running, like the synthetic snapshots
+		if i%5 < 3 {
+			p.Spec.NodeName = "node-1"
+			p.Status.Phase = corev1.PodRunning
+		}
+	}
+	byNs, cluster, namespaces := makeThrottles(nThr)
+	podsByNs := map[string][]*corev1.Pod{}
+	counted := 0
+	for _, p := range pods {
+		if p.Spec.NodeName != "" {
+			podsByNs[p.Namespace] = append(podsByNs[p.Namespace], p)
+			counted++
+		}
+	}
+	throttled := 0
+	b.ResetTimer()
+	for it := 0; it < b.N; it++ {
+		for ns := range byNs {
+			for i := range byNs[ns] {
+				thr := &byNs[ns][i]
+				used := v1alpha1.ResourceAmount{}
+				for _, p := range podsByNs[ns] {
+					if ok, err := thr.Spec.Selector.MatchesToPod(p); err == nil && ok {
+						used = used.Add(v1alpha1.ResourceAmountOfPod(p))
+					}
+				}
+				if thr.Spec.Threshold.IsThrottled(used, true).ResourceCounts.Pod {
+					throttled++
+				}
+			}
+		}
+		for i := range cluster {
+			thr := &cluster[i]
+			used := v1alpha1.ResourceAmount{}
+			for nsName, ns := range namespaces {
+				if ok, err := thr.Spec.Selector.MatchesToNamespace(ns); err != nil || !ok {
+					continue
+				}
+				for _, p := range podsByNs[nsName] {
+					if ok, err := thr.Spec.Selector.MatchesToPod(p, ns); err == nil && ok {
+						used = used.Add(v1alpha1.ResourceAmountOfPod(p))
+					}
+				}
+			}
+			if thr.Spec.Threshold.IsThrottled(used, true).ResourceCounts.Pod {
+				throttled++
+			}
+		}
+	}
+	b.StopTimer()
+	b.ReportMetric(float64(b.N)*float64(counted)*float64(nThr)/b.Elapsed().Seconds(), "pairs/s")
+	_ = throttled
 }
