@@ -277,6 +277,11 @@ bool valid_label_key(const std::string& k) {
   return valid_name_part(k.substr(slash + 1));
 }
 bool valid_label_value(const std::string& v) { return v.empty() || valid_name_part(v); }
+}  // namespace
+// exported for the CPU cross-check against the Python restatement (objects.py)
+bool ValidLabelKey(const std::string& k) { return valid_label_key(k); }
+bool ValidLabelValue(const std::string& v) { return valid_label_value(v); }
+namespace {
 
 template <class K>
 struct RowTable {  // key -> dense row with a free list

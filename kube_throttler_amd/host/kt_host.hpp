@@ -47,6 +47,11 @@ inline void AddQuantity(Quantity* q, const Quantity& y) {
 bool ScaledValue(const Quantity& q, int scale, int64_t* out);
 std::string FormatDecimalSI(const Quantity& q);
 
+// k8s.io/apimachinery validation.IsQualifiedName / IsValidLabelValue (restated): what makes
+// LabelSelectorAsSelector fail on a key or a value.
+bool ValidLabelKey(const std::string& key);
+bool ValidLabelValue(const std::string& value);
+
 // Go time.Parse(time.RFC3339, text) -> (unix seconds, nanoseconds).
 bool ParseRFC3339(const std::string& text, int64_t* sec, int32_t* nsec, std::string* err);
 

@@ -2,6 +2,7 @@
 // the independent Python implementations (kube_throttler_amd/quantity.py).
 //   kt_host_tool quantity <text>...   -> "<nano value> <DecimalSI text> <canonical text in its own format>" or "error: ..."
 //   kt_host_tool time <rfc3339>...    -> "<sec> <nsec>" or "error: ..."
+//   kt_host_tool label <text>...      -> "<valid as label key 0/1> <valid as label value 0/1>"
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -25,6 +26,8 @@ int main(int argc, char** argv) {
       kth::Quantity q;
       if (kth::ParseQuantity(argv[i], &q, &err)) printf("%s %s %s\n", i128(q.nano).c_str(), kth::FormatDecimalSI(q).c_str(), kth::FormatQuantity(q).c_str());
       else printf("error: %s\n", err.c_str());
+    } else if (!strcmp(argv[1], "label")) {
+      printf("%d %d\n", kth::ValidLabelKey(argv[i]) ? 1 : 0, kth::ValidLabelValue(argv[i]) ? 1 : 0);
     } else {
       int64_t s;
       int32_t ns;

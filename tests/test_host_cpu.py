@@ -157,3 +157,29 @@ def test_index_builder_against_cpu_scan_replay(tool):
     out = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "all expectations held" in out.stdout
+
+
+def test_label_key_value_validation(tool):
+    """What makes LabelSelectorAsSelector fail on a key / value (validation.IsQualifiedName, IsValidLabelValue of
+    apimachinery v0.26.4, restated — parity unpinned: no reference test feeds a malformed label): known answers, and the
+    C++ mirror agrees with the Python translation layer on all of them."""
+    from kube_throttler_amd.objects import _valid_label_key, _valid_label_value
+    x63, x64 = "x" * 63, "x" * 64
+    dns253 = ".".join(["a" * 61] * 4) + "." + "b" * 5          # 4*61 + 4 dots + 5 = 253
+    cases = {   # text: (valid key, valid value)
+        "app": (1, 1), "a": (1, 1), "A": (1, 1), "a.b": (1, 1), "a-b_c.d": (1, 1), "1": (1, 1), x63: (1, 1),
+        "example.com/name": (1, 0), "k8s.io/a": (1, 0), "a.b.c/x-y": (1, 0), "kubernetes.io/metadata.name": (1, 0),
+        dns253 + "/n": (1, 0), "a-b.c/n": (1, 0),
+        "-a": (0, 0), "a-": (0, 0), "_a": (0, 0), "a_": (0, 0), ".a": (0, 0), "a b": (0, 0), x64: (0, 0),
+        "a/b/c": (0, 0), "/name": (0, 0), "example.com/": (0, 0), "Example.com/name": (0, 0), "ex_ample.com/name": (0, 0),
+        "-a.com/n": (0, 0), "a-.com/n": (0, 0), "a..b/n": (0, 0), ".a.com/n": (0, 0), "a.com./n": (0, 0),
+        dns253 + "b/n": (0, 0), "a.com/" + x64: (0, 0), "a.com/-n": (0, 0),
+    }
+    texts = list(cases)
+    out = subprocess.check_output([tool, "label"] + texts).decode().splitlines()
+    assert len(out) == len(texts)
+    for text, line in zip(texts, out):
+        want = cases[text]
+        assert (int(_valid_label_key(text)), int(_valid_label_value(text))) == want, text
+        assert tuple(int(v) for v in line.split()) == want, (text, line)
+    assert _valid_label_value("") and not _valid_label_key("")     # the empty VALUE is fine, the empty key is not
