@@ -19,6 +19,9 @@
 using namespace kt;
 
 static int g_fail = 0;
+static long g_peel_steps = 0, g_peel_busy = 0;      // today's peel loop on the same full tiles
+static long g_decide_steps = 0, g_busy_lanes = 0;
+static long g_pair2_fail = 0;  // candidates that only fail their second matchLabels pair (what a second row family would never list)  // lane-parallel blueprint: decision steps and the lanes busy in them
 #define EXPECT(cond, ...)                                             \
   do {                                                                \
     if (!(cond)) {                                                    \
@@ -216,6 +219,148 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
   return out;
 }
 
+// ---- step count of TODAY's wave-level loop on a tile (kt_bitmap_scan.h: peel while any lane has a bit, else advance
+//      all lanes): only the control flow, to put the blueprint's occupancy next to the current one on the same inputs
+static void count_current_steps(const HostIndex& ix, const std::vector<PodLabels>& tile, long* peel_steps, long* busy) {
+  for (const BmChunk& ch : ix.bm_chunks) {
+    const unsigned char* img = ix.bm_images.data() + ch.img_off;
+    const uint64_t* rows = (const uint64_t*)img;
+    const uint64_t* nsrows = (const uint64_t*)(img + ch.off_nsrows);
+    const uint32_t* nsw_off = (const uint32_t*)(img + ch.off_nsw_off);
+    const uint32_t* nsw = (const uint32_t*)(img + ch.off_nsw);
+    const size_t n = tile.size();
+    std::vector<uint32_t> k(n), k1(n);
+    std::vector<uint64_t> x(n, 0);
+    std::vector<std::vector<uint32_t>> prow(n);
+    for (size_t l = 0; l < n; ++l) {
+      prow[l].push_back(0);
+      for (uint32_t pr : tile[l].pairs) prow[l].push_back(row_of_atom(ix, pr));
+      if (ix.bm_has_key_rows)
+        for (uint32_t key : tile[l].keys) prow[l].push_back(row_of_atom(ix, kKeyAtom | key));
+      k[l] = nsw_off[tile[l].ns], k1[l] = nsw_off[tile[l].ns + 1];
+    }
+    for (;;) {
+      long has = 0;
+      for (size_t l = 0; l < n; ++l) has += x[l] != 0;
+      if (has) {
+        ++*peel_steps, *busy += has;
+        for (size_t l = 0; l < n; ++l) x[l] &= x[l] - 1;
+        continue;
+      }
+      bool adv = false;
+      for (size_t l = 0; l < n; ++l)
+        if (k[l] < k1[l]) {
+          const uint32_t w = nsw[k[l]++];
+          uint64_t xx = 0;
+          for (uint32_t r : prow[l]) xx |= rows[(size_t)r * ch.stride + w];
+          x[l] = xx & nsrows[(size_t)tile[l].ns * ch.stride + w];
+          adv = true;
+        }
+      if (!adv) break;
+    }
+  }
+}
+
+// ---- blueprint of the lane-parallel scan planned for dense programs (DESIGN.md 7, next lever 4), written the way a
+//      wave executes it: every "step" below is one pass over the 64 lanes, ballots are explicit masks.
+//   advance : a lane without candidate bits takes its next word (as today);
+//   expand  : every lane moves up to kQuota of its candidate bits into the wave's LDS list as (lane, term) entries;
+//             slots come from an exclusive prefix sum of the per-lane counts (no decisions, no dependent reads);
+//   decide  : whenever kListCap - 64 * kQuota entries are waiting (and at the end) the list is decided 64 entries at a
+//             time with lane = entry; a match of a multi-term throttle counts only if its bit in
+//             seen[pod lane][chunk-local throttle rank] was clear (LDS atomic OR returning the old word).
+static std::vector<std::map<uint32_t, int>> scan_tile_lane_parallel(const Program& p, const HostIndex& ix,
+                                                                   const std::vector<PodLabels>& tile, long* decide_steps,
+                                                                   long* busy_lanes) {
+  constexpr uint32_t kQuota = 4, kListCap = 512;
+  const size_t n = tile.size();  // <= 64
+  std::vector<std::map<uint32_t, int>> out(n);
+  struct Entry { uint32_t lane, c; };
+  for (const BmChunk& ch : ix.bm_chunks) {
+    const unsigned char* img = ix.bm_images.data() + ch.img_off;
+    const uint64_t* rows = (const uint64_t*)img;
+    const uint64_t* nsrows = (const uint64_t*)(img + ch.off_nsrows);
+    const uint32_t* nsw_off = (const uint32_t*)(img + ch.off_nsw_off);
+    const uint32_t* nsw = (const uint32_t*)(img + ch.off_nsw);
+    const TermRec* trec = (const TermRec*)(img + ch.off_trec);
+    const TermX* trecx = (const TermX*)(img + ch.off_trecx);
+    const uint32_t seen_words = (ch.n_thr + 63) / 64;
+    std::vector<uint64_t> seen((size_t)64 * (seen_words ? seen_words : 1), 0ull);  // cleared per tile and chunk
+    std::vector<std::vector<uint32_t>> prow(n);
+    std::vector<uint32_t> k(n), k1(n), w(n, 0);
+    std::vector<uint64_t> x(n, 0);
+    for (size_t l = 0; l < n; ++l) {
+      prow[l].push_back(0);
+      for (uint32_t pr : tile[l].pairs) prow[l].push_back(row_of_atom(ix, pr));
+      if (ix.bm_has_key_rows)
+        for (uint32_t key : tile[l].keys) prow[l].push_back(row_of_atom(ix, kKeyAtom | key));
+      k[l] = nsw_off[tile[l].ns], k1[l] = nsw_off[tile[l].ns + 1];
+    }
+    std::vector<Entry> list;
+    auto decide = [&]() {
+      for (size_t base = 0; base < list.size(); base += 64) {
+        ++*decide_steps;
+        // lane = entry: everything below is per-lane work on registers / LDS reads, one LDS atomic for kPostAdj matches
+        for (size_t e = base; e < std::min(list.size(), base + 64); ++e) {
+          ++*busy_lanes;
+          const PodLabels& pod = tile[list[e].lane];
+          const TermRec& tr = trec[list[e].c];
+          bool ok = !(tr.flags & kPostPair2) || pod.has_pair(tr.pair2);
+          g_pair2_fail += !ok;
+          if (ok && (tr.flags & kPostInline)) ok = extra_ok(trecx[list[e].c].e[0], pod) && extra_ok(trecx[list[e].c].e[1], pod);
+          if (ok && (tr.flags & kPostComplex)) ok = term_ok(p, tr.g, pod);
+          if (ok && (tr.flags & kPostAdj)) {
+            const uint32_t rank = tr.flags >> 8;
+            uint64_t& word = seen[(size_t)list[e].lane * seen_words + (rank >> 6)];
+            const uint64_t bit = 1ull << (rank & 63);
+            ok = !(word & bit);  // ds_or_rtn_b64: first match of this (pod, throttle) wins, whatever the order
+            word |= bit;
+          }
+          if (ok) {
+            EXPECT(!out[list[e].lane].count(tr.t), "throttle %u reported twice (lane-parallel)", tr.t);
+            out[list[e].lane][tr.t] = 1;
+          }
+        }
+      }
+      list.clear();
+    };
+    for (;;) {
+      // advance
+      bool any = false;
+      for (size_t l = 0; l < n; ++l) {
+        if (x[l] == 0 && k[l] < k1[l]) {
+          w[l] = nsw[k[l]++];
+          uint64_t xx = 0;
+          for (uint32_t r : prow[l]) xx |= rows[(size_t)r * ch.stride + w[l]];
+          x[l] = xx & nsrows[(size_t)tile[l].ns * ch.stride + w[l]];
+        }
+        any |= x[l] != 0 || k[l] < k1[l];
+      }
+      if (!any) break;
+      // expand: per-lane counts -> exclusive prefix sum -> entries in (lane-major, ascending term) order
+      uint32_t cnt[64] = {0}, pre[64] = {0}, total = 0;
+      for (size_t l = 0; l < n; ++l) cnt[l] = std::min<uint32_t>((uint32_t)__builtin_popcountll(x[l]), kQuota);
+      for (size_t l = 0; l < n; ++l) pre[l] = total, total += cnt[l];
+      const size_t at = list.size();
+      list.resize(at + total);
+      for (size_t l = 0; l < n; ++l)
+        for (uint32_t q = 0; q < cnt[l]; ++q) {
+          list[at + pre[l] + q] = Entry{(uint32_t)l, w[l] * 64 + (uint32_t)__builtin_ctzll(x[l])};
+          x[l] &= x[l] - 1;
+        }
+      EXPECT(list.size() <= kListCap, "list overflow %zu", list.size());
+      if (list.size() > kListCap - 64 * kQuota) decide();
+    }
+    decide();
+  }
+  for (size_t l = 0; l < n; ++l)
+    for (uint32_t t : ix.slow_thr) {
+      const int r = brute(p, t, tile[l]);
+      if (r) out[l][t] = r;
+    }
+  return out;
+}
+
 static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
   uint32_t w = 0, rank = 0;
   const size_t bucket_bytes = ix.bm_buckets.size() * sizeof(AtomBucket);
@@ -274,6 +419,20 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
               [&](uint32_t t) { return p.thr[t]; }, n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes);
   check_structure(p, ix, agg_budget, chk_budget, thr_bytes);
   long matches = 0;
+  std::vector<PodLabels> tile;
+  auto flush_tile = [&]() {
+    if (tile.empty()) return;
+    const auto got = scan_tile_lane_parallel(p, ix, tile, &g_decide_steps, &g_busy_lanes);
+    if (tile.size() == 64) count_current_steps(ix, tile, &g_peel_steps, &g_peel_busy);
+    for (size_t l = 0; l < tile.size(); ++l)
+      for (uint32_t t = 0; t < T; ++t) {
+        const int want = brute(p, t, tile[l]);
+        const auto it = got[l].find(t);
+        EXPECT((it == got[l].end() ? 0 : it->second) == want, "seed %u throttle %u: lane-parallel scan says %d, program says %d",
+               seed, t, it == got[l].end() ? 0 : it->second, want);
+      }
+    tile.clear();
+  };
   for (int i = 0; i < n_pods; ++i) {
     PodLabels pod;
     pod.ns = rng() % n_ns;
@@ -287,11 +446,86 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
       EXPECT(have == want, "seed %u pod %d throttle %u: index says %d, program says %d", seed, i, t, have, want);
       matches += want == 1;
     }
+    tile.push_back(pod);
+    if (tile.size() == 64) flush_tile();
   }
+  flush_tile();
   return (long)ix.bm_chunks.size() * 1000000L + matches % 1000000L;
 }
 
-int main() {
+// ---- file mode: the REAL selector program of a BASELINE config + a pod sample (tools/dump_program.py)
+static std::vector<uint32_t> read_array(FILE* fh) {
+  uint32_t n = 0;
+  if (fread(&n, 4, 1, fh) != 1) return {};
+  std::vector<uint32_t> v(n);
+  if (n && fread(v.data(), 4, n, fh) != n) v.clear();
+  return v;
+}
+static int run_file(const char* path) {
+  FILE* fh = fopen(path, "rb");
+  if (!fh) { fprintf(stderr, "cannot open %s\n", path); return 2; }
+  const std::vector<uint32_t> hdr = read_array(fh);
+  Program p;
+  p.thr_term_off = read_array(fh);
+  p.term_thr = read_array(fh);
+  for (uint32_t f : read_array(fh)) p.term_flags.push_back((uint8_t)f);
+  p.term_req_off = read_array(fh);
+  for (uint32_t o : read_array(fh)) p.req_op.push_back((uint8_t)o);
+  p.req_key = read_array(fh);
+  p.req_val_off = read_array(fh);
+  p.req_val = read_array(fh);
+  const std::vector<uint32_t> live = read_array(fh), cluster = read_array(fh), thr_ns = read_array(fh);
+  p.ns_term_ok = read_array(fh);
+  const std::vector<uint32_t> pod_ns = read_array(fh), loff = read_array(fh), lkey = read_array(fh), lpair = read_array(fh);
+  fclose(fh);
+  const uint32_t T = hdr[0], NS = hdr[2], D = hdr[5];
+  p.n_ns = NS, p.gw = hdr[3];
+  for (uint32_t t = 0; t < T; ++t) p.thr.push_back(ThrInfo{live[t] != 0, cluster[t] != 0, thr_ns[t]});
+  HostIndex ix;
+  const uint32_t thr_bytes = 8 * D + 8;
+  build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+              [&](uint32_t t) { return p.thr[t]; }, NS, p.ns_term_ok, p.gw, 160u * 1024u - aggregate_fixed_lds(),
+              160u * 1024u - check_fixed_lds(), thr_bytes);
+  check_structure(p, ix, 160u * 1024u - aggregate_fixed_lds(), 160u * 1024u - check_fixed_lds(), thr_bytes);
+  std::vector<PodLabels> tile;
+  long cand = 0, matches = 0, pods = 0;
+  for (size_t i = 0; i < pod_ns.size(); ++i) {
+    PodLabels pod;
+    pod.ns = pod_ns[i];
+    for (uint32_t j = loff[i]; j < loff[i + 1]; ++j) pod.keys.push_back(lkey[j]), pod.pairs.push_back(lpair[j]);
+    tile.push_back(pod);
+    if (tile.size() < 64) continue;
+    const auto got = scan_tile_lane_parallel(p, ix, tile, &g_decide_steps, &g_busy_lanes);
+    count_current_steps(ix, tile, &g_peel_steps, &g_peel_busy);
+    for (size_t l = 0; l < 64; ++l) {
+      if (pods % 16 == 0) {  // brute force (T x terms per pod) on a sample; the per-pod replay on the same pods
+        const auto one = scan(p, ix, tile[l]);
+        for (uint32_t t = 0; t < T; ++t) {
+          const int want = brute(p, t, tile[l]);
+          const auto a = got[l].find(t), b = one.find(t);
+          EXPECT((a == got[l].end() ? 0 : a->second) == want && (b == one.end() ? 0 : b->second) == want, "pod %ld throttle %u", pods, t);
+        }
+      }
+      matches += (long)got[l].size();
+      ++pods;
+    }
+    tile.clear();
+  }
+  cand = g_busy_lanes;
+  printf("%s: %u throttles, %zu terms, %u namespaces -> %zu chunks (max image %u B, max %u throttles per chunk), %zu slow\n", path, T,
+         p.term_thr.size(), NS, ix.bm_chunks.size(), ix.bm_max_img, ix.bm_max_thr, ix.slow_thr.size());
+  printf("  %ld pods: %.1f candidate terms and %.1f matches per pod (%.1f candidates per pod fail only their second matchLabels pair)\n", pods,
+         (double)cand / (double)pods, (double)matches / (double)pods, (double)g_pair2_fail / (double)pods);
+  printf("  today's peel loop      : %8ld steps per 64-pod tile x chunk walk, %5.1f %% of lanes busy\n", g_peel_steps,
+         100.0 * (double)g_peel_busy / (64.0 * (double)g_peel_steps));
+  printf("  lane-parallel blueprint: %8ld decision steps,                    %5.1f %% of lanes busy  (%.1fx fewer steps)\n", g_decide_steps,
+         100.0 * (double)g_busy_lanes / (64.0 * (double)g_decide_steps), (double)g_peel_steps / (double)g_decide_steps);
+  if (g_fail) fprintf(stderr, "%d expectation(s) failed\n", g_fail);
+  return g_fail ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) return run_file(argv[1]);
   long chunks_seen = 0, matches = 0;
   auto acc = [&](long r) { chunks_seen = std::max(chunks_seen, r / 1000000L), matches += r % 1000000L; };
   for (uint32_t seed = 1; seed <= 40; ++seed) {
@@ -311,6 +545,8 @@ int main() {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;
   }
-  printf("index_sim_test: all expectations held (max %ld chunks, %ld matches)\n", chunks_seen, matches);
+  printf("index_sim_test: all expectations held (max %ld chunks, %ld matches; lane-parallel blueprint: %ld decision steps at %.0f %% lane occupancy, today's peel loop: %ld steps at %.0f %%)\n",
+         chunks_seen, matches, g_decide_steps, g_decide_steps ? 100.0 * (double)g_busy_lanes / (64.0 * (double)g_decide_steps) : 0.0,
+         g_peel_steps, g_peel_steps ? 100.0 * (double)g_peel_busy / (64.0 * (double)g_peel_steps) : 0.0);
   return 0;
 }

@@ -183,3 +183,20 @@ def test_label_key_value_validation(tool):
         assert (int(_valid_label_key(text)), int(_valid_label_value(text))) == want, text
         assert tuple(int(v) for v in line.split()) == want, (text, line)
     assert _valid_label_value("") and not _valid_label_key("")     # the empty VALUE is fine, the empty key is not
+
+
+def test_scan_replay_on_the_headline_program(tool, tmp_path):
+    """The CPU scan replay on the REAL selector program of BASELINE configs[2] (1k throttles) with a pod sample
+    (tools/dump_program.py -> index_sim_test <file>): the index is one chunk, every sampled pod's matches equal brute
+    force, and the replay reports the step counts behind DESIGN.md's next levers."""
+    import re
+    import sys
+    subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
+    dump = tmp_path / "cfg2.bin"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "2", "--pods", "2048", str(dump)],
+                          stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "1000 throttles, 1000 terms" in out.stdout and "-> 1 chunks" in out.stdout
+    cand, matches = (float(x) for x in re.search(r"([\d.]+) candidate terms and ([\d.]+) matches per pod", out.stdout).groups())
+    assert 1.0 < matches <= cand < 10.0
