@@ -21,7 +21,8 @@ using namespace kt;
 static int g_fail = 0;
 static long g_peel_steps = 0, g_peel_busy = 0;      // today's peel loop on the same full tiles
 static long g_decide_steps = 0, g_busy_lanes = 0;
-static long g_pair2_fail = 0;  // candidates that only fail their second matchLabels pair (what a second row family would never list)  // lane-parallel blueprint: decision steps and the lanes busy in them
+static long g_pair2_fail = 0;
+static long g_expand_steps = 0, g_adv_today = 0;  // advance/expand rounds of the blueprint; advance rounds of today's loop  // candidates that only fail their second matchLabels pair (what a second row family would never list)  // lane-parallel blueprint: decision steps and the lanes busy in them
 #define EXPECT(cond, ...)                                             \
   do {                                                                \
     if (!(cond)) {                                                    \
@@ -257,6 +258,7 @@ static void count_current_steps(const HostIndex& ix, const std::vector<PodLabels
           adv = true;
         }
       if (!adv) break;
+      ++g_adv_today;
     }
   }
 }
@@ -337,6 +339,7 @@ static std::vector<std::map<uint32_t, int>> scan_tile_lane_parallel(const Progra
         any |= x[l] != 0 || k[l] < k1[l];
       }
       if (!any) break;
+      ++g_expand_steps;
       // expand: per-lane counts -> exclusive prefix sum -> entries in (lane-major, ascending term) order
       uint32_t cnt[64] = {0}, pre[64] = {0}, total = 0;
       for (size_t l = 0; l < n; ++l) cnt[l] = std::min<uint32_t>((uint32_t)__builtin_popcountll(x[l]), kQuota);
@@ -520,6 +523,8 @@ static int run_file(const char* path) {
          100.0 * (double)g_peel_busy / (64.0 * (double)g_peel_steps));
   printf("  lane-parallel blueprint: %8ld decision steps,                    %5.1f %% of lanes busy  (%.1fx fewer steps)\n", g_decide_steps,
          100.0 * (double)g_busy_lanes / (64.0 * (double)g_decide_steps), (double)g_peel_steps / (double)g_decide_steps);
+  printf("  rounds without decisions : today %ld advance rounds, blueprint %ld advance+expand rounds (up to 4 candidates per lane each)\n",
+         g_adv_today, g_expand_steps);
   if (g_fail) fprintf(stderr, "%d expectation(s) failed\n", g_fail);
   return g_fail ? 1 : 0;
 }
