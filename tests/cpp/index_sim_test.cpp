@@ -517,6 +517,27 @@ static int run_file(const char* path) {
   cand = g_busy_lanes;
   printf("%s: %u throttles, %zu terms, %u namespaces -> %zu chunks (max image %u B, max %u throttles per chunk), %zu slow\n", path, T,
          p.term_thr.size(), NS, ix.bm_chunks.size(), ix.bm_max_img, ix.bm_max_thr, ix.slow_thr.size());
+  {  // what the LDS image is made of, and which decision shapes the program has
+    long n_pair2 = 0, n_inline = 0, n_complex = 0, n_plain = 0, n_adj = 0;
+    for (const BmChunk& ch : ix.bm_chunks) {
+      const TermRec* trec = (const TermRec*)(ix.bm_images.data() + ch.img_off + ch.off_trec);
+      const uint64_t* rows = (const uint64_t*)(ix.bm_images.data() + ch.img_off);
+      for (uint32_t c = 0; c < ch.n_words * 64; ++c) {
+        bool real = false;
+        for (uint32_t r = 0; r < ix.bm_rows && !real; ++r) real = (rows[(size_t)r * ch.stride + (c >> 6)] >> (c & 63)) & 1ull;
+        if (!real) continue;
+        const uint32_t f = trec[c].flags;
+        n_pair2 += (f & kPostPair2) != 0, n_inline += (f & kPostInline) != 0, n_complex += (f & kPostComplex) != 0;
+        n_plain += !(f & (kPostPair2 | kPostInline | kPostComplex)), n_adj += (f & kPostAdj) != 0;
+      }
+    }
+    const BmChunk& c0 = ix.bm_chunks[0];
+    printf("  term shapes: %ld anchor only, %ld + second pair, %ld + inline extras (TermX), %ld generic walk; %ld in multi-term throttles\n",
+           n_plain, n_pair2, n_inline, n_complex, n_adj);
+    printf("  image of chunk 0 (%u B): rows %u B, nsrows %u B, word lists %u B, TermRec %u B, TermX %u B; atom buckets %zu B, %u rows\n",
+           c0.img_bytes, c0.off_nsrows, c0.off_nsw_off - c0.off_nsrows, c0.off_trec - c0.off_nsw_off, c0.off_trecx - c0.off_trec,
+           c0.img_bytes - c0.off_trecx, ix.bm_buckets.size() * sizeof(AtomBucket), ix.bm_rows);
+  }
   printf("  %ld pods: %.1f candidate terms and %.1f matches per pod (%.1f candidates per pod fail only their second matchLabels pair)\n", pods,
          (double)cand / (double)pods, (double)matches / (double)pods, (double)g_pair2_fail / (double)pods);
   printf("  today's peel loop      : %8ld steps per 64-pod tile x chunk walk, %5.1f %% of lanes busy\n", g_peel_steps,
