@@ -228,7 +228,11 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         const size_t nw = cand - w0;
         const size_t img = ((nw | 1) * ((size_t)R + n_ns)) * 8 + nw * (per_word - (size_t)R * 8 - (size_t)n_ns * 8) +
                            ((size_t)n_ns + 1) * 4 + (size_t)n_ns * nw * 4 + 256;
-        const bool fits = img <= chk_room && img + (size_t)nthr * thr_bytes + 16 <= agg_room;
+        // the kernels lay LDS out ONCE for all chunks — the largest image next to the table of the largest throttle
+        // count — so a chunk has to fit together with the maxima of the chunks cut before it, not only on its own
+        const size_t img_hi = std::max(img, (size_t)out.bm_max_img);
+        const size_t thr_hi = std::max((size_t)nthr, (size_t)out.bm_max_thr);
+        const bool fits = img_hi <= chk_room && img_hi + thr_hi * thr_bytes + 16 <= agg_room;
         if (!fits && w1 != 0) break;
         if (cand == W || splittable[cand]) {
           w1 = cand;

@@ -403,6 +403,15 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
     EXPECT(ch.img_bytes <= ix.bm_max_img && ch.n_thr <= ix.bm_max_thr, "chunk %zu maxima", i);
     w += ch.n_words;
   }
+  // the launchers size LDS from the LARGEST image and the LARGEST throttle count of any chunk (kt_kernels_aggregate.hip
+  // make_bm_agg_args): the pair of maxima has to fit too, or the engine refuses the program
+  bool all_fit = true;
+  for (const BmChunk& ch : ix.bm_chunks)
+    all_fit &= bucket_bytes + ch.img_bytes <= chk_budget && bucket_bytes + ch.img_bytes + (size_t)ch.n_thr * thr_bytes + 16 <= agg_budget;
+  if (all_fit)
+    EXPECT(bucket_bytes + ix.bm_max_img + (size_t)ix.bm_max_thr * thr_bytes + 16 <= agg_budget,
+           "largest image %u B + table of the largest chunk (%u throttles) = %zu B exceed the aggregate budget %u B", ix.bm_max_img,
+           ix.bm_max_thr, bucket_bytes + ix.bm_max_img + (size_t)ix.bm_max_thr * thr_bytes + 16, agg_budget);
   EXPECT(w == ix.bm_words, "chunks cover %u of %u words", w, ix.bm_words);
   EXPECT(rank == ix.bm_rank_t.size(), "ranks cover %u of %zu", rank, ix.bm_rank_t.size());
   for (uint32_t t : ix.bm_rank_t) {
