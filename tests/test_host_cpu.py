@@ -200,3 +200,20 @@ def test_scan_replay_on_the_headline_program(tool, tmp_path):
     assert "1000 throttles, 1000 terms" in out.stdout and "-> 1 chunks" in out.stdout
     cand, matches = (float(x) for x in re.search(r"([\d.]+) candidate terms and ([\d.]+) matches per pod", out.stdout).groups())
     assert 1.0 < matches <= cand < 10.0
+
+
+def test_scan_replay_on_the_10k_throttle_program(tool, tmp_path):
+    """Same replay on the program of BASELINE configs[4] (10k throttles, ~30k multi-requirement terms, 256 namespaces):
+    dozens of LDS-sized chunks at the real budgets, the launchers' LDS sizing holds, sampled pods match brute force."""
+    import re
+    import sys
+    subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
+    dump = tmp_path / "cfg4.bin"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "4", "--pods", "512", str(dump)],
+                          stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    chunks = int(re.search(r"-> (\d+) chunks", out.stdout).group(1))
+    assert "10000 throttles" in out.stdout and 20 <= chunks <= 80
+    cand, matches = (float(x) for x in re.search(r"([\d.]+) candidate terms and ([\d.]+) matches per pod", out.stdout).groups())
+    assert 50.0 < matches <= cand < 500.0
