@@ -12,6 +12,11 @@ constexpr int64_t kInf = INT64_MAX;
 // pod_flags word in HBM: bits 0-3 = KT_POD_* state, bits 16-31 = request-key presence mask.
 constexpr uint32_t kPodValid = 0x1u, kPodSchedMatch = 0x2u, kPodScheduled = 0x4u, kPodFinished = 0x8u;
 constexpr int kPresentShift = 16;
+// pod meta word (PodTable::meta), the one 8-byte record the indexed scans read per pod besides its atom row:
+//   bits 0-26 namespace row | 27 kMetaOverflow | 28-31 KT_POD_* state | 32-47 request-key presence | 48-63 non-zero mask
+constexpr uint64_t kMetaNsMask = 0x07FFFFFFull;
+constexpr uint64_t kMetaOverflow = 1ull << 27;  // more relevant atoms than the atom row holds: decided by the dense path
+constexpr int kMetaStateShift = 28, kMetaPresentShift = 32, kMetaNzShift = 48;
 
 constexpr uint32_t kThrValid = 0x1u, kThrCluster = 0x2u, kThrResponsible = 0x4u, kThrCalcAtNonzero = 0x8u,
                    kThrThrottledPod = 0x10u;
@@ -31,12 +36,16 @@ struct PodTable {
   int64_t* req;     // [cap][DS]  effective request (ResourceAmountOfPod), 0 where absent
   uint32_t* lpair;  // [cap][LS]  (key,value) pair ids, 0 = empty slot
   uint32_t* lkey;   // [cap][LS]  key ids
+  uint64_t* meta;   // [cap]      ns | state | presence | non-zero mask (kMeta*): what the indexed scans stream
+  uint16_t* latom;  // [cap][LA]  ids of the pod's REFERENCED label atoms (kt_index.h), 0 = empty slot; rewritten by
+                    //            kt_translate_pods whenever the selector program changes
   int64_t cap;
   int32_t D, L;
-  int32_t DS, LS;   // row strides: DS = D rounded up to even, LS = 4 / 8 / 16 >= L
+  int32_t DS, LS;   // row strides: DS = D rounded up to even, LS = 4 / 8 / 16 / 32 / 64 >= L
+  int32_t LA;       // atom slots per pod (8 / 16 / 32), chosen per selector program
 };
 inline int req_stride(int D) { return (D + 1) & ~1; }
-inline int label_stride(int L) { return L <= 4 ? 4 : L <= 8 ? 8 : 16; }
+inline int label_stride(int L) { return L <= 4 ? 4 : L <= 8 ? 8 : L <= 16 ? 16 : L <= 32 ? 32 : 64; }
 
 // ResourceAmount rows, row-major [n][D] like kt_amounts.
 struct AmountTab {
@@ -102,6 +111,13 @@ struct ReconcileOut {
 // so that CheckThrottledFor's steps 1 and 4 become  nz(pod,d) && pod[d] > thr[d] / head[d]
 // and steps 2+3 collapse into one bitmask (see DESIGN.md "Check algebra").
 constexpr uint32_t kRecExceedsByCount = 0x1u, kRecActiveByCount = 0x2u, kRecInsufficientByCount = 0x4u;
+// kRecTight: SOME pod of this engine could exceed thr[] / head[] in some dimension (judged against the per-dimension
+// upper bound of all effective requests, ReqBound).  Without it the verdict of a matched pod follows from the count
+// flags and (non-zero mask & active_mask) alone: neither its request row nor thr[] / head[] has to be read.
+constexpr uint32_t kRecTight = 0x8u;
+struct ReqBound {
+  int64_t v[16];  // >= every pod's effective request per dimension (host-maintained; INT64_MAX = unknown)
+};
 // thr[] and head[] of a throttle share one 128-byte line at DT = 8 (the (match, dimension) lanes of the check
 // kernels gather them as 16-byte pieces); {flags, active_mask} is ALSO kept as a compact array behind the
 // records (rec_flags()), small enough to be staged in LDS.

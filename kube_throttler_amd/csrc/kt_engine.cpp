@@ -140,6 +140,9 @@ struct kt_engine {
   kt::PodTable pods{};
   int64_t pod_rows_hi = 0;             // 1 + highest row ever upserted
   unsigned __int128 max_abs[KT_MAX_DIMS] = {0};  // max |effective request| bound per dimension
+  DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
+  DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
+  unsigned long long n_overflow = 0;
 
   // ---- host mirrors of the small tables
   std::vector<HostNamespace> ns;
@@ -195,6 +198,7 @@ struct kt_engine {
   DevBuf<uint8_t> d_status;
   DevBuf<int64_t> d_rows;
   int64_t check_n = 0;
+  int32_t check_T = 0, reconcile_T = 0;  // throttle rows in effect when the last check / reconcile was launched
   bool check_has_status = false;
   bool check_ready = false;
   hipStream_t last_stream = nullptr;
@@ -483,28 +487,45 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_out_thrl_has.reserve(T + 1));
   KT_HIP(e, e->d_recs.reserve(kt::recs_bytes((int)T)));
   // index for the work ~ (pods + matches) kernels
-  kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val,
-                  [&](uint32_t t) {
-                    const HostThrottle& h = e->thr[t];
-                    const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
-                    kt::ThrInfo ti;
-                    ti.live = (h.flags & need) == need;
-                    ti.cluster = (h.flags & KT_THR_CLUSTER) != 0;
-                    ti.ns = h.ns;
-                    return ti;
-                  },
-                  (uint32_t)NS, ns_term_ok, gw,
-                  // KT_CHUNK_BUDGET (bytes): test hook that forces small chunks so that tiny programs exercise the
-                  // multi-chunk path too
-                  getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::aggregate_fixed_lds(),
-                  getenv("KT_CHUNK_BUDGET") ? (uint32_t)atoi(getenv("KT_CHUNK_BUDGET")) : 160u * 1024u - kt::check_fixed_lds(),
-                  (uint32_t)(e->incremental ? 12 * D + 4 : 8 * D + 8));
+  {
+    auto thr_info = [&](uint32_t t) {
+      const HostThrottle& h = e->thr[t];
+      const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
+      kt::ThrInfo ti;
+      ti.live = (h.flags & need) == need;
+      ti.cluster = (h.flags & KT_THR_CLUSTER) != 0;
+      ti.ns = h.ns;
+      return ti;
+    };
+    // KT_CHUNK_BUDGET (bytes): test hook that forces small chunks so that tiny programs exercise the multi-chunk path too
+    const char* hook = getenv("KT_CHUNK_BUDGET");
+    const uint32_t lds_all = 160u * 1024u;
+    const uint32_t agg_budget = hook ? (uint32_t)atoi(hook) : lds_all - kt::aggregate_fixed_lds();
+    const uint32_t thr_bytes = (uint32_t)(e->incremental ? 12 * D + 4 : 8 * D + 8);
+    // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
+    // for one workgroup per CU (fewer, larger chunks)
+    const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();
+    kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
+                    (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L);
+    if (!hook && e->hindex.bm_chunks.size() > 1)
+      kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
+                      (uint32_t)NS, ns_term_ok, gw, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, e->L);
+  }
   e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
     hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
     if (he != hipSuccess) return e->fail(KT_ERR_DEVICE, "upload_index: %s", hipGetErrorString(he));
   }
+  // the pods' labels as atom ids of THIS program (labels no selector mentions drop out here)
+  e->pods.LA = (int32_t)e->hindex.la;
+  KT_HIP(e, e->d_latom.reserve((size_t)e->cfg.pod_capacity * (size_t)e->pods.LA + 64));
+  e->pods.latom = e->d_latom.p;
+  KT_HIP(e, e->d_overflow.reserve(1));
+  KT_HIP(e, hipMemsetAsync(e->d_overflow.p, 0, 8, s));
+  kt::launch_translate_pods(e->pods, e->pod_rows_hi, nullptr, 0, e->dindex, e->d_overflow.p, s);
+  KT_HIP(e, hipGetLastError());
+  KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
   e->sp.thr_term_off = e->d_thr_term_off.p;
   e->sp.term_thr = e->d_term_thr.p;
@@ -576,6 +597,14 @@ void amount_to_table(const HostAmount& h, const kt_amounts& a, size_t i, int D) 
 }
 
 constexpr unsigned __int128 kSumBound = (unsigned __int128)1 << 60;
+
+// upper bound of every pod's effective request per dimension, for kRecTight (kt_device.h)
+kt::ReqBound req_bound(const kt_engine* e) {
+  kt::ReqBound b;
+  for (int d = 0; d < 16; ++d)
+    b.v[d] = d < e->D ? (e->max_abs[d] > (unsigned __int128)INT64_MAX ? INT64_MAX : (int64_t)e->max_abs[d]) : 0;
+  return b;
+}
 inline unsigned __int128 uabs(int64_t x) { return x < 0 ? (unsigned __int128)(-(__int128)x) : (unsigned __int128)x; }
 
 bool amount_in_bound(const HostAmount& a, int D) {
@@ -656,7 +685,13 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   if (r == hipSuccess) r = hipMalloc((void**)&e->pods.req, cap * 8 * e->pods.DS);
   if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lpair, cap * 4 * e->pods.LS);
   if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lkey, cap * 4 * e->pods.LS);
+  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.meta, cap * 8);
+  e->pods.LA = 8;
   if (r == hipSuccess) r = hipMemsetAsync(e->pods.flags, 0, cap * 4, e->own_stream);
+  if (r == hipSuccess) r = hipMemsetAsync(e->pods.meta, 0, cap * 8, e->own_stream);
+  // rows that were never upserted are read by kt_translate_pods: empty label slots
+  if (r == hipSuccess) r = hipMemsetAsync(e->pods.lpair, 0, cap * 4 * e->pods.LS, e->own_stream);
+  if (r == hipSuccess) r = hipMemsetAsync(e->pods.lkey, 0, cap * 4 * e->pods.LS, e->own_stream);
   if (r == hipSuccess) r = hipStreamSynchronize(e->own_stream);
   if (r != hipSuccess) {
     g_create_error = std::string("device setup failed: ") + hipGetErrorString(r);
@@ -678,6 +713,9 @@ int32_t kt_engine_destroy(kt_engine* e) {
   if (e->pods.req) (void)hipFree(e->pods.req);
   if (e->pods.lpair) (void)hipFree(e->pods.lpair);
   if (e->pods.lkey) (void)hipFree(e->pods.lkey);
+  if (e->pods.meta) (void)hipFree(e->pods.meta);
+  e->d_latom.release();
+  e->d_overflow.release();
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
@@ -772,7 +810,10 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       return e->fail(KT_ERR_OVERFLOW_RISK,
                      "dimension %d: max |request| x pod_capacity exceeds 2^60; use a coarser scale for it", d);
   }
-  for (int d = 0; d < D; ++d) e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
+  for (int d = 0; d < D; ++d) {
+    if (batch_max[d] > e->max_abs[d]) e->recs_valid = false;  // kRecTight was judged against the old bound
+    e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
+  }
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
   const int64_t chunk = 1 << 20;
@@ -827,6 +868,11 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     if (drc != KT_OK) return drc;
     kt::launch_ingest_pods(e->pods, pb, s);
     KT_HIP(e, hipGetLastError());
+    if (!e->program_dirty && e->pods.latom) {  // atom rows of the new content (a dirty program translates every row when compiled)
+      kt::launch_translate_pods(e->pods, cn, pb.rows, pb.row0, e->dindex, e->d_overflow.p, s);
+      KT_HIP(e, hipGetLastError());
+      KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
+    }
     if ((drc = delta_scan(e, cn, pb.rows, pb.row0, +1, s)) != KT_OK) return drc;
     KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
   }
@@ -872,6 +918,13 @@ static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const
       return e->fail(KT_ERR_OUT_OF_RANGE, "throttle %d: namespace id %u", i, b->thr_ns[i]);
   }
   if (b->n_thr <= 0) return KT_OK;
+  for (int32_t i = 0; i < b->n_thr; ++i) {  // the whole batch is validated before the first row is stored
+    HostAmount u, r;
+    amount_from_table(b->thr_used, (size_t)i, D, u);
+    amount_from_table(b->thr_reserved, (size_t)i, D, r);
+    if (!amount_in_bound(u, D) || !amount_in_bound(r, D))
+      return e->fail(KT_ERR_OVERFLOW_RISK, "throttle %d: status.used / reserved beyond 2^60", i);
+  }
   int32_t rc = sync_status_to_host(e);
   if (rc != KT_OK) return rc;
   for (int32_t i = 0; i < b->n_thr; ++i) {
@@ -882,8 +935,6 @@ static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const
     amount_from_table(b->thr_calc, (size_t)i, D, h.calc);
     amount_from_table(b->thr_used, (size_t)i, D, h.used);
     amount_from_table(b->thr_reserved, (size_t)i, D, h.reserved);
-    if (!amount_in_bound(h.used, D) || !amount_in_bound(h.reserved, D))
-      return e->fail(KT_ERR_OVERFLOW_RISK, "throttle %d: status.used / reserved beyond 2^60", i);
     h.thrl_flag = b->thr_thrl_flag[i] & ((1u << D) - 1u);
     h.thrl_has = b->thr_thrl_has[i] & ((1u << D) - 1u);
     h.status_fp = b->thr_status_msgs_fp[i];
@@ -911,6 +962,8 @@ static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const
   }
   e->program_dirty = true;
   e->status_host_dirty = true;
+  // results of earlier launches describe the old throttle set (and its row count): not fetchable any more
+  e->reconcile_ready = e->check_ready = false;
   return KT_OK;
 }
 
@@ -933,6 +986,7 @@ int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* rows) {
   for (int32_t i = 0; i < n; ++i) e->thr[(size_t)rows[i]] = HostThrottle();
   e->program_dirty = true;
   e->status_host_dirty = true;
+  e->reconcile_ready = e->check_ready = false;
   return KT_OK;
 }
 
@@ -945,6 +999,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   // clear
   KT_HIP(e, hipMemsetAsync(e->pods.flags, 0, (size_t)e->cfg.pod_capacity * 4, e->own_stream));
+  KT_HIP(e, hipMemsetAsync(e->pods.meta, 0, (size_t)e->cfg.pod_capacity * 8, e->own_stream));
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   e->pod_rows_hi = 0;
   for (auto& m : e->max_abs) m = 0;
@@ -1046,7 +1101,9 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     else {
       kt::AggScan sc;
       sc.n = e->pod_rows_hi, sc.counts = e->incremental;
-      const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->partial(), e->d_slab.p, s, after_scan);
+      if (e->n_overflow)
+        return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
+      const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
       e->last_kernel[KT_KERNEL_AGGREGATE] = k;
     }
@@ -1068,7 +1125,7 @@ static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int6
   if (!e->incremental || !e->agg_valid || n <= 0 || e->thr_rows_hi == 0) return KT_OK;
   kt::AggScan sc;
   sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign;
-  const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->uses_keys, e->d_agg.p, e->d_slab.p, s, nullptr);
+  const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->d_agg.p, e->d_slab.p, s, nullptr);
   if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget");
   KT_HIP(e, hipGetLastError());
   return KT_OK;
@@ -1086,7 +1143,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
     kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
-                        e->recs_eq, s);
+                        e->recs_eq, req_bound(e), s);
   }
   KT_HIP(e, hipGetLastError());
   if (apply) {
@@ -1095,6 +1152,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
     e->recs_DT = rec_DT;
   }
   e->reconcile_ready = true;
+  e->reconcile_T = e->thr_rows_hi;
   e->last_stream = s;
   return KT_OK;
 }
@@ -1149,7 +1207,7 @@ int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
   std::lock_guard<std::mutex> lk(e->mu);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch before a reconcile launch");
-  if (n < 0 || n > e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows=%d", n, e->thr_rows_hi);
+  if (n < 0 || n > e->reconcile_T) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows of the last reconcile=%d", n, e->reconcile_T);
   hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
   const size_t N = (size_t)n;
   const int D = e->D;
@@ -1180,7 +1238,7 @@ int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_
   std::lock_guard<std::mutex> lk(e->mu);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch_next_override before a reconcile launch");
-  if (n < 0 || n > e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows=%d", n, e->thr_rows_hi);
+  if (n < 0 || n > e->reconcile_T) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows of the last reconcile=%d", n, e->reconcile_T);
   hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
   if (n) {
     KT_HIP(e, hipMemcpyAsync(next_s, e->d_out_next_s.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
@@ -1227,7 +1285,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   // changed since they were last built (by kt_prepare_check or by kt_finalize with APPLY)
   if (!(e->recs_valid && e->recs_eq == (on_equal != 0) && e->recs_DT == DT)) {
     TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
-    kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, s);
+    kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, req_bound(e), s);
     e->recs_valid = true;
     e->recs_eq = on_equal != 0;
     e->recs_DT = DT;
@@ -1239,7 +1297,9 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
-      const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex, e->uses_keys,
+      if (e->n_overflow)
+        return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
+      const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
                                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
@@ -1247,6 +1307,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   }
   KT_HIP(e, hipGetLastError());
   e->check_n = n;
+  e->check_T = e->thr_rows_hi;
   e->check_has_status = want_status;
   e->check_ready = true;
   e->last_stream = s;
@@ -1323,8 +1384,8 @@ static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary
   if (out_status && !e->check_has_status) return e->fail(KT_ERR_NOT_READY, "status matrix was not requested at launch");
   hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
   if (n && out_summary) KT_HIP(e, hipMemcpyAsync(out_summary, e->d_summary.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-  if (n && out_status && e->thr_rows_hi)
-    KT_HIP(e, hipMemcpyAsync(out_status, e->d_status.p, (size_t)n * (size_t)e->thr_rows_hi, hipMemcpyDeviceToHost, s));
+  if (n && out_status && e->check_T)  // the matrix was written with the row stride in effect at launch
+    KT_HIP(e, hipMemcpyAsync(out_status, e->d_status.p, (size_t)n * (size_t)e->check_T, hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));
   return KT_OK;
 }

@@ -1,20 +1,35 @@
-// kt_index.h — inverted index from label atoms to selector terms, so that the pod x throttle scans do
-// work proportional to (pods + candidate terms) instead of P x T.
+// kt_index.h — the selector side of all throttles compiled into EXACT term bitmaps over label atoms, so that the
+// pod x throttle scans do work proportional to (pods + matches) instead of P x T, with no per-candidate decisions.
 //
-// Every term of a live throttle (valid, responsible, no unconvertible podSelector) is filed under ONE
-// anchor requirement:
-//   In{key, values}  -> under every (key,value) pair id of the set            (atom = pair id)
-//   Exists{key}      -> under the key                                         (atom = 0x80000000 | key id)
-// A pod carries at most one value per key, so a matching term is reached through exactly one of the
-// pod's labels.  Terms with no positive requirement (empty selector, only NotIn/DoesNotExist) are filed under
-// row 0 ("every pod"); throttles that contain an unconvertible podSelector term go to a "slow" list and are
-// walked term by term in order (error semantics of throttle_selector.go:30-42 depend on term order).
+// Atoms.  Every (key,value) pair id that occurs in an In / NotIn requirement and every key that occurs in an
+// Exists / DoesNotExist requirement (atom = kKeyAtom | key id) of an indexed term is a *referenced atom* and gets a
+// dense 16-bit id (1..A; 0 = "nothing").  Pod labels are translated to these ids once per program change / ingest
+// (kt_translate_pods: PodTable::latom) — labels no selector mentions cannot influence any decision and are dropped
+// there, which is also what lifts the label-count cap of the scan kernels.
+//
+// Terms.  Every term of a live throttle (valid, responsible, no unconvertible podSelector) gets a number c; terms with
+// the same namespace-admission set (a "class") are numbered contiguously — throttles ordered by the admission set of
+// their first term, the terms of a throttle kept together — and a class of <= 64 terms never straddles a 64-bit word.
+// Two bitmap families over c, one row per atom:
+//     any [a] : terms with a POSITIVE requirement (In / Exists) that atom a satisfies
+//     veto[a] : terms with a NEGATIVE requirement (NotIn / DoesNotExist) that atom a violates
+// A pod carries at most one value per key, so it carries at most ONE atom of any requirement's atom set: the number
+// of rows of `any` in which a term's bit is met while OR-ing the pod's atom rows IS the number of its positive
+// requirements the pod satisfies.  With need(c) = number of positive requirements (0..3):
+//     match(pod)[w] = hits>=need (any / two / three accumulators, masks m2 m3) & ~OR veto & nsmask[ns][w]
+// is EXACT — no TermRec, no second-pair compare, no inline extras.  Terms outside that shape (more than three
+// positive requirements, or one atom in two positive requirements of the same term) keep only their anchor
+// requirement in `any` and are flagged in the word header's `slow` mask: their candidates are decided by the generic
+// requirement walk.  Throttles that contain an unconvertible podSelector term go to a "slow list" and are walked term
+// by term in order (error semantics of throttle_selector.go:30-42 depend on term order).
 // The namespace side of every term (implicit namespace equality of a Throttle, throttle_controller.go:249;
-// namespaceSelector of a ClusterThrottle) is pre-evaluated into SelProgram::ns_term_ok and enters as a bitmap.
+// namespaceSelector of a ClusterThrottle) is pre-evaluated into SelProgram::ns_term_ok and enters as per-namespace
+// (word, mask) lists.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -24,36 +39,11 @@ namespace kt {
 
 constexpr uint32_t kKeyAtom = 0x80000000u;
 
-// TermRec flags
-constexpr uint32_t kPostComplex = 0x1u;  // needs the generic requirement walk (term_match)
-constexpr uint32_t kPostPair2 = 0x10u;   // pod must also carry `pair2`
-
-// ---- bitmap form of the whole selector side ----------------------------------------------------------
-// Every indexed term gets a number c; terms with the same namespace-admission set (a "class") are numbered
-// contiguously — throttles ordered by the admission set of their first term, the terms of a throttle kept
-// together — and a class of <= 64 terms never straddles a 64-bit word (larger classes start on a word boundary;
-// unused numbers are padding), so a namespace only ever touches a few words of any bitmap:
-//     candidates(pod)[w] = (rows[0][w] | OR_l rows[row_of(label_l)][w]) & nsrows[ns][w]   for w in nswords[ns]
-// rows[0] = terms without a positive requirement, rows[1] = all zero (unknown atoms).  Atoms are found in
-// 4-entry buckets (branch-free probe).  TermRec carries what a visit needs.
-struct alignas(16) TermRec {
-  uint32_t g, t, pair2, flags;  // flags: kPost* in the low byte, the chunk-local throttle rank above
-};
-// Bitmap-form extras of a term (flag kPostInline): up to two requirements besides the anchor, small enough to be
-// decided from registers.  e[k] = {op (KT_OP_*; 0xFF = none), up to three atoms (pair ids for In / NotIn, the key id
-// for Exists / DoesNotExist; kNoAtom = unused)}.
-constexpr uint32_t kPostInline = 0x20u;  // TermX holds the remaining requirements
-constexpr uint32_t kPostAdj = 0x40u;     // multi-term throttle: a match repeating the lane's previous throttle is dropped
-constexpr uint32_t kNoAtom = 0xFFFFFFFFu;
-struct alignas(16) TermX {
-  uint32_t e[2][4];
-};
-struct alignas(16) AtomBucket {
-  uint32_t atom[4];  // 0 = empty
-  uint32_t row[4];
-};
-// bucket of an atom: multiplicative hash; the builder tries several odd multipliers per table size before doubling it
-__host__ __device__ inline uint32_t atom_bucket(uint32_t atom, uint32_t mask, uint32_t mult) { return ((atom * mult) >> 9) & mask; }
+// term_t[] entry of a chunk image: throttle row | flags
+constexpr uint32_t kTermAdj = 0x80000000u;   // multi-term throttle: a match repeating the lane's previous throttle is dropped
+constexpr uint32_t kTermReal = 0x40000000u;  // term number in use (not class padding)
+constexpr uint32_t kTermRowMask = 0x000FFFFFu;
+constexpr uint16_t kRankAdj = 0x8000u;       // term_rank[] entry: chunk-local throttle rank | kRankAdj
 
 struct ThrInfo {
   bool live;
@@ -61,34 +51,65 @@ struct ThrInfo {
   uint32_t ns;
 };
 
-// One LDS-sized slice of the bitmap form: 64-bit words [w0, w0 + n_words) of every row, with the TermRecs of those
-// term numbers and the per-namespace lists of words that can hold candidates.  The terms of a throttle never
-// straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers —
-// TermRec::flags carries the chunk-local rank in bits 8+.
+// per-word header of a chunk image
+struct alignas(16) WordHdr {
+  uint64_t univ;  // terms without a positive requirement (hit by every pod)
+  uint64_t m2;    // terms that need >= 2 positive hits
+  uint64_t m3;    // terms that need 3
+  uint64_t slow;  // candidates that the generic requirement walk has to confirm
+};
+// one entry of a namespace's word list
+struct alignas(16) NsWord {
+  uint32_t w, pad;
+  uint64_t mask;  // terms of word w whose namespace side admits the namespace
+};
+
+// One LDS-sized slice of the bitmap form: 64-bit words [w0, w0 + n_words) of every row.  The terms of a throttle never
+// straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers.
+// Image layout (all offsets relative to img_off, every section 16-byte aligned):
+//   [0, lds_bytes)        what the scan keeps in LDS:  rows | WordHdr[n_words] | nsl_off u32[n_ns+1] | NsWord[]
+//     rows: u64 [n_rows][stride]        (program without negative requirements)
+//           u64 [n_rows][stride][2]     {any, veto} interleaved (one 128-bit read per atom and word)
+//   off_term_t            u32 [n_words*64]  throttle row | kTerm*       (check: staged into LDS next to the CheckRec flags)
+//   off_term_rank         u16 [n_words*64]  chunk-local rank | kRankAdj  (aggregate)
+//   off_term_g            u32 [n_words*64]  selector-program term of the number (only read for `slow` candidates)
 struct BmChunk {
   uint32_t w0, n_words;
   uint32_t rank0, n_thr;
-  uint32_t img_off, img_bytes;  // image inside the blob (multiple of 16): rows first
-  uint32_t off_nsrows, off_nsw_off, off_nsw, off_trec, off_trecx;  // relative to the image
-  uint32_t stride;              // 64-bit words per row inside the image (odd: column reads spread over LDS banks)
-  uint32_t slab_off;            // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
-  uint32_t pad[3];
+  uint32_t img_off, lds_bytes;
+  uint32_t off_hdr, off_nsl_off, off_nsl;
+  uint32_t off_term_t, off_term_rank, off_term_g;
+  uint32_t stride;    // 64-bit words per row and family inside the image (odd: column reads spread over LDS banks)
+  uint32_t slab_off;  // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
+  uint32_t has_slow;  // some term of the chunk needs the generic walk
+  uint32_t img_bytes;
+};
+
+struct AtomId {
+  uint32_t atom, id;
 };
 
 struct HostIndex {
   std::vector<uint32_t> slow_thr;
   uint32_t bm_words = 0;  // W: 64-bit words per full bitmap row
-  uint32_t bm_rows = 0;
-  uint32_t bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u;
+  uint32_t bm_rows = 0;   // A + 1 (row 0 = no atom: all zero)
+  bool has_veto = false;  // some indexed term has a NotIn / DoesNotExist requirement
+  uint32_t max_need = 0;  // largest number of positive requirements of an exactly-indexed term (<= 3)
+  uint32_t n_pair_keys = 0, n_key_atoms = 0;  // distinct keys behind the referenced pair atoms / referenced key atoms
+  bool has_slow = false;  // some indexed term needs the generic walk
+  uint32_t la = 8;        // atom slots per pod the scan kernels are instantiated for (8 / 16 / 32)
+  bool rich = false;      // image in the {any, veto} form, kernels in the <VETO, NEED 3> instantiation
+  std::vector<AtomId> atoms;               // referenced atom -> id (1..A)
+  std::vector<uint64_t> atom_table;        // open-addressing table for the device: atom | id << 32, 0 = empty
   std::vector<BmChunk> bm_chunks;
-  std::vector<unsigned char> bm_images;  // chunk images back to back
-  std::vector<uint32_t> bm_rank_t;       // dense throttle rank (term order) -> throttle row
-  std::vector<AtomBucket> bm_buckets;
-  uint32_t bm_max_img = 0, bm_max_thr = 0;
+  std::vector<unsigned char> bm_images;    // chunk images back to back
+  std::vector<uint32_t> bm_rank_t;         // dense throttle rank (term order) -> throttle row
+  uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
-  bool bm_has_key_rows = false;  // some term is anchored on an Exists requirement
-  bool bm_has_inline = false;    // some term carries TermX
 };
+
+// slot of an atom in an open-addressing table of 2^k entries (linear probing)
+__host__ __device__ inline uint32_t atom_slot(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 7) & mask; }
 
 struct IndexDev {
   uint32_t* slow_thr = nullptr;
@@ -96,33 +117,43 @@ struct IndexDev {
   unsigned char* bm_blob = nullptr;  // chunk images
   BmChunk* bm_chunks = nullptr;
   uint32_t* bm_rank_t = nullptr;
-  AtomBucket* bm_buckets = nullptr;
+  uint64_t* atom_table = nullptr;
+  uint32_t atom_mask = 0;
   std::vector<BmChunk> h_chunks;     // host copy (launch planning)
-  uint32_t n_chunks = 0, bm_max_img = 0, bm_max_thr = 0, bm_bucket_bytes = 0;
+  uint32_t n_chunks = 0, bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0, bm_rows = 0;
   uint64_t bm_slab_bytes = 0;
-  uint32_t bm_bucket_mask = 0, bm_bucket_mult = 0x9E3779B1u, bm_has_key_rows = 0, bm_has_inline = 0;
-  size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_buckets = 0, cap_slow = 0;
+  uint32_t has_veto = 0, max_need = 0, n_atoms = 0, has_key_atoms = 0, la = 8;
+  bool rich = false;
+  size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_atom_table = 0, cap_slow = 0;
 };
 
-// agg_budget / chk_budget: LDS bytes left for (atom buckets + chunk image + table of the chunk's throttles, thr_bytes
-// each) in kt_aggregate_bitmap and for (atom buckets + chunk image) in kt_check_bitmap
+// LDS budgets: a chunk must satisfy
+//   check     : lds_bytes + n_words*64*8 (term info)                      <= chk_budget
+//   aggregate : lds_bytes + n_words*64*2 (ranks) + n_thr * thr_bytes      <= agg_budget
+// (both kernels lay LDS out once, for the maxima over all chunks, so the maxima have to fit too).
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
-                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
+                 const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
+                 int max_labels);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
+// translated atoms per pod the scan kernels are instantiated for, given the program and the label capacity L: a pod
+// carries at most min(L, keys behind referenced pairs) pair atoms and min(L, referenced key atoms) key atoms.
+// 8 / 16 / 32; pods that still carry more relevant atoms are flagged kMetaOverflow.
+inline uint32_t atom_slots(uint32_t n_pair_keys, uint32_t n_key_atoms, int L) {
+  const uint32_t ub = std::min<uint32_t>((uint32_t)L, n_pair_keys) + std::min<uint32_t>((uint32_t)L, n_key_atoms);
+  return ub <= 8 ? 8u : ub <= 16 ? 16u : 32u;
+}
+
 struct PodTable;
 struct SelProgram;
-// LDS the two scan kernels need beside the atom buckets, the chunk image and (aggregate) the chunk's table
+// LDS the two scan kernels need beside the chunk image and its per-term / per-throttle tables
 uint32_t aggregate_fixed_lds();
 uint32_t check_fixed_lds();
-// sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched.
-// after_scan (nullable) is invoked on the host right after the scan kernel is enqueued and before the slab
-// reduction kernel (if any) — the engine uses it to bracket the two kernels with separate timing events.
 // which pods an aggregate scan covers and how they enter the target buffer
 struct AggScan {
   int64_t n = 0;                 // pods
@@ -131,11 +162,18 @@ struct AggScan {
   bool counts = false;           // exact per-key pod counts (incremental engines) instead of presence masks
   int sign = 1;                  // -1: remove the scanned pods' contribution (delta scans)
 };
+// sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
+// does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued
+// and before the slab reduction kernel — the engine uses it to bracket the two kernels with separate timing events.
 const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& scan, const SelProgram& sp, const SelProgram* sp_dev,
-                              const IndexDev& ix, bool keys, unsigned long long* partial, void* slab, hipStream_t s,
+                              const IndexDev& ix, unsigned long long* partial, void* slab, hipStream_t s,
                               const std::function<void()>& after_scan = nullptr);
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
-                          const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
+                          const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s);
+// labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)
+// n_overflow (device counter): valid pods with more relevant atoms than PodTable::LA
+void launch_translate_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t row0, const IndexDev& ix,
+                           unsigned long long* n_overflow, hipStream_t s);
 
 }  // namespace kt

@@ -1,8 +1,9 @@
 // kt_kernels.hip — hand-written HIP kernels for gfx950 (CDNA4, wave64): pod ingest, per-throttle
 // finalize / check-record preparation, and the DENSE pod x throttle scans (reference loop shape).
-// The indexed (work ~ pods + matches) scans live in kt_kernels_index.hip.
+// The indexed (work ~ pods + matches) scans live in kt_kernels_check.hip / kt_kernels_aggregate.hip (kt_scan.h).
 //
 // Everything here is integer / compare work on row tables in HBM: no MFMA, no floating point.
+#include "kt_index.h"
 #include "kt_kernels_common.h"
 #include "kt_launch.h"
 
@@ -56,9 +57,15 @@ __global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatch
         if ((op >> d) & 1u) c[d] += b.ovh[i * D + d];
       cp |= op & 0xFFFFu;
     }
+    cp &= (1u << D) - 1u;
+    uint32_t nz = 0;
+    for (int d = 0; d < D; ++d) nz |= (((cp >> d) & 1u) && c[d] != 0 ? 1u : 0u) << d;
     for (int d = 0; d < pods.DS; ++d) pods.req[(int64_t)row * pods.DS + d] = (d < D && ((cp >> d) & 1u)) ? c[d] : 0;
     pods.ns[row] = b.ns[i];
     pods.flags[row] = (b.flags[i] & 0xFu) | (cp << kPresentShift);
+    // the record the indexed scans stream (kMeta*); the atom row follows from kt_translate_pods
+    pods.meta[row] = (uint64_t)(b.ns[i] & (uint32_t)kMetaNsMask) | (uint64_t)(b.flags[i] & 0xFu) << kMetaStateShift |
+                     (uint64_t)cp << kMetaPresentShift | (uint64_t)nz << kMetaNzShift;
     const uint32_t l0 = b.label_off[i] - b.label_base, l1 = b.label_off[i + 1] - b.label_base;
     for (int l = 0; l < pods.LS; ++l) {
       const bool have = l < L && l0 + l < l1;
@@ -69,8 +76,79 @@ __global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatch
 }
 
 __global__ __launch_bounds__(kBlock) void kt_delete_pods(PodTable pods, int64_t n, const int64_t* rows) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     pods.flags[rows[i]] = 0;
+    pods.meta[rows[i]] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_translate_pods — a pod's labels as the ids of the atoms the selector program REFERENCES (kt_index.h): every
+// (key,value) pair id and every key id is looked up in the index's open-addressing table; labels no selector mentions
+// are dropped.  Runs over all pods after a program change and over the ingested rows after an upsert.  One thread per
+// pod; the atom row is assembled in LDS and written with 16-byte stores.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t atom_id_of(const uint64_t* table, uint32_t mask, uint32_t atom) {
+  uint32_t s = atom_slot(atom, mask);
+  for (;;) {
+    const uint64_t e = table[s];
+    if (e == 0ull) return 0u;
+    if ((uint32_t)e == atom) return (uint32_t)(e >> 32);
+    s = (s + 1) & mask;
+  }
+}
+
+template <int LA>
+__global__ __launch_bounds__(kBlock) void kt_translate_pods(PodTable pods, int64_t n, const int64_t* rows, int64_t row0,
+                                                           const uint64_t* table, uint32_t mask, int key_atoms,
+                                                           unsigned long long* n_overflow) {
+  __shared__ __attribute__((aligned(16))) uint16_t out[kBlock][LA];
+  const int LS = pods.LS;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = i0 + threadIdx.x;
+    if (i < n) {
+      const int64_t row = rows ? rows[i] : row0 + i;
+      uint32_t cnt = 0;
+      for (int l = 0; l < LS; ++l) {
+        const uint32_t pr = pods.lpair[row * LS + l];
+        if (pr == 0u) continue;  // empty slot
+        uint32_t id = atom_id_of(table, mask, pr);
+        if (id) {
+          if (cnt < (uint32_t)LA) out[threadIdx.x][cnt] = (uint16_t)id;
+          ++cnt;
+        }
+        if (key_atoms) {
+          id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
+          if (id) {
+            if (cnt < (uint32_t)LA) out[threadIdx.x][cnt] = (uint16_t)id;
+            ++cnt;
+          }
+        }
+      }
+      for (uint32_t k = cnt; k < (uint32_t)LA; ++k) out[threadIdx.x][k] = 0;
+      const bool over = cnt > (uint32_t)LA;
+      const uint64_t m = pods.meta[row];
+      if (over) {
+        if ((m >> kMetaStateShift) & kPodValid) atomicAdd(n_overflow, 1ull);
+        pods.meta[row] = m | kMetaOverflow;
+      } else if (m & kMetaOverflow) {
+        pods.meta[row] = m & ~kMetaOverflow;
+      }
+      const kt_u32x4* src = (const kt_u32x4*)&out[threadIdx.x][0];
+      kt_u32x4* dst = (kt_u32x4*)(pods.latom + row * LA);
+#pragma unroll
+      for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
+    }
+  }
+}
+
+void launch_translate_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t row0, const IndexDev& ix,
+                           unsigned long long* n_overflow, hipStream_t s) {
+  if (n <= 0) return;
+  const dim3 g(grid_for(n)), b(kBlock);
+  if (pods.LA == 8) hipLaunchKernelGGL(kt_translate_pods<8>, g, b, 0, s, pods, n, rows_dev, row0, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow);
+  else if (pods.LA == 16) hipLaunchKernelGGL(kt_translate_pods<16>, g, b, 0, s, pods, n, rows_dev, row0, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow);
+  else hipLaunchKernelGGL(kt_translate_pods<32>, g, b, 0, s, pods, n, rows_dev, row0, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow);
 }
 
 __global__ __launch_bounds__(kBlock) void kt_gather_pod_requests(PodTable pods, int64_t n, const int64_t* rows,
@@ -197,7 +275,7 @@ __device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int 
                                                 uint32_t th_p, bool th_hc, int64_t th_c, const int64_t (&u_v)[DT], uint32_t u_p,
                                                 bool u_hc, int64_t u_c_, const int64_t (&r_v)[DT], uint32_t r_p, bool r_hc,
                                                 int64_t r_c_, uint32_t thrl_flag, uint32_t thrl_has, bool eq,
-                                                CheckRec<DT>* recs) {
+                                                const ReqBound& vmax, CheckRec<DT>* recs) {
   const int64_t u_c = u_hc ? u_c_ : 0, r_c = r_hc ? r_c_ : 0;
   const bool eq3 = (fl & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
   CheckRec<DT> rec;
@@ -224,6 +302,9 @@ __device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int 
     }
     rec.thr[d] = thr;
     rec.head[d] = head;
+    // could ANY pod of this engine exceed the threshold in this dimension — or the headroom, where that can still
+    // change the verdict (a pod that requests an already-active dimension is `active` whatever the headroom says)
+    if (d < D && (vmax.v[d] > thr || (!act_pod && !((act_mask >> d) & 1u) && vmax.v[d] > head))) f |= kRecTight;
   }
   if (act_pod) f |= kRecActiveByCount;
   rec.flags = f;
@@ -234,7 +315,8 @@ __device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int 
 
 // the CheckRec of throttle t from the status as stored in the tables
 template <int DT>
-__device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int t, int T, int D, bool eq, CheckRec<DT>* recs) {
+__device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int t, int T, int D, bool eq, const ReqBound& vmax,
+                                                       CheckRec<DT>* recs) {
   const uint32_t fl = tt.flags[t];
   // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
   const AmountTab& th = (fl & kThrCalcAtNonzero) ? tt.calc : tt.spec;
@@ -247,13 +329,13 @@ __device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int 
   }
   build_check_rec<DT>(tt, t, T, D, fl, th_v, th.present[t], th.has_count[t] != 0, th.count[t], u_v, tt.used.present[t],
                       tt.used.has_count[t] != 0, tt.used.count[t], r_v, tt.reserved.present[t],
-                      tt.reserved.has_count[t] != 0, tt.reserved.count[t], tt.thrl_flag[t], tt.thrl_has[t], eq, recs);
+                      tt.reserved.has_count[t] != 0, tt.reserved.count[t], tt.thrl_flag[t], tt.thrl_has[t], eq, vmax, recs);
 }
 
 template <int DT>
 __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
                                                      int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
-                                                     CheckRec<DT>* recs, int rec_eq) {
+                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax) {
   // recs (nullable): also leave the CheckRec of every throttle for the check that follows (kt_prepare_check fused in:
   // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -296,7 +378,7 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
     out.error[t] = error ? 1 : 0;
     out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
     out.next_ns[t] = 0;
-    if (recs) build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, recs);
+    if (recs) build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, vmax, recs);
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
@@ -420,24 +502,24 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
       }
       _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d >= D) u_v[d] = 0;
       build_check_rec<DT>(tt, t, T, D, nf, th_v, th_p, th_hc, th_c, u_v, u_p, u_hc, u_c, r_v, r_p, r_hc, r_c, th_flag, c_p,
-                          rec_eq != 0, recs);
+                          rec_eq != 0, vmax, recs);
     }
   } else if (recs) {
-    build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, recs);
+    build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, vmax, recs);
   }
 }
 
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     hipStream_t s) {
+                     const ReqBound& vmax, hipStream_t s) {
   if (sp.T <= 0) return;
   // one wave per 64 throttles (T is small: spread over as many CUs as possible; everything is latency)
   const dim3 g((sp.T + 63) / 64), b(64);
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
   const int eq = rec_eq ? 1 : 0;
-  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq);
-  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq);
-  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq);
+  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax);
+  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -445,18 +527,18 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const uns
 // the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts).
 // ---------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs) {
+__global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs, const ReqBound vmax) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
-  build_check_rec_stored<DT>(tt, t, T, D, on_equal != 0, recs);
+  build_check_rec_stored<DT>(tt, t, T, D, on_equal != 0, vmax, recs);
 }
 
-void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s) {
+void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s) {
   if (T <= 0) return;
   dim3 g((T + 63) / 64), b(64);
-  if (DT == 4) hipLaunchKernelGGL(kt_prepare_check<4>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<4>*)recs);
-  else if (DT == 8) hipLaunchKernelGGL(kt_prepare_check<8>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<8>*)recs);
-  else hipLaunchKernelGGL(kt_prepare_check<16>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<16>*)recs);
+  if (DT == 4) hipLaunchKernelGGL(kt_prepare_check<4>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<4>*)recs, vmax);
+  else if (DT == 8) hipLaunchKernelGGL(kt_prepare_check<8>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<8>*)recs, vmax);
+  else hipLaunchKernelGGL(kt_prepare_check<16>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<16>*)recs, vmax);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,31 +1,35 @@
-// kt_kernels_check.hip — kt_check_bitmap: PreFilter for n pods through the bitmap form of the selector index (gfx950).
-#include "kt_bitmap_scan.h"
+// kt_kernels_check.hip — kt_check_bitmap: PreFilter for n pods through the exact term bitmaps of the selector index (gfx950).
+#include "kt_scan.h"
 
 namespace kt {
 
 // ---------------------------------------------------------------------------------------------------
-// kt_check_bitmap — PreFilter for n pods (plugin.go:148-215): CheckThrottled of both controllers through the
-// bitmap form of the selector index (kt_index.h), LDS-resident when it fits (LDSIX; the small-T regime: up to a
-// few thousand terms), else read through L2.
-// WAVE-AUTONOMOUS: after the one-time staging of the tables, every wave walks its own 64-pod tiles and
-// never meets a workgroup barrier again — all of a tile's state (class counters, match list, request
-// rows) belongs to the wave that owns the 64 pods.
-//   phase 1, lane = pod: the pod's record arrives as 128-bit row loads (2 for 8 labels, 4 for 8 request
-//            dimensions) issued back to back; bitmap_scan_tile (kt_bitmap_scan.h) turns it into the
-//            tile's dense match list.
-//   phase 2, lane = (match, dimension pair): CheckThrottledFor through the CheckRec algebra; the pod's
-//            request row comes from the wave's LDS tile, thr[] / head[] as 16-byte pieces from L2.
-//   phase 3, lane = pod: the 8-byte summary word.
+// kt_check_bitmap — PreFilter for n pods (plugin.go:148-215): CheckThrottled of both controllers
+// (throttle_controller.go:349-397, clusterthrottle_controller.go:378-425) + CheckThrottledFor
+// (throttle_types.go:128-153, clusterthrottle_types.go:30-55) through the CheckRec algebra.
+// WAVE-AUTONOMOUS: after a chunk of the index is staged, every wave walks its own 64-pod tiles and never meets a
+// workgroup barrier until the next chunk — all of a tile's state belongs to the wave that owns the 64 pods.
+//   lane = pod : the pod's record arrives as one 8-byte meta word + its atom row (LA/8 128-bit loads); scan_tile
+//                (kt_scan.h) yields the pod's matched terms.  The term's throttle and the pod-independent part of its
+//                verdict sit in one 8-byte LDS word (TermInfo, staged per chunk from the CheckRec flags): unless the
+//                throttle is `tight` (kRecTight: some pod could exceed thr[] / head[]) the status follows from it and
+//                the pod's non-zero mask — no request row, no threshold read — and is counted in the lane's registers.
+//   lane = (tight match) : the few matches that need the comparison are listed per wave and drained with
+//                lane = match: request row + thr[] / head[] gathered as 16-byte pieces, verdict back to the pod's
+//                counters through LDS.
+//   lane = pod : the 8-byte summary word.
 // ---------------------------------------------------------------------------------------------------
 
-// Everything the kernel needs, and nothing else: a compact argument block keeps the scalar register file
-// free of the (large) generic table descriptors, which are reached through `sp` only on rare paths.
-constexpr uint32_t kListCap = 256;  // match-list entries per wave (1 KB)
+constexpr uint32_t kListCap = 128;  // tight-match list entries per wave (512 B)
+// TermInfo word 0: throttle row | kTiAdj | CheckRec flags << 24 ; word 1: active_mask
+constexpr uint32_t kTiAdj = 0x00100000u;
+constexpr int kTiFlagShift = 24;
+
 struct BmCheckArgs {
-  const uint32_t* ns;  // pod tables
-  const uint32_t* flags;
+  const uint64_t* meta;  // pod tables
+  const uint16_t* latom;
   const int64_t* req;
-  const uint32_t* lpair;
+  const uint32_t* lpair;  // raw labels: slow paths only
   const uint32_t* lkey;
   const int64_t* rows;
   const void* recs;
@@ -36,16 +40,16 @@ struct BmCheckArgs {
   const uint32_t* slow_thr;
   int64_t n;
   BmIndexArgs ix;
-  uint32_t off_cnt, off_list, off_req, off_rflags;
+  uint32_t off_cnt, off_list, off_tinfo;
   uint32_t n_slow;
   int32_t DS, LS, T;
 };
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
                                       const SelProgram* sp_dev, const IndexDev& ix, const void* recs,
-                                      uint64_t* summary, uint8_t* status, bool one_chunk, uint32_t* total) {
+                                      uint64_t* summary, uint8_t* status, uint32_t* total) {
   BmCheckArgs a{};
-  a.ns = pods.ns, a.flags = pods.flags, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
+  a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
   a.sp = sp_dev, a.ns_valid = sp.ns_valid, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow;
   a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
@@ -53,190 +57,206 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
   a.off_list = take((kBlockIx / kWave) * kListCap * 4);
-  a.off_req = take(kBlockIx * 4);
-  a.off_rflags = one_chunk ? take((uint32_t)sp.T * 8) : 0u;  // several chunks: the flags are read through L2
+  a.off_tinfo = take(ix.bm_max_words * 64u * 8u);
   plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
 }
 
-// OR over the LPM consecutive lanes of a match group (LPM = 4 or 8): data-parallel primitives, no LDS traffic
-template <int LPM>
-__device__ __forceinline__ uint32_t group_or(uint32_t v) {
-  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-  v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-  if (LPM == 8) v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
-  return v;
-}
+uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
 
-// ONE: the whole program is one chunk (the small-T regime): throttle flags live in LDS and the summary is written
-// once.  Otherwise the kernel walks the chunks: chunk image in, every tile of the workgroup scanned against it, the
-// per-pod class counters carried from chunk to chunk in the summary words (finished by the last chunk).
-template <int DT, int LT, bool KEYS, bool ONE>
-__global__ __launch_bounds__(kBlockIx) void kt_check_bitmap(const BmCheckArgs a) {
+// WPE: waves per SIMD the register allocation has to leave room for (4: one workgroup per CU, 8: two)
+template <int DT, int LA, bool VETO, int NEED, int WPE>
+__global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
-  lds_stage16((KT_LDS u32x4*)(lds + a.ix.lds_buckets), a.ix.buckets, a.ix.bucket_bytes / 16u);
-  if (ONE) {  // {flags, active_mask} of every throttle: 8 bytes each, rewritten by every kt_prepare_check
-    KT_LDS u32x2* dst = (KT_LDS u32x2*)(lds + a.off_rflags);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)a.T; i += kBlockIx) dst[i] = g_rflags[i];
-  }
-  const KT_LDS u32x2* l_rflags = (const KT_LDS u32x2*)(lds + a.off_rflags);
   const int64_t n = a.n;
   const int DS = a.DS;
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   // this wave's private LDS areas
-  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;         // [64] class counters
-  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;    // match list
-  lds_u32wp prow = (lds_u32wp)(lds + a.off_req) + wave * kWave;       // [64] pod table rows of the tile
-  // phase-2 lane mapping: LPM lanes per match, two dimensions each
-  constexpr int LPM = DT / 2, MPW = kWave / LPM;
-  const uint32_t dp = lane % LPM, ml = lane / LPM;
-  const bool dp_in = (int)(2 * dp) < DS;
-  const uint32_t dpo = dp_in ? 2 * dp : 0u;
+  lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;       // [64] class counters coming back from the drain
+  lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;  // tight matches: lane << 20 | throttle row
+  KT_LDS u32x2* tinfo = (KT_LDS u32x2*)(lds + a.off_tinfo);
   const int64_t n_wtiles = (n + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
-
-  // A tile's selector-side records: 2 + LT/4 (+ LT/4) 128-bit loads per lane, issued back to back and always from
-  // valid addresses (lanes past the end re-read the last pod and are switched off by `on`).  The request rows are
-  // gathered by phase 2, for matched pods only.  (Loading tiles a round ahead, or touching the request rows early,
-  // measurably does not help: the 16 waves of a CU already overlap each other's memory phases, and early touches
-  // are evicted from L2 before they are used.)
-  struct Tile {
-    uint32_t fl, ns, p;
-    uint32_t lp[LT], lk[LT];
-  };
-  auto load_tile = [&](int64_t wt, Tile& t) {
-    const int64_t i = min(wt * kWave + lane, n - 1);
-    const int64_t p = a.rows ? a.rows[i] : i;
-    t.p = (uint32_t)p;  // pod_capacity <= 2^31
-    t.fl = a.flags[p];
-    t.ns = a.ns[p];
-    load_labels<LT, KEYS>(a.lpair, a.lkey, a.LS, p, t.lp, t.lk);
-  };
-  const uint32_t n_chunks = ONE ? 1u : a.ix.n_chunks;
+  const uint32_t n_chunks = a.ix.n_chunks;
   for (uint32_t ci = 0; ci < n_chunks; ++ci) {
-  const bool first = ci == 0, last = ci + 1 == n_chunks;
-  __syncthreads();  // nobody reads the previous image any more
-  const BmView bm = open_chunk(lds, a.ix, a.ix.chunks[ci]);
-  __syncthreads();
-  int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-  for (; wt < n_wtiles; wt += wstep) {
-    Tile cur;
-    load_tile(wt, cur);
-    // ---- phase 1: lane = pod
-    const int64_t i = wt * kWave + lane;
-    const bool in = i < n;
-    // class counters so far (bit 1 = error) ride in the summary word between chunks
-    const unsigned long long carried =
-        (!ONE && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    cnt[lane] = carried & ~3ull;
-    prow[lane] = cur.p;
-    const bool on = in && (cur.fl & kPodValid) != 0;
-    const uint32_t ns = on ? cur.ns : 0u;
-    // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
-    bool pod_err = (carried & 2ull) != 0 || (on & (a.ns_valid[ns] == 0));
-
-    auto drain = [&](uint32_t n_items) {
-      // ---- phase 2: lane = (match, dimension pair); operands are fetched one step ahead of their use
-      struct Ops {
-        uint32_t vv, pl, tt;
-        u32x2 fa;
-        kt_i64x2 xx, th, hd;
-      };
-      auto fetch = [&](uint32_t base, Ops& o) {
-        const uint32_t j = base + ml;
-        o.vv = j < n_items ? 1u : 0u;
-        const uint32_t e = list[o.vv ? j : 0u];
-        o.pl = e >> 20;
-        o.tt = e & 0xFFFFFu;
-        const CheckRec<DT>* rc = recs + o.tt;
-        o.th = *(const kt_i64x2*)(rc->thr + 2 * dp);
-        o.hd = *(const kt_i64x2*)(rc->head + 2 * dp);
-        o.fa = ONE ? l_rflags[o.tt] : g_rflags[o.tt];  // {flags, active_mask}
-        o.xx = *(const kt_i64x2*)(a.req + (uint64_t)prow[o.pl] * (uint32_t)DS + dpo);
-      };
-      Ops c;
-      fetch(0, c);
-      for (uint32_t base = 0; base < n_items; base += MPW) {
-        Ops nx;
-        fetch(base + MPW, nx);
-        const bool live = c.vv && dp_in;
-        const bool nz0 = live && c.xx.x != 0, nz1 = live && c.xx.y != 0;
-        const uint32_t am = c.fa.y >> (2 * dp);
-        uint32_t bits = ((nz0 && c.xx.x > c.th.x) || (nz1 && c.xx.y > c.th.y)) ? 1u : 0u;  // exceeds
-        bits |= ((nz0 && (am & 1u)) || (nz1 && (am & 2u))) ? 2u : 0u;                       // active
-        bits |= ((nz0 && c.xx.x > c.hd.x) || (nz1 && c.xx.y > c.hd.y)) ? 4u : 0u;          // insufficient
-        bits = group_or<LPM>(bits);
-        const uint32_t ff = c.fa.x;
-        const bool exc = (ff & kRecExceedsByCount) || (bits & 1u);
-        const bool act = (ff & kRecActiveByCount) || (bits & 2u);
-        const bool ins = (ff & kRecInsufficientByCount) || (bits & 4u);
-        const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
-        if (dp == 0 && c.vv) {
-          if (st != 1u) lds_add64(cnt + c.pl, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-          if (a.status) a.status[(wt * kWave + c.pl) * a.T + c.tt] = (uint8_t)st;
+    const bool first = ci == 0, last = ci + 1 == n_chunks;
+    const BmChunk ch = a.ix.chunks[ci];
+    __syncthreads();  // nobody reads the previous image any more
+    const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
+    {  // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
+      const uint32_t* term_t = (const uint32_t*)(a.ix.blob + ch.img_off + ch.off_term_t);
+      for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx) {
+        const uint32_t tt = term_t[c];
+        u32x2 ti = {0u, 0u};
+        if (tt & kTermReal) {
+          const uint32_t t = tt & kTermRowMask;
+          const u32x2 rf = g_rflags[t];  // {flags, active_mask}
+          ti.x = t | ((tt & kTermAdj) ? kTiAdj : 0u) | rf.x << kTiFlagShift;
+          ti.y = rf.y;
         }
-        c = nx;
+        tinfo[c] = ti;
       }
-    };
-    // throttles with unconvertible selectors are walked once, with the first chunk
-    bitmap_scan_tile<LT, KEYS, kListCap, false>(bm, a.sp, a.slow_thr, first ? a.n_slow : 0u, on, on, ns, cur.lp, cur.lk,
-                                                list, lane, drain, [&](uint32_t) { pod_err = true; }, [](uint32_t) {});
-    // ---- phase 3: lane = pod
-    if (in) {
-      const unsigned long long c = cnt[lane];
-      if (last) {
-        a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
-        if (a.status && pod_err)
-          for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
-      } else {
-        a.summary[i] = c | (pod_err ? 2ull : 0ull);
+    }
+    __syncthreads();
+    int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+    for (; wt < n_wtiles; wt += wstep) {
+      // ---- the tile's records: always from valid addresses (lanes past the end re-read the last pod and are
+      //      switched off by `on`)
+      const int64_t i = wt * kWave + lane;
+      const bool in = i < n;
+      const int64_t ic = min(i, n - 1);
+      const int64_t p = a.rows ? a.rows[ic] : ic;
+      const uint64_t meta = a.meta[p];
+      u32x4 raw[LA / 8];
+      load_atoms<LA>(a.latom, p, raw);
+      // class counters so far (bit 1 = error) ride in the summary word between chunks
+      const unsigned long long carried =
+          (!first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      cnt[lane] = 0ull;
+      unsigned long long my = carried & ~3ull;  // this lane's class counters
+      const bool on = in && ((meta >> kMetaStateShift) & kPodValid) != 0;
+      const uint32_t ns = on ? (uint32_t)(meta & kMetaNsMask) : 0u;
+      const uint32_t nz = (uint32_t)(meta >> kMetaNzShift);
+      // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
+      bool pod_err = (carried & 2ull) != 0 || (on & (a.ns_valid[ns] == 0));
+      uint32_t ro[LA];
+      atom_row_offsets<LA>(raw, bm.row_bytes, ro);
+      uint32_t n_list = 0;  // wave-uniform
+      uint32_t last_t = 0xFFFFFFFFu;
+
+      auto drain = [&]() {
+        // ---- lane = listed (pod lane, throttle): the full comparison; pod row / non-zero mask come from the pod's
+        //      lane by ds_bpermute
+        for (uint32_t base = 0; base < n_list; base += kWave) {
+          const uint32_t j = base + lane;
+          const bool vv = j < n_list;
+          const uint32_t e = list[vv ? j : 0u];
+          const uint32_t pl = e >> 20, t = e & kTermRowMask;
+          const uint32_t prow = (uint32_t)__shfl((int)(uint32_t)p, (int)pl);
+          const uint32_t pnz = (uint32_t)__shfl((int)nz, (int)pl);
+          const CheckRec<DT>* rc = recs + t;
+          const u32x2 fa = g_rflags[t];
+          const kt_i64x2* xr = (const kt_i64x2*)(a.req + (uint64_t)prow * (uint32_t)DS);
+          bool exc = (fa.x & kRecExceedsByCount) != 0, ins = (fa.x & kRecInsufficientByCount) != 0;
+#pragma unroll
+          for (int q = 0; q < DT / 2; ++q) {
+            const kt_i64x2 x = xr[2 * q < DS ? q : 0];  // pieces past the row re-read piece 0 and are masked by pnz
+            const kt_i64x2 th = *(const kt_i64x2*)(rc->thr + 2 * q);
+            const kt_i64x2 hd = *(const kt_i64x2*)(rc->head + 2 * q);
+            const bool nz0 = (pnz >> (2 * q)) & 1u, nz1 = (pnz >> (2 * q + 1)) & 1u;
+            exc |= (nz0 && x.x > th.x) || (nz1 && x.y > th.y);
+            ins |= (nz0 && x.x > hd.x) || (nz1 && x.y > hd.y);
+          }
+          const bool act = (fa.x & kRecActiveByCount) || (pnz & fa.y);
+          const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
+          if (vv) {
+            if (st != 1u) lds_add64(cnt + pl, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
+            if (a.status) a.status[(wt * kWave + pl) * a.T + t] = (uint8_t)st;
+          }
+        }
+        n_list = 0;
+      };
+      auto push = [&](bool want, uint32_t t) {  // wave-wide append of (lane, t)
+        const uint64_t mk = __ballot(want);
+        if (mk == 0ull) return;
+        if (want) list[n_list + lane_rank(mk)] = lane << 20 | t;
+        n_list += (uint32_t)__popcll(mk);
+        if (n_list > kListCap - kWave) drain();
+      };
+
+      // ---- throttles with unconvertible selectors: walked once, with the first chunk (error semantics depend on
+      //      term order, throttle_selector.go:30-42); their matches take the full comparison
+      if (first && a.n_slow) {
+        const SelProgram& sp = *a.sp;
+        const uint32_t* lp = a.lpair + (uint64_t)p * (uint32_t)a.LS;
+        const uint32_t* lk = a.lkey + (uint64_t)p * (uint32_t)a.LS;
+        for (uint32_t ks = 0; ks < a.n_slow; ++ks) {
+          const int ts = (int)a.slow_thr[ks];
+          const uint32_t res = walk_slow_mem(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, on, lp, lk, a.LS);
+          if (res & kSlowError) pod_err = true;
+          push((res & kSlowMatched) && on, (uint32_t)ts);
+        }
+      }
+
+      scan_tile<LA, VETO, NEED>(
+          bm, on, ns, ro,
+          [&](bool has, uint32_t c) {
+            const u32x2 ti = tinfo[c];
+            const uint32_t t = ti.x & kTermRowMask;
+            // a throttle with several terms is reported once
+            const bool ok = has && !((ti.x & kTiAdj) && t == last_t);
+            if (ok) last_t = t;
+            const uint32_t f = ti.x >> kTiFlagShift;
+            const bool tight = (f & kRecTight) != 0;
+            const bool act = (f & kRecActiveByCount) || (nz & ti.y);
+            const uint32_t st = (f & kRecExceedsByCount) ? 4u : act ? 2u : (f & kRecInsufficientByCount) ? 3u : 1u;
+            if (ok && !tight) {
+              my += st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : st == 3u ? 1ull << 44 : 0ull;
+              if (a.status) a.status[i * a.T + t] = (uint8_t)st;
+            }
+            push(ok && tight, t);
+          },
+          [&](uint32_t c) {
+            return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
+          });
+      if (n_list) drain();
+      // ---- lane = pod: the 8-byte summary word
+      if (in) {
+        const unsigned long long c = my + cnt[lane];
+        if (last) {
+          a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
+          if (a.status && pod_err)
+            for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
+        } else {
+          a.summary[i] = c | (pod_err ? 2ull : 0ull);
+        }
       }
     }
   }
-  }
 }
 
-uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + kBlockIx * 4 + 64; }
-
-#define KT_BM_CASE(DT_, LT_, KEYS_)                                                                            \
-  {                                                                                                           \
-    auto kfn = one ? kt_check_bitmap<DT_, LT_, KEYS_, true> : kt_check_bitmap<DT_, LT_, KEYS_, false>;         \
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                   \
+#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_)                                                              \
+  {                                                                                                             \
+    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_>;                                                   \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                     \
   }
+#define KT_BM_CASE(DT_, LA_, VETO_, NEED_) \
+  { if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8) else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4) }
 
 // returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
-                          const SelProgram* sp_dev, const IndexDev& ix, bool keys, const void* recs, uint64_t* summary,
+                          const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s) {
   if (n <= 0) return "";
-  const int DT = dt_bucket_ix(pods.D), LT = lt_bucket(pods.L);
+  const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
-  int64_t nb = (n + kBlockIx - 1) / kBlockIx;
-  if (nb > kCUs) nb = kCUs;
-  dim3 g_((unsigned)nb), b_(kBlockIx);
   uint32_t bm_total = 0;
-  bool one = ix.n_chunks == 1;
-  BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, one, &bm_total);
-  if (one && bm_total > (uint32_t)kMaxLds) {  // the flags of all throttles do not fit beside the image
-    one = false;
-    bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, false, &bm_total);
-  }
+  BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, &bm_total);
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
   const size_t lds_bytes = bm_total;
+  // two workgroups per CU (8 waves per SIMD) when two LDS footprints fit; KT_CHECK_WGS_PER_CU=1 forces one (A/B runs)
+  static const int force_wgs = getenv("KT_CHECK_WGS_PER_CU") ? atoi(getenv("KT_CHECK_WGS_PER_CU")) : 0;
+  const bool two_per_cu = force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds;
+  int64_t nb = (n + kBlockIx - 1) / kBlockIx;
+  const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
+  if (nb > max_b) nb = max_b;
+  dim3 g_((unsigned)nb), b_(kBlockIx);
+  static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
+  if (dbg_lds) fprintf(stderr, "kt_check_bitmap: lds=%u (%d per CU) chunks=%u LA=%d veto=%u need=%u\n", bm_total, two_per_cu ? 2 : 1, ix.n_chunks, LA, ix.has_veto, ix.max_need);
+  const bool rich = ix.rich;
 #ifdef KT_FAST_BUILD
-  KT_BM_CASE(8, 8, false)
+  KT_BM_CASE(8, 8, false, 2)
 #else
-  if (DT <= 8 && LT == 8) { if (keys) KT_BM_CASE(8, 8, true) else KT_BM_CASE(8, 8, false) }
-  else if (DT <= 8) { if (keys) KT_BM_CASE(8, 16, true) else KT_BM_CASE(8, 16, false) }
-  else if (LT == 8) { if (keys) KT_BM_CASE(16, 8, true) else KT_BM_CASE(16, 8, false) }
-  else { if (keys) KT_BM_CASE(16, 16, true) else KT_BM_CASE(16, 16, false) }
+  if (!rich) { if (DT <= 8) KT_BM_CASE(8, 8, false, 2) else KT_BM_CASE(16, 8, false, 2) }
+  else if (LA <= 16) { if (DT <= 8) KT_BM_CASE(8, 16, true, 3) else KT_BM_CASE(16, 16, true, 3) }
+  else { if (DT <= 8) KT_BM_CASE(8, 32, true, 3) else KT_BM_CASE(16, 32, true, 3) }
 #endif
-  return one ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
+  return ix.n_chunks == 1 ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
 }
 
 }  // namespace kt

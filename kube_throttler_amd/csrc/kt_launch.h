@@ -36,8 +36,8 @@ void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgr
 // recs (nullable): also build the CheckRec<rec_DT> of every throttle for isThrottledOnEqual = rec_eq
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     hipStream_t s);
-void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, hipStream_t s);
+                     const ReqBound& vmax, hipStream_t s);
+void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s);
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
                         const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s);
 

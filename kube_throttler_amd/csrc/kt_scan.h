@@ -1,0 +1,175 @@
+// kt_scan.h — the wave-autonomous selector scan shared by kt_check_bitmap and kt_aggregate_bitmap (gfx950).
+//
+// The exact term bitmaps of the selector program (kt_index.h) are cut into chunks that fit LDS; the kernels make one
+// chunk resident at a time (open_chunk) and scan every tile of the workgroup against it.  One wave owns a tile of 64
+// pods, lane = pod:
+//
+//   advance : every lane that still has words takes the next (word, namespace mask) entry of its namespace's list and
+//             accumulates its atom rows over that word: `any |= r`, `two |= any & r`, `three |= two & r`, `veto |= r'`
+//             (one ds_read per atom: 64 bits, or 128 bits {any, veto} when the program has negative requirements).
+//             A pod carries at most one atom of any requirement, so the accumulators count satisfied positive
+//             requirements per term and
+//                 x = select(need: any / two / three) & ~veto & nsmask
+//             are the terms of the word the pod MATCHES — exactly, no candidates to confirm (except the rare shapes
+//             flagged in the word header's `slow` mask, confirmed on the spot by the generic walk);
+//   peel    : while any lane holds match bits, each such lane takes its lowest bit and hands the term number to the
+//             kernel's consumer (lane = pod throughout: the consumer keeps its per-pod state in registers).
+//
+// All control flow is wave-uniform (ballots); per-lane work is predicated and every LDS read is issued from an
+// always-valid address.  A throttle with several selector terms is reported once: its terms are numbered contiguously
+// and a lane meets its matches in ascending number, so the consumers drop a match that repeats the lane's previous
+// throttle.
+#pragma once
+#include "kt_index_device.h"
+
+namespace kt {
+
+// What the kernels need of the index (IndexDev)
+struct BmIndexArgs {
+  const unsigned char* blob;  // chunk images
+  const BmChunk* chunks;
+  uint32_t n_chunks, n_rows;
+  uint32_t lds_img;  // LDS offset of the resident image part
+};
+
+template <class Take>
+static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, Take&& take) {
+  a.blob = ix.bm_blob, a.chunks = ix.bm_chunks;
+  a.n_chunks = ix.n_chunks, a.n_rows = ix.bm_rows;
+  a.lds_img = take(ix.bm_max_lds);
+}
+
+// The tables of the chunk that is resident in LDS
+struct BmView {
+  KT_LDS const unsigned char* rows;  // [n_rows][stride]{any} or [n_rows][stride]{any, veto}
+  KT_LDS const WordHdr* hdr;         // [n_words]
+  lds_u32p nsl_off;                  // [n_ns + 1]
+  KT_LDS const NsWord* nsl;
+  const uint32_t* term_g;            // (HBM) selector-program term of every number: `slow` candidates only
+  uint32_t row_bytes;                // bytes per atom row
+  uint32_t has_slow;
+};
+
+// all threads of the workgroup: n16 16-byte pieces from src to dst, four independent loads in flight per thread
+__device__ __forceinline__ void lds_stage16(KT_LDS u32x4* dst, const u32x4* src, uint32_t n16) {
+  for (uint32_t i = threadIdx.x; i < n16; i += 4 * kBlockIx) {
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = src[min(i + k * kBlockIx, n16 - 1u)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k * kBlockIx < n16) dst[i + k * kBlockIx] = v[k];
+  }
+}
+
+// Makes chunk `ch` resident (the caller barriers before — nobody still reads the previous image — and after)
+template <bool VETO>
+__device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const BmIndexArgs& a, const BmChunk& ch) {
+  lds_stage16((KT_LDS u32x4*)(lds + a.lds_img), (const u32x4*)(a.blob + ch.img_off), ch.lds_bytes / 16u);
+  KT_LDS unsigned char* base = lds + a.lds_img;
+  BmView v;
+  v.rows = base;
+  v.hdr = (KT_LDS const WordHdr*)(base + ch.off_hdr);
+  v.nsl_off = (lds_u32p)(base + ch.off_nsl_off);
+  v.nsl = (KT_LDS const NsWord*)(base + ch.off_nsl);
+  v.term_g = (const uint32_t*)(a.blob + ch.img_off + ch.off_term_g);
+  v.row_bytes = ch.stride * (VETO ? 16u : 8u);
+  v.has_slow = ch.has_slow;
+  return v;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// A pod's atom row (PodTable::latom, LA u16 ids) as byte offsets of its bitmap rows: LA/8 128-bit loads, issued from
+// an always-valid address.
+template <int LA>
+__device__ __forceinline__ void load_atoms(const uint16_t* latom, int64_t p, u32x4 (&raw)[LA / 8]) {
+  const u32x4* a = (const u32x4*)(latom + p * LA);
+#pragma unroll
+  for (int q = 0; q < LA / 8; ++q) raw[q] = a[q];
+}
+template <int LA>
+__device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uint32_t row_bytes, uint32_t (&ro)[LA]) {
+#pragma unroll
+  for (int q = 0; q < LA / 8; ++q) {
+    const uint32_t w[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ro[8 * q + 2 * k] = (w[k] & 0xFFFFu) * row_bytes;
+      ro[8 * q + 2 * k + 1] = (w[k] >> 16) * row_bytes;
+    }
+  }
+}
+
+// One 64-pod tile against the resident chunk.  `ns` must be a valid namespace row for EVERY lane (callers pass 0 for
+// lanes without a pod).
+//   lane_on    : the lane's pod takes part in selector matching
+//   ro[]       : byte offsets of the pod's atom rows (atom_row_offsets; 0 = the all-zero row)
+//   match(has, c) : wave-wide call per peel step; lanes with `has` matched term number c of this chunk (c = 0 for the
+//                others).  Ascending c per lane.
+//   confirm(c) : lane-divergent — does the lane's pod satisfy ALL requirements of `slow` term number c
+template <int LA, bool VETO, int NEED, class Match, class Confirm>
+__device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_t ns, const uint32_t (&ro)[LA], Match&& match,
+                                          Confirm&& confirm) {
+  uint32_t k = b.nsl_off[ns];
+  const uint32_t k1 = lane_on ? b.nsl_off[ns + 1] : k;
+  uint64_t x = 0;
+  uint32_t w = 0;
+  for (;;) {
+    const bool has = x != 0;
+    if (__ballot(has) != 0ull) {
+      // ---- peel: one matched term per lane that has any
+      const uint32_t c = has ? w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u : 0u;
+      x &= x - 1ull;
+      match(has, c);
+    } else if (__ballot(k < k1) != 0ull) {
+      // ---- advance: next word of every lane that still has one
+      const bool adv = k < k1;
+      const u32x4 e = *(lds_u4p)(b.nsl + (adv ? k : 0u));  // {w, -, mask lo, mask hi}
+      w = e.x;
+      const u64x2 h0 = *(KT_LDS const u64x2*)(b.hdr + w);  // {univ, m2}
+      uint64_t any = h0.x, two = 0, three = 0, vet = 0;
+      KT_LDS const unsigned char* col = b.rows + w * (VETO ? 16u : 8u);
+#pragma unroll
+      for (int l = 0; l < LA; ++l) {
+        uint64_t r;
+        if (VETO) {
+          const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
+          r = rv.x;
+          vet |= rv.y;
+        } else {
+          r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+        }
+        if (NEED >= 3) three |= two & r;
+        if (NEED >= 2) two |= any & r;
+        any |= r;
+      }
+      uint64_t xx = any;
+      if (NEED >= 2) xx = (any & ~h0.y) | (two & h0.y);
+      uint64_t slow = 0;
+      if (NEED >= 3 || VETO) {  // the rich instantiation also serves programs with `slow` shapes
+        const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
+        if (NEED >= 3) xx = (xx & ~h1.x) | (three & h1.x);
+        slow = h1.y;
+      }
+      xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
+      xx = adv ? xx : 0ull;
+      if ((NEED >= 3 || VETO) && b.has_slow) {
+        uint64_t sl = xx & slow;
+        while (sl) {  // rare shapes: every requirement through the generic walk (lane-divergent)
+          const uint32_t bit = (uint32_t)__ffsll((unsigned long long)sl) - 1u;
+          sl &= sl - 1ull;
+          if (!confirm(w * 64u + bit)) xx &= ~(1ull << bit);
+        }
+      }
+      x = xx;
+      k += adv ? 1u : 0u;
+    } else {
+      break;
+    }
+  }
+}
+
+}  // namespace kt
