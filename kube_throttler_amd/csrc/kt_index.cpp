@@ -144,7 +144,15 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     while (j < order.size() && bts[first_of[order[j]]].adm == bts[first_of[order[i]]].adm) ++j;
     const uint32_t sz = (uint32_t)(j - i);
     if ((pos & (gran - 1)) != 0 && ((pos & (gran - 1)) + sz > gran)) pos = (pos + gran - 1) & ~(gran - 1);
-    for (size_t q = i; q < j; ++q) num[order[q]] = pos++;
+    for (size_t q = i; q < j;) {
+      // the terms of one throttle (contiguous in `order`) never straddle a 64-bit word when they fit one: every word
+      // boundary then is a place where a chunk may be cut
+      size_t q1 = q;
+      while (q1 < j && first_of[order[q1]] == first_of[order[q]]) ++q1;
+      const uint32_t nt = (uint32_t)(q1 - q);
+      if (nt <= 64 && (pos & 63u) + nt > 64u) pos = (pos + 63u) & ~63u;
+      for (; q < q1; ++q) num[order[q]] = pos++;
+    }
     i = j;
   }
   const uint32_t G2 = pos;
@@ -165,6 +173,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     // the simple instantiation <8 atoms, no veto family, need <= 2> covers matchLabels-style programs; everything else
     // takes the rich one, whose images carry {any, veto} pairs
     out.rich = out.has_veto || out.has_slow || out.max_need > 2 || out.la != 8;
+    if (out.rich && out.la < 16) out.la = 16;  // the rich instantiations start at 16 atom slots
     std::sort(atoms.begin(), atoms.end());
     atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
     for (uint32_t i = 0; i < atoms.size(); ++i) out.atoms.push_back(AtomId{atoms[i], i + 1});
@@ -327,6 +336,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     out.bm_max_thr = std::max(out.bm_max_thr, ch.n_thr);
     out.bm_max_words = std::max(out.bm_max_words, ch.n_words);
     out.bm_chunks.push_back(ch);
+    if (getenv("KT_DEBUG_CHUNKS")) fprintf(stderr, "chunk %zu: words [%u,%u) lds %u B thr %u\n", out.bm_chunks.size() - 1, w0, w1, ch.lds_bytes, ch.n_thr);
     out.bm_slab_bytes = slab_run;
     w0 = w1;
   }

@@ -65,21 +65,24 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
 
 uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
 
-// WPE: waves per SIMD the register allocation has to leave room for (4: one workgroup per CU, 8: two)
-template <int DT, int LA, bool VETO, int NEED, int WPE>
+// WPE:  waves per SIMD the register allocation has to leave room for (4: one workgroup per CU, 8: two)
+// FULL: the launch also wants the status matrix and / or has throttles on the slow list — the lean instantiation
+//       (summary words only, no slow list: the PreFilter sweep) keeps neither code path nor their registers
+template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
+  constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
-  const int64_t n = a.n;
+  const uint32_t n = (uint32_t)a.n;  // pod_capacity <= 2^31
   const int DS = a.DS;
   const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   // this wave's private LDS areas
   lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;       // [64] class counters coming back from the drain
   lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;  // tight matches: lane << 20 | throttle row
   KT_LDS u32x2* tinfo = (KT_LDS u32x2*)(lds + a.off_tinfo);
-  const int64_t n_wtiles = (n + kWave - 1) / kWave;
-  const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
+  const uint32_t n_wtiles = (n + kWave - 1) / kWave;
+  const uint32_t wstep = gridDim.x * (kBlockIx / kWave);
   const uint32_t n_chunks = a.ix.n_chunks;
   for (uint32_t ci = 0; ci < n_chunks; ++ci) {
     const bool first = ci == 0, last = ci + 1 == n_chunks;
@@ -101,14 +104,13 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
     }
     __syncthreads();
-    int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-    for (; wt < n_wtiles; wt += wstep) {
+    for (uint32_t wt = blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
       // ---- the tile's records: always from valid addresses (lanes past the end re-read the last pod and are
       //      switched off by `on`)
-      const int64_t i = wt * kWave + lane;
+      const uint32_t i = wt * kWave + lane;
       const bool in = i < n;
-      const int64_t ic = min(i, n - 1);
-      const int64_t p = a.rows ? a.rows[ic] : ic;
+      const uint32_t ic = min(i, n - 1u);
+      const uint32_t p = a.rows ? (uint32_t)a.rows[ic] : ic;
       const uint64_t meta = a.meta[p];
       u32x4 raw[LA / 8];
       load_atoms<LA>(a.latom, p, raw);
@@ -135,13 +137,13 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const bool vv = j < n_list;
           const uint32_t e = list[vv ? j : 0u];
           const uint32_t pl = e >> 20, t = e & kTermRowMask;
-          const uint32_t prow = (uint32_t)__shfl((int)(uint32_t)p, (int)pl);
+          const uint32_t prow = (uint32_t)__shfl((int)p, (int)pl);
           const uint32_t pnz = (uint32_t)__shfl((int)nz, (int)pl);
           const CheckRec<DT>* rc = recs + t;
           const u32x2 fa = g_rflags[t];
           const kt_i64x2* xr = (const kt_i64x2*)(a.req + (uint64_t)prow * (uint32_t)DS);
           bool exc = (fa.x & kRecExceedsByCount) != 0, ins = (fa.x & kRecInsufficientByCount) != 0;
-#pragma unroll
+#pragma unroll kDrainUnroll
           for (int q = 0; q < DT / 2; ++q) {
             const kt_i64x2 x = xr[2 * q < DS ? q : 0];  // pieces past the row re-read piece 0 and are masked by pnz
             const kt_i64x2 th = *(const kt_i64x2*)(rc->thr + 2 * q);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
           if (vv) {
             if (st != 1u) lds_add64(cnt + pl, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-            if (a.status) a.status[(wt * kWave + pl) * a.T + t] = (uint8_t)st;
+            if (FULL && a.status) a.status[((uint64_t)wt * kWave + pl) * (uint32_t)a.T + t] = (uint8_t)st;
           }
         }
         n_list = 0;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 
       // ---- throttles with unconvertible selectors: walked once, with the first chunk (error semantics depend on
       //      term order, throttle_selector.go:30-42); their matches take the full comparison
-      if (first && a.n_slow) {
+      if (FULL && first && a.n_slow) {
         const SelProgram& sp = *a.sp;
         const uint32_t* lp = a.lpair + (uint64_t)p * (uint32_t)a.LS;
         const uint32_t* lk = a.lkey + (uint64_t)p * (uint32_t)a.LS;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
             const uint32_t st = (f & kRecExceedsByCount) ? 4u : act ? 2u : (f & kRecInsufficientByCount) ? 3u : 1u;
             if (ok && !tight) {
               my += st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : st == 3u ? 1ull << 44 : 0ull;
-              if (a.status) a.status[i * a.T + t] = (uint8_t)st;
+              if (FULL && a.status) a.status[(uint64_t)i * (uint32_t)a.T + t] = (uint8_t)st;
             }
             push(ok && tight, t);
           },
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         const unsigned long long c = my + cnt[lane];
         if (last) {
           a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
-          if (a.status && pod_err)
-            for (int t = 0; t < a.T; ++t) a.status[i * a.T + t] = 255;
+          if (FULL && a.status && pod_err)
+            for (int t = 0; t < a.T; ++t) a.status[(uint64_t)i * (uint32_t)a.T + t] = 255;
         } else {
           a.summary[i] = c | (pod_err ? 2ull : 0ull);
         }
@@ -218,14 +220,18 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   }
 }
 
-#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_)                                                              \
+#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_)                                                       \
   {                                                                                                             \
-    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_>;                                                   \
+    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_, FULL_>;                                            \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
     hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                     \
   }
-#define KT_BM_CASE(DT_, LA_, VETO_, NEED_) \
-  { if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8) else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4) }
+#define KT_BM_CASE(DT_, LA_, VETO_, NEED_)                                                   \
+  {                                                                                          \
+    if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true)                                  \
+    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false)                      \
+    else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false)                                      \
+  }
 
 // returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
 // beside the working buffers (a single throttle with thousands of terms)
@@ -241,7 +247,8 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   const size_t lds_bytes = bm_total;
   // two workgroups per CU (8 waves per SIMD) when two LDS footprints fit; KT_CHECK_WGS_PER_CU=1 forces one (A/B runs)
   static const int force_wgs = getenv("KT_CHECK_WGS_PER_CU") ? atoi(getenv("KT_CHECK_WGS_PER_CU")) : 0;
-  const bool two_per_cu = force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds;
+  const bool full = status != nullptr || ix.n_slow != 0;  // the lean instantiation serves the PreFilter sweep
+  const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;

@@ -298,7 +298,7 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   // atom ids are dense, unique and fit 16 bits; the table finds every one of them
   EXPECT(ix.atoms.size() + 1 == ix.bm_rows && ix.bm_rows <= 65536, "atom ids");
   for (const AtomId& a : ix.atoms) EXPECT(atom_id_of(ix, a.atom) == a.id && a.id >= 1 && a.id < ix.bm_rows, "atom %u", a.atom);
-  EXPECT(ix.rich == (ix.has_veto || ix.has_slow || ix.max_need > 2 || ix.la != 8), "rich flag");
+  EXPECT(ix.rich == (ix.has_veto || ix.has_slow || ix.max_need > 2 || ix.la != 8) && (ix.la == 8 || ix.la == 16 || ix.la == 32), "rich flag / atom slots");
 }
 
 static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint32_t V, int max_terms, int max_reqs, double p_bad,

@@ -187,8 +187,8 @@ def test_label_key_value_validation(tool):
 
 def test_scan_replay_on_the_headline_program(tool, tmp_path):
     """The CPU scan replay on the REAL selector program of BASELINE configs[2] (1k throttles) with a pod sample
-    (tools/dump_program.py -> index_sim_test <file>): the index is one chunk, every sampled pod's matches equal brute
-    force, and the replay reports the step counts behind DESIGN.md's next levers."""
+    (tools/dump_program.py -> index_sim_test <file>): the index is one chunk in the simple {any} form and small enough
+    for two workgroups per CU, every sampled pod's exact match bits equal brute force."""
     import re
     import sys
     subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
@@ -197,23 +197,28 @@ def test_scan_replay_on_the_headline_program(tool, tmp_path):
                           stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "1000 throttles, 1000 terms" in out.stdout and "-> 1 chunks" in out.stdout
-    cand, matches = (float(x) for x in re.search(r"([\d.]+) candidate terms and ([\d.]+) matches per pod", out.stdout).groups())
-    assert 1.0 < matches <= cand < 10.0
+    assert "1000 throttles, 1000 terms" in out.stdout and "-> 1 chunks" in out.stdout and "simple {any}" in out.stdout
+    matches = float(re.search(r"([\d.]+) matches per pod", out.stdout).group(1))
+    assert 1.0 < matches < 10.0
+    assert int(re.search(r"LDS: check (\d+) B", out.stdout).group(1)) <= 80 * 1024
 
 
 def test_scan_replay_on_the_10k_throttle_program(tool, tmp_path):
     """Same replay on the program of BASELINE configs[4] (10k throttles, ~30k multi-requirement terms, 256 namespaces):
-    dozens of LDS-sized chunks at the real budgets, the launchers' LDS sizing holds, sampled pods match brute force."""
+    dozens of LDS-sized chunks at the real budgets in the rich {any, veto} form (NotIn / Exists / DoesNotExist and up to
+    three positive requirements decided by the bitmaps alone), the launchers' LDS sizing holds, sampled pods match brute
+    force."""
     import re
     import sys
     subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
     dump = tmp_path / "cfg4.bin"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "4", "--pods", "512", str(dump)],
                           stdout=subprocess.DEVNULL)
-    out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump)], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    chunks = int(re.search(r"-> (\d+) chunks", out.stdout).group(1))
-    assert "10000 throttles" in out.stdout and 20 <= chunks <= 80
-    cand, matches = (float(x) for x in re.search(r"([\d.]+) candidate terms and ([\d.]+) matches per pod", out.stdout).groups())
-    assert 50.0 < matches <= cand < 500.0
+    for budget, lo, hi in (("147000", 20, 45), ("65000", 50, 100)):  # one / two workgroups per CU
+        out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump), budget], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        chunks = int(re.search(r"-> (\d+) chunks", out.stdout).group(1))
+        assert "10000 throttles" in out.stdout and lo <= chunks <= hi and "rich {any, veto}" in out.stdout
+        assert " 0 slow confirmations" in out.stdout
+        matches = float(re.search(r"([\d.]+) matches per pod", out.stdout).group(1))
+        assert 50.0 < matches < 500.0
