@@ -117,10 +117,12 @@ def main():
 
     def step():
         with torch.cuda.stream(ts):
-            eng.aggregate_launch(stream)
             if world > 1:
+                eng.aggregate_launch(stream)
                 KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
-            eng.finalize_launch(now, True, stream)
+                eng.finalize_launch(now, True, stream)
+            else:
+                eng.reconcile_launch(now, True, stream)  # one GPU: nothing to exchange between scan and finalize
             eng.check_launch(per_gpu, None, False, False, stream)
 
     def fence():

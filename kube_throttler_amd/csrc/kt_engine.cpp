@@ -501,7 +501,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const char* hook = getenv("KT_CHUNK_BUDGET");
     const uint32_t lds_all = 160u * 1024u;
     const uint32_t agg_budget = hook ? (uint32_t)atoi(hook) : lds_all - kt::aggregate_fixed_lds();
-    const uint32_t thr_bytes = (uint32_t)(e->incremental ? 12 * D + 4 : 8 * D + 8);
+    const uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();

@@ -108,6 +108,13 @@ struct HostIndex {
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
 };
 
+// One throttle's record in the aggregate's LDS table / slab (16-byte granules):
+//   v i64[D] | presence mask u32 | pods u32                      (full scans)
+//   v i64[D] | pods carrying the key u32[D] | pods u32           (counts mode: incremental engines)
+__host__ __device__ inline uint32_t agg_rec_bytes(int D, bool counts) {
+  return (uint32_t)(((size_t)D * 8 + (counts ? (size_t)D * 4 + 4 : 8) + 15) & ~(size_t)15);
+}
+
 // slot of an atom in an open-addressing table of 2^k entries (linear probing)
 __host__ __device__ inline uint32_t atom_slot(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 7) & mask; }
 

@@ -332,120 +332,154 @@ __device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int 
                       tt.reserved.has_count[t] != 0, tt.reserved.count[t], tt.thrl_flag[t], tt.thrl_has[t], eq, vmax, recs);
 }
 
+// Everything kt_finalize needs of one throttle's stored state, requested as ONE batch of independent loads (the
+// kernel is a latency chain: every load that waits for a branch outcome is another round trip).
 template <int DT>
-__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
-                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
-                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax) {
-  // recs (nullable): also leave the CheckRec of every throttle for the check that follows (kt_prepare_check fused in:
-  // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= T) return;
-  const int stride = partial_stride(D);
-  const uint32_t fl = tt.flags[t];
-  // reserved amounts (only the fused CheckRec needs them): loaded with everything else, up front
-  int64_t r_v[DT];
-  uint32_t r_p = 0;
-  bool r_hc = false;
-  int64_t r_c = 0;
-  if (recs) {
-    r_p = tt.reserved.present[t], r_hc = tt.reserved.has_count[t] != 0, r_c = tt.reserved.count[t];
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) r_v[d] = d < D ? tt.reserved.v[(size_t)t * D + d] : 0;
+struct ThrRegs {
+  uint32_t fl, thrl_flag, thrl_has, ovr0, ovr1;
+  uint64_t status_fp, spec_fp;
+  int64_t calc_v[DT], used_v[DT], spec_v[DT], res_v[DT];
+  uint32_t calc_p, used_p, spec_p, res_p;
+  int64_t calc_c, used_c, spec_c, res_c;
+  bool calc_hc, used_hc, spec_hc, res_hc;
+};
+template <int DT>
+__device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, ThrRegs<DT>& r) {
+  r.fl = tt.flags[t], r.thrl_flag = tt.thrl_flag[t], r.thrl_has = tt.thrl_has[t];
+  r.ovr0 = tt.ovr_off[t], r.ovr1 = tt.ovr_off[t + 1];
+  r.status_fp = tt.status_msgs_fp[t], r.spec_fp = tt.spec_msgs_fp[t];
+  r.calc_p = tt.calc.present[t], r.used_p = tt.used.present[t], r.spec_p = tt.spec.present[t], r.res_p = tt.reserved.present[t];
+  r.calc_c = tt.calc.count[t], r.used_c = tt.used.count[t], r.spec_c = tt.spec.count[t], r.res_c = tt.reserved.count[t];
+  r.calc_hc = tt.calc.has_count[t] != 0, r.used_hc = tt.used.has_count[t] != 0, r.spec_hc = tt.spec.has_count[t] != 0,
+  r.res_hc = tt.reserved.has_count[t] != 0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    const size_t i = (size_t)t * D + (d < D ? d : 0);
+    const int64_t c = tt.calc.v[i], u = tt.used.v[i], sp = tt.spec.v[i], rs = tt.reserved.v[i];
+    r.calc_v[d] = d < D ? c : 0, r.used_v[d] = d < D ? u : 0, r.spec_v[d] = d < D ? sp : 0, r.res_v[d] = d < D ? rs : 0;
   }
-  const unsigned long long* prow = partial + (size_t)t * stride;
+}
+
+// the CheckRec of throttle t from the stored status held in registers
+template <int DT>
+__device__ __forceinline__ void build_check_rec_regs(const ThrTables& tt, int t, int T, int D, const ThrRegs<DT>& r, bool eq,
+                                                     const ReqBound& vmax, CheckRec<DT>* recs) {
+  // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
+  const bool calc = (r.fl & kThrCalcAtNonzero) != 0;
+  int64_t th_v[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) th_v[d] = calc ? r.calc_v[d] : r.spec_v[d];
+  build_check_rec<DT>(tt, t, T, D, r.fl, th_v, calc ? r.calc_p : r.spec_p, calc ? r.calc_hc : r.spec_hc, calc ? r.calc_c : r.spec_c,
+                      r.used_v, r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag, r.thrl_has, eq, vmax,
+                      recs);
+}
+
+// One throttle of kt_finalize.  pv / pc / pods / errs: its row of the partial buffer (values, per-key contributor
+// counts, pod count, error count).
+template <int DT>
+__device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, int T, int D, const ThrRegs<DT>& r,
+                                                  const unsigned long long (&pv)[DT], const unsigned long long (&pc)[DT],
+                                                  unsigned long long pods, unsigned long long errs, int64_t now_s, int32_t now_ns,
+                                                  int apply, const ReconcileOut& out, CheckRec<DT>* recs, int rec_eq,
+                                                  const ReqBound& vmax) {
+  // recs (nullable): also leave the CheckRec of the throttle for the check that follows (kt_prepare_check fused in:
+  // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
+  const uint32_t fl = r.fl;
   const bool live = (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
-  const bool error = live && prow[2 * D + 1] != 0;
-  // ---- stored status (returned unchanged for rows that are not reconciled)
-  int64_t s_calc_v[DT];
-  const uint32_t s_calc_p = tt.calc.present[t];
-  const bool s_calc_hc = tt.calc.has_count[t] != 0;
-  const int64_t s_calc_c = tt.calc.count[t];
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) s_calc_v[d] = tt.calc.v[(size_t)t * D + d];
-  if (!live || error) {
+  const bool error = live && errs != 0;
+  if (!live || error) {  // the stored status is returned unchanged
     _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-      out.used.v[(size_t)t * D + d] = tt.used.v[(size_t)t * D + d];
-      out.calc.v[(size_t)t * D + d] = s_calc_v[d];
+      out.used.v[(size_t)t * D + d] = r.used_v[d];
+      out.calc.v[(size_t)t * D + d] = r.calc_v[d];
     }
-    out.used.present[t] = tt.used.present[t];
-    out.used.count[t] = tt.used.count[t];
-    out.used.has_count[t] = tt.used.has_count[t];
-    out.calc.present[t] = s_calc_p;
-    out.calc.count[t] = s_calc_c;
-    out.calc.has_count[t] = s_calc_hc;
+    out.used.present[t] = r.used_p;
+    out.used.count[t] = r.used_c;
+    out.used.has_count[t] = r.used_hc;
+    out.calc.present[t] = r.calc_p;
+    out.calc.count[t] = r.calc_c;
+    out.calc.has_count[t] = r.calc_hc;
     out.calc_updated[t] = 0;
-    out.thrl_flag[t] = tt.thrl_flag[t];
-    out.thrl_has[t] = tt.thrl_has[t];
+    out.thrl_flag[t] = r.thrl_flag;
+    out.thrl_has[t] = r.thrl_has;
     out.thrl_pod[t] = (fl & kThrThrottledPod) ? 1 : 0;
     out.error[t] = error ? 1 : 0;
     out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
     out.next_ns[t] = 0;
-    if (recs) build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, vmax, recs);
+    if (recs) build_check_rec_regs<DT>(tt, t, T, D, r, rec_eq != 0, vmax, recs);
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
   int64_t u_v[DT];
   uint32_t u_p = 0;
-  const int64_t u_c = (int64_t)prow[2 * D];
+  const int64_t u_c = (int64_t)pods;
   const bool u_hc = u_c > 0;
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-    // a key is present when some counted pod carried it: the presence count says so, and so does a non-zero sum
-    // (the L2-form aggregate skips the presence increment for positive values)
-    const bool pr = prow[D + d] != 0 || prow[d] != 0;
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) {
+    // a key is present when some counted pod carried it: the contributor count says so, and so does a non-zero sum
+    const bool pr = d < D && (pc[d] != 0 || pv[d] != 0);
     u_p |= (pr ? 1u : 0u) << d;
-    u_v[d] = pr ? (int64_t)prow[d] : 0;
+    u_v[d] = pr ? (int64_t)pv[d] : 0;
   }
   // ---- CalculateThreshold(now)
   int64_t c_v[DT];
   uint32_t c_p = 0;
   bool c_hc = false, active_found = false, any_err = false;
   int64_t c_c = 0;
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = 0;
+  _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = 0;
   // NextOverrideHappensIn (throttle_types.go:37-63): earliest begin / end instant strictly after now
   int64_t nx_s = INT64_MAX;
   int32_t nx_ns = 0;
   auto sooner = [&](int64_t s_, int32_t ns_) {
     if (instant_cmp(s_, ns_, now_s, now_ns) > 0 && instant_cmp(s_, ns_, nx_s, nx_ns) < 0) nx_s = s_, nx_ns = ns_;
   };
-  for (uint32_t o = tt.ovr_off[t]; o < tt.ovr_off[t + 1]; ++o) {
-    if (tt.ovr_flags[o] & kOvrParseError) {
+  for (uint32_t o = r.ovr0; o < r.ovr1; ++o) {
+    // one batch of loads per override
+    const uint8_t of = tt.ovr_flags[o];
+    const int64_t ob_s = tt.ovr_begin_s[o], oe_s = tt.ovr_end_s[o];
+    const int32_t ob_ns = tt.ovr_begin_ns[o], oe_ns = tt.ovr_end_ns[o];
+    const bool o_hc = tt.ovr_thr.has_count[o] != 0;
+    const int64_t o_c = tt.ovr_thr.count[o];
+    const uint32_t op = tt.ovr_thr.present[o];
+    int64_t o_v[DT];
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) o_v[d] = tt.ovr_thr.v[(size_t)o * D + (d < D ? d : 0)];
+    if (of & kOvrParseError) {
       any_err = true;
-      if (tt.ovr_flags[o] & kOvrBeginParsed) sooner(tt.ovr_begin_s[o], tt.ovr_begin_ns[o]);  // only `end` is bad
+      if (of & kOvrBeginParsed) sooner(ob_s, ob_ns);  // only `end` is bad
       continue;
     }
-    sooner(tt.ovr_begin_s[o], tt.ovr_begin_ns[o]);
-    sooner(tt.ovr_end_s[o], tt.ovr_end_ns[o]);
-    const bool begin = instant_cmp(tt.ovr_begin_s[o], tt.ovr_begin_ns[o], now_s, now_ns) <= 0;
-    const bool end_zero = tt.ovr_end_s[o] == kZeroTimeS && tt.ovr_end_ns[o] == 0;
-    const bool end = end_zero || instant_cmp(now_s, now_ns, tt.ovr_end_s[o], tt.ovr_end_ns[o]) <= 0;
+    sooner(ob_s, ob_ns);
+    sooner(oe_s, oe_ns);
+    const bool begin = instant_cmp(ob_s, ob_ns, now_s, now_ns) <= 0;
+    const bool end_zero = oe_s == kZeroTimeS && oe_ns == 0;
+    const bool end = end_zero || instant_cmp(now_s, now_ns, oe_s, oe_ns) <= 0;
     if (!(begin && end)) continue;
     active_found = true;
-    if (!c_hc && tt.ovr_thr.has_count[o]) {  // first active override wins, per resource and for counts
+    if (!c_hc && o_hc) {  // first active override wins, per resource and for counts
       c_hc = true;
-      c_c = tt.ovr_thr.count[o];
+      c_c = o_c;
     }
-    const uint32_t op = tt.ovr_thr.present[o];
     _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
       if (((op >> d) & 1u) && !((c_p >> d) & 1u)) {
         c_p |= 1u << d;
-        c_v[d] = tt.ovr_thr.v[(size_t)o * D + d];
+        c_v[d] = o_v[d];
       }
   }
   if (!active_found) {  // no active override: spec.threshold; otherwise the merged override REPLACES it
-    c_p = tt.spec.present[t];
-    c_hc = tt.spec.has_count[t] != 0;
-    c_c = tt.spec.count[t];
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = ((c_p >> d) & 1u) ? tt.spec.v[(size_t)t * D + d] : 0;
+    c_p = r.spec_p;
+    c_hc = r.spec_hc;
+    c_c = r.spec_c;
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = ((c_p >> d) & 1u) ? r.spec_v[d] : 0;
   }
-  const uint64_t c_fp = any_err ? tt.spec_msgs_fp[t] : 0ull;
+  const uint64_t c_fp = any_err ? r.spec_fp : 0ull;
   // ---- replace the stored calculatedThreshold only if threshold or messages differ by value
-  bool same = (c_hc == s_calc_hc) && (!c_hc || c_c == s_calc_c) && (c_p == s_calc_p);
+  bool same = (c_hc == r.calc_hc) && (!c_hc || c_c == r.calc_c) && (c_p == r.calc_p);
   _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
-    if ((c_p >> d) & 1u) same &= c_v[d] == s_calc_v[d];
-  const bool replace = !same || tt.status_msgs_fp[t] != c_fp;
+    if ((c_p >> d) & 1u) same &= c_v[d] == r.calc_v[d];
+  const bool replace = !same || r.status_fp != c_fp;
   if (!replace) {
-    c_p = s_calc_p;
-    c_hc = s_calc_hc;
-    c_c = s_calc_c;
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) c_v[d] = s_calc_v[d];
+    c_p = r.calc_p;
+    c_hc = r.calc_hc;
+    c_c = r.calc_c;
+    _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = r.calc_v[d];
   }
   // ---- throttled = calculatedThreshold.IsThrottled(used, onEqual = true)
   const bool th_pod = c_hc && u_hc && u_c >= c_c;
@@ -491,22 +525,34 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, co
     tt.thrl_flag[t] = th_flag;
     tt.thrl_has[t] = c_p;
     if (recs) {  // from the registers that were just stored (no re-read of this thread's own writes)
+      const bool calc = (nf & kThrCalcAtNonzero) != 0;  // calculatedAt still zero: spec.threshold
       int64_t th_v[DT];
-      uint32_t th_p = c_p;
-      bool th_hc = c_hc;
-      int64_t th_c = c_c;
-      _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = d < D ? c_v[d] : 0;
-      if (!(nf & kThrCalcAtNonzero)) {  // calculatedAt still zero: spec.threshold
-        th_p = tt.spec.present[t], th_hc = tt.spec.has_count[t] != 0, th_c = tt.spec.count[t];
-        _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = d < D ? tt.spec.v[(size_t)t * D + d] : 0;
-      }
-      _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d >= D) u_v[d] = 0;
-      build_check_rec<DT>(tt, t, T, D, nf, th_v, th_p, th_hc, th_c, u_v, u_p, u_hc, u_c, r_v, r_p, r_hc, r_c, th_flag, c_p,
-                          rec_eq != 0, vmax, recs);
+      _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = calc ? c_v[d] : r.spec_v[d];
+      build_check_rec<DT>(tt, t, T, D, nf, th_v, calc ? c_p : r.spec_p, calc ? c_hc : r.spec_hc, calc ? c_c : r.spec_c, u_v, u_p, u_hc,
+                          u_c, r.res_v, r.res_p, r.res_hc, r.res_c, th_flag, c_p, rec_eq != 0, vmax, recs);
     }
   } else if (recs) {
-    build_check_rec_stored<DT>(tt, t, T, D, rec_eq != 0, vmax, recs);
+    build_check_rec_regs<DT>(tt, t, T, D, r, rec_eq != 0, vmax, recs);
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
+                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  const int stride = partial_stride(D);
+  ThrRegs<DT> r;
+  load_thr<DT>(tt, t, D, r);
+  const unsigned long long* prow = partial + (size_t)t * stride;
+  unsigned long long pv[DT], pc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    const unsigned long long a = prow[d < D ? d : 0], b = prow[D + (d < D ? d : 0)];
+    pv[d] = d < D ? a : 0ull, pc[d] = d < D ? b : 0ull;
+  }
+  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, prow[2 * D], prow[2 * D + 1], now_s, now_ns, apply, out, recs, rec_eq, vmax);
 }
 
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,

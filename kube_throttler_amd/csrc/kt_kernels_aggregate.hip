@@ -5,13 +5,9 @@
 
 namespace kt {
 
-// LDS table of one chunk, 16-byte granules:
-//   tv i64[n_thr][D] | tpres u32[n_thr] (request-key presence MASK) | tpods u32[n_thr]
-//   counts mode (incremental engines): tv i64[n_thr][D] | tcnt u32[n_thr][D] (pods carrying the key) | tpods u32[n_thr]
-__host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool counts) {
-  const size_t per = (size_t)D * 8 + (counts ? (size_t)D * 4 + 4 : 8);
-  return (uint32_t)(((size_t)n_thr * per + 15) & ~(size_t)15);
-}
+// LDS table of one chunk: one record per throttle (agg_rec_bytes, kt_index.h) — the slab a workgroup spills is the
+// same bytes, so that the reduction streams whole records as 16-byte pieces
+__host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool counts) { return n_thr * agg_rec_bytes(D, counts); }
 
 struct BmAggArgs {
   const uint64_t* meta;  // pod tables
@@ -55,9 +51,8 @@ uint32_t aggregate_fixed_lds() { return 64; }
 // (throttle_controller.go:116-119,221-246; clusterthrottle_controller.go:119-122,224-270).
 // The workgroup walks the chunks of the index: chunk image in, table of the chunk's throttles zeroed, every tile of
 // the workgroup scanned against it — wave-autonomous like kt_check_bitmap, lane = pod throughout: the lane holds its
-// pod's request row in registers (loaded for counted pods only) and folds ResourceAmountOfPod into the LDS table
-//   tv i64[n_thr][D] | tpres u32[n_thr] (request-key presence mask) | tpods u32[n_thr]
-// for every term scan_tile reports (ds_add_u64 per non-zero dimension) — then the table is spilled to this
+// pod's request row in registers (loaded for counted pods only) and folds ResourceAmountOfPod into the throttle's record
+// of the LDS table (v i64[D] | presence mask u32 | pods u32) for every term scan_tile reports (ds_add_u64 per non-zero dimension) — then the table is spilled to this
 // (chunk, workgroup)'s slab; kt_reduce_bitmap_slabs sums the slabs into the partial buffer.
 // No global atomics except for throttles with unconvertible selectors (the "slow" list).
 template <int DT, int LA, bool VETO, int NEED>
@@ -65,7 +60,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const int D = a.D, DS = a.DS;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const int pstride = partial_stride(D);
-  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
   const int64_t n_rows = a.n_rows;
   const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
@@ -75,9 +71,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const BmChunk ch = a.ix.chunks[ci];
     const uint32_t n_thr = ch.n_thr;
     const uint32_t tab_bytes = agg_tab_bytes(n_thr, D, counts);
-    lds_u64wp tv = (lds_u64wp)(lds + a.off_tab);
-    lds_u32wp tpres = (lds_u32wp)(lds + a.off_tab + n_thr * (uint32_t)D * 8);  // mask [n] or counts [n][D]
-    lds_u32wp tpods = tpres + (counts ? n_thr * (uint32_t)D : n_thr);
+    const uint32_t rec = agg_rec_bytes(D, counts);
+    KT_LDS unsigned char* tab = lds + a.off_tab;
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
     lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
@@ -142,17 +137,21 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
             if (ok) {
               last_r = r;
+              KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
+              lds_u64wp tv = (lds_u64wp)rp;
+              lds_u32wp tu = (lds_u32wp)(rp + (uint32_t)D * 8);
 #pragma unroll
               for (int d = 0; d < DT; ++d)
-                if (v[d] != 0) lds_add64(tv + r * (uint32_t)D + d, (unsigned long long)v[d]);  // padding dimensions hold 0
+                if (v[d] != 0) lds_add64(tv + d, (unsigned long long)v[d]);  // padding dimensions hold 0
               if (counts) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
-                  if ((present >> d) & 1u) lds_add(tpres + r * (uint32_t)D + d, 1u);
+                  if ((present >> d) & 1u) lds_add(tu + d, 1u);
+                lds_add(tu + D, 1u);
               } else {
-                (void)__hip_atomic_fetch_or(tpres + r, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(tu, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_add(tu + 1, 1u);
               }
-              lds_add(tpods + r, 1u);
             }
           },
           [&](uint32_t c) {
@@ -166,55 +165,78 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   }
 }
 
-// partial[t][j] += sum over the workgroups' slabs of t's chunk: j < D values; D <= j < 2D: key seen by the slab
-// (0/1); j == 2D: pods.  "+=": throttles of the slow list were written by the scan kernel with atomics, and so was
-// every error word (2D+1), which is left alone.  grid = (word groups, chunks).
-__global__ __launch_bounds__(1024) void kt_reduce_bitmap_slabs(const unsigned char* slab, const BmChunk* chunks,
+// kt_reduce_bitmap_slabs — partial[t][*] += sum over the workgroups' slabs of t's chunk.  Every slab is an array of
+// per-throttle records (agg_rec_bytes).  grid = (piece groups, chunks, slab splits): a wave streams 64 consecutive
+// 16-byte pieces of the chunk's table (1 KB, fully coalesced) over its share of the slabs, the block's four waves meet
+// in LDS, and the owner of a piece adds its words to the partial buffer with atomics (kSlabSplits blocks per piece —
+// the split is what puts every CU on the stream): values -> [0,D), key seen (>= 1) or per-key pod counts -> [D,2D),
+// pods -> 2D.  Throttles of the slow list were written by the scan kernel with atomics too, and so was every error
+// word (2D+1), which is left alone.
+constexpr int kSlabSplits = 4;
+__global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned char* slab, const BmChunk* chunks,
                                                               const uint32_t* rank_t, int n_slabs, int D, int counts, int sign,
                                                               unsigned long long* partial) {
-  constexpr int G = 16;  // slab groups: every thread streams n_slabs / 16 independent loads
-  __shared__ unsigned long long part[G][64];
+  constexpr int G = 4;  // waves per block
+  __shared__ unsigned long long part[G][64][4];
   const BmChunk ch = chunks[blockIdx.y];
-  const int n_thr = (int)ch.n_thr;
-  const int stride = partial_stride(D);
-  const size_t pitch = agg_tab_bytes(ch.n_thr, D, counts != 0);
-  const unsigned char* base0 = slab + (size_t)ch.slab_off * 16;
-  const int words = n_thr * stride;
-  if ((int)blockIdx.x * 64 >= words) return;
-  const int wl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int w = blockIdx.x * 64 + wl;
-  unsigned long long acc = 0;
-  int j = 0, r = 0;
-  if (w < words) {
-    r = w / stride;
-    j = w - r * stride;
-    if (j < D) {
-      const unsigned char* base = base0 + ((size_t)r * D + j) * 8;
-#pragma unroll 16
-      for (int b = g; b < n_slabs; b += G) acc += *(const unsigned long long*)(base + b * pitch);
-    } else if (j < 2 * D) {
-      if (counts) {
-        const unsigned char* base = base0 + (size_t)n_thr * D * 8 + ((size_t)r * D + (j - D)) * 4;
-#pragma unroll 16
-        for (int b = g; b < n_slabs; b += G) acc += *(const unsigned int*)(base + b * pitch);
+  const uint32_t rec = agg_rec_bytes(D, counts != 0), ppr = rec / 16u;  // pieces per record
+  const uint32_t n_pieces = ch.n_thr * ppr;
+  if (blockIdx.x * 64u >= n_pieces) return;
+  const size_t pitch = (size_t)ch.n_thr * rec;
+  const uint32_t wl = threadIdx.x & 63u, g = threadIdx.x >> 6;
+  const uint32_t pi = blockIdx.x * 64u + wl;
+  const bool in = pi < n_pieces;
+  const uint32_t r = in ? pi / ppr : 0u, q = in ? pi - r * ppr : 0u;
+  // kind of the piece's four dwords: 0 = half of an int64 value (the pair is added as one), 1 = u32 sum, 2 = u32 OR, 3 = padding
+  const uint32_t dw0 = q * 4u, n_val = 2u * (uint32_t)D, n_u32 = counts ? (uint32_t)D + 1u : 2u;
+  uint32_t kind[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t dw = dw0 + k;
+    kind[k] = dw < n_val ? 0u : dw < n_val + n_u32 ? ((!counts && dw == n_val) ? 2u : 1u) : 3u;
+  }
+  unsigned long long acc[4] = {0, 0, 0, 0};
+  const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)(in ? pi : 0u) * 16;
+  const int step = G * kSlabSplits;
+#pragma unroll 8
+  for (int b = (int)(blockIdx.z * G + g); b < n_slabs; b += step) {
+    const u32x4 x = *(const u32x4*)(base + (size_t)b * pitch);
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (kind[2 * h] == 0u) {
+        acc[2 * h] += (unsigned long long)w[2 * h] | (unsigned long long)w[2 * h + 1] << 32;
       } else {
-        const unsigned char* base = base0 + (size_t)n_thr * D * 8 + (size_t)r * 4;
-#pragma unroll 16
-        for (int b = g; b < n_slabs; b += G) acc += (*(const unsigned int*)(base + b * pitch) >> (j - D)) & 1u;
+        acc[2 * h] = kind[2 * h] == 2u ? (acc[2 * h] | w[2 * h]) : acc[2 * h] + w[2 * h];
+        acc[2 * h + 1] = kind[2 * h + 1] == 2u ? (acc[2 * h + 1] | w[2 * h + 1]) : acc[2 * h + 1] + w[2 * h + 1];
       }
-    } else if (j == 2 * D) {
-      const unsigned char* base = base0 + (size_t)n_thr * D * 8 + (size_t)n_thr * 4 * (counts ? D : 1) + (size_t)r * 4;
-#pragma unroll 16
-      for (int b = g; b < n_slabs; b += G) acc += *(const unsigned int*)(base + b * pitch);
     }
   }
-  part[g][wl] = acc;
-  __syncthreads();
-  if (g == 0 && w < words && j != 2 * D + 1) {
-    unsigned long long sum = 0;
 #pragma unroll
-    for (int k = 0; k < G; ++k) sum += part[k][wl];
-    partial[(size_t)rank_t[ch.rank0 + r] * stride + j] += (unsigned long long)((long long)sign * (long long)sum);
+  for (int k = 0; k < 4; ++k) part[g][wl][k] = acc[k];
+  __syncthreads();
+  if (g == 0 && in) {
+    const int stride = partial_stride(D);
+    unsigned long long* prow = partial + (size_t)rank_t[ch.rank0 + r] * stride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (kind[k] == 3u || (kind[k] == 0u && (k & 1))) continue;
+      unsigned long long sum = 0;
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) sum = kind[k] == 2u ? (sum | part[gg][wl][k]) : sum + part[gg][wl][k];
+      if (sum == 0ull) continue;
+      const uint32_t dw = dw0 + k;
+      if (kind[k] == 0u) {
+        atomicAdd(prow + dw / 2u, (unsigned long long)((long long)sign * (long long)sum));
+      } else if (kind[k] == 2u) {  // presence mask: key seen by some slab of this split
+        for (int d = 0; d < D; ++d)
+          if ((sum >> d) & 1ull) atomicAdd(prow + D + d, 1ull);
+      } else {
+        const uint32_t u = dw - n_val;  // counts mode: u < D per-key pod counts, u == D pods; mask mode: u == 1 pods
+        const int j = counts ? (u < (uint32_t)D ? D + (int)u : 2 * D) : 2 * D;
+        atomicAdd(prow + j, (unsigned long long)((long long)sign * (long long)sum));
+      }
+    }
   }
 }
 
@@ -255,10 +277,10 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 3) else KT_AGG_BM_CASE(16, 32, true, 3) }
 #endif
   if (after_scan) after_scan();
-  const int max_words = (int)ix.bm_max_thr * partial_stride(pods.D);
-  if (max_words > 0)
-    hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_words + 63) / 64, ix.n_chunks), dim3(1024), 0, s, slab, ix.bm_chunks,
-                       ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, partial);
+  const uint32_t max_pieces = ix.bm_max_thr * (agg_rec_bytes(pods.D, sc.counts) / 16u);
+  if (max_pieces > 0)
+    hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_pieces + 63) / 64, ix.n_chunks, kSlabSplits), dim3(256), 0, s, slab,
+                       ix.bm_chunks, ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, partial);
   return ix.n_chunks == 1 ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_chunked";
 }
 

@@ -43,6 +43,7 @@ struct BmCheckArgs {
   uint32_t off_cnt, off_list, off_tinfo;
   uint32_t n_slow;
   int32_t DS, LS, T;
+  uint32_t exp;  // KT_EXP (timing experiments only; results are wrong when set): 1 no drain, 2 no peel work, 4 no scan
 };
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
@@ -53,6 +54,8 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
   a.sp = sp_dev, a.ns_valid = sp.ns_valid, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow;
   a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
+  static const uint32_t exp_env = getenv("KT_EXP") ? (uint32_t)atoi(getenv("KT_EXP")) : 0u;
+  a.exp = exp_env;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
   const uint32_t n = (uint32_t)a.n;  // pod_capacity <= 2^31
   const int DS = a.DS;
-  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
   // this wave's private LDS areas
   lds_u64wp cnt = (lds_u64wp)(lds + a.off_cnt) + wave * kWave;       // [64] class counters coming back from the drain
   lds_u32wp list = (lds_u32wp)(lds + a.off_list) + wave * kListCap;  // tight matches: lane << 20 | throttle row
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       uint32_t last_t = 0xFFFFFFFFu;
 
       auto drain = [&]() {
+        if (a.exp & 1u) { n_list = 0; return; }
         // ---- lane = listed (pod lane, throttle): the full comparison; pod row / non-zero mask come from the pod's
         //      lane by ds_bpermute
         for (uint32_t base = 0; base < n_list; base += kWave) {
@@ -183,9 +188,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         }
       }
 
+      if (!(a.exp & 4u))
       scan_tile<LA, VETO, NEED>(
           bm, on, ns, ro,
           [&](bool has, uint32_t c) {
+            if (a.exp & 2u) return;
             const u32x2 ti = tinfo[c];
             const uint32_t t = ti.x & kTermRowMask;
             // a throttle with several terms is reported once
