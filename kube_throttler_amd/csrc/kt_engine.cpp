@@ -143,6 +143,10 @@ struct kt_engine {
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
   unsigned long long n_overflow = 0;
+  DevBuf<int64_t> d_countable;                   // rows of the pods a reconcile scans (kt_compact_countable)
+  DevBuf<unsigned long long> d_n_countable;
+  unsigned long long n_countable = 0;
+  bool countable_valid = false;                  // d_countable describes the current pod table
 
   // ---- host mirrors of the small tables
   std::vector<HostNamespace> ns;
@@ -716,6 +720,8 @@ int32_t kt_engine_destroy(kt_engine* e) {
   if (e->pods.meta) (void)hipFree(e->pods.meta);
   e->d_latom.release();
   e->d_overflow.release();
+  e->d_countable.release();
+  e->d_n_countable.release();
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
@@ -814,6 +820,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     if (batch_max[d] > e->max_abs[d]) e->recs_valid = false;  // kRecTight was judged against the old bound
     e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
   }
+  e->countable_valid = false;
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
   const int64_t chunk = 1 << 20;
@@ -898,6 +905,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
+  e->countable_valid = false;
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
     int32_t drc = delta_scan(e, n, e->d_rows.p, 0, -1, e->own_stream);
@@ -1001,6 +1009,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   KT_HIP(e, hipMemsetAsync(e->pods.flags, 0, (size_t)e->cfg.pod_capacity * 4, e->own_stream));
   KT_HIP(e, hipMemsetAsync(e->pods.meta, 0, (size_t)e->cfg.pod_capacity * 8, e->own_stream));
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
+  e->countable_valid = false;
   e->pod_rows_hi = 0;
   for (auto& m : e->max_abs) m = 0;
   for (auto& n : e->ns) n = HostNamespace();
@@ -1087,6 +1096,16 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     e->last_stream = s;
     return KT_OK;
   }
+  if (e->cfg.kernel_variant != 1 && !e->countable_valid) {  // pods changed since the last scan: which rows does a reconcile look at
+    KT_HIP(e, e->d_countable.reserve((size_t)e->pod_rows_hi + 1));
+    KT_HIP(e, e->d_n_countable.reserve(1));
+    KT_HIP(e, hipMemsetAsync(e->d_n_countable.p, 0, 8, s));
+    kt::launch_compact_countable(e->pods, e->pod_rows_hi, e->d_countable.p, e->d_n_countable.p, s);
+    KT_HIP(e, hipGetLastError());
+    KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipStreamSynchronize(s));
+    e->countable_valid = true;
+  }
   if (words) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
@@ -1100,7 +1119,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else {
       kt::AggScan sc;
-      sc.n = e->pod_rows_hi, sc.counts = e->incremental;
+      sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental;
       if (e->n_overflow)
         return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
