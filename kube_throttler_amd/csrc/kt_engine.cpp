@@ -511,7 +511,8 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();
     kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
                     (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L);
-    if (!hook && e->hindex.bm_chunks.size() > 1)
+    // KT_CHUNK_HALF=1 (A/B runs): keep the half-LDS chunks — more of them, but two workgroups per CU
+    if (!hook && !getenv("KT_CHUNK_HALF") && e->hindex.bm_chunks.size() > 1)
       kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
                       (uint32_t)NS, ns_term_ok, gw, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, e->L);
   }

@@ -470,7 +470,7 @@ def test_api_errors():
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full-size configurations: parity on samples + size-independent properties
 # ---------------------------------------------------------------------------------------------------
-def _full_size_checks(cfg, oracle_mod, n_check_sample=4096, n_thr_sample=12, with_dense=False):
+def _full_size_checks(cfg, oracle_mod, n_check_sample=65536, n_thr_sample=100, with_dense=True, nthreads=64):
     snap = W.generate(cfg)
     now = (cfg.now_s, 0)
     P, T = snap.n_pods, snap.n_thr
@@ -480,7 +480,7 @@ def _full_size_checks(cfg, oracle_mod, n_check_sample=4096, n_thr_sample=12, wit
         # (1) reconcile: `used` of a throttle sample (each oracle row scans every pod) is bit-exact
         rows = responsible_rows(snap)
         pick = rows[np.linspace(0, len(rows) - 1, n_thr_sample).astype(int)]
-        want = o.reconcile(now, rows=pick, nthreads=16)
+        want = o.reconcile(now, rows=pick, nthreads=nthreads)
         got = eng.reconcile(now, apply=True)
         assert not got.error[:T].any()
         for f in ("v", "present", "count", "has_count"):
@@ -496,7 +496,7 @@ def _full_size_checks(cfg, oracle_mod, n_check_sample=4096, n_thr_sample=12, wit
         # (3) check: a pod sample, full status rows, bit-exact against the oracle on the engine's own status
         snap.apply_status(got.used, got.calc, got.calc_updated, got.thrl_flag, got.thrl_has, got.thrl_pod, got.error)
         sample = np.unique(np.linspace(0, P - 1, n_check_sample).astype(np.int64))
-        st_w, sm_w = o.check(rows=sample, nthreads=16)
+        st_w, sm_w = o.check(rows=sample, nthreads=nthreads)
         st_g, sm_g = eng.check(rows=sample, want_status=True)
         np.testing.assert_array_equal(st_g, st_w)
         np.testing.assert_array_equal(sm_g, sm_w)
@@ -528,9 +528,10 @@ def _full_size_checks(cfg, oracle_mod, n_check_sample=4096, n_thr_sample=12, wit
 
 
 def test_config2_full_size(oracle_mod):
-    """configs[2]: 1M pods x 1k Throttle+ClusterThrottle, D=8 — sample parity, properties, and the dense
-    (reference-shaped) kernels agree with the indexed ones on ALL 10^9 decisions."""
-    _full_size_checks(W.preset(2), oracle_mod, with_dense=True)
+    """configs[2]: 1M pods x 1k Throttle+ClusterThrottle, D=8 — 65 536 pods x all throttles and 100 throttles' `used`
+    against the oracle, properties, and the dense (reference-shaped) kernels agree with the indexed ones on ALL 10^9
+    decisions and every `used` vector."""
+    _full_size_checks(W.preset(2), oracle_mod)
 
 
 def test_config3_overrides_full_size(oracle_mod):
@@ -543,7 +544,8 @@ def test_config3_overrides_full_size(oracle_mod):
 
 
 def test_config4_one_shard(oracle_mod):
-    """configs[4]: 10M pods x 10k throttles with multi-term OR-of-AND selectors — one 1/8 shard's rows
-    (the per-GPU slice of the 8-GPU configuration) against the oracle on samples."""
+    """configs[4]: 10M pods x 10k throttles with multi-term OR-of-AND selectors — one 1/8 shard's rows (the per-GPU
+    slice of the 8-GPU configuration): 16 384 pods x all throttles and 100 throttles' `used` against the oracle, the dense
+    kernels on all 1.25e10 decisions of the shard."""
     cfg = W.preset(4).shard(3, 8)
-    _full_size_checks(cfg, oracle_mod, n_check_sample=1024, n_thr_sample=6)
+    _full_size_checks(cfg, oracle_mod, n_check_sample=16384, n_thr_sample=100)

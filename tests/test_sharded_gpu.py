@@ -1,0 +1,148 @@
+"""The multi-GPU result, pinned on ONE GPU: the pod rows of a snapshot are cut into `world` contiguous shards exactly as
+bench.py --gpus N cuts them, every shard runs through its own engine (kt_aggregate_launch into a caller
+buffer), the partial-`used` buffers are summed the way the RCCL all-reduce sums them, the sum is handed back to every
+shard's engine (kt_use_partial_buffer + kt_finalize_launch, APPLY) and each shard's PreFilter sweep follows.  Everything
+that comes out — `used`, calculated thresholds, throttled flags of every sampled throttle, the status rows and summary
+words of every sampled pod of every shard — must equal the CPU oracle's answer on the UNSHARDED snapshot, bit for bit
+(throttle_controller.go:116-133 semantics: one reconcile over all pods).  Integer sums are associative, so this is the
+result any number of GPUs produces; what an 8-GPU node adds is only the transport of the sum."""
+import numpy as np
+import pytest
+
+from kube_throttler_amd import engine as E
+from kube_throttler_amd import snapshot as S
+from kube_throttler_amd import workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _responsible(snap):
+    need = S.THR_VALID | S.THR_RESPONSIBLE
+    return np.nonzero((snap.thr_flags[:snap.n_thr] & need) == need)[0]
+
+
+def _sharded_pipeline(full_cfg, world, oracle_mod, n_thr_sample, n_pod_sample, nthreads=32):
+    import torch
+    full = W.generate(full_cfg)
+    now = (full_cfg.now_s, 0)
+    T, D = full.n_thr, full.D
+    words = T * (2 * D + 2)
+    # ---- pass 1: every shard's partial buffer; the host-side sum stands in for the all-reduce
+    total = torch.zeros(words, dtype=torch.int64, device="cuda")
+    shard_rows = []
+    for r in range(world):
+        cfg = full_cfg.shard(r, world)
+        shard_rows.append((int(cfg.pod_begin), int(cfg.n_pods)))
+        snap = W.generate(cfg)
+        eng = E.Engine.for_snapshot(snap)
+        try:
+            assert eng.partial_words() == words
+            part = torch.zeros(words, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(part.data_ptr(), words)
+            eng.aggregate_launch()
+            eng.synchronize()
+            total += part
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(None, 0)
+        finally:
+            eng.close()
+    assert sum(n for _, n in shard_rows) == full.n_pods
+    # ---- the oracle on the unsharded snapshot
+    o = oracle_mod.Oracle(full)
+    rows = _responsible(full)
+    pick = rows[np.unique(np.linspace(0, len(rows) - 1, min(n_thr_sample, len(rows))).astype(int))]
+    want = o.reconcile(now, rows=pick, nthreads=nthreads)
+    # ---- pass 2: the sum goes back to every shard: finalize (APPLY) + PreFilter sweep of the shard's pods
+    first = None
+    for r in range(world):
+        snap = W.generate(full_cfg.shard(r, world))
+        eng = E.Engine.for_snapshot(snap)
+        try:
+            buf = total.clone()
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(buf.data_ptr(), words)
+            eng.finalize_launch(now, apply=True)
+            got = eng.reconcile_fetch()
+            assert not got.error[:T].any()
+            for f in ("v", "present", "count", "has_count"):
+                np.testing.assert_array_equal(getattr(got.used, f)[pick], getattr(want.used, f)[:len(pick)], err_msg=f"shard {r} used.{f}")
+                np.testing.assert_array_equal(getattr(got.calc, f)[pick], getattr(want.calc, f)[:len(pick)], err_msg=f"shard {r} calc.{f}")
+            np.testing.assert_array_equal(got.thrl_flag[pick], want.thrl_flag[:len(pick)], err_msg=f"shard {r}")
+            np.testing.assert_array_equal(got.thrl_pod[pick], want.thrl_pod[:len(pick)], err_msg=f"shard {r}")
+            if first is None:
+                first = got
+                # the status every replica now holds, for the oracle's PreFilter
+                full.apply_status(got.used, got.calc, got.calc_updated, got.thrl_flag, got.thrl_has, got.thrl_pod, got.error)
+            else:  # every replica finalizes the same sums: identical results on every rank
+                for f in ("v", "present", "count"):
+                    np.testing.assert_array_equal(getattr(got.used, f)[:T], getattr(first.used, f)[:T])
+                np.testing.assert_array_equal(got.thrl_flag[:T], first.thrl_flag[:T])
+                np.testing.assert_array_equal(got.calc_updated[:T], first.calc_updated[:T])
+            begin, n = shard_rows[r]
+            local = np.unique(np.linspace(0, n - 1, min(n_pod_sample, n)).astype(np.int64))
+            st_w, sm_w = o.check(rows=local + begin, nthreads=nthreads)
+            st_g, sm_g = eng.check(rows=local, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w, err_msg=f"shard {r} status rows")
+            np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"shard {r} summaries")
+            _, sm_all = eng.check(n=n, want_status=False)
+            np.testing.assert_array_equal(sm_all[local], sm_w, err_msg=f"shard {r} sweep")
+            eng.use_partial_buffer(None, 0)
+        finally:
+            eng.close()
+
+
+def test_eight_shards_of_a_multi_term_program(oracle_mod):
+    """configs[4] scaled down (80k pods x 2k throttles, 2-4 terms per throttle, every selector operator, 256
+    namespaces): 8 shards, every throttle and 2048 pods per shard against the oracle."""
+    cfg = W.preset(4)
+    cfg.n_pods_total = cfg.n_pods = 80000
+    cfg.n_thr, cfg.n_cluster = 2000, 1000
+    _sharded_pipeline(cfg, 8, oracle_mod, n_thr_sample=2000, n_pod_sample=2048)
+
+
+def test_eight_shards_of_config2(oracle_mod):
+    """configs[2] at full size (1M pods x 1k throttles) in 8 shards of 125k pods: 200 throttles' `used` and 8192 pods
+    per shard against the oracle on the unsharded snapshot."""
+    _sharded_pipeline(W.preset(2), 8, oracle_mod, n_thr_sample=200, n_pod_sample=8192, nthreads=64)
+
+
+def test_three_uneven_shards_with_selector_errors(oracle_mod):
+    """Shards of different length (2001 pods over 3 ranks), unconvertible selectors and missing Namespace objects:
+    the error words of the partial buffer travel through the sum as well."""
+    cfg = W.small(seed=21, n_pods=2001, n_thr=96, n_cluster=48, n_invalid_pod_sel=3, n_invalid_ns_sel=2, n_missing_ns=1)
+    import torch
+    full = W.generate(cfg)
+    now = (cfg.now_s, 0)
+    T, D = full.n_thr, full.D
+    words = T * (2 * D + 2)
+    total = torch.zeros(words, dtype=torch.int64, device="cuda")
+    for r in range(3):
+        eng = E.Engine.for_snapshot(W.generate(cfg.shard(r, 3)))
+        try:
+            part = torch.zeros(words, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(part.data_ptr(), words)
+            eng.aggregate_launch()
+            eng.synchronize()
+            total += part
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(None, 0)
+        finally:
+            eng.close()
+    want = oracle_mod.Oracle(full).reconcile(now)
+    eng = E.Engine.for_snapshot(W.generate(cfg.shard(0, 3)))
+    try:
+        eng.use_partial_buffer(total.data_ptr(), words)
+        eng.finalize_launch(now, apply=False)
+        got = eng.reconcile_fetch()
+        rows = _responsible(full)
+        np.testing.assert_array_equal(got.error[rows] != 0, want.error[rows] != 0)
+        assert want.error[rows].any()
+        ok = rows[want.error[rows] == 0]
+        np.testing.assert_array_equal(got.used.v[ok], want.used.v[ok])
+        np.testing.assert_array_equal(got.used.count[ok], want.used.count[ok])
+        np.testing.assert_array_equal(got.thrl_flag[ok], want.thrl_flag[ok])
+        eng.use_partial_buffer(None, 0)
+    finally:
+        eng.close()
