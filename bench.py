@@ -173,25 +173,42 @@ def main():
     dominant = "check" if k_ms["check"] >= k_ms["aggregate"] else "aggregate"
     dom_bytes = chk_bytes if dominant == "check" else agg_bytes
     achieved = dom_bytes / (k_ms[dominant] * 1e-3) / 1e9 if k_ms[dominant] > 0 else 0.0
+    # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/profile.sh + tools/pmc_summary.py) is only quoted when it
+    # was measured on the SAME kernel sources as the library that just ran (kt_version() carries their hash)
     traffic = None
+    engine_version = E.version()
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    pmc_kernels = {}
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            ent = pmc.get(f"config{args.config}_{args.variant}", {}).get(eng.kernel_name(
-                E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE))
-            if ent:
-                traffic = ent.get("hbm_bytes_per_launch")
+            key = f"config{args.config}_{args.variant}"
+            src = pmc.get("_source", {}).get(key)
+            if isinstance(src, dict) and src.get("engine_version") == engine_version:
+                pmc_kernels = pmc.get(key, {})
         except Exception:
-            traffic = None
+            pmc_kernels = {}
+    dom_kernel = eng.kernel_name(E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE)
+    sym = lambda k: k.replace("_chunked", "")  # "..._chunked" is the same kernel symbol walking several index chunks
+    if sym(dom_kernel) in pmc_kernels:
+        traffic = pmc_kernels[sym(dom_kernel)].get("hbm_bytes_per_launch")
+
+    def kernel_roofline(name, fam, nbytes):
+        ms = k_ms[name]
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kn = eng.kernel_name(fam)
+        return {"kernel": kn, "avg_launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": nbytes,
+                "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
+                "traffic": pmc_kernels.get(sym(kn), {}).get("hbm_bytes_per_launch")}
+
     roofline = {
-        "bound": "hbm", "kernel": eng.kernel_name(E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE),
+        "bound": "hbm", "kernel": dom_kernel,
         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
         "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(k_ms[dominant], 6),
         "per_kernel_ms": {k: round(v, 6) for k, v in k_ms.items()},
-        "check_GBps": round(chk_bytes / max(k_ms["check"], 1e-9) / 1e6, 3),
-        "aggregate_GBps": round(agg_bytes / max(k_ms["aggregate"], 1e-9) / 1e6, 3),
+        "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes),
+        "aggregate": kernel_roofline("aggregate", E.KERNEL_AGGREGATE, agg_bytes),
     }
 
     # ---- CPU baseline: the C restatement of the reference algorithm on this box's host cores (rank 0, N=1)
@@ -238,7 +255,7 @@ def main():
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
                        "step": "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
-                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2)},
+                       "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

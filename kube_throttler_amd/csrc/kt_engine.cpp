@@ -147,6 +147,7 @@ struct kt_engine {
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
   bool countable_valid = false;                  // d_countable describes the current pod table
+  bool neg_seen = false;                         // some pod was fed with a negative request (sums may cancel)
 
   // ---- host mirrors of the small tables
   std::vector<HostNamespace> ns;
@@ -636,7 +637,10 @@ void reqs_from_pool(const kt_reqs& pool, uint32_t b, uint32_t e_, std::vector<Re
 // ===================================================================================================
 extern "C" {
 
-const char* kt_version(void) { return "kt-engine 0.1 (gfx950, HIP)"; }
+#ifndef KT_SRC_HASH
+#define KT_SRC_HASH "unknown"
+#endif
+const char* kt_version(void) { return "kt-engine 0.2 (gfx950, HIP) src=" KT_SRC_HASH; }
 
 const char* kt_last_error(kt_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -805,10 +809,16 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     unsigned __int128 sum[KT_MAX_DIMS] = {0};
     for (uint32_t k = b->pod_ctr_off[i]; k < b->pod_ctr_off[i + 1]; ++k)
       for (int d = 0; d < D; ++d)
-        if ((b->ctr_present[k] >> d) & 1u) sum[d] += uabs(b->ctr_req[(size_t)k * D + d]);
+        if ((b->ctr_present[k] >> d) & 1u) {
+          sum[d] += uabs(b->ctr_req[(size_t)k * D + d]);
+          if (b->ctr_req[(size_t)k * D + d] < 0) e->neg_seen = true;
+        }
     if (b->pod_ovh_present[i] >> 31)
       for (int d = 0; d < D; ++d)
-        if ((b->pod_ovh_present[i] >> d) & 1u) sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
+        if ((b->pod_ovh_present[i] >> d) & 1u) {
+          sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
+          if (b->pod_ovh[(size_t)i * D + d] < 0) e->neg_seen = true;
+        }
     for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]);
   }
   for (int d = 0; d < D; ++d) {
@@ -1012,6 +1022,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   e->countable_valid = false;
   e->pod_rows_hi = 0;
+  e->neg_seen = false;
   for (auto& m : e->max_abs) m = 0;
   for (auto& n : e->ns) n = HostNamespace();
   for (auto& t : e->thr) t = HostThrottle();
@@ -1120,7 +1131,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else {
       kt::AggScan sc;
-      sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental;
+      sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
       if (e->n_overflow)
         return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);

@@ -168,6 +168,7 @@ struct AggScan {
   int64_t row0 = 0;              // ... the contiguous range row0 + [0, n)
   bool counts = false;           // exact per-key pod counts (incremental engines) instead of presence masks
   int sign = 1;                  // -1: remove the scanned pods' contribution (delta scans)
+  bool nonneg = false;           // no pod carries a negative request (lets the scan skip most presence updates)
 };
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
 // does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued

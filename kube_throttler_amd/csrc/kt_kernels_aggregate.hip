@@ -27,12 +27,13 @@ struct BmAggArgs {
   int32_t D, DS, LS, T;
   int32_t counts;  // table keeps per-key pod counts instead of the presence mask
   int32_t sign;    // +1 / -1: the scanned pods are added to / removed from the target (delta scans)
+  int32_t nonneg;  // no pod of the engine carries a negative request: a non-zero value then implies a non-zero sum
 };
 
 static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const SelProgram& sp, const SelProgram* sp_dev,
                                   const IndexDev& ix, unsigned long long* partial, unsigned char* slab, uint32_t* total) {
   BmAggArgs a{};
-  a.rows = sc.rows, a.row0 = sc.row0, a.n_rows = sc.n, a.counts = sc.counts ? 1 : 0, a.sign = sc.sign;
+  a.rows = sc.rows, a.row0 = sc.row0, a.n_rows = sc.n, a.counts = sc.counts ? 1 : 0, a.sign = sc.sign, a.nonneg = sc.nonneg ? 1 : 0;
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab;
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
@@ -96,6 +97,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       if (__ballot(countable) == 0ull) continue;
       const uint32_t ns = countable ? (uint32_t)(meta & kMetaNsMask) : 0u;
       const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
+      // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
+      // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
+      const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
       // ResourceAmountOfPod: the request row, for counted pods only (exec-masked 128-bit loads)
       int64_t v[DT];
 #pragma unroll
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
                   if ((present >> d) & 1u) lds_add(tu + d, 1u);
                 lds_add(tu + D, 1u);
               } else {
-                (void)__hip_atomic_fetch_or(tu, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (need_pres) (void)__hip_atomic_fetch_or(tu, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 lds_add(tu + 1, 1u);
               }
             }

@@ -21,9 +21,12 @@ namespace kt {
 // ---------------------------------------------------------------------------------------------------
 
 constexpr uint32_t kListCap = 128;  // tight-match list entries per wave (512 B)
-// TermInfo word 0: throttle row | kTiAdj | CheckRec flags << 24 ; word 1: active_mask
-constexpr uint32_t kTiAdj = 0x00100000u;
-constexpr int kTiFlagShift = 24;
+// TermInfo word 0: throttle row | kTiAdj
+//          word 1: active_mask (16 bits) | counter shift when the pod requests an active dimension << 16
+//                  | counter shift otherwise << 22 | kTiTight
+// counter shifts: 4 = exceeds, 24 = active, 44 = insufficient, 0 = not throttled (nothing to count)
+constexpr uint32_t kTiAdj = 0x00100000u, kTiTight = 0x10000000u;
+constexpr int kTiShActive = 16, kTiShIdle = 22;
 
 struct BmCheckArgs {
   const uint64_t* meta;  // pod tables
@@ -101,8 +104,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         if (tt & kTermReal) {
           const uint32_t t = tt & kTermRowMask;
           const u32x2 rf = g_rflags[t];  // {flags, active_mask}
-          ti.x = t | ((tt & kTermAdj) ? kTiAdj : 0u) | rf.x << kTiFlagShift;
-          ti.y = rf.y;
+          const uint32_t sh_act = (rf.x & kRecExceedsByCount) ? 4u : 24u;
+          const uint32_t sh_idle = (rf.x & kRecExceedsByCount) ? 4u : (rf.x & kRecActiveByCount) ? 24u : (rf.x & kRecInsufficientByCount) ? 44u : 0u;
+          ti.x = t | ((tt & kTermAdj) ? kTiAdj : 0u);
+          ti.y = (rf.y & 0xFFFFu) | sh_act << kTiShActive | sh_idle << kTiShIdle | ((rf.x & kRecTight) ? kTiTight : 0u);
         }
         tinfo[c] = ti;
       }
@@ -193,19 +198,19 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           bm, on, ns, ro,
           [&](bool has, uint32_t c) {
             if (a.exp & 2u) return;
+            // branch-free: the term's TermInfo word carries both verdicts a non-tight throttle can give (as the bit
+            // position of the class counter to bump: 4 / 24 / 44, 0 = not throttled), chosen by the pod's non-zero mask
             const u32x2 ti = tinfo[c];
             const uint32_t t = ti.x & kTermRowMask;
             // a throttle with several terms is reported once
             const bool ok = has && !((ti.x & kTiAdj) && t == last_t);
-            if (ok) last_t = t;
-            const uint32_t f = ti.x >> kTiFlagShift;
-            const bool tight = (f & kRecTight) != 0;
-            const bool act = (f & kRecActiveByCount) || (nz & ti.y);
-            const uint32_t st = (f & kRecExceedsByCount) ? 4u : act ? 2u : (f & kRecInsufficientByCount) ? 3u : 1u;
-            if (ok && !tight) {
-              my += st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : st == 3u ? 1ull << 44 : 0ull;
-              if (FULL && a.status) a.status[(uint64_t)i * (uint32_t)a.T + t] = (uint8_t)st;
-            }
+            last_t = ok ? t : last_t;
+            const bool tight = (ti.y & kTiTight) != 0;
+            const uint32_t sh = (nz & ti.y & 0xFFFFu) ? (ti.y >> kTiShActive) & 63u : (ti.y >> kTiShIdle) & 63u;
+            const bool fast = ok && !tight;
+            const unsigned long long inc = 1ull << sh;
+            my += (fast && sh != 0u) ? inc : 0ull;
+            if (FULL && a.status && fast) a.status[(uint64_t)i * (uint32_t)a.T + t] = (uint8_t)(sh == 4u ? 4u : sh == 24u ? 2u : sh == 44u ? 3u : 1u);
             push(ok && tight, t);
           },
           [&](uint32_t c) {

@@ -38,6 +38,11 @@ EXPORTS = [
 ]
 
 
+def version() -> str:
+    """kt_version(): library version + hash of the kernel sources it was built from."""
+    return lib().kt_version().decode()
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")

@@ -73,7 +73,17 @@ def main():
         with open(path) as fh:
             allp = json.load(fh)
     allp[key] = summ
-    allp.setdefault("_source", {})[key] = f"{rnd}_{tag}"
+    # which kernel sources the counters belong to: the engine_version the profiled bench.py run itself reported
+    version = None
+    for leg in ("fetch", "write", "trace"):
+        j = os.path.join(src, leg + ".json")
+        try:
+            with open(j) as fh:
+                version = json.loads(fh.read().strip().splitlines()[-1])["config"]["engine_version"]
+            break
+        except Exception:
+            continue
+    allp.setdefault("_source", {})[key] = {"tag": f"{rnd}_{tag}", "engine_version": version}
     with open(path, "w") as fh:
         json.dump(allp, fh, indent=1, sort_keys=True)
     for r in rows:
