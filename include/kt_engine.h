@@ -122,7 +122,8 @@ int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt
  *      clusterthrottle_controller.go:106-136) for EVERY responsible throttle in one pass:
  *      affectedPods (:221-246 / :224-270) -> used = fold ResourceAmount.Add (resource_amount.go:91-110)
  *      -> CalculateThreshold(now) (throttle_types.go:65-106) -> throttled = IsThrottled(used, true)
- *      (resource_amount.go:127-159).  kt_reconcile_launch = aggregate + finalize on one GPU.
+ *      (resource_amount.go:127-159).  kt_reconcile_launch = aggregate + finalize on one GPU (it leaves the partial
+ *      buffer zeroed: the sums are consumed by the finalize, the next scan starts from a clean buffer).
  *      Multi-GPU (pods row-sharded, throttles replicated): kt_aggregate_launch, all-reduce(sum, int64)
  *      over the buffer kt_partial_used_buffer returns, then kt_finalize_launch. -------------------------- */
 #define KT_RECONCILE_APPLY 0x1u /* store the new status as the engine's stored status (UpdateStatus) */

@@ -190,6 +190,7 @@ struct kt_engine {
   unsigned long long* ext_partial = nullptr;  // caller-owned partial buffer (kt_use_partial_buffer)
   int64_t ext_partial_words = 0;
   unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
+  const void* clean_partial = nullptr;  // the partial buffer known to hold zeros (left behind by a consuming finalize)
   AmountDev d_out_used, d_out_calc;
   DevBuf<uint8_t> d_out_calc_updated, d_out_thrl_pod, d_out_error;
   DevBuf<int64_t> d_out_next_s;
@@ -481,6 +482,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
   // result / scratch buffers sized by T
   KT_HIP(e, e->d_partial.reserve(T * kt::partial_stride(D) + 1));
+  e->clean_partial = nullptr;
   KT_HIP(e, e->d_out_used.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
@@ -1118,7 +1120,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     KT_HIP(e, hipStreamSynchronize(s));
     e->countable_valid = true;
   }
-  if (words) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
+  if (words && e->clean_partial != (const void*)e->partial()) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
+  e->clean_partial = nullptr;
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
     std::unique_ptr<TimedLaunch> tr;
@@ -1162,7 +1165,8 @@ static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int6
   return KT_OK;
 }
 
-static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s) {
+// consume: kt_reconcile_launch — nobody reads the partials after this finalize, which leaves them zeroed for the next scan
+static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s, bool consume = false) {
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
@@ -1173,9 +1177,10 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   const int rec_DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
-    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
+    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
                         e->recs_eq, req_bound(e), s);
   }
+  e->clean_partial = consume ? (const void*)e->partial() : nullptr;
   KT_HIP(e, hipGetLastError());
   if (apply) {
     e->status_dev_newer = true;
@@ -1213,6 +1218,7 @@ int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64) {
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   e->ext_partial = (unsigned long long*)device_ptr;
   e->ext_partial_words = device_ptr ? n_int64 : 0;
+  e->clean_partial = nullptr;
   return KT_OK;
 }
 
@@ -1230,7 +1236,7 @@ int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_
   hipStream_t s = pick_stream(e, stream);
   int32_t rc = aggregate_locked(e, s);
   if (rc != KT_OK) return rc;
-  return finalize_locked(e, now_s, now_ns, flags, s);
+  return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
 }
 
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {

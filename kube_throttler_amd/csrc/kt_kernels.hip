@@ -561,25 +561,29 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
 }
 
 template <int DT>
-__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, const unsigned long long* partial,
+__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, int consume,
                                                      int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
                                                      CheckRec<DT>* recs, int rec_eq, const ReqBound vmax) {
+  // consume: leave the row zeroed behind (kt_reconcile_launch: the next aggregate then needs no clearing pass)
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
   const int stride = partial_stride(D);
   ThrRegs<DT> r;
   load_thr<DT>(tt, t, D, r);
-  const unsigned long long* prow = partial + (size_t)t * stride;
+  unsigned long long* prow = partial + (size_t)t * stride;
   unsigned long long pv[DT], pc[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
     const unsigned long long a = prow[d < D ? d : 0], b = prow[D + (d < D ? d : 0)];
     pv[d] = d < D ? a : 0ull, pc[d] = d < D ? b : 0ull;
   }
-  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, prow[2 * D], prow[2 * D + 1], now_s, now_ns, apply, out, recs, rec_eq, vmax);
+  const unsigned long long pods = prow[2 * D], errs = prow[2 * D + 1];
+  if (consume)
+    for (int j = 0; j < stride; ++j) prow[j] = 0ull;
+  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax);
 }
 
-void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
+void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
                      const ReqBound& vmax, hipStream_t s) {
   if (sp.T <= 0) return;
@@ -587,9 +591,9 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const uns
   const dim3 g((sp.T + 63) / 64), b(64);
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
   const int eq = rec_eq ? 1 : 0;
-  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax);
-  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax);
-  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax);
+  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax);
+  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax);
 }
 
 // ---------------------------------------------------------------------------------------------------

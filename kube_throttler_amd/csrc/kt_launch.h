@@ -36,7 +36,8 @@ void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* 
 void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgram& sp, bool keys,
                             unsigned long long* partial, hipStream_t s);
 // recs (nullable): also build the CheckRec<rec_DT> of every throttle for isThrottledOnEqual = rec_eq
-void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, const unsigned long long* partial,
+// consume: the kernel leaves the partial rows zeroed behind
+void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
                      const ReqBound& vmax, hipStream_t s);
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s);
