@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="exchange the partials with the engine's own RCCL communicator (kt_comm_*) instead of torch.distributed")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,9 +117,19 @@ def main():
     ts.synchronize()
     eng.use_partial_buffer(partial.data_ptr(), partial.numel())
 
+    if args.native_comm:  # the framework-free exchange: torch.distributed only carries the 128-byte id to the ranks
+        ids = [E.Engine.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(rank, world, ids[0])
+
     def step():
         with torch.cuda.stream(ts):
-            if world > 1:
+            if args.native_comm:
+                eng.aggregate_launch(stream)
+                eng.comm_allreduce_partial(stream)  # ncclAllReduce(int64, sum) on the kernels' stream
+                eng.finalize_launch(now, True, stream)
+            elif world > 1:
                 eng.aggregate_launch(stream)
                 KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
                 eng.finalize_launch(now, True, stream)
@@ -255,10 +267,13 @@ def main():
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
                        "step": "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
+                       "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
+    if args.native_comm:
+        eng.comm_destroy()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

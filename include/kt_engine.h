@@ -102,6 +102,31 @@ int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* thr_rows);
 /* Clears everything and ingests a whole snapshot (rows = indices). */
 int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s);
 
+/* ---- single-object forms of the state feed: what ONE informer event handler call pushes (OnAdd / OnUpdate of a
+ *      Pod, Throttle / ClusterThrottle, Namespace: throttle_controller.go:400-536, clusterthrottle_controller.go:428-570).
+ *      Every pointer is a direct argument to pointer-free memory, no struct of pointers crosses the boundary: a cgo
+ *      call may pass Go slices' backing arrays as they are (cgo pointer rule, also on the reference's go 1.20 — no
+ *      runtime.Pinner needed).  Same semantics, validation and errors as the batch forms above. -------------------- */
+int32_t kt_upsert_namespace(kt_engine* e, int32_t ns_row, int32_t exists, int32_t n_labels, const uint32_t* label_keys,
+                            const uint32_t* label_pairs);
+/* ctr_req: [n_ctr][D] (D = kt_config.n_dims); ovh: [D] or NULL; ovh_present: bit 31 = spec.overhead != nil */
+int32_t kt_upsert_pod(kt_engine* e, int64_t pod_row, uint32_t ns, uint32_t flags, int32_t n_labels, const uint32_t* label_keys,
+                      const uint32_t* label_pairs, int32_t n_ctr, const uint8_t* ctr_init, const uint32_t* ctr_present,
+                      const int64_t* ctr_req, uint32_t ovh_present, const int64_t* ovh);
+/* amounts of the throttle as four rows — 0 spec.threshold, 1 status.calculatedThreshold.threshold, 2 status.used,
+ * 3 reserved: amt_v [4][D], amt_present [4], amt_count [4], amt_has_count [4].  Overrides: n_ovr rows (ovr_v [n_ovr][D]).
+ * Selector: n_terms terms; term_preq_off / term_nreq_off [n_terms+1] index the two requirement pools, each given as
+ * (n, op [n], key [n], val_off [n+1], val []) like kt_reqs. */
+int32_t kt_upsert_throttle(kt_engine* e, int32_t thr_row, uint32_t flags, uint32_t ns, const int64_t* amt_v,
+                           const uint32_t* amt_present, const int64_t* amt_count, const uint8_t* amt_has_count,
+                           uint32_t thrl_flag, uint32_t thrl_has, uint64_t status_msgs_fp, uint64_t spec_msgs_fp, int32_t n_ovr,
+                           const int64_t* ovr_begin_s, const int32_t* ovr_begin_ns, const int64_t* ovr_end_s,
+                           const int32_t* ovr_end_ns, const uint8_t* ovr_flags, const int64_t* ovr_v, const uint32_t* ovr_present,
+                           const int64_t* ovr_count, const uint8_t* ovr_has_count, int32_t n_terms, const uint8_t* term_flags,
+                           const uint32_t* term_preq_off, const uint32_t* term_nreq_off, uint32_t n_preq, const uint8_t* preq_op,
+                           const uint32_t* preq_key, const uint32_t* preq_val_off, const uint32_t* preq_val, uint32_t n_nreq,
+                           const uint8_t* nreq_op, const uint32_t* nreq_key, const uint32_t* nreq_val_off, const uint32_t* nreq_val);
+
 /* Scheduler-side reserved amounts per throttle — the value reservedResourceAmount(nn) returns
  * (pkg/controllers/reserved_resource_amounts.go:113-126,148-156); the pod map itself stays in Go. */
 int32_t kt_set_reserved(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt_amounts* reserved);
@@ -134,6 +159,19 @@ int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64
  * storage of a framework tensor handed to RCCL) instead of the engine's own. NULL restores the default. */
 int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64);
 int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
+/* ---- multi-GPU without any framework: one process (or thread) per GPU, each with its own engine over its shard of
+ *      the pod rows and a replica of the throttles.  The only exchange of a reconcile is the sum of the partial-`used`
+ *      buffers; kt_comm_* runs it as ONE RCCL all-reduce (ncclInt64, ncclSum; xGMI between the GPUs of a node) on the
+ *      stream the kernels run on:   kt_aggregate_launch -> kt_comm_allreduce_partial -> kt_finalize_launch.
+ *      Rank 0 creates the 128-byte id and hands it to the other ranks by any channel the host has (the Go side would
+ *      use its own RPC / a ConfigMap); librccl.so is loaded on the first kt_comm_* call. ------------------------------ */
+#define KT_COMM_ID_BYTES 128
+int32_t kt_comm_unique_id(void* out_id128);
+int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id128);
+/* in-place sum over all ranks of this engine's partial buffer (the caller's, if kt_use_partial_buffer set one) */
+int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream);
+int32_t kt_comm_destroy(kt_engine* e);
+
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out);
 /* ThrottleSpecBase.NextOverrideHappensIn(now) (throttle_types.go:37-63) of the last reconcile for throttle rows

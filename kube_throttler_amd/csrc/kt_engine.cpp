@@ -6,6 +6,7 @@
 // stream, time them with HIP events.  No compute happens here: without a gfx950 device
 // kt_engine_create fails (KT_ERR_NO_DEVICE) — there is no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -211,6 +212,10 @@ struct kt_engine {
 
   // ---- staging
   DevBuf<uint8_t> d_stage;
+
+  // ---- RCCL communicator (kt_comm_*): opaque ncclComm_t, rank / world
+  void* comm = nullptr;
+  int32_t comm_rank = 0, comm_world = 1;
 
   const char* last_kernel[KT_KERNEL_COUNT] = {"", "", "kt_finalize", "kt_prepare_check", "kt_reduce_bitmap_slabs"};
 
@@ -634,6 +639,43 @@ void reqs_from_pool(const kt_reqs& pool, uint32_t b, uint32_t e_, std::vector<Re
 
 }  // namespace
 
+namespace {
+struct Rccl {
+  struct Id128 {  // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+    char b[128];
+  };
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      r.err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) r.err = "librccl.so lacks the nccl* entry points";
+  });
+  return &r;
+}
+constexpr int kNcclInt64 = 4, kNcclSum = 0;  // rccl.h: ncclInt64, ncclSum
+}  // namespace
+
 // ===================================================================================================
 // C-ABI
 // ===================================================================================================
@@ -719,6 +761,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   if (!e) return KT_OK;
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
+  if (e->comm) (void)rccl()->CommDestroy(e->comm);
   if (e->pods.ns) (void)hipFree(e->pods.ns);
   if (e->pods.flags) (void)hipFree(e->pods.flags);
   if (e->pods.req) (void)hipFree(e->pods.req);
@@ -1008,6 +1051,152 @@ int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* rows) {
   e->program_dirty = true;
   e->status_host_dirty = true;
   e->reconcile_ready = e->check_ready = false;
+  return KT_OK;
+}
+
+// ---- single-object forms: a kt_snapshot is assembled HERE (C memory) around the caller's flat arrays
+int32_t kt_upsert_namespace(kt_engine* e, int32_t ns_row, int32_t exists, int32_t n_labels, const uint32_t* label_keys,
+                            const uint32_t* label_pairs) {
+  if (!e || n_labels < 0 || (n_labels > 0 && (!label_keys || !label_pairs))) return KT_ERR_INVALID_ARGUMENT;
+  kt_snapshot b{};
+  uint8_t valid = exists ? 1 : 0;
+  uint32_t off[2] = {0u, (uint32_t)n_labels};
+  b.n_ns = 1, b.ns_valid = &valid, b.ns_label_off = off;
+  b.ns_label_key = const_cast<uint32_t*>(label_keys), b.ns_label_pair = const_cast<uint32_t*>(label_pairs);
+  return kt_upsert_namespaces(e, &b, &ns_row);
+}
+
+int32_t kt_upsert_pod(kt_engine* e, int64_t pod_row, uint32_t ns, uint32_t flags, int32_t n_labels, const uint32_t* label_keys,
+                      const uint32_t* label_pairs, int32_t n_ctr, const uint8_t* ctr_init, const uint32_t* ctr_present,
+                      const int64_t* ctr_req, uint32_t ovh_present, const int64_t* ovh) {
+  if (!e || n_labels < 0 || n_ctr < 0 || (n_labels > 0 && (!label_keys || !label_pairs)) ||
+      (n_ctr > 0 && (!ctr_init || !ctr_present || !ctr_req)))
+    return KT_ERR_INVALID_ARGUMENT;
+  kt_snapshot b{};
+  int64_t zero_ovh[KT_MAX_DIMS] = {0};
+  uint32_t loff[2] = {0u, (uint32_t)n_labels}, coff[2] = {0u, (uint32_t)n_ctr};
+  b.D = e->D, b.L = e->L, b.n_pods = 1;
+  b.pod_ns = &ns, b.pod_flags = &flags, b.pod_label_off = loff;
+  b.pod_label_key = const_cast<uint32_t*>(label_keys), b.pod_label_pair = const_cast<uint32_t*>(label_pairs);
+  b.pod_ctr_off = coff, b.ctr_init = const_cast<uint8_t*>(ctr_init), b.ctr_present = const_cast<uint32_t*>(ctr_present);
+  b.ctr_req = const_cast<int64_t*>(ctr_req);
+  if (!ovh) ovh_present &= ~0x80000000u;
+  b.pod_ovh_present = &ovh_present, b.pod_ovh = ovh ? const_cast<int64_t*>(ovh) : zero_ovh;
+  return kt_upsert_pods(e, &b, &pod_row);
+}
+
+int32_t kt_upsert_throttle(kt_engine* e, int32_t thr_row, uint32_t flags, uint32_t ns, const int64_t* amt_v,
+                           const uint32_t* amt_present, const int64_t* amt_count, const uint8_t* amt_has_count,
+                           uint32_t thrl_flag, uint32_t thrl_has, uint64_t status_msgs_fp, uint64_t spec_msgs_fp, int32_t n_ovr,
+                           const int64_t* ovr_begin_s, const int32_t* ovr_begin_ns, const int64_t* ovr_end_s,
+                           const int32_t* ovr_end_ns, const uint8_t* ovr_flags, const int64_t* ovr_v, const uint32_t* ovr_present,
+                           const int64_t* ovr_count, const uint8_t* ovr_has_count, int32_t n_terms, const uint8_t* term_flags,
+                           const uint32_t* term_preq_off, const uint32_t* term_nreq_off, uint32_t n_preq, const uint8_t* preq_op,
+                           const uint32_t* preq_key, const uint32_t* preq_val_off, const uint32_t* preq_val, uint32_t n_nreq,
+                           const uint8_t* nreq_op, const uint32_t* nreq_key, const uint32_t* nreq_val_off, const uint32_t* nreq_val) {
+  if (!e || !amt_v || !amt_present || !amt_count || !amt_has_count || n_ovr < 0 || n_terms < 0 ||
+      (n_ovr > 0 && (!ovr_begin_s || !ovr_begin_ns || !ovr_end_s || !ovr_end_ns || !ovr_flags || !ovr_v || !ovr_present || !ovr_count ||
+                     !ovr_has_count)) ||
+      (n_terms > 0 && (!term_flags || !term_preq_off || !term_nreq_off)) ||
+      (n_preq > 0 && (!preq_op || !preq_key || !preq_val_off)) || (n_nreq > 0 && (!nreq_op || !nreq_key || !nreq_val_off)))
+    return KT_ERR_INVALID_ARGUMENT;
+  const int D = e->D;
+  kt_snapshot b{};
+  b.D = D, b.L = e->L, b.n_thr = 1;
+  b.thr_flags = &flags, b.thr_ns = &ns;
+  kt_amounts* rows[4] = {&b.thr_spec, &b.thr_calc, &b.thr_used, &b.thr_reserved};
+  for (int k = 0; k < 4; ++k) {
+    rows[k]->v = const_cast<int64_t*>(amt_v) + (size_t)k * D;
+    rows[k]->present = const_cast<uint32_t*>(amt_present) + k;
+    rows[k]->count = const_cast<int64_t*>(amt_count) + k;
+    rows[k]->has_count = const_cast<uint8_t*>(amt_has_count) + k;
+  }
+  b.thr_thrl_flag = &thrl_flag, b.thr_thrl_has = &thrl_has, b.thr_status_msgs_fp = &status_msgs_fp, b.thr_spec_msgs_fp = &spec_msgs_fp;
+  uint32_t ooff[2] = {0u, (uint32_t)n_ovr}, toff[2] = {0u, (uint32_t)n_terms};
+  b.thr_ovr_off = ooff;
+  b.ovr_begin_s = const_cast<int64_t*>(ovr_begin_s), b.ovr_begin_ns = const_cast<int32_t*>(ovr_begin_ns);
+  b.ovr_end_s = const_cast<int64_t*>(ovr_end_s), b.ovr_end_ns = const_cast<int32_t*>(ovr_end_ns);
+  b.ovr_flags = const_cast<uint8_t*>(ovr_flags);
+  b.ovr_thr = kt_amounts{const_cast<int64_t*>(ovr_v), const_cast<uint32_t*>(ovr_present), const_cast<int64_t*>(ovr_count),
+                         const_cast<uint8_t*>(ovr_has_count)};
+  b.thr_term_off = toff;
+  uint32_t zero2[2] = {0u, 0u};
+  b.term_flags = const_cast<uint8_t*>(term_flags);
+  b.term_preq_off = n_terms ? const_cast<uint32_t*>(term_preq_off) : zero2;
+  b.term_nreq_off = n_terms ? const_cast<uint32_t*>(term_nreq_off) : zero2;
+  uint32_t zero1[1] = {0u};
+  b.preq = kt_reqs{n_preq, const_cast<uint8_t*>(preq_op), const_cast<uint32_t*>(preq_key),
+                   n_preq ? const_cast<uint32_t*>(preq_val_off) : zero1, const_cast<uint32_t*>(preq_val)};
+  b.nreq = kt_reqs{n_nreq, const_cast<uint8_t*>(nreq_op), const_cast<uint32_t*>(nreq_key),
+                   n_nreq ? const_cast<uint32_t*>(nreq_val_off) : zero1, const_cast<uint32_t*>(nreq_val)};
+  if (n_terms > 0 && (term_preq_off[n_terms] > n_preq || term_nreq_off[n_terms] > n_nreq))
+    return e->fail(KT_ERR_OUT_OF_RANGE, "selector terms reference %u / %u requirements, pools hold %u / %u", term_preq_off[n_terms],
+                   term_nreq_off[n_terms], n_preq, n_nreq);
+  return kt_upsert_throttles(e, &b, &thr_row);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kt_comm_*: the reconcile's one exchange as a native RCCL all-reduce (no framework in the process).
+// librccl.so is loaded on first use: an engine that never talks to another GPU does not depend on it.
+// ---------------------------------------------------------------------------------------------------
+int32_t kt_comm_unique_id(void* out_id128) {
+  if (!out_id128) return KT_ERR_INVALID_ARGUMENT;
+  Rccl* r = rccl();
+  if (!r->err.empty()) {
+    g_create_error = r->err;
+    return KT_ERR_UNSUPPORTED;
+  }
+  const int rc = r->GetUniqueId(out_id128);
+  if (rc != 0) {
+    g_create_error = std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error");
+    return KT_ERR_DEVICE;
+  }
+  return KT_OK;
+}
+
+int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id128) {
+  if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  Rccl* r = rccl();
+  if (!r->err.empty()) return e->fail(KT_ERR_UNSUPPORTED, "%s", r->err.c_str());
+  if (e->comm) return e->fail(KT_ERR_INVALID_ARGUMENT, "kt_comm_init: the engine already has a communicator");
+  Rccl::Id128 id;
+  memcpy(id.b, id128, sizeof id.b);
+  const int rc = r->CommInitRank(&e->comm, world, id, rank);
+  if (rc != 0) {
+    e->comm = nullptr;
+    return e->fail(KT_ERR_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString ? r->GetErrorString(rc) : "error");
+  }
+  e->comm_rank = rank, e->comm_world = world;
+  return KT_OK;
+}
+
+int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->comm) return e->fail(KT_ERR_NOT_READY, "kt_comm_allreduce_partial before kt_comm_init");
+  hipStream_t s = pick_stream(e, stream);
+  const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  if (!words) return KT_OK;
+  if (!e->partial()) return e->fail(KT_ERR_NOT_READY, "no partial buffer yet: kt_aggregate_launch first");
+  Rccl* r = rccl();
+  const int rc = r->AllReduce(e->partial(), e->partial(), words, kNcclInt64, kNcclSum, e->comm, s);
+  if (rc != 0) return e->fail(KT_ERR_DEVICE, "ncclAllReduce: %s", r->GetErrorString ? r->GetErrorString(rc) : "error");
+  e->last_stream = s;
+  return KT_OK;
+}
+
+int32_t kt_comm_destroy(kt_engine* e) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->comm) return KT_OK;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  (void)rccl()->CommDestroy(e->comm);
+  e->comm = nullptr;
+  e->comm_world = 1, e->comm_rank = 0;
   return KT_OK;
 }
 

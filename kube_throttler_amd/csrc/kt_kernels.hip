@@ -163,25 +163,38 @@ __global__ __launch_bounds__(kBlock) void kt_gather_pod_requests(PodTable pods, 
 // kt_compact_countable — the rows of the pods a reconcile has to look at (shouldCountIn, throttle_controller.go:217-219:
 // valid, scheduled by the target scheduler, bound to a node; finished ones included — they still matter for selector
 // errors), as a dense list: the aggregate scan then spends no lanes on pending / foreign pods.  Rebuilt only after pod
-// events.  Order: ascending inside a wave, waves in arrival order (sums do not care).
-__global__ __launch_bounds__(kBlock) void kt_compact_countable(PodTable pods, int64_t n, int64_t* out_rows, unsigned long long* out_n) {
-  const int64_t n_round = (n + kWave - 1) / kWave * kWave;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * kBlock) {
+// events.  Order: ascending inside a 1024-pod block, blocks in arrival order (sums do not care).
+__global__ __launch_bounds__(1024) void kt_compact_countable(PodTable pods, int64_t n, int64_t* out_rows, unsigned long long* out_n) {
+  // one atomic per 1024-pod block: wave ballots -> LDS counts -> block base
+  __shared__ uint32_t wcnt[16];
+  __shared__ unsigned long long bbase;
+  const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int64_t n_round = (n + 1023) / 1024 * 1024;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024; i0 < n_round; i0 += (int64_t)gridDim.x * 1024) {
+    const int64_t i = i0 + threadIdx.x;
     const uint32_t st = i < n ? (uint32_t)(pods.meta[i] >> kMetaStateShift) & 0xFu : 0u;
     const bool countable = (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
     const uint64_t mk = __ballot(countable);
-    if (mk == 0ull) continue;
-    unsigned long long base = 0;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    if (lane == 0) base = atomicAdd(out_n, (unsigned long long)__popcll(mk));
-    base = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0) << 32;
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(mk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < 16; ++w) {
+        const uint32_t c = wcnt[w];
+        wcnt[w] = tot;  // exclusive prefix
+        tot += c;
+      }
+      bbase = tot ? atomicAdd(out_n, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-    if (countable) out_rows[base + rank] = i;
+    if (countable) out_rows[bbase + wcnt[wave] + rank] = i;
+    __syncthreads();  // wcnt / bbase are rewritten by the next round
   }
 }
 void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows, unsigned long long* out_n, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(kt_compact_countable, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, out_rows, out_n);
+  hipLaunchKernelGGL(kt_compact_countable, dim3(grid_for(n, 1024, 2048)), dim3(1024), 0, s, pods, n, out_rows, out_n);
 }
 
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {

@@ -34,7 +34,8 @@ EXPORTS = [
     "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
-    "kt_check",
+    "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
+    "kt_comm_allreduce_partial", "kt_comm_destroy",
 ]
 
 
@@ -102,6 +103,10 @@ def lib():
         L.kt_check_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_check_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.kt_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.kt_comm_unique_id.argtypes = [C.c_void_p]
+        L.kt_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.kt_comm_allreduce_partial.argtypes = [C.c_void_p, C.c_void_p]
+        L.kt_comm_destroy.argtypes = [C.c_void_p]
         L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.kt_fetch_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -239,6 +244,24 @@ class Engine:
 
     def use_partial_buffer(self, device_ptr, n_int64):
         self._ck(lib().kt_use_partial_buffer(self._h, device_ptr, n_int64))
+
+    # ---- native RCCL exchange of the partials (kt_comm_*): multi-GPU without a framework in the process
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib().kt_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(rc, lib().kt_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        self._ck(lib().kt_comm_init(self._h, rank, world, C.create_string_buffer(unique_id, 128)))
+
+    def comm_allreduce_partial(self, stream=None):
+        self._ck(lib().kt_comm_allreduce_partial(self._h, stream))
+
+    def comm_destroy(self):
+        self._ck(lib().kt_comm_destroy(self._h))
 
     def partial_words(self) -> int:
         return self.throttle_rows() * (2 * self.D + 2)
