@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (tools/latency_bench.py)")
     ap.add_argument("--native-comm", action="store_true",
                     help="exchange the partials with the engine's own RCCL communicator (kt_comm_*) instead of torch.distributed")
     args = ap.parse_args()
@@ -254,9 +255,25 @@ def main():
                       f"(oracle/kt_oracle.c, OpenMP over pods on {cores} threads, klog eager-argument work included); "
                       f"NOT the reference Go binary",
         }
+        # the single-pod yardstick for the latency leg: PreFilter of ONE pod on ONE core, reference loop shape
+        one = sample[:256]
+        t0 = time.perf_counter()
+        o.check(rows=one, want_status=False, nthreads=1, mimic_log_args=True)
+        cpu_baseline["prefilter_one_pod_us_1core"] = round((time.perf_counter() - t0) / len(one) * 1e6, 1)
         if args.verify:
             _, sm_gpu = eng.check(rows=sample, want_status=False)
             assert np.array_equal(sm_gpu, sm_cpu), "GPU summaries differ from the oracle on the sample"
+
+    # ---- what the scheduler would feel: single-call latencies through the C-ABI (rank 0, N=1; after the timed region)
+    latency = None
+    if rank == 0 and world == 1 and not args.no_latency and not args.native_comm:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import latency_bench
+            eng.use_partial_buffer(None, 0)
+            latency = latency_bench.measure(eng, snap, n_check=4000, n_upsert=200, now=now)
+        except Exception as ex:  # never lose the bench line over the side measurement
+            latency = {"error": repr(ex)}
 
     if rank == 0:
         out = {
@@ -269,7 +286,7 @@ def main():
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
                        "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "latency": latency,
         }
         print(json.dumps(out))
     if args.native_comm:

@@ -279,6 +279,73 @@ class Snapshot:
         self._keep = s
         return s
 
+    # -- sub-batches: what ONE informer event (or a few) pushes -------------------------------------
+    def pod_batch(self, rows) -> "Snapshot":
+        """A pods-only batch holding this snapshot's pods `rows`, in that order (for kt_upsert_pods)."""
+        rows = np.asarray(rows)
+        b = Snapshot(self.D, self.L)
+        b.alloc_namespaces(0, 0)
+        b.alloc_throttles(0, 0, 0)
+        nl = int(sum(int(self.pod_label_off[r + 1]) - int(self.pod_label_off[r]) for r in rows))
+        nc = int(sum(int(self.pod_ctr_off[r + 1]) - int(self.pod_ctr_off[r]) for r in rows))
+        b.alloc_pods(len(rows), nl, nc)
+        lo = co = 0
+        for i, r in enumerate(rows):
+            b.pod_ns[i], b.pod_flags[i] = self.pod_ns[r], self.pod_flags[r]
+            l0, l1 = int(self.pod_label_off[r]), int(self.pod_label_off[r + 1])
+            b.pod_label_key[lo:lo + l1 - l0] = self.pod_label_key[l0:l1]
+            b.pod_label_pair[lo:lo + l1 - l0] = self.pod_label_pair[l0:l1]
+            lo += l1 - l0
+            b.pod_label_off[i + 1] = lo
+            c0, c1 = int(self.pod_ctr_off[r]), int(self.pod_ctr_off[r + 1])
+            b.ctr_init[co:co + c1 - c0] = self.ctr_init[c0:c1]
+            b.ctr_present[co:co + c1 - c0] = self.ctr_present[c0:c1]
+            b.ctr_req[co:co + c1 - c0] = self.ctr_req[c0:c1]
+            co += c1 - c0
+            b.pod_ctr_off[i + 1] = co
+            b.pod_ovh_present[i] = self.pod_ovh_present[r]
+            b.pod_ovh[i] = self.pod_ovh[r]
+        return b
+
+    def throttle_batch(self, rows) -> "Snapshot":
+        """A throttles-only batch holding this snapshot's throttle rows `rows` (spec, selector, overrides, stored status,
+        reserved amounts), for kt_upsert_throttles."""
+        rows = np.asarray(rows)
+        b = Snapshot(self.D, self.L)
+        b.alloc_namespaces(0, 0)
+        b.alloc_pods(0, 0, 0)
+        n_ovr = int(sum(int(self.thr_ovr_off[t + 1]) - int(self.thr_ovr_off[t]) for t in rows))
+        n_term = int(sum(int(self.thr_term_off[t + 1]) - int(self.thr_term_off[t]) for t in rows))
+        b.alloc_throttles(len(rows), n_ovr, n_term)
+        pools = []
+        for pool in (self.preq, self.nreq):
+            op, key, val_off, val = pool.arrays() if hasattr(pool, "arrays") else (pool.op, pool.key, pool.val_off, pool.val)
+            pools.append((np.asarray(op), np.asarray(key), np.asarray(val_off), np.asarray(val)))
+        oo = gg = 0
+        for i, t in enumerate(rows):
+            b.thr_flags[i], b.thr_ns[i] = self.thr_flags[t], self.thr_ns[t]
+            for dst, src in ((b.thr_spec, self.thr_spec), (b.thr_calc, self.thr_calc), (b.thr_used, self.thr_used),
+                             (b.thr_reserved, self.thr_reserved)):
+                dst.v[i], dst.present[i], dst.count[i], dst.has_count[i] = src.v[t], src.present[t], src.count[t], src.has_count[t]
+            b.thr_thrl_flag[i], b.thr_thrl_has[i] = self.thr_thrl_flag[t], self.thr_thrl_has[t]
+            b.thr_status_msgs_fp[i], b.thr_spec_msgs_fp[i] = self.thr_status_msgs_fp[t], self.thr_spec_msgs_fp[t]
+            for o in range(int(self.thr_ovr_off[t]), int(self.thr_ovr_off[t + 1])):
+                b.ovr_begin_s[oo], b.ovr_begin_ns[oo] = self.ovr_begin_s[o], self.ovr_begin_ns[o]
+                b.ovr_end_s[oo], b.ovr_end_ns[oo], b.ovr_flags[oo] = self.ovr_end_s[o], self.ovr_end_ns[o], self.ovr_flags[o]
+                b.ovr_thr.v[oo], b.ovr_thr.present[oo] = self.ovr_thr.v[o], self.ovr_thr.present[o]
+                b.ovr_thr.count[oo], b.ovr_thr.has_count[oo] = self.ovr_thr.count[o], self.ovr_thr.has_count[o]
+                oo += 1
+            b.thr_ovr_off[i + 1] = oo
+            for g in range(int(self.thr_term_off[t]), int(self.thr_term_off[t + 1])):
+                b.term_flags[gg] = self.term_flags[g]
+                for dst, offs, (op, key, val_off, val) in ((b.preq, self.term_preq_off, pools[0]), (b.nreq, self.term_nreq_off, pools[1])):
+                    for r in range(int(offs[g]), int(offs[g + 1])):
+                        dst.add(int(op[r]), int(key[r]), [int(v) for v in val[int(val_off[r]):int(val_off[r + 1])]])
+                gg += 1
+                b.term_preq_off[gg], b.term_nreq_off[gg] = len(b.preq), len(b.nreq)
+            b.thr_term_off[i + 1] = gg
+        return b
+
     # -- status write-back (what UpdateStatus would persist) ----------------------------------
     def apply_status(self, used: Amounts, calc: Amounts, calc_updated, thrl_flag, thrl_has, thrl_pod,
                      error=None, rows=None):

@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""What the scheduler would feel: latencies of the single-object calls of the drop-in boundary (host wall clock, through
+the C-ABI, engine already holding the snapshot).
+
+  check1        kt_check(n=1): PreFilter of ONE pod (plugin.go:148-215) — H2D of the row, kernels, D2H of the summary
+  check1_busy   the same while another thread runs kt_reconcile_launch + kt_reconcile_fetch in a loop (one engine lock)
+  upsert_pod1   kt_upsert_pods(1): a pod informer event (stage + kt_ingest_pods + kt_translate_pods)
+  recompile     the first kt_check after ONE kt_upsert_throttles: selector program recompile + index rebuild + upload +
+                re-translation of every pod's labels (what ANY throttle / namespace event costs)
+(bench.py's cpu_baseline leg adds the CPU restatement's PreFilter of one pod on one core as the yardstick.)
+
+    python tools/latency_bench.py --config 2        (prints one JSON object)
+bench.py embeds the same object as "latency" (N = 1 runs)."""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _pct(xs):
+    a = np.sort(np.asarray(xs)) * 1e6
+    return {"p50_us": round(float(a[len(a) // 2]), 1), "p99_us": round(float(a[min(len(a) - 1, int(len(a) * 0.99))]), 1),
+            "mean_us": round(float(a.mean()), 1), "n": int(len(a))}
+
+
+def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
+    from kube_throttler_amd import snapshot as S
+    P = snap.n_pods
+    rng = np.random.default_rng(7)
+    rows = rng.integers(0, P, size=n_check).astype(np.int64)
+    out = {}
+    eng.reconcile(now, apply=True)
+    eng.check_atomic(rows=rows[:1], want_status=False)  # warm: CheckRecs built, buffers sized
+
+    def sweep(rs):
+        ts = []
+        for r in rs:
+            t0 = time.perf_counter()
+            eng.check_atomic(rows=np.array([r], dtype=np.int64), want_status=False)
+            ts.append(time.perf_counter() - t0)
+        return ts
+    out["check1"] = _pct(sweep(rows))
+    # ---- the same next to a reconcile loop on another thread
+    stop = threading.Event()
+    n_rec = [0]
+
+    def reconciler():
+        while not stop.is_set():
+            eng.reconcile(now, apply=True)
+            n_rec[0] += 1
+    th = threading.Thread(target=reconciler)
+    th.start()
+    try:
+        busy = sweep(rows[:max(1000, n_check // 4)])
+    finally:
+        stop.set()
+        th.join()
+    out["check1_busy"] = dict(_pct(busy), reconciles_meanwhile=n_rec[0])
+    # ---- one pod event
+    ts = []
+    for r in rng.integers(0, P, size=n_upsert):
+        one = snap.pod_batch(np.array([int(r)], dtype=np.int64))
+        t0 = time.perf_counter()
+        eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
+        ts.append(time.perf_counter() - t0)
+    out["upsert_pod1"] = _pct(ts)
+    # ---- one throttle event: the next call recompiles the program, rebuilds the index and re-translates the pods
+    ts = []
+    for k in range(5):
+        t = int(rng.integers(0, snap.n_thr))
+        one = snap.throttle_batch(np.array([t], dtype=np.int32))
+        eng.upsert_throttles(one, rows=np.array([t], dtype=np.int32))
+        t0 = time.perf_counter()
+        eng.check_atomic(rows=rows[:1], want_status=False)
+        ts.append(time.perf_counter() - t0)
+    out["recompile"] = {"mean_ms": round(float(np.mean(ts)) * 1e3, 2), "min_ms": round(float(np.min(ts)) * 1e3, 2), "n": len(ts),
+                        "throttles": int(snap.n_thr), "pods": int(P)}
+    return out
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--pods", type=int, default=0)
+    args = ap.parse_args()
+    from kube_throttler_amd import engine as E, workload as W
+    cfg = W.preset(args.config)
+    if args.config == 4 and not args.pods:
+        cfg = cfg.shard(0, 8)
+    if args.pods:
+        cfg.n_pods_total = cfg.n_pods = args.pods
+    snap = W.generate(cfg)
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        res = measure(eng, snap, now=(cfg.now_s, 0))
+    finally:
+        eng.close()
+    print(json.dumps({"workload": f"configs[{args.config}]", "pods": int(snap.n_pods), "throttles": int(snap.n_thr), "latency": res}))
+
+
+if __name__ == "__main__":
+    main()
