@@ -205,6 +205,9 @@ struct kt_engine {
   DevBuf<uint8_t> d_status;
   DevBuf<int64_t> d_rows;
   int64_t check_n = 0;
+  DevBuf<uint32_t> d_ticket;          // arrival counters of small check launches (kt_check_bitmap SMALL)
+  uint64_t* h_small = nullptr;        // pinned host copy of a small launch's summary words (kCheckSmallMax)
+  bool check_in_h_small = false;      // the last check left its summaries in h_small
   int32_t check_T = 0, reconcile_T = 0;  // throttle rows in effect when the last check / reconcile was launched
   bool check_has_status = false;
   bool check_ready = false;
@@ -772,6 +775,8 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_overflow.release();
   e->d_countable.release();
   e->d_n_countable.release();
+  e->d_ticket.release();
+  if (e->h_small) (void)hipHostFree(e->h_small);
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
@@ -1481,8 +1486,9 @@ int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_
 // ---------------------------------------------------------------------------------------------------
 // check
 // ---------------------------------------------------------------------------------------------------
+// allow_small: false for callers that go on working on the device-side rows / summaries (kt_admit_launch)
 static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
-                                   hipStream_t s) {
+                                   hipStream_t s, bool allow_small = true) {
   if (pod_rows) {
     for (int64_t i = 0; i < n; ++i)
       if (pod_rows[i] < 0 || pod_rows[i] >= e->cfg.pod_capacity)
@@ -1501,7 +1507,23 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
     if (want_status) KT_HIP(e, e->d_status.reserve((size_t)n * T + 64));  // slack: kt_admit_sequential reads rows 16 bytes at a time
     if (pod_rows) KT_HIP(e, e->d_rows.reserve((size_t)n + 1));
   }
-  if (pod_rows && n) {
+  // a handful of pods (one PreFilter call): rows by value, one workgroup per index chunk, summaries to pinned memory
+  const bool small = allow_small && e->cfg.kernel_variant != 1 && n > 0 && n <= kt::kCheckSmallMax;
+  kt::CheckSmall sm{};
+  if (small) {
+    if (!e->h_small) {
+      KT_HIP(e, hipHostMalloc((void**)&e->h_small, (size_t)kt::kCheckSmallMax * 8, hipHostMallocMapped));
+      KT_HIP(e, e->d_ticket.reserve(16));
+      KT_HIP(e, hipMemsetAsync(e->d_ticket.p, 0, 16 * 4, s));
+    }
+    sm.ticket = e->d_ticket.p;
+    sm.host_summary = e->h_small;
+    if (pod_rows && n <= 8) {
+      sm.n_inline = (uint32_t)n;
+      for (int64_t k = 0; k < 8; ++k) sm.inline_rows[k] = pod_rows[k < n ? k : n - 1];
+    }
+  }
+  if (pod_rows && n && !sm.n_inline) {
     KT_HIP(e, hipMemcpyAsync(e->d_rows.p, pod_rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
     KT_HIP(e, hipStreamSynchronize(s));  // caller memory must not be referenced after return
   }
@@ -1526,13 +1548,15 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
       if (e->n_overflow)
         return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
       const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
-                                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s);
+                                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
+                                               small ? &sm : nullptr);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
     }
   }
   KT_HIP(e, hipGetLastError());
   e->check_n = n;
+  e->check_in_h_small = small;
   e->check_T = e->thr_rows_hi;
   e->check_has_status = want_status;
   e->check_ready = true;
@@ -1558,7 +1582,7 @@ int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   if ((double)n * (double)e->thr_rows_hi > 2147483648.0)
     return e->fail(KT_ERR_OUT_OF_RANGE, "admit queue: n x throttle_rows = %lld x %d exceeds 2^31 matrix bytes", (long long)n, e->thr_rows_hi);
   // (a) who affects whom, for the whole queue in parallel (statuses against the current reserved amounts)
-  int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, KT_CHECK_STATUS_MATRIX, s);
+  int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, KT_CHECK_STATUS_MATRIX, s, /*allow_small=*/false);
   if (rc != KT_OK || n == 0 || e->thr_rows_hi == 0) return rc;
   // (b) the queue in order, one wave, reserved amounts in LDS
   const bool commit = (flags & KT_ADMIT_COMMIT) != 0;
@@ -1609,10 +1633,12 @@ static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary
   if (n < 0 || n > e->check_n) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%lld, last check had %lld pods", (long long)n, (long long)e->check_n);
   if (out_status && !e->check_has_status) return e->fail(KT_ERR_NOT_READY, "status matrix was not requested at launch");
   hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
-  if (n && out_summary) KT_HIP(e, hipMemcpyAsync(out_summary, e->d_summary.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  const bool from_pinned = e->check_in_h_small && e->h_small;  // the kernel already wrote the words to host memory
+  if (n && out_summary && !from_pinned) KT_HIP(e, hipMemcpyAsync(out_summary, e->d_summary.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
   if (n && out_status && e->check_T)  // the matrix was written with the row stride in effect at launch
     KT_HIP(e, hipMemcpyAsync(out_status, e->d_status.p, (size_t)n * (size_t)e->check_T, hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));
+  if (n && out_summary && from_pinned) memcpy(out_summary, e->h_small, (size_t)n * 8);
   return KT_OK;
 }
 

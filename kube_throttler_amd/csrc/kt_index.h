@@ -176,9 +176,17 @@ struct AggScan {
 const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& scan, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, unsigned long long* partial, void* slab, hipStream_t s,
                               const std::function<void()>& after_scan = nullptr);
+// small launches (n <= kCheckSmallMax): one workgroup per (chunk, tile); see kt_check_bitmap's SMALL instantiation
+constexpr int64_t kCheckSmallMax = 256;
+struct CheckSmall {
+  uint32_t* ticket;        // device, >= kCheckSmallMax / 64 words, zero between launches
+  uint64_t* host_summary;  // pinned host buffer of kCheckSmallMax words (device-accessible), or nullptr
+  uint32_t n_inline;       // 0, or n (<= 8): the pod rows are passed by value
+  int64_t inline_rows[8];
+};
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s);
+                          uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr);
 // labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)
 // n_overflow (device counter): valid pods with more relevant atoms than PodTable::LA
 void launch_translate_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t row0, const IndexDev& ix,

@@ -47,6 +47,11 @@ struct BmCheckArgs {
   uint32_t n_slow;
   int32_t DS, LS, T;
   uint32_t exp;  // KT_EXP (timing experiments only; results are wrong when set): 1 no drain, 2 no peel work, 4 no scan
+  // small launches (SMALL instantiation: one workgroup per (chunk, tile), results met by atomics)
+  uint32_t* ticket;        // [tiles] arrival counters, zero between launches
+  uint64_t* host_summary;  // nullable: pinned host copy of the final summary words
+  uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
+  int64_t inline_rows[8];
 };
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
@@ -71,10 +76,14 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
 
 uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
 
+// SMALL: a launch of a few pods (one PreFilter call, an admission queue): grid = (chunks, tiles), every workgroup scans
+//        ONE tile against ONE chunk, so that the chunks of a large program are walked side by side instead of one after
+//        the other; the class counters meet in the summary word by atomics, the last workgroup of a tile (arrival
+//        ticket) writes the word's final form — also to a pinned host copy, which saves the D2H copy of the fetch.
 // WPE:  waves per SIMD the register allocation has to leave room for (4: one workgroup per CU, 8: two)
 // FULL: the launch also wants the status matrix and / or has throttles on the slow list — the lean instantiation
 //       (summary words only, no slow list: the PreFilter sweep) keeps neither code path nor their registers
-template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL>
+template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
@@ -91,7 +100,8 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   const uint32_t n_wtiles = (n + kWave - 1) / kWave;
   const uint32_t wstep = gridDim.x * (kBlockIx / kWave);
   const uint32_t n_chunks = a.ix.n_chunks;
-  for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+  const uint32_t c_lo = SMALL ? blockIdx.x : 0u, c_hi = SMALL ? blockIdx.x + 1u : n_chunks;
+  for (uint32_t ci = c_lo; ci < c_hi; ++ci) {
     const bool first = ci == 0, last = ci + 1 == n_chunks;
     const BmChunk ch = a.ix.chunks[ci];
     __syncthreads();  // nobody reads the previous image any more
@@ -113,19 +123,20 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
     }
     __syncthreads();
-    for (uint32_t wt = blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles; wt += wstep) {
+    for (uint32_t wt = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles;
+         wt += SMALL ? n_wtiles : wstep) {
       // ---- the tile's records: always from valid addresses (lanes past the end re-read the last pod and are
       //      switched off by `on`)
       const uint32_t i = wt * kWave + lane;
       const bool in = i < n;
       const uint32_t ic = min(i, n - 1u);
-      const uint32_t p = a.rows ? (uint32_t)a.rows[ic] : ic;
+      const uint32_t p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
       const uint64_t meta = a.meta[p];
       u32x4 raw[LA / 8];
       load_atoms<LA>(a.latom, p, raw);
       // class counters so far (bit 1 = error) ride in the summary word between chunks
       const unsigned long long carried =
-          (!first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          (!SMALL && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       cnt[lane] = 0ull;
       unsigned long long my = carried & ~3ull;  // this lane's class counters
       const bool on = in && ((meta >> kMetaStateShift) & kPodValid) != 0;
@@ -218,7 +229,30 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           });
       if (n_list) drain();
       // ---- lane = pod: the 8-byte summary word
-      if (in) {
+      if (SMALL) {
+        // this workgroup's share of the tile's counters; the last workgroup to arrive gives the words their final form
+        if (in) {
+          const unsigned long long c = my + cnt[lane];
+          if (c) (void)__hip_atomic_fetch_add((unsigned long long*)a.summary + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pod_err) (void)__hip_atomic_fetch_or((unsigned long long*)a.summary + i, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(a.ticket + wt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived + 1u == n_chunks) {
+          if (in) {
+            const unsigned long long w = __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long c = w & ~3ull;
+            const unsigned long long fin = !on ? 0ull : (w & 2ull) ? 2ull : (c | (c ? 1ull : 0ull));
+            a.summary[i] = fin;
+            if (a.host_summary) a.host_summary[i] = fin;
+            if (FULL && a.status && on && (w & 2ull))
+              for (int t = 0; t < a.T; ++t) a.status[(uint64_t)i * (uint32_t)a.T + t] = 255;
+          }
+          if (lane == 0) a.ticket[wt] = 0u;  // ready for the next launch
+        }
+      } else if (in) {
         const unsigned long long c = my + cnt[lane];
         if (last) {
           a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
@@ -232,24 +266,25 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   }
 }
 
-#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_)                                                       \
+#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_)                                               \
   {                                                                                                             \
-    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_, FULL_>;                                            \
+    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_>;                                    \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
     hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                     \
   }
 #define KT_BM_CASE(DT_, LA_, VETO_, NEED_)                                                   \
   {                                                                                          \
-    if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true)                                  \
-    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false)                      \
-    else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false)                                      \
+    if (small) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, true)                           \
+    else if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, false)                      \
+    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false)               \
+    else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false, false)                               \
   }
 
 // returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s) {
+                          uint8_t* status, hipStream_t s, const CheckSmall* sm) {
   if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -259,12 +294,20 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   const size_t lds_bytes = bm_total;
   // two workgroups per CU (8 waves per SIMD) when two LDS footprints fit; KT_CHECK_WGS_PER_CU=1 forces one (A/B runs)
   static const int force_wgs = getenv("KT_CHECK_WGS_PER_CU") ? atoi(getenv("KT_CHECK_WGS_PER_CU")) : 0;
+  const bool small = sm != nullptr && n <= kCheckSmallMax;
+  if (small) {
+    (void)hipMemsetAsync(summary, 0, (size_t)n * 8, s);  // the counters meet by atomics
+    bm_args.ticket = sm->ticket, bm_args.host_summary = sm->host_summary;
+    bm_args.n_inline = sm->n_inline;
+    for (int k = 0; k < 8; ++k) bm_args.inline_rows[k] = sm->inline_rows[k];
+  }
   const bool full = status != nullptr || ix.n_slow != 0;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;
   dim3 g_((unsigned)nb), b_(kBlockIx);
+  if (small) g_ = dim3(ix.n_chunks, (unsigned)((n + kWave - 1) / kWave));
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds) fprintf(stderr, "kt_check_bitmap: lds=%u (%d per CU) chunks=%u LA=%d veto=%u need=%u\n", bm_total, two_per_cu ? 2 : 1, ix.n_chunks, LA, ix.has_veto, ix.max_need);
   const bool rich = ix.rich;
@@ -275,7 +318,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   else if (LA <= 16) { if (DT <= 8) KT_BM_CASE(8, 16, true, 3) else KT_BM_CASE(16, 16, true, 3) }
   else { if (DT <= 8) KT_BM_CASE(8, 32, true, 3) else KT_BM_CASE(16, 32, true, 3) }
 #endif
-  return ix.n_chunks == 1 ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
+  return small ? "kt_check_bitmap_small" : ix.n_chunks == 1 ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
 }
 
 }  // namespace kt
