@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 #define KT_MAX_DIMS 16   /* resource dimensions per engine */
-#define KT_MAX_LABELS 16 /* labels per pod / namespace kept by the engine */
+#define KT_MAX_LABELS 64 /* labels per pod the engine stores (raw); the scans read only the atoms selectors reference,
+                            so wide label sets cost HBM, not scan time.  A requirement's values are pair ids of ITS key. */
 
 /* pod_flags bits (pkg/controllers/throttle_controller.go:217-219, pod_util.go:22-28) */
 #define KT_POD_VALID 0x1u        /* row in use */

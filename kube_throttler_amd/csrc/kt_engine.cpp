@@ -215,6 +215,7 @@ struct kt_engine {
 
   // ---- staging
   DevBuf<uint8_t> d_stage;
+  uint8_t* h_stage = nullptr;  // pinned: small batches cross in one copy
 
   // ---- RCCL communicator (kt_comm_*): opaque ncclComm_t, rank / world
   void* comm = nullptr;
@@ -613,6 +614,7 @@ void amount_to_table(const HostAmount& h, const kt_amounts& a, size_t i, int D) 
 }
 
 constexpr unsigned __int128 kSumBound = (unsigned __int128)1 << 60;
+constexpr size_t kPinnedStageBytes = 1u << 20;
 
 // upper bound of every pod's effective request per dimension, for kRecTight (kt_device.h)
 kt::ReqBound req_bound(const kt_engine* e) {
@@ -777,6 +779,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_n_countable.release();
   e->d_ticket.release();
   if (e->h_small) (void)hipHostFree(e->h_small);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
@@ -898,7 +901,15 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
                  o_op = sect(cn * 4), o_ov = sect((size_t)cn * 8 * D);
     KT_HIP(e, e->d_stage.reserve(off + 16));
     uint8_t* st = e->d_stage.p;
-#define CP(o, src, bytes) if ((bytes) > 0) KT_HIP(e, hipMemcpyAsync(st + (o), (src), (bytes), hipMemcpyHostToDevice, s))
+    // a small batch (an informer event) is packed in pinned host memory and crosses in ONE copy; a bulk load copies
+    // its sections straight from the caller's arrays
+    const bool packed = off <= kPinnedStageBytes;
+    if (packed && !e->h_stage) KT_HIP(e, hipHostMalloc((void**)&e->h_stage, kPinnedStageBytes, hipHostMallocDefault));
+#define CP(o, src, bytes)                                                                               \
+  if ((bytes) > 0) {                                                                                    \
+    if (packed) memcpy(e->h_stage + (o), (src), (bytes));                                               \
+    else KT_HIP(e, hipMemcpyAsync(st + (o), (src), (bytes), hipMemcpyHostToDevice, s));                 \
+  }
     if (rows) CP(o_rows, rows + c0, (size_t)cn * 8);
     CP(o_ns, b->pod_ns + c0, (size_t)cn * 4);
     CP(o_fl, b->pod_flags + c0, (size_t)cn * 4);
@@ -912,6 +923,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     CP(o_op, b->pod_ovh_present + c0, (size_t)cn * 4);
     CP(o_ov, b->pod_ovh + (size_t)c0 * D, (size_t)cn * 8 * D);
 #undef CP
+    if (packed) KT_HIP(e, hipMemcpyAsync(st, e->h_stage, off, hipMemcpyHostToDevice, s));
     kt::PodBatchDev pb{};
     pb.n = cn;
     pb.rows = rows ? (const int64_t*)(st + o_rows) : nullptr;
@@ -1329,8 +1341,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     else {
       kt::AggScan sc;
       sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
-      if (e->n_overflow)
-        return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
+      sc.overflow_pods = e->n_overflow != 0;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
       e->last_kernel[KT_KERNEL_AGGREGATE] = k;
@@ -1352,7 +1363,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
 static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, int sign, hipStream_t s) {
   if (!e->incremental || !e->agg_valid || n <= 0 || e->thr_rows_hi == 0) return KT_OK;
   kt::AggScan sc;
-  sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign;
+  sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign, sc.overflow_pods = e->n_overflow != 0;
   const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->d_agg.p, e->d_slab.p, s, nullptr);
   if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget");
   KT_HIP(e, hipGetLastError());
@@ -1545,11 +1556,9 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
-      if (e->n_overflow)
-        return e->fail(KT_ERR_UNSUPPORTED, "%llu pods carry more than %d selector-relevant label atoms (use kernel_variant 1)", e->n_overflow, e->pods.LA);
       const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
                                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
-                                               small ? &sm : nullptr);
+                                               small ? &sm : nullptr, e->n_overflow != 0);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
     }

@@ -169,6 +169,7 @@ struct AggScan {
   bool counts = false;           // exact per-key pod counts (incremental engines) instead of presence masks
   int sign = 1;                  // -1: remove the scanned pods' contribution (delta scans)
   bool nonneg = false;           // no pod carries a negative request (lets the scan skip most presence updates)
+  bool overflow_pods = false;    // some pod is flagged kMetaOverflow: its lane walks every throttle over the raw labels
 };
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
 // does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued
@@ -186,7 +187,7 @@ struct CheckSmall {
 };
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr);
+                          uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false);
 // labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)
 // n_overflow (device counter): valid pods with more relevant atoms than PodTable::LA
 void launch_translate_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t row0, const IndexDev& ix,

@@ -3,9 +3,7 @@
 // The indexed (work ~ pods + matches) scans live in kt_kernels_check.hip / kt_kernels_aggregate.hip (kt_scan.h).
 //
 // Everything here is integer / compare work on row tables in HBM: no MFMA, no floating point.
-#include "kt_index.h"
-#include "kt_kernels_common.h"
-#include "kt_launch.h"
+#include "kt_index_device.h"
 
 namespace kt {
 
@@ -672,6 +670,78 @@ __global__ __launch_bounds__(kBlock) void kt_check_dense(PodTable pods, int64_t 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The dense scans for label rows wider than 16 slots: same loop shape, the selector walk reads the pod's raw label
+// row from HBM (walk_slow_mem) instead of holding it in registers.
+// ---------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(kBlock) void kt_aggregate_dense_mem(PodTable pods, int64_t n_rows, SelProgram sp, unsigned long long* partial) {
+  const int D = pods.D, stride = partial_stride(D);
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * kBlock) {
+    const uint32_t fl = pods.flags[p];
+    const bool countable = (fl & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+    if (!countable) continue;
+    int64_t v[DT];
+    load_requests<DT>(pods.req, pods.DS, p, v);
+    const uint32_t present = fl >> kPresentShift;
+    const bool not_finished = !(fl & kPodFinished);
+    const uint32_t* ns_row = sp.ns_term_ok + (size_t)pods.ns[p] * sp.gw;
+    const uint32_t* lp = pods.lpair + p * pods.LS;
+    const uint32_t* lk = pods.lkey + p * pods.LS;
+    for (int t = 0; t < sp.T; ++t) {
+      const uint32_t res = walk_slow_mem(sp, t, ns_row, true, lp, lk, pods.LS);
+      unsigned long long* row = partial + (size_t)t * stride;
+      if (res & kSlowError) atomicAdd(row + 2 * D + 1, 1ull);
+      if ((res & kSlowMatched) && not_finished) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          if (d < D && ((present >> d) & 1u)) {
+            if (v[d] != 0) atomicAdd(row + d, (unsigned long long)v[d]);
+            atomicAdd(row + D + d, 1ull);
+          }
+        atomicAdd(row + 2 * D, 1ull);
+      }
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void kt_check_dense_mem(PodTable pods, int64_t n, const int64_t* rows, SelProgram sp,
+                                                            const void* recs_, uint64_t* summary, uint8_t* status) {
+  const CheckRec<DT>* recs = (const CheckRec<DT>*)recs_;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t p = rows ? rows[i] : i;
+    const uint32_t fl = pods.flags[p];
+    const bool on = (fl & kPodValid) != 0;
+    const uint32_t ns = on ? pods.ns[p] : 0u;
+    int64_t v[DT];
+    load_requests<DT>(pods.req, pods.DS, p, v);
+    uint32_t nzmask = 0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) nzmask |= (v[d] != 0 ? 1u : 0u) << d;
+    bool pod_err = on && !sp.ns_valid[ns];
+    const uint32_t* ns_row = sp.ns_term_ok + (size_t)ns * sp.gw;
+    const uint32_t* lp = pods.lpair + p * pods.LS;
+    const uint32_t* lk = pods.lkey + p * pods.LS;
+    uint32_t n_exc = 0, n_act = 0, n_ins = 0;
+    for (int t = 0; t < sp.T; ++t) {
+      const uint32_t res = walk_slow_mem(sp, t, ns_row, on, lp, lk, pods.LS);
+      pod_err |= (res & kSlowError) != 0;
+      uint32_t st = 0;
+      if (res & kSlowMatched) {
+        st = classify<DT>(recs + t, v, nzmask);
+        n_exc += st == 4u;
+        n_act += st == 2u;
+        n_ins += st == 3u;
+      }
+      if (status) status[i * sp.T + t] = (uint8_t)st;
+    }
+    summary[i] = on ? pack_summary(n_exc, n_act, n_ins, pod_err) : 0ull;
+    if (status && pod_err)
+      for (int t = 0; t < sp.T; ++t) status[i * sp.T + t] = 255;
+  }
+}
+
 #define KT_DISPATCH(KERNEL, DT_, LT_, KEYS_, ...)                                                              \
   do {                                                                                                         \
     if (DT_ == 4 && LT_ == 8 && !KEYS_) hipLaunchKernelGGL((KERNEL<4, 8, false>), __VA_ARGS__);                \
@@ -692,6 +762,12 @@ void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgr
                             unsigned long long* partial, hipStream_t s) {
   if (n_rows <= 0 || sp.T <= 0) return;
   const int DT = dt_bucket(pods.D), LT = lt_bucket(pods.L);
+  if (pods.LS > 16) {  // wide label rows: walked from HBM
+    if (DT == 4) hipLaunchKernelGGL(kt_aggregate_dense_mem<4>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+    else if (DT == 8) hipLaunchKernelGGL(kt_aggregate_dense_mem<8>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+    else hipLaunchKernelGGL(kt_aggregate_dense_mem<16>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+    return;
+  }
   KT_DISPATCH(kt_aggregate_dense, DT, LT, keys, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
 }
 
@@ -699,6 +775,12 @@ void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev
                         const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s) {
   if (n <= 0) return;
   const int DT = dt_bucket(pods.D), LT = lt_bucket(pods.L);
+  if (pods.LS > 16) {  // wide label rows: walked from HBM
+    if (DT == 4) hipLaunchKernelGGL(kt_check_dense_mem<4>, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, sp, recs, summary, status);
+    else if (DT == 8) hipLaunchKernelGGL(kt_check_dense_mem<8>, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, sp, recs, summary, status);
+    else hipLaunchKernelGGL(kt_check_dense_mem<16>, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, sp, recs, summary, status);
+    return;
+  }
   KT_DISPATCH(kt_check_dense, DT, LT, keys, dim3(grid_for(n)), dim3(kBlock), 0, s, pods, n, rows_dev, sp, recs, summary,
               status);
 }

@@ -28,12 +28,13 @@ struct BmAggArgs {
   int32_t counts;  // table keeps per-key pod counts instead of the presence mask
   int32_t sign;    // +1 / -1: the scanned pods are added to / removed from the target (delta scans)
   int32_t nonneg;  // no pod of the engine carries a negative request: a non-zero value then implies a non-zero sum
+  int32_t has_overflow;  // some pod is flagged kMetaOverflow
 };
 
 static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const SelProgram& sp, const SelProgram* sp_dev,
                                   const IndexDev& ix, unsigned long long* partial, unsigned char* slab, uint32_t* total) {
   BmAggArgs a{};
-  a.rows = sc.rows, a.row0 = sc.row0, a.n_rows = sc.n, a.counts = sc.counts ? 1 : 0, a.sign = sc.sign, a.nonneg = sc.nonneg ? 1 : 0;
+  a.rows = sc.rows, a.row0 = sc.row0, a.n_rows = sc.n, a.counts = sc.counts ? 1 : 0, a.sign = sc.sign, a.nonneg = sc.nonneg ? 1 : 0, a.has_overflow = sc.overflow_pods ? 1 : 0;
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab;
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
@@ -109,14 +110,15 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       atom_row_offsets<LA>(raw, bm.row_bytes, ro);
 
       // ---- throttles with unconvertible selectors have no rank: walked once (with the first chunk), straight to the
-      //      result buffer
-      if (ci == 0 && a.n_slow) {
+      //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).
+      const bool overflow = a.has_overflow && countable && (meta & kMetaOverflow) != 0;
+      const bool scan_counted = counted && !overflow;
+      if (ci == 0 && (a.n_slow || a.has_overflow)) {
         const SelProgram& sp = *a.sp;
         const uint32_t* lp = a.lpair + (uint64_t)p * (uint32_t)a.LS;
         const uint32_t* lk = a.lkey + (uint64_t)p * (uint32_t)a.LS;
-        for (uint32_t ks = 0; ks < a.n_slow; ++ks) {
-          const uint32_t t = a.slow_thr[ks];
-          const uint32_t res = walk_slow_mem(sp, (int)t, sp.ns_term_ok + (size_t)ns * sp.gw, countable, lp, lk, a.LS);
+        auto walk_one = [&](uint32_t t, bool lane_on) {
+          const uint32_t res = walk_slow_mem(sp, (int)t, sp.ns_term_ok + (size_t)ns * sp.gw, lane_on, lp, lk, a.LS);
           unsigned long long* pr = a.partial + (size_t)t * pstride;
           if (res & kSlowError) atomicAdd(pr + 2 * D + 1, (unsigned long long)(long long)a.sign);
           if ((res & kSlowMatched) && counted) {
@@ -128,12 +130,15 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
               }
             atomicAdd(pr + 2 * D, (unsigned long long)(long long)a.sign);
           }
-        }
+        };
+        for (uint32_t ks = 0; ks < a.n_slow; ++ks) walk_one(a.slow_thr[ks], countable && !overflow);
+        if (__ballot(overflow) != 0ull)
+          for (int t = 0; t < a.T; ++t) walk_one((uint32_t)t, overflow);
       }
 
       uint32_t last_r = 0xFFFFFFFFu;
       scan_tile<LA, VETO, NEED>(
-          bm, counted, ns, ro,
+          bm, scan_counted, ns, ro,
           [&](bool has, uint32_t c) {
             const uint32_t tr = trank[c];
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank

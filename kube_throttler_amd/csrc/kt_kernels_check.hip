@@ -50,6 +50,7 @@ struct BmCheckArgs {
   // small launches (SMALL instantiation: one workgroup per (chunk, tile), results met by atomics)
   uint32_t* ticket;        // [tiles] arrival counters, zero between launches
   uint64_t* host_summary;  // nullable: pinned host copy of the final summary words
+  uint32_t has_overflow;   // some pod carries more relevant atoms than its atom row holds (kMetaOverflow)
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
 };
@@ -190,23 +191,33 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         if (n_list > kListCap - kWave) drain();
       };
 
+      // a pod whose relevant atoms did not fit its atom row is not scanned through the bitmaps: its lane walks EVERY
+      // throttle's terms over the raw labels instead (with the first chunk)
+      const bool overflow = FULL && a.has_overflow && on && (meta & kMetaOverflow) != 0;
+      const bool scan_on = on && !overflow;
       // ---- throttles with unconvertible selectors: walked once, with the first chunk (error semantics depend on
       //      term order, throttle_selector.go:30-42); their matches take the full comparison
-      if (FULL && first && a.n_slow) {
+      if (FULL && first && (a.n_slow || a.has_overflow)) {
         const SelProgram& sp = *a.sp;
         const uint32_t* lp = a.lpair + (uint64_t)p * (uint32_t)a.LS;
         const uint32_t* lk = a.lkey + (uint64_t)p * (uint32_t)a.LS;
         for (uint32_t ks = 0; ks < a.n_slow; ++ks) {
           const int ts = (int)a.slow_thr[ks];
-          const uint32_t res = walk_slow_mem(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, on, lp, lk, a.LS);
+          const uint32_t res = walk_slow_mem(sp, ts, sp.ns_term_ok + (size_t)ns * sp.gw, scan_on, lp, lk, a.LS);
           if (res & kSlowError) pod_err = true;
-          push((res & kSlowMatched) && on, (uint32_t)ts);
+          push((res & kSlowMatched) && scan_on, (uint32_t)ts);
         }
+        if (__ballot(overflow) != 0ull)
+          for (int t = 0; t < a.T; ++t) {
+            const uint32_t res = walk_slow_mem(sp, t, sp.ns_term_ok + (size_t)ns * sp.gw, overflow, lp, lk, a.LS);
+            if (res & kSlowError) pod_err = true;
+            push((res & kSlowMatched) && overflow, (uint32_t)t);
+          }
       }
 
       if (!(a.exp & 4u))
       scan_tile<LA, VETO, NEED>(
-          bm, on, ns, ro,
+          bm, scan_on, ns, ro,
           [&](bool has, uint32_t c) {
             if (a.exp & 2u) return;
             // branch-free: the term's TermInfo word carries both verdicts a non-tight throttle can give (as the bit
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* sm) {
+                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods) {
   if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -301,7 +312,8 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     bm_args.n_inline = sm->n_inline;
     for (int k = 0; k < 8; ++k) bm_args.inline_rows[k] = sm->inline_rows[k];
   }
-  const bool full = status != nullptr || ix.n_slow != 0;  // the lean instantiation serves the PreFilter sweep
+  bm_args.has_overflow = overflow_pods ? 1u : 0u;
+  const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;

@@ -75,6 +75,10 @@ class MetricsRecorder:
         used = reconcile.used if reconcile is not None else snap.thr_used
         calc = reconcile.calc if reconcile is not None else snap.thr_calc
         for i, manifest in enumerate(built.cs.throttles):
+            # the reference records inside reconcile (throttle_controller.go:159,187), which only ever runs for throttles
+            # this throttler is responsible for (event handlers, :404-420)
+            if not int(snap.thr_flags[i]) & S.THR_RESPONSIBLE:
+                continue
             kind = manifest["kind"]
             self._amount(built, kind, manifest, "spec_threshold", snap.thr_spec, i)
             self._amount(built, kind, manifest, "status_used", used, i)

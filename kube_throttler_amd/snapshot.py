@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 KT_MAX_DIMS = 16
-KT_MAX_LABELS = 16
+KT_MAX_LABELS = 64
 
 POD_VALID, POD_SCHED_MATCH, POD_SCHEDULED, POD_FINISHED = 0x1, 0x2, 0x4, 0x8
 THR_VALID, THR_CLUSTER, THR_RESPONSIBLE, THR_CALC_AT_NONZERO, THR_THROTTLED_POD = 0x1, 0x2, 0x4, 0x8, 0x10
