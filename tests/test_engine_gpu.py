@@ -146,6 +146,21 @@ def test_edge_shapes(variant, oracle_mod):
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
+def test_wide_label_sets(variant, oracle_mod):
+    """Pods with more labels than the scan kernels keep atom slots for: the reference matches labels.Set(pod.Labels) of
+    any size (throttle_selector.go:48-54).  24 labels over 24 keys (every label relevant: 16-/32-slot atom rows), 40 labels
+    over 48 keys with selectors touching most keys (pods whose relevant atoms overflow 32 slots walk the raw labels),
+    and 40 labels of which the selectors reference only a few keys (the irrelevant ones are dropped at translation)."""
+    for cfg in (W.small(seed=21, n_pods=1500, n_thr=64, n_cluster=32, D=4, n_ns=4, K=24, V=2, L=24, terms=(1, 3), reqs=(1, 3)),
+                W.small(seed=22, n_pods=1500, n_thr=160, n_cluster=96, D=4, n_ns=4, K=48, V=2, L=40, terms=(1, 3), reqs=(1, 4)),
+                W.small(seed=23, n_pods=1500, n_thr=6, n_cluster=2, D=4, n_ns=4, K=64, V=2, L=40, terms=(1, 2), reqs=(1, 2))):
+        snap = W.generate(cfg)
+        assert snap.L > 16
+        st, sm, rec = run_full_parity(snap, oracle_mod, variant)
+        assert (st == S.NOT_THROTTLED).any() or (st == S.ACTIVE).any()
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)
 def test_config1_full(variant, oracle_mod):
     """BASELINE.json configs[1]: 10k pods x 100 Throttles, D=4, single selectorTerm — full matrix."""
     snap = W.generate(W.preset(1))
