@@ -148,6 +148,12 @@ struct kt_engine {
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
   bool countable_valid = false;                  // d_countable describes the current pod table
+  bool countable_by_ns = false;                  // ... ordered by namespace (multi-chunk index: kt_order_rows_by_ns)
+  DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
+  bool order_all_valid = false;
+  DevBuf<unsigned long long> d_ns_cursor;        // counting-sort scratch (one word per namespace row)
+  DevBuf<uint32_t> d_slab_tag;                   // [chunks][256] epoch of the launch that last spilled a slab
+  uint32_t slab_epoch = 0;
   bool neg_seen = false;                         // some pod was fed with a negative request (sums may cancel)
 
   // ---- host mirrors of the small tables
@@ -776,6 +782,9 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_latom.release();
   e->d_overflow.release();
   e->d_countable.release();
+  e->d_order_all.release();
+  e->d_ns_cursor.release();
+  e->d_slab_tag.release();
   e->d_n_countable.release();
   e->d_ticket.release();
   if (e->h_small) (void)hipHostFree(e->h_small);
@@ -885,6 +894,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
   }
   e->countable_valid = false;
+  e->order_all_valid = false;
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
   const int64_t chunk = 1 << 20;
@@ -979,6 +989,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
   e->countable_valid = false;
+  e->order_all_valid = false;
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
     int32_t drc = delta_scan(e, n, e->d_rows.p, 0, -1, e->own_stream);
@@ -1229,6 +1240,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   KT_HIP(e, hipMemsetAsync(e->pods.meta, 0, (size_t)e->cfg.pod_capacity * 8, e->own_stream));
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   e->countable_valid = false;
+  e->order_all_valid = false;
   e->pod_rows_hi = 0;
   e->neg_seen = false;
   for (auto& m : e->max_abs) m = 0;
@@ -1302,6 +1314,29 @@ int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* rows, const kt_sta
 // ---------------------------------------------------------------------------------------------------
 // reconcile
 // ---------------------------------------------------------------------------------------------------
+static bool getenv_flag(const char* name) {
+  const char* v = getenv(name);
+  return v && *v && *v != '0';
+}
+
+// every aggregate launch gets an epoch; a workgroup stamps the slabs it spills with it (kt_reduce_bitmap_slabs then
+// leaves alone what a namespace-ordered scan did not write)
+static int32_t slab_tags(kt_engine* e, kt::AggScan& sc, hipStream_t s) {
+  const size_t need = (size_t)e->dindex.n_chunks * 256 + 1;
+  if (e->d_slab_tag.cap < need) {
+    if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+    KT_HIP(e, e->d_slab_tag.reserve(need));
+    KT_HIP(e, hipMemsetAsync(e->d_slab_tag.p, 0, e->d_slab_tag.cap * 4, s));
+    e->slab_epoch = 0;
+  }
+  if (++e->slab_epoch == 0u) {  // wrapped: start over with clean tags
+    KT_HIP(e, hipMemsetAsync(e->d_slab_tag.p, 0, e->d_slab_tag.cap * 4, s));
+    e->slab_epoch = 1;
+  }
+  sc.slab_tag = e->d_slab_tag.p, sc.epoch = e->slab_epoch;
+  return KT_OK;
+}
+
 static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
@@ -1316,11 +1351,20 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     e->last_stream = s;
     return KT_OK;
   }
-  if (e->cfg.kernel_variant != 1 && !e->countable_valid) {  // pods changed since the last scan: which rows does a reconcile look at
+  // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
+  const bool by_ns = e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_NS_ORDER");
+  if (e->cfg.kernel_variant != 1 && (!e->countable_valid || e->countable_by_ns != by_ns)) {  // pods changed since the last scan: which rows does a reconcile look at
     KT_HIP(e, e->d_countable.reserve((size_t)e->pod_rows_hi + 1));
     KT_HIP(e, e->d_n_countable.reserve(1));
-    KT_HIP(e, hipMemsetAsync(e->d_n_countable.p, 0, 8, s));
-    kt::launch_compact_countable(e->pods, e->pod_rows_hi, e->d_countable.p, e->d_n_countable.p, s);
+    if (by_ns) {
+      KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->cfg.namespace_capacity + 1));
+      kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/true, (uint32_t)e->cfg.namespace_capacity,
+                                  e->d_ns_cursor.p, e->d_countable.p, e->d_n_countable.p, s);
+    } else {
+      KT_HIP(e, hipMemsetAsync(e->d_n_countable.p, 0, 8, s));
+      kt::launch_compact_countable(e->pods, e->pod_rows_hi, e->d_countable.p, e->d_n_countable.p, s);
+    }
+    e->countable_by_ns = by_ns;
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
@@ -1342,6 +1386,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       kt::AggScan sc;
       sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
       sc.overflow_pods = e->n_overflow != 0;
+      sc.by_ns = e->countable_by_ns;
+      if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
       e->last_kernel[KT_KERNEL_AGGREGATE] = k;
@@ -1364,6 +1410,8 @@ static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int6
   if (!e->incremental || !e->agg_valid || n <= 0 || e->thr_rows_hi == 0) return KT_OK;
   kt::AggScan sc;
   sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign, sc.overflow_pods = e->n_overflow != 0;
+  int32_t rc = slab_tags(e, sc, s);
+  if (rc != KT_OK) return rc;
   const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->d_agg.p, e->d_slab.p, s, nullptr);
   if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget");
   KT_HIP(e, hipGetLastError());
@@ -1556,9 +1604,20 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
-      const char* k = kt::launch_check_indexed(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
+      // a sweep over every row of a multi-chunk index runs in namespace order (results stay indexed by pod row)
+      const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_NS_ORDER");
+      if (by_ns && !e->order_all_valid) {
+        KT_HIP(e, e->d_order_all.reserve((size_t)e->pod_rows_hi + 1));
+        KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->cfg.namespace_capacity + 1));
+        KT_HIP(e, e->d_n_countable.reserve(1));
+        kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->cfg.namespace_capacity,
+                                    e->d_ns_cursor.p, e->d_order_all.p, e->d_n_countable.p, s);
+        KT_HIP(e, hipGetLastError());
+        e->order_all_valid = true;
+      }
+      const char* k = kt::launch_check_indexed(e->pods, n, by_ns ? e->d_order_all.p : pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
                                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
-                                               small ? &sm : nullptr, e->n_overflow != 0);
+                                               small ? &sm : nullptr, e->n_overflow != 0, by_ns);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
     }

@@ -128,27 +128,85 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   }
   out.n_pair_keys = (uint32_t)pair_keys.size();
   out.n_key_atoms = (uint32_t)key_atoms.size();
-  // order: throttles by the admission set of their FIRST term (namespaces then touch few words as long as the
-  // terms of a throttle agree on it — always for namespaced Throttles), terms of a throttle contiguous
-  std::vector<uint32_t> order(bts.size());
+  // ---- groups.  For one namespace the terms of a throttle that can match are those whose namespace side admits it; the
+  //      namespaces are partitioned by WHICH of the throttle's terms admit them ("cells": at most a handful per
+  //      throttle — one for a namespaced Throttle).  Every cell becomes a group of term COPIES (the admitted terms, in
+  //      term order, each with the cell's namespaces as its admission set).  For any pod exactly one group of a
+  //      throttle is live, its copies are numbered contiguously (so the "reported once" rule of the scans holds), and
+  //      groups sort by their admission set: the words of the bitmaps become class-pure even when the terms of a
+  //      ClusterThrottle select different namespaces, and a pod only visits the words of classes that admit its
+  //      namespace (config 4: 73 instead of 320 word steps per pod).
+  struct TC { uint32_t bt, grp; };
+  struct Grp { uint32_t t; std::vector<uint32_t> adm; };
+  std::vector<TC> tcs;
+  std::vector<Grp> grps;
+  for (size_t i = 0; i < bts.size();) {
+    size_t j = i;
+    while (j < bts.size() && first_of[j] == first_of[i]) ++j;
+    const size_t nt = j - i;
+    bool same = true;
+    for (size_t q = i + 1; q < j && same; ++q) same = bts[q].adm == bts[i].adm;
+    if (same || nt > 64) {
+      // one group; with more than 64 terms the copies keep their own admission sets (class = that of the first)
+      grps.push_back(Grp{bts[i].t, bts[i].adm});
+      for (size_t q = i; q < j; ++q) tcs.push_back(TC{(uint32_t)q, (uint32_t)grps.size() - 1});
+    } else {
+      std::vector<uint64_t> pat(n_ns, 0ull);
+      for (size_t q = i; q < j; ++q)
+        for (uint32_t n = 0; n < n_ns; ++n)
+          if ((bts[q].adm[n >> 5] >> (n & 31)) & 1u) pat[n] |= 1ull << (q - i);
+      std::unordered_map<uint64_t, uint32_t> cell_of;  // pattern -> group
+      const size_t g0 = grps.size();
+      for (uint32_t n = 0; n < n_ns; ++n) {
+        if (!pat[n]) continue;
+        auto it = cell_of.find(pat[n]);
+        if (it == cell_of.end()) {
+          it = cell_of.emplace(pat[n], (uint32_t)grps.size()).first;
+          grps.push_back(Grp{bts[i].t, std::vector<uint32_t>(nsw, 0u)});
+        }
+        grps[it->second].adm[n >> 5] |= 1u << (n & 31);
+      }
+      // copies in group order, term order inside a group (cell_of iterates in no particular order: walk the groups)
+      std::vector<uint64_t> pat_of(grps.size() - g0, 0ull);
+      for (auto& kv : cell_of) pat_of[kv.second - g0] = kv.first;
+      for (size_t g = g0; g < grps.size(); ++g)
+        for (size_t q = i; q < j; ++q)
+          if ((pat_of[g - g0] >> (q - i)) & 1ull) tcs.push_back(TC{(uint32_t)q, (uint32_t)g});
+    }
+    i = j;
+  }
+  std::vector<uint8_t> grp_own_adm(grps.size(), 0);  // group of a >64-term throttle: copies use the term's own set
+  {
+    std::vector<uint32_t> cnt(grps.size(), 0u);
+    for (const TC& c : tcs) ++cnt[c.grp];
+    for (const TC& c : tcs)
+      if (cnt[c.grp] > 64) grp_own_adm[c.grp] = 1;
+  }
+  // order: groups by admission set, copies of a group contiguous
+  std::vector<uint32_t> order(tcs.size());
   for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(),
-                   [&](uint32_t a, uint32_t b) { return bts[first_of[a]].adm < bts[first_of[b]].adm; });
-  // term numbers: a class (run of throttles with the same first admission set) never straddles a 64-bit word of
-  // the bitmaps unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
-  const uint32_t gran = bts.size() <= 4096 ? 64u : 128u;
-  std::vector<uint32_t> num(bts.size());
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (tcs[a].grp == tcs[b].grp) return false;
+    const auto& x = grps[tcs[a].grp].adm;
+    const auto& y = grps[tcs[b].grp].adm;
+    if (x != y) return x < y;
+    return tcs[a].grp < tcs[b].grp;
+  });
+  // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
+  // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
+  const uint32_t gran = tcs.size() <= 4096 ? 64u : 128u;
+  std::vector<uint32_t> num(tcs.size());
   uint32_t pos = 0;
   for (size_t i = 0; i < order.size();) {
     size_t j = i;
-    while (j < order.size() && bts[first_of[order[j]]].adm == bts[first_of[order[i]]].adm) ++j;
+    while (j < order.size() && grps[tcs[order[j]].grp].adm == grps[tcs[order[i]].grp].adm) ++j;
     const uint32_t sz = (uint32_t)(j - i);
     if ((pos & (gran - 1)) != 0 && ((pos & (gran - 1)) + sz > gran)) pos = (pos + gran - 1) & ~(gran - 1);
     for (size_t q = i; q < j;) {
-      // the terms of one throttle (contiguous in `order`) never straddle a 64-bit word when they fit one: every word
-      // boundary then is a place where a chunk may be cut
+      // the copies of one group never straddle a 64-bit word when they fit one: every word boundary then is a place
+      // where a chunk may be cut
       size_t q1 = q;
-      while (q1 < j && first_of[order[q1]] == first_of[order[q]]) ++q1;
+      while (q1 < j && tcs[order[q1]].grp == tcs[order[q]].grp) ++q1;
       const uint32_t nt = (uint32_t)(q1 - q);
       if (nt <= 64 && (pos & 63u) + nt > 64u) pos = (pos + 63u) & ~63u;
       for (; q < q1; ++q) num[order[q]] = pos++;
@@ -203,12 +261,15 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   out.bm_rank_t.clear();
   {
     std::vector<uint32_t> by_num(G2, ~0u);
-    for (size_t q = 0; q < bts.size(); ++q) by_num[num[q]] = (uint32_t)q;
-    uint32_t last_t = ~0u;
+    for (size_t q = 0; q < tcs.size(); ++q) by_num[num[q]] = (uint32_t)q;
+    uint32_t last_g = ~0u;
     for (uint32_t c = 0; c < G2; ++c) {
       if (by_num[c] == ~0u) continue;  // padding
-      const BT& b = bts[by_num[c]];
-      if (b.t != last_t) out.bm_rank_t.push_back(b.t), last_t = b.t;
+      const TC& tc = tcs[by_num[c]];
+      const BT& b = bts[tc.bt];
+      // dense ranks: one per GROUP in number order (a throttle with several cells has several; the slab reduction
+      // adds them all into the throttle's row)
+      if (tc.grp != last_g) out.bm_rank_t.push_back(b.t), last_g = tc.grp;
       term_rank[c] = (uint32_t)out.bm_rank_t.size() - 1;
       real[c] = 1;
       const uint64_t bit = 1ull << (c & 63);
@@ -222,8 +283,9 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       if (b.need >= 2) hdr[w].m2 |= bit;
       if (b.need >= 3) hdr[w].m3 |= bit;
       if (b.slow) hdr[w].slow |= bit;
+      const std::vector<uint32_t>& adm = grp_own_adm[tc.grp] ? b.adm : grps[tc.grp].adm;
       for (uint32_t n = 0; n < n_ns; ++n)
-        if ((b.adm[n >> 5] >> (n & 31)) & 1u) nsrows[(size_t)n * W + w] |= bit;
+        if ((adm[n >> 5] >> (n & 31)) & 1u) nsrows[(size_t)n * W + w] |= bit;
     }
   }
   // ---- chunks: word ranges whose LDS part (rows | headers | namespace word lists) plus the per-term / per-throttle
@@ -246,6 +308,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   uint64_t slab_run = 0;
   out.bm_chunks.clear();
   out.bm_images.clear();
+  out.bm_chunk_ns.clear();
+  out.ns_words = nsw ? nsw : 1u;
   out.bm_max_lds = 0, out.bm_max_thr = 0, out.bm_max_words = 0, out.bm_slab_bytes = 0;
   uint32_t w0 = 0;
   while (w0 < W) {
@@ -302,6 +366,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         if (m) nsl.push_back(NsWord{w, 0u, m});
       }
       nsl_off[n + 1] = (uint32_t)nsl.size();
+    }
+    {  // which namespaces have words here (the sorted scans skip the chunk for workgroups without any of them)
+      const size_t b0 = out.bm_chunk_ns.size();
+      out.bm_chunk_ns.resize(b0 + out.ns_words, 0u);
+      for (uint32_t n = 0; n < n_ns; ++n)
+        if (nsl_off[n + 1] > nsl_off[n]) out.bm_chunk_ns[b0 + (n >> 5)] |= 1u << (n & 31);
     }
     std::vector<uint32_t> it(term_t.begin() + (size_t)w0 * 64, term_t.begin() + (size_t)w1 * 64);
     std::vector<uint32_t> ig(term_g.begin() + (size_t)w0 * 64, term_g.begin() + (size_t)w1 * 64);
@@ -364,6 +434,8 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   if ((e = up(d.bm_blob, d.cap_bm_blob, h.bm_images, s)) != hipSuccess) return e;
   if ((e = up(d.bm_chunks, d.cap_bm_chunks, h.bm_chunks, s)) != hipSuccess) return e;
   if ((e = up(d.bm_rank_t, d.cap_bm_rank_t, h.bm_rank_t, s)) != hipSuccess) return e;
+  if ((e = up(d.bm_chunk_ns, d.cap_bm_chunk_ns, h.bm_chunk_ns, s)) != hipSuccess) return e;
+  d.ns_words = h.ns_words;
   if ((e = up(d.atom_table, d.cap_atom_table, h.atom_table, s)) != hipSuccess) return e;
   d.atom_mask = (uint32_t)h.atom_table.size() - 1;
   d.h_chunks = h.bm_chunks;
@@ -386,6 +458,7 @@ void release_index(IndexDev& d) {
   if (d.bm_blob) (void)hipFree(d.bm_blob);
   if (d.bm_chunks) (void)hipFree(d.bm_chunks);
   if (d.bm_rank_t) (void)hipFree(d.bm_rank_t);
+  if (d.bm_chunk_ns) (void)hipFree(d.bm_chunk_ns);
   if (d.atom_table) (void)hipFree(d.atom_table);
   d = IndexDev();
 }

@@ -103,7 +103,9 @@ struct HostIndex {
   std::vector<uint64_t> atom_table;        // open-addressing table for the device: atom | id << 32, 0 = empty
   std::vector<BmChunk> bm_chunks;
   std::vector<unsigned char> bm_images;    // chunk images back to back
-  std::vector<uint32_t> bm_rank_t;         // dense throttle rank (term order) -> throttle row
+  std::vector<uint32_t> bm_rank_t;         // dense rank (one per group, number order) -> throttle row
+  std::vector<uint32_t> bm_chunk_ns;       // [chunks][ns_words] bit n: namespace n has words in the chunk
+  uint32_t ns_words = 0;                   // 32-bit words per row of bm_chunk_ns
   uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
 };
@@ -124,6 +126,8 @@ struct IndexDev {
   unsigned char* bm_blob = nullptr;  // chunk images
   BmChunk* bm_chunks = nullptr;
   uint32_t* bm_rank_t = nullptr;
+  uint32_t* bm_chunk_ns = nullptr;
+  uint32_t ns_words = 0;
   uint64_t* atom_table = nullptr;
   uint32_t atom_mask = 0;
   std::vector<BmChunk> h_chunks;     // host copy (launch planning)
@@ -131,7 +135,7 @@ struct IndexDev {
   uint64_t bm_slab_bytes = 0;
   uint32_t has_veto = 0, max_need = 0, n_atoms = 0, has_key_atoms = 0, la = 8;
   bool rich = false;
-  size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_atom_table = 0, cap_slow = 0;
+  size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_chunk_ns = 0, cap_atom_table = 0, cap_slow = 0;
 };
 
 // LDS budgets: a chunk must satisfy
@@ -170,6 +174,10 @@ struct AggScan {
   int sign = 1;                  // -1: remove the scanned pods' contribution (delta scans)
   bool nonneg = false;           // no pod carries a negative request (lets the scan skip most presence updates)
   bool overflow_pods = false;    // some pod is flagged kMetaOverflow: its lane walks every throttle over the raw labels
+  bool by_ns = false;            // `rows` is ordered by namespace (launch_order_rows_by_ns): contiguous tile ranges per
+                                 // workgroup, chunks without words of the range's namespaces skipped
+  uint32_t* slab_tag = nullptr;  // [chunks][256] epoch of the last launch that spilled this (chunk, workgroup) slab
+  uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
 };
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
 // does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued
@@ -187,7 +195,10 @@ struct CheckSmall {
 };
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false);
+                          uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,
+                          bool by_ns = false);
+// by_ns: rows_dev lists ALL n pod rows ordered by namespace (launch_order_rows_by_ns); summary / status are then
+// indexed by POD ROW (as a launch without a row list would), the scan runs in namespace order
 // labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)
 // n_overflow (device counter): valid pods with more relevant atoms than PodTable::LA
 void launch_translate_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t row0, const IndexDev& ix,

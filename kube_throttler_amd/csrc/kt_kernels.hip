@@ -195,6 +195,71 @@ void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows
   hipLaunchKernelGGL(kt_compact_countable, dim3(grid_for(n, 1024, 2048)), dim3(1024), 0, s, pods, n, out_rows, out_n);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kt_order_rows_by_ns — pod rows ordered by namespace (counting sort: histogram, scan, scatter), the scan order of the
+// indexed kernels when the selector index has several chunks: the 64 pods of a tile then share their namespace's word
+// list (all lanes advance and peel together instead of waiting for each other's words), and a workgroup's contiguous
+// range of tiles touches only the chunks that hold words of ITS namespaces.
+//   countable_only: the rows kt_compact_countable would list (the aggregate's scan), else every row in [0, n)
+// Order inside a namespace is arrival order of the atomics (sums and per-pod verdicts do not care).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool order_takes(uint64_t meta, bool countable_only) {
+  const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
+  return !countable_only || (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+}
+__global__ __launch_bounds__(1024) void kt_ns_histogram(const uint64_t* meta, int64_t n, int countable_only, uint32_t n_keys,
+                                                       unsigned long long* counts) {
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+    const uint64_t m = meta[i];
+    if (order_takes(m, countable_only != 0)) atomicAdd(counts + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1ull);
+  }
+}
+// one workgroup: counts[k] -> first position of key k (exclusive prefix sum), *total = number of listed rows
+__global__ __launch_bounds__(1024) void kt_ns_scan(unsigned long long* counts, uint32_t n_keys, unsigned long long* total) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t per = (n_keys + 1023u) / 1024u;
+  const uint32_t k0 = threadIdx.x * per, k1 = min(k0 + per, n_keys);
+  unsigned long long sum = 0;
+  for (uint32_t k = k0; k < k1; ++k) sum += counts[k];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const unsigned long long c = part[t];
+      part[t] = run;
+      run += c;
+    }
+    *total = run;
+  }
+  __syncthreads();
+  unsigned long long run = part[threadIdx.x];
+  for (uint32_t k = k0; k < k1; ++k) {
+    const unsigned long long c = counts[k];
+    counts[k] = run;
+    run += c;
+  }
+}
+__global__ __launch_bounds__(1024) void kt_ns_scatter(const uint64_t* meta, int64_t n, int countable_only, uint32_t n_keys,
+                                                     unsigned long long* cursor, int64_t* out_rows) {
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+    const uint64_t m = meta[i];
+    if (order_takes(m, countable_only != 0)) out_rows[atomicAdd(cursor + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1ull)] = i;
+  }
+}
+void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
+                             int64_t* out_rows, unsigned long long* out_n, hipStream_t s) {
+  (void)hipMemsetAsync(cursor, 0, (size_t)n_keys * 8, s);
+  if (n <= 0) {
+    (void)hipMemsetAsync(out_n, 0, 8, s);
+    return;
+  }
+  const dim3 g(grid_for(n, 1024, 2048)), b(1024);
+  hipLaunchKernelGGL(kt_ns_histogram, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor);
+  hipLaunchKernelGGL(kt_ns_scan, dim3(1), b, 0, s, cursor, n_keys, out_n);
+  hipLaunchKernelGGL(kt_ns_scatter, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
+}
+
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {
   if (b.n <= 0) return;
   hipLaunchKernelGGL(kt_ingest_pods, dim3(grid_for(b.n)), dim3(kBlock), 0, s, pods, b);

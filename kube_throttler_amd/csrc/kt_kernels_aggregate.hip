@@ -29,6 +29,8 @@ struct BmAggArgs {
   int32_t sign;    // +1 / -1: the scanned pods are added to / removed from the target (delta scans)
   int32_t nonneg;  // no pod of the engine carries a negative request: a non-zero value then implies a non-zero sum
   int32_t has_overflow;  // some pod is flagged kMetaOverflow
+  uint32_t* slab_tag;    // [chunks][256]: epoch of the launch that last spilled the (chunk, workgroup) slab
+  uint32_t epoch;
 };
 
 static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const SelProgram& sp, const SelProgram* sp_dev,
@@ -38,11 +40,13 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab;
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
+  a.slab_tag = sc.slab_tag, a.epoch = sc.epoch;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
   a.off_tab = take(agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
   plan_bitmap_index(ix, a.ix, take);
+  a.ix.by_ns = (sc.by_ns && sc.rows) ? 1u : 0u;
   *total = o;
   return a;
 }
@@ -69,7 +73,21 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
   KT_LDS const uint16_t* trank = (KT_LDS const uint16_t*)(lds + a.off_rank);
   const bool counts = a.counts != 0;
+  // namespace order (a.ix.by_ns): this workgroup owns the tiles [t_lo, t_hi) and only walks — and only spills the
+  // tables of — the chunks that hold words of their namespaces
+  const bool by_ns = a.ix.by_ns != 0u;
+  int64_t t_lo = 0, t_hi = n_wtiles;
+  uint32_t ns_lo = 0, ns_hi = 0;
+  if (by_ns) {
+    const int64_t tpb = (n_wtiles + gridDim.x - 1) / gridDim.x;
+    t_lo = min((int64_t)blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
+    if (t_lo >= t_hi) return;
+    ns_lo = (uint32_t)(a.meta[a.rows[t_lo * kWave]] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.meta[a.rows[min(t_hi * kWave, n_rows) - 1]] & kMetaNsMask);
+    ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
+  }
   for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
+    if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
     const BmChunk ch = a.ix.chunks[ci];
     const uint32_t n_thr = ch.n_thr;
     const uint32_t tab_bytes = agg_tab_bytes(n_thr, D, counts);
@@ -80,8 +98,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
-    int64_t wt = (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-    for (; wt < n_wtiles; wt += wstep) {
+    int64_t wt = by_ns ? t_lo + wave : (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+    for (; wt < t_hi; wt += by_ns ? (int64_t)(kBlockIx / kWave) : wstep) {
       // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off)
       const int64_t i = wt * kWave + lane;
       const bool in = i < n_rows;
@@ -171,6 +189,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
     lds_u4p src = (lds_u4p)(lds + a.off_tab);
     for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+    if (threadIdx.x == 0) a.slab_tag[ci * 256u + blockIdx.x] = a.epoch;  // the reduction skips slabs this launch left alone
   }
 }
 
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
 constexpr int kSlabSplits = 4;
 __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned char* slab, const BmChunk* chunks,
                                                               const uint32_t* rank_t, int n_slabs, int D, int counts, int sign,
-                                                              unsigned long long* partial) {
+                                                              const uint32_t* slab_tag, uint32_t epoch, unsigned long long* partial) {
   constexpr int G = 4;  // waves per block
   __shared__ unsigned long long part[G][64][4];
   const BmChunk ch = chunks[blockIdx.y];
@@ -207,8 +226,10 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
   unsigned long long acc[4] = {0, 0, 0, 0};
   const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)(in ? pi : 0u) * 16;
   const int step = G * kSlabSplits;
+  const uint32_t* tag = slab_tag + blockIdx.y * 256u;
 #pragma unroll 8
   for (int b = (int)(blockIdx.z * G + g); b < n_slabs; b += step) {
+    if (tag[b] != epoch) continue;  // that workgroup had no pods for this chunk (namespace-ordered scans)
     const u32x4 x = *(const u32x4*)(base + (size_t)b * pitch);
     const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -289,7 +310,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   const uint32_t max_pieces = ix.bm_max_thr * (agg_rec_bytes(pods.D, sc.counts) / 16u);
   if (max_pieces > 0)
     hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_pieces + 63) / 64, ix.n_chunks, kSlabSplits), dim3(256), 0, s, slab,
-                       ix.bm_chunks, ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, partial);
+                       ix.bm_chunks, ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, sc.slab_tag, sc.epoch, partial);
   return ix.n_chunks == 1 ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_chunked";
 }
 

@@ -102,8 +102,22 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   const uint32_t wstep = gridDim.x * (kBlockIx / kWave);
   const uint32_t n_chunks = a.ix.n_chunks;
   const uint32_t c_lo = SMALL ? blockIdx.x : 0u, c_hi = SMALL ? blockIdx.x + 1u : n_chunks;
+  // namespace order (a.ix.by_ns; rows[] sorted by namespace, results indexed by pod row): this workgroup owns the
+  // tiles [t_lo, t_hi) and only walks the chunks that hold words of their namespaces
+  const bool by_ns = !SMALL && a.ix.by_ns != 0u;
+  uint32_t t_lo = 0, t_hi = n_wtiles, ns_lo = 0, ns_hi = 0, last_ci = n_chunks - 1u;
+  if (by_ns) {
+    const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
+    t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
+    if (t_lo >= t_hi) return;
+    ns_lo = (uint32_t)(a.meta[a.rows[(uint64_t)t_lo * kWave]] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.meta[a.rows[min((uint64_t)t_hi * kWave, (uint64_t)n) - 1u]] & kMetaNsMask);
+    ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
+    last_ci = last_relevant_chunk(a.ix, ns_lo, ns_hi);
+  }
   for (uint32_t ci = c_lo; ci < c_hi; ++ci) {
-    const bool first = ci == 0, last = ci + 1 == n_chunks;
+    if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
+    const bool first = ci == 0, last = ci == last_ci;
     const BmChunk ch = a.ix.chunks[ci];
     __syncthreads();  // nobody reads the previous image any more
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
@@ -124,20 +138,21 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
     }
     __syncthreads();
-    for (uint32_t wt = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : blockIdx.x * (kBlockIx / kWave) + wave; wt < n_wtiles;
-         wt += SMALL ? n_wtiles : wstep) {
+    for (uint32_t wt = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : by_ns ? t_lo + wave : blockIdx.x * (kBlockIx / kWave) + wave;
+         wt < t_hi; wt += SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep) {
       // ---- the tile's records: always from valid addresses (lanes past the end re-read the last pod and are
       //      switched off by `on`)
       const uint32_t i = wt * kWave + lane;
       const bool in = i < n;
       const uint32_t ic = min(i, n - 1u);
       const uint32_t p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
+      const uint32_t si = by_ns ? p : i;  // the pod's index in the summary words / status matrix
       const uint64_t meta = a.meta[p];
       u32x4 raw[LA / 8];
       load_atoms<LA>(a.latom, p, raw);
       // class counters so far (bit 1 = error) ride in the summary word between chunks
       const unsigned long long carried =
-          (!SMALL && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          (!SMALL && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       cnt[lane] = 0ull;
       unsigned long long my = carried & ~3ull;  // this lane's class counters
       const bool on = in && ((meta >> kMetaStateShift) & kPodValid) != 0;
@@ -160,6 +175,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const uint32_t e = list[vv ? j : 0u];
           const uint32_t pl = e >> 20, t = e & kTermRowMask;
           const uint32_t prow = (uint32_t)__shfl((int)p, (int)pl);
+          const uint32_t psi = FULL ? (uint32_t)__shfl((int)si, (int)pl) : 0u;
           const uint32_t pnz = (uint32_t)__shfl((int)nz, (int)pl);
           const CheckRec<DT>* rc = recs + t;
           const u32x2 fa = g_rflags[t];
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
           if (vv) {
             if (st != 1u) lds_add64(cnt + pl, st == 4u ? 1ull << 4 : st == 2u ? 1ull << 24 : 1ull << 44);
-            if (FULL && a.status) a.status[((uint64_t)wt * kWave + pl) * (uint32_t)a.T + t] = (uint8_t)st;
+            if (FULL && a.status) a.status[(uint64_t)psi * (uint32_t)a.T + t] = (uint8_t)st;
           }
         }
         n_list = 0;
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
             const bool fast = ok && !tight;
             const unsigned long long inc = 1ull << sh;
             my += (fast && sh != 0u) ? inc : 0ull;
-            if (FULL && a.status && fast) a.status[(uint64_t)i * (uint32_t)a.T + t] = (uint8_t)(sh == 4u ? 4u : sh == 24u ? 2u : sh == 44u ? 3u : 1u);
+            if (FULL && a.status && fast) a.status[(uint64_t)si * (uint32_t)a.T + t] = (uint8_t)(sh == 4u ? 4u : sh == 24u ? 2u : sh == 44u ? 3u : 1u);
             push(ok && tight, t);
           },
           [&](uint32_t c) {
@@ -266,11 +282,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       } else if (in) {
         const unsigned long long c = my + cnt[lane];
         if (last) {
-          a.summary[i] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
+          a.summary[si] = !on ? 0ull : pod_err ? 2ull : (c | (c ? 1ull : 0ull));
           if (FULL && a.status && pod_err)
-            for (int t = 0; t < a.T; ++t) a.status[(uint64_t)i * (uint32_t)a.T + t] = 255;
+            for (int t = 0; t < a.T; ++t) a.status[(uint64_t)si * (uint32_t)a.T + t] = 255;
         } else {
-          a.summary[i] = c | (pod_err ? 2ull : 0ull);
+          a.summary[si] = c | (pod_err ? 2ull : 0ull);
         }
       }
     }
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods) {
+                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods, bool by_ns) {
   if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -313,6 +329,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     for (int k = 0; k < 8; ++k) bm_args.inline_rows[k] = sm->inline_rows[k];
   }
   bm_args.has_overflow = overflow_pods ? 1u : 0u;
+  bm_args.ix.by_ns = (by_ns && !small && rows_dev) ? 1u : 0u;
   const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;

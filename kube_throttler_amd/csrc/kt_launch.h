@@ -29,6 +29,10 @@ struct IndexTables;  // kt_index.h
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s);
 // dense list of the countable pod rows among [0, n) (out_n: device counter, zeroed by the caller)
 void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
+// pod rows of [0, n) ordered by namespace (all of them, or the countable ones); cursor: n_keys device words of scratch,
+// n_keys = namespace capacity; out_n: device counter receiving the number of listed rows
+void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
+                             int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
                                 uint32_t* out_present, hipStream_t s);

@@ -30,6 +30,10 @@ struct BmIndexArgs {
   const BmChunk* chunks;
   uint32_t n_chunks, n_rows;
   uint32_t lds_img;  // LDS offset of the resident image part
+  // scans in namespace order (rows ordered by launch_order_rows_by_ns)
+  const uint32_t* chunk_ns;  // [n_chunks][ns_words] bit n: namespace n has words in the chunk
+  uint32_t ns_words;
+  uint32_t by_ns;    // the workgroup takes a contiguous range of tiles and skips chunks without words of its namespaces
 };
 
 template <class Take>
@@ -37,6 +41,28 @@ static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, Take&& 
   a.blob = ix.bm_blob, a.chunks = ix.bm_chunks;
   a.n_chunks = ix.n_chunks, a.n_rows = ix.bm_rows;
   a.lds_img = take(ix.bm_max_lds);
+  a.chunk_ns = ix.bm_chunk_ns, a.ns_words = ix.ns_words, a.by_ns = 0u;
+}
+
+// Scans in namespace order: does chunk ci hold words of some namespace in [ns_lo, ns_hi]?  Chunk 0 always counts (it
+// carries the once-per-pod work).  Wave-uniform arguments: scalar loads.
+__device__ __forceinline__ bool chunk_relevant(const BmIndexArgs& a, uint32_t ci, uint32_t ns_lo, uint32_t ns_hi) {
+  if (ci == 0) return true;
+  const uint32_t* m = a.chunk_ns + (size_t)ci * a.ns_words;
+  const uint32_t w_lo = ns_lo >> 5, w_hi = ns_hi >> 5;
+  for (uint32_t w = w_lo; w <= w_hi; ++w) {
+    uint32_t mask = 0xFFFFFFFFu;
+    if (w == w_lo) mask &= 0xFFFFFFFFu << (ns_lo & 31u);
+    if (w == w_hi) mask &= 0xFFFFFFFFu >> (31u - (ns_hi & 31u));
+    if (m[w] & mask) return true;
+  }
+  return false;
+}
+__device__ __forceinline__ uint32_t last_relevant_chunk(const BmIndexArgs& a, uint32_t ns_lo, uint32_t ns_hi) {
+  uint32_t last = 0;
+  for (uint32_t ci = 1; ci < a.n_chunks; ++ci)
+    if (chunk_relevant(a, ci, ns_lo, ns_hi)) last = ci;
+  return last;
 }
 
 // The tables of the chunk that is resident in LDS
