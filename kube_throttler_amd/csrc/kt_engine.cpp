@@ -152,6 +152,10 @@ struct kt_engine {
   DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
   bool order_all_valid = false;
   DevBuf<unsigned long long> d_ns_cursor;        // counting-sort scratch (one word per namespace row)
+  // scan-ordered copies of the listed pods' records (kt_build_scan_view): countable list / all-rows list
+  DevBuf<uint64_t> d_vc_meta, d_va_meta, d_carry;
+  DevBuf<uint16_t> d_vc_latom, d_va_latom;
+  DevBuf<int64_t> d_vc_req;
   DevBuf<uint32_t> d_slab_tag;                   // [chunks][256] epoch of the launch that last spilled a slab
   uint32_t slab_epoch = 0;
   bool neg_seen = false;                         // some pod was fed with a negative request (sums may cancel)
@@ -548,6 +552,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, hipMemsetAsync(e->d_overflow.p, 0, 8, s));
   kt::launch_translate_pods(e->pods, e->pod_rows_hi, nullptr, 0, e->dindex, e->d_overflow.p, s);
   KT_HIP(e, hipGetLastError());
+  e->countable_valid = false, e->order_all_valid = false;  // the scan views hold copies of the atom rows
   KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
   e->sp.thr_term_off = e->d_thr_term_off.p;
@@ -783,6 +788,8 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_overflow.release();
   e->d_countable.release();
   e->d_order_all.release();
+  e->d_vc_meta.release(); e->d_va_meta.release(); e->d_carry.release();
+  e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release();
   e->d_ns_cursor.release();
   e->d_slab_tag.release();
   e->d_n_countable.release();
@@ -1368,6 +1375,14 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
+    if (by_ns) {
+      const size_t nc = (size_t)e->n_countable + 1;
+      KT_HIP(e, e->d_vc_meta.reserve(nc));
+      KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
+      KT_HIP(e, e->d_vc_req.reserve(nc * (size_t)e->pods.DS));
+      kt::launch_build_scan_view(e->pods, (int64_t)e->n_countable, e->d_countable.p, e->d_vc_meta.p, e->d_vc_latom.p, e->d_vc_req.p, s);
+      KT_HIP(e, hipGetLastError());
+    }
     e->countable_valid = true;
   }
   if (words && e->clean_partial != (const void*)e->partial()) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
@@ -1387,6 +1402,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
       sc.overflow_pods = e->n_overflow != 0;
       sc.by_ns = e->countable_by_ns;
+      if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->d_vc_req.p;
       if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
@@ -1613,11 +1629,18 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
         kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->cfg.namespace_capacity,
                                     e->d_ns_cursor.p, e->d_order_all.p, e->d_n_countable.p, s);
         KT_HIP(e, hipGetLastError());
+        const size_t na = (size_t)e->pod_rows_hi + 1;
+        KT_HIP(e, e->d_va_meta.reserve(na));
+        KT_HIP(e, e->d_va_latom.reserve(na * (size_t)e->pods.LA));
+        KT_HIP(e, e->d_carry.reserve(na));
+        kt::launch_build_scan_view(e->pods, e->pod_rows_hi, e->d_order_all.p, e->d_va_meta.p, e->d_va_latom.p, nullptr, s);
+        KT_HIP(e, hipGetLastError());
         e->order_all_valid = true;
       }
+      const kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
       const char* k = kt::launch_check_indexed(e->pods, n, by_ns ? e->d_order_all.p : pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
                                                e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
-                                               small ? &sm : nullptr, e->n_overflow != 0, by_ns);
+                                               small ? &sm : nullptr, e->n_overflow != 0, by_ns ? &view : nullptr);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
     }

@@ -50,11 +50,41 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         break;
       }
   }
+  // ---- referenced atoms.  A pod label (k, v) is ONE atom: the pair (k, v) when some In / NotIn requirement names it,
+  //      else the key atom of k when some Exists / DoesNotExist requirement names k (else nothing).  A key-level
+  //      requirement therefore covers the key atom AND every referenced pair of that key.
+  const uint32_t nsw = (n_ns + 31) / 32;
+  std::unordered_set<uint32_t> pair_keys, key_atoms;
+  std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key;
+  for (size_t t = 0; t < T; ++t) {
+    const ThrInfo ti = thr_info((uint32_t)t);
+    if (!ti.live || is_slow_thr[t]) continue;
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
+      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
+        if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
+          if (req_val_off[r + 1] > req_val_off[r]) pair_keys.insert(req_key[r]);
+          auto& v = pairs_of_key[req_key[r]];
+          v.insert(v.end(), req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
+        } else {
+          key_atoms.insert(req_key[r]);
+        }
+      }
+  }
+  for (auto& kv : pairs_of_key) {
+    std::sort(kv.second.begin(), kv.second.end());
+    kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+  }
+  auto whole_key = [&](uint32_t key) {  // every atom a pod carrying `key` can show up with, sorted
+    std::vector<uint32_t> a;
+    auto it = pairs_of_key.find(key);
+    if (it != pairs_of_key.end()) a = it->second;
+    a.push_back(kKeyAtom | key);
+    std::sort(a.begin(), a.end());
+    return a;
+  };
   // ---- terms
   std::vector<BT> bts;
   std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
-  const uint32_t nsw = (n_ns + 31) / 32;
-  std::unordered_set<uint32_t> pair_keys, key_atoms;
   for (size_t t = 0; t < T; ++t) {
     const ThrInfo ti = thr_info((uint32_t)t);
     if (!ti.live || is_slow_thr[t]) continue;
@@ -71,29 +101,40 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) b.adm[n >> 5] |= 1u << (n & 31), any_ns = true;
       if (!any_ns) continue;  // admitted nowhere: can never match
       bool never = false;
+      // positive requirements are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S): a pod carries
+      // one atom per key, so the number of rows in which the term's bit is met is the number of satisfied positive keys
+      std::vector<std::pair<uint32_t, std::vector<uint32_t>>> pos_by_key;  // key -> atom set (sorted)
       for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
+        const bool pair_op = req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN;
         std::vector<uint32_t> atoms;
-        if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
+        if (pair_op) {
           atoms.assign(req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
           std::sort(atoms.begin(), atoms.end());
           atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
         } else {
-          atoms.push_back(kKeyAtom | req_key[r]);
+          atoms = whole_key(req_key[r]);
         }
         if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_EXISTS) {
-          if (atoms.empty()) never = true;  // In with no values: never satisfied
-          b.pos.push_back(std::move(atoms));
+          size_t q = 0;
+          while (q < pos_by_key.size() && pos_by_key[q].first != req_key[r]) ++q;
+          if (q == pos_by_key.size()) {
+            pos_by_key.emplace_back(req_key[r], std::move(atoms));
+          } else {
+            std::vector<uint32_t> both;
+            std::set_intersection(pos_by_key[q].second.begin(), pos_by_key[q].second.end(), atoms.begin(), atoms.end(), std::back_inserter(both));
+            pos_by_key[q].second = std::move(both);
+          }
         } else {
           for (uint32_t a : atoms) b.neg.push_back(a);  // NotIn with no values: always satisfied
         }
       }
+      for (auto& pk : pos_by_key) {
+        if (pk.second.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
+        b.pos.push_back(std::move(pk.second));
+      }
       if (never) continue;
-      // exact shape: <= 3 positive requirements with pairwise disjoint atom sets
-      bool exact = b.pos.size() <= 3;
-      for (size_t i = 0; i < b.pos.size() && exact; ++i)
-        for (size_t j = i + 1; j < b.pos.size() && exact; ++j)
-          for (uint32_t a : b.pos[i])
-            if (std::binary_search(b.pos[j].begin(), b.pos[j].end(), a)) exact = false;
+      // exact shape: <= 3 positive keys (their atom sets are disjoint by construction)
+      const bool exact = b.pos.size() <= 3;
       if (exact) {
         b.need = (uint32_t)b.pos.size();
       } else {
@@ -113,21 +154,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       bts.push_back(std::move(b));
     }
   }
-  // referenced atoms (those of the rows) and the translation bound of a pod's atom list
-  for (size_t t = 0; t < T; ++t) {
-    const ThrInfo ti = thr_info((uint32_t)t);
-    if (!ti.live || is_slow_thr[t]) continue;
-    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
-      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
-        if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
-          if (req_val_off[r + 1] > req_val_off[r]) pair_keys.insert(req_key[r]);
-        } else {
-          key_atoms.insert(req_key[r]);
-        }
-      }
-  }
   out.n_pair_keys = (uint32_t)pair_keys.size();
   out.n_key_atoms = (uint32_t)key_atoms.size();
+  {
+    std::unordered_set<uint32_t> keys = pair_keys;
+    keys.insert(key_atoms.begin(), key_atoms.end());
+    out.n_keys = (uint32_t)keys.size();
+  }
   // ---- groups.  For one namespace the terms of a throttle that can match are those whose namespace side admits it; the
   //      namespaces are partitioned by WHICH of the throttle's terms admit them ("cells": at most a handful per
   //      throttle — one for a namespaced Throttle).  Every cell becomes a group of term COPIES (the admitted terms, in
@@ -227,11 +260,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       out.has_slow |= b.slow;
       if (!b.slow) out.max_need = std::max(out.max_need, b.need);
     }
-    out.la = atom_slots(out.n_pair_keys, out.n_key_atoms, max_labels);
+    out.la = atom_slots(out.n_keys, max_labels);
     // the simple instantiation <8 atoms, no veto family, need <= 2> covers matchLabels-style programs; everything else
     // takes the rich one, whose images carry {any, veto} pairs
     out.rich = out.has_veto || out.has_slow || out.max_need > 2 || out.la != 8;
-    if (out.rich && out.la < 16) out.la = 16;  // the rich instantiations start at 16 atom slots
     std::sort(atoms.begin(), atoms.end());
     atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
     for (uint32_t i = 0; i < atoms.size(); ++i) out.atoms.push_back(AtomId{atoms[i], i + 1});

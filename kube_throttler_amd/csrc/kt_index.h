@@ -4,8 +4,10 @@
 // Atoms.  Every (key,value) pair id that occurs in an In / NotIn requirement and every key that occurs in an
 // Exists / DoesNotExist requirement (atom = kKeyAtom | key id) of an indexed term is a *referenced atom* and gets a
 // dense 16-bit id (1..A; 0 = "nothing").  Pod labels are translated to these ids once per program change / ingest
-// (kt_translate_pods: PodTable::latom) — labels no selector mentions cannot influence any decision and are dropped
-// there, which is also what lifts the label-count cap of the scan kernels.
+// (kt_translate_pods: PodTable::latom), ONE atom per label: the pair when it is referenced, else the key atom when
+// that is — labels no selector mentions cannot influence any decision and are dropped there, which is also what lifts
+// the label-count cap of the scan kernels.  A key-level requirement (Exists / DoesNotExist) is entered in the key
+// atom's row AND in the rows of all referenced pairs of that key.
 //
 // Terms.  Every term of a live throttle (valid, responsible, no unconvertible podSelector) gets a number c; terms with
 // the same namespace-admission set (a "class") are numbered contiguously — throttles ordered by the admission set of
@@ -96,6 +98,7 @@ struct HostIndex {
   bool has_veto = false;  // some indexed term has a NotIn / DoesNotExist requirement
   uint32_t max_need = 0;  // largest number of positive requirements of an exactly-indexed term (<= 3)
   uint32_t n_pair_keys = 0, n_key_atoms = 0;  // distinct keys behind the referenced pair atoms / referenced key atoms
+  uint32_t n_keys = 0;                        // distinct keys referenced either way
   bool has_slow = false;  // some indexed term needs the generic walk
   uint32_t la = 8;        // atom slots per pod the scan kernels are instantiated for (8 / 16 / 32)
   bool rich = false;      // image in the {any, veto} form, kernels in the <VETO, NEED 3> instantiation
@@ -153,10 +156,10 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
 // translated atoms per pod the scan kernels are instantiated for, given the program and the label capacity L: a pod
-// carries at most min(L, keys behind referenced pairs) pair atoms and min(L, referenced key atoms) key atoms.
-// 8 / 16 / 32; pods that still carry more relevant atoms are flagged kMetaOverflow.
-inline uint32_t atom_slots(uint32_t n_pair_keys, uint32_t n_key_atoms, int L) {
-  const uint32_t ub = std::min<uint32_t>((uint32_t)L, n_pair_keys) + std::min<uint32_t>((uint32_t)L, n_key_atoms);
+// carries one atom per label whose key some selector references.  8 / 16 / 32; pods that still carry more relevant
+// atoms are flagged kMetaOverflow.
+inline uint32_t atom_slots(uint32_t n_keys, int L) {
+  const uint32_t ub = std::min<uint32_t>((uint32_t)L, n_keys);
   return ub <= 8 ? 8u : ub <= 16 ? 16u : 32u;
 }
 
@@ -176,6 +179,9 @@ struct AggScan {
   bool overflow_pods = false;    // some pod is flagged kMetaOverflow: its lane walks every throttle over the raw labels
   bool by_ns = false;            // `rows` is ordered by namespace (launch_order_rows_by_ns): contiguous tile ranges per
                                  // workgroup, chunks without words of the range's namespaces skipped
+  const uint64_t* v_meta = nullptr;   // by_ns: scan-ordered copies of the listed pods' meta words, atom rows and request
+  const uint16_t* v_latom = nullptr;  //        rows (launch_build_scan_view) — record j belongs to pod rows[j]
+  const int64_t* v_req = nullptr;
   uint32_t* slab_tag = nullptr;  // [chunks][256] epoch of the last launch that spilled this (chunk, workgroup) slab
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
 };
@@ -193,10 +199,17 @@ struct CheckSmall {
   uint32_t n_inline;       // 0, or n (<= 8): the pod rows are passed by value
   int64_t inline_rows[8];
 };
+// namespace-ordered sweep: scan-ordered copies of the listed pods' meta words / atom rows, and n words of scratch
+// that carry the class counters from chunk to chunk
+struct CheckByNs {
+  const uint64_t* v_meta;
+  const uint16_t* v_latom;
+  uint64_t* carry;
+};
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,
-                          bool by_ns = false);
+                          const CheckByNs* by_ns = nullptr);
 // by_ns: rows_dev lists ALL n pod rows ordered by namespace (launch_order_rows_by_ns); summary / status are then
 // indexed by POD ROW (as a launch without a row list would), the scan runs in namespace order
 // labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)

@@ -7,6 +7,8 @@
 
 namespace kt {
 
+typedef uint32_t u128 __attribute__((ext_vector_type(4)));
+
 constexpr int kBlock = 256;
 
 static inline int grid_for(int64_t n, int per_block = kBlock, int max_blocks = 256 * 8) {
@@ -110,17 +112,12 @@ __global__ __launch_bounds__(kBlock) void kt_translate_pods(PodTable pods, int64
       for (int l = 0; l < LS; ++l) {
         const uint32_t pr = pods.lpair[row * LS + l];
         if (pr == 0u) continue;  // empty slot
+        // one atom per label: the pair when some selector names it, else the key atom when some selector names the key
         uint32_t id = atom_id_of(table, mask, pr);
+        if (!id && key_atoms) id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
         if (id) {
           if (cnt < (uint32_t)LA) out[threadIdx.x][cnt] = (uint16_t)id;
           ++cnt;
-        }
-        if (key_atoms) {
-          id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
-          if (id) {
-            if (cnt < (uint32_t)LA) out[threadIdx.x][cnt] = (uint16_t)id;
-            ++cnt;
-          }
         }
       }
       for (uint32_t k = cnt; k < (uint32_t)LA; ++k) out[threadIdx.x][k] = 0;
@@ -258,6 +255,31 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
   hipLaunchKernelGGL(kt_ns_histogram, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor);
   hipLaunchKernelGGL(kt_ns_scan, dim3(1), b, 0, s, cursor, n_keys, out_n);
   hipLaunchKernelGGL(kt_ns_scatter, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
+}
+
+// kt_build_scan_view — the records the namespace-ordered scans stream, copied into scan order once per ordering so that
+// a tile reads 64 consecutive records instead of gathering them through the row list on every chunk visit:
+// meta word, atom row, and (aggregate view) the request row of every listed pod.
+__global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t n, const int64_t* rows, uint64_t* v_meta,
+                                                         uint16_t* v_latom, int64_t* v_req) {
+  const int LA = pods.LA, DS = pods.DS;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+    const int64_t p = rows[j];
+    v_meta[j] = pods.meta[p];
+    const u128* src = (const u128*)(pods.latom + p * LA);
+    u128* dst = (u128*)(v_latom + j * LA);
+    for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
+    if (v_req) {
+      const u128* rs = (const u128*)(pods.req + p * DS);
+      u128* rd = (u128*)(v_req + j * DS);
+      for (int q = 0; q < DS / 2; ++q) rd[q] = rs[q];
+    }
+  }
+}
+void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
+                            int64_t* v_req, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(kt_build_scan_view, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, pods, n, rows, v_meta, v_latom, v_req);
 }
 
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {

@@ -29,6 +29,9 @@ struct BmAggArgs {
   int32_t sign;    // +1 / -1: the scanned pods are added to / removed from the target (delta scans)
   int32_t nonneg;  // no pod of the engine carries a negative request: a non-zero value then implies a non-zero sum
   int32_t has_overflow;  // some pod is flagged kMetaOverflow
+  const uint64_t* v_meta;  // namespace order (ix.by_ns): scan-ordered copies, record j belongs to pod rows[j]
+  const uint16_t* v_latom;
+  const int64_t* v_req;
   uint32_t* slab_tag;    // [chunks][256]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
 };
@@ -41,12 +44,13 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab;
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   a.slab_tag = sc.slab_tag, a.epoch = sc.epoch;
+  a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
   a.off_tab = take(agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
   plan_bitmap_index(ix, a.ix, take);
-  a.ix.by_ns = (sc.by_ns && sc.rows) ? 1u : 0u;
+  a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && sc.v_req) ? 1u : 0u;
   *total = o;
   return a;
 }
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const int64_t tpb = (n_wtiles + gridDim.x - 1) / gridDim.x;
     t_lo = min((int64_t)blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
     if (t_lo >= t_hi) return;
-    ns_lo = (uint32_t)(a.meta[a.rows[t_lo * kWave]] & kMetaNsMask);
-    ns_hi = (uint32_t)(a.meta[a.rows[min(t_hi * kWave, n_rows) - 1]] & kMetaNsMask);
+    ns_lo = (uint32_t)(a.v_meta[t_lo * kWave] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.v_meta[min(t_hi * kWave, n_rows) - 1] & kMetaNsMask);
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
   }
   for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
@@ -105,9 +109,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       const bool in = i < n_rows;
       const int64_t ic = min(i, n_rows - 1);
       const int64_t p = a.rows ? a.rows[ic] : a.row0 + ic;
-      const uint64_t meta = a.meta[p];
+      const uint64_t meta = by_ns ? a.v_meta[ic] : a.meta[p];
       u32x4 raw[LA / 8];
-      load_atoms<LA>(a.latom, p, raw);
+      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : p, raw);
       const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
       // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
       // (isNotFinished, pod_util.go:26-28) and only matter for error detection (slow list)
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       int64_t v[DT];
 #pragma unroll
       for (int d = 0; d < DT; ++d) v[d] = 0;
-      if (counted) load_requests<DT>(a.req, DS, p, v);
+      if (counted) load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : p, v);
       uint32_t ro[LA];
       atom_row_offsets<LA>(raw, bm.row_bytes, ro);
 
@@ -303,6 +307,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   KT_AGG_BM_CASE(8, 8, false, 2)
 #else
   if (!ix.rich) { if (DT <= 8) KT_AGG_BM_CASE(8, 8, false, 2) else KT_AGG_BM_CASE(16, 8, false, 2) }
+  else if (LA <= 8) { if (DT <= 8) KT_AGG_BM_CASE(8, 8, true, 3) else KT_AGG_BM_CASE(16, 8, true, 3) }
   else if (LA <= 16) { if (DT <= 8) KT_AGG_BM_CASE(8, 16, true, 3) else KT_AGG_BM_CASE(16, 16, true, 3) }
   else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 3) else KT_AGG_BM_CASE(16, 32, true, 3) }
 #endif

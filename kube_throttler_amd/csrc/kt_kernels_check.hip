@@ -51,6 +51,10 @@ struct BmCheckArgs {
   uint32_t* ticket;        // [tiles] arrival counters, zero between launches
   uint64_t* host_summary;  // nullable: pinned host copy of the final summary words
   uint32_t has_overflow;   // some pod carries more relevant atoms than its atom row holds (kMetaOverflow)
+  // namespace-ordered sweeps (ix.by_ns): record j of the views belongs to pod rows[j]
+  const uint64_t* v_meta;
+  const uint16_t* v_latom;
+  uint64_t* carry;         // [n] class counters between chunks
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
 };
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
     t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
     if (t_lo >= t_hi) return;
-    ns_lo = (uint32_t)(a.meta[a.rows[(uint64_t)t_lo * kWave]] & kMetaNsMask);
-    ns_hi = (uint32_t)(a.meta[a.rows[min((uint64_t)t_hi * kWave, (uint64_t)n) - 1u]] & kMetaNsMask);
+    ns_lo = (uint32_t)(a.v_meta[(uint64_t)t_lo * kWave] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.v_meta[min((uint64_t)t_hi * kWave, (uint64_t)n) - 1u] & kMetaNsMask);
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
     last_ci = last_relevant_chunk(a.ix, ns_lo, ns_hi);
   }
@@ -147,12 +151,13 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       const uint32_t ic = min(i, n - 1u);
       const uint32_t p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
       const uint32_t si = by_ns ? p : i;  // the pod's index in the summary words / status matrix
-      const uint64_t meta = a.meta[p];
+      const uint64_t meta = by_ns ? a.v_meta[ic] : a.meta[p];
       u32x4 raw[LA / 8];
-      load_atoms<LA>(a.latom, p, raw);
-      // class counters so far (bit 1 = error) ride in the summary word between chunks
+      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : p, raw);
+      // class counters so far (bit 1 = error) ride in the summary word (namespace order: the carry word) between chunks
+      unsigned long long* carry_w = by_ns ? (unsigned long long*)a.carry + ic : (unsigned long long*)a.summary + si;
       const unsigned long long carried =
-          (!SMALL && !first && in) ? __hip_atomic_load((unsigned long long*)a.summary + si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          (!SMALL && !first && in) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       cnt[lane] = 0ull;
       unsigned long long my = carried & ~3ull;  // this lane's class counters
       const bool on = in && ((meta >> kMetaStateShift) & kPodValid) != 0;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           if (FULL && a.status && pod_err)
             for (int t = 0; t < a.T; ++t) a.status[(uint64_t)si * (uint32_t)a.T + t] = 255;
         } else {
-          a.summary[si] = c | (pod_err ? 2ull : 0ull);
+          *carry_w = c | (pod_err ? 2ull : 0ull);
         }
       }
     }
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods, bool by_ns) {
+                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods, const CheckByNs* by_ns) {
   if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -329,7 +334,10 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     for (int k = 0; k < 8; ++k) bm_args.inline_rows[k] = sm->inline_rows[k];
   }
   bm_args.has_overflow = overflow_pods ? 1u : 0u;
-  bm_args.ix.by_ns = (by_ns && !small && rows_dev) ? 1u : 0u;
+  if (by_ns && !small && rows_dev) {
+    bm_args.ix.by_ns = 1u;
+    bm_args.v_meta = by_ns->v_meta, bm_args.v_latom = by_ns->v_latom, bm_args.carry = by_ns->carry;
+  }
   const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
@@ -344,6 +352,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   KT_BM_CASE(8, 8, false, 2)
 #else
   if (!rich) { if (DT <= 8) KT_BM_CASE(8, 8, false, 2) else KT_BM_CASE(16, 8, false, 2) }
+  else if (LA <= 8) { if (DT <= 8) KT_BM_CASE(8, 8, true, 3) else KT_BM_CASE(16, 8, true, 3) }
   else if (LA <= 16) { if (DT <= 8) KT_BM_CASE(8, 16, true, 3) else KT_BM_CASE(16, 16, true, 3) }
   else { if (DT <= 8) KT_BM_CASE(8, 32, true, 3) else KT_BM_CASE(16, 32, true, 3) }
 #endif

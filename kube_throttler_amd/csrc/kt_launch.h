@@ -33,6 +33,9 @@ void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows
 // n_keys = namespace capacity; out_n: device counter receiving the number of listed rows
 void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
                              int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
+// scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
+void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
+                            int64_t* v_req, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
                                 uint32_t* out_present, hipStream_t s);

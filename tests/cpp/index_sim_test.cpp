@@ -153,12 +153,9 @@ static uint32_t atom_id_of(const HostIndex& ix, uint32_t atom) {
 static std::vector<uint32_t> translate(const HostIndex& ix, const PodLabels& pod, bool* overflow) {
   std::vector<uint32_t> ids;
   for (size_t l = 0; l < pod.pairs.size(); ++l) {
-    uint32_t id = atom_id_of(ix, pod.pairs[l]);
+    uint32_t id = atom_id_of(ix, pod.pairs[l]);  // kt_translate_pods: one atom per label
+    if (!id && ix.n_key_atoms) id = atom_id_of(ix, kKeyAtom | pod.keys[l]);
     if (id) ids.push_back(id);
-    if (ix.n_key_atoms) {
-      id = atom_id_of(ix, kKeyAtom | pod.keys[l]);
-      if (id) ids.push_back(id);
-    }
   }
   *overflow = ids.size() > ix.la;
   EXPECT(ids.size() <= ix.la, "pod carries %zu relevant atoms, index promised <= %u", ids.size(), ix.la);
