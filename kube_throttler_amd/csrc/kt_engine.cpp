@@ -1359,7 +1359,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     return KT_OK;
   }
   // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
-  const bool by_ns = e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_NS_ORDER");
+  const bool by_ns = (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
   if (e->cfg.kernel_variant != 1 && (!e->countable_valid || e->countable_by_ns != by_ns)) {  // pods changed since the last scan: which rows does a reconcile look at
     KT_HIP(e, e->d_countable.reserve((size_t)e->pod_rows_hi + 1));
     KT_HIP(e, e->d_n_countable.reserve(1));
@@ -1375,7 +1375,9 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
-    if (by_ns) {
+    if (!getenv_flag("KT_NO_SCAN_VIEW")) {
+      // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
+      // (namespace order for a multi-chunk index, ascending rows otherwise)
       const size_t nc = (size_t)e->n_countable + 1;
       KT_HIP(e, e->d_vc_meta.reserve(nc));
       KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
@@ -1401,7 +1403,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       kt::AggScan sc;
       sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
       sc.overflow_pods = e->n_overflow != 0;
-      sc.by_ns = e->countable_by_ns;
+      // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
+      sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
       if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->d_vc_req.p;
       if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
@@ -1621,7 +1624,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
       // a sweep over every row of a multi-chunk index runs in namespace order (results stay indexed by pod row)
-      const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_NS_ORDER");
+      const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
       if (by_ns && !e->order_all_valid) {
         KT_HIP(e, e->d_order_all.reserve((size_t)e->pod_rows_hi + 1));
         KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->cfg.namespace_capacity + 1));
