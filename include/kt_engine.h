@@ -153,6 +153,13 @@ int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* thr_rows, const kt
  *      over the buffer kt_partial_used_buffer returns, then kt_finalize_launch. -------------------------- */
 #define KT_RECONCILE_APPLY 0x1u /* store the new status as the engine's stored status (UpdateStatus) */
 int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream);
+/* The same for a SUBSET of throttle rows — the reference reconciles ONE throttle per workqueue key
+ * (pkg/controllers/throttle_controller.go:84-133, controller.go:89-122): only the listed rows resolve
+ * CalculateThreshold(now), get a new `used` / `throttled` and (with KT_RECONCILE_APPLY) have their stored status
+ * replaced; every other row keeps its stored status and reports it unchanged (calc_at_nonzero = 0, no next-override
+ * instant).  The scan itself still covers all throttles (it is one pass over the pods either way). */
+int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
+                                 const int32_t* throttle_rows, void* stream);
 int32_t kt_aggregate_launch(kt_engine* e, void* stream);
 int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64);
 /* Optional: aggregate into / finalize from a CALLER-owned device buffer of >= n_int64 words (e.g. the
@@ -206,6 +213,10 @@ int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_eq
  *      out_status[i][*] are what PreFilter returned for pod i AT ITS TURN.
  *      flags: KT_ADMIT_COMMIT keeps the resulting reserved amounts in the engine (as if Reserve had been called
  *      for every admitted pod; read them back with kt_fetch_reserved); without it the call is a dry run.
+ *      Every admitted pod ADDS its amount: the reference's cache is a map keyed by pod (reserved_resource_amounts.go:
+ *      130-135), so a pod whose amount is already part of the reserved totals, or that occurs twice in the queue, must
+ *      not be in it — the caller ends the queue there and takes that pod through kt_check + its own map (the C++ plugin
+ *      mirror's AdmitQueue does exactly that).
  *      Limit: n x throttle_rows <= 2^31 (the status matrix).  The reserved amounts of all throttles live in LDS while
  *      they fit (throttle_rows x (8 x n_dims + 16) <= ~156 KB), beyond that in HBM (same results, L2 latency per
  *      pod). ---------------------------------------------------------------------------------------------------- */

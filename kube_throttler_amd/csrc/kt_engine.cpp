@@ -156,6 +156,7 @@ struct kt_engine {
   DevBuf<uint64_t> d_vc_meta, d_va_meta, d_carry;
   DevBuf<uint16_t> d_vc_latom, d_va_latom;
   DevBuf<int64_t> d_vc_req;
+  DevBuf<uint8_t> d_row_mask;                    // kt_reconcile_rows_launch: the keys of the reconcile, a byte per throttle row
   DevBuf<uint32_t> d_slab_tag;                   // [chunks][256] epoch of the launch that last spilled a slab
   uint32_t slab_epoch = 0;
   bool neg_seen = false;                         // some pod was fed with a negative request (sums may cancel)
@@ -792,6 +793,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release();
   e->d_ns_cursor.release();
   e->d_slab_tag.release();
+  e->d_row_mask.release();
   e->d_n_countable.release();
   e->d_ticket.release();
   if (e->h_small) (void)hipHostFree(e->h_small);
@@ -889,6 +891,15 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
           if (b->pod_ovh[(size_t)i * D + d] < 0) e->neg_seen = true;
         }
     for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]);
+  }
+  if (e->incremental && rows && n > 1) {
+    // the delta scans remove every row's old content and add its new one, once per occurrence: a row named twice in
+    // one batch would be applied twice
+    std::vector<int64_t> sorted(rows, rows + n);
+    std::sort(sorted.begin(), sorted.end());
+    for (int64_t i = 1; i < n; ++i)
+      if (sorted[(size_t)i] == sorted[(size_t)i - 1])
+        return e->fail(KT_ERR_INVALID_ARGUMENT, "pod row %lld appears twice in one batch (incremental engine)", (long long)sorted[(size_t)i]);
   }
   for (int d = 0; d < D; ++d) {
     const unsigned __int128 m = std::max(batch_max[d], e->max_abs[d]);
@@ -1438,7 +1449,8 @@ static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int6
 }
 
 // consume: kt_reconcile_launch — nobody reads the partials after this finalize, which leaves them zeroed for the next scan
-static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s, bool consume = false) {
+static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s, bool consume = false,
+                               const uint8_t* row_mask = nullptr) {
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
@@ -1450,7 +1462,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
     kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
-                        e->recs_eq, req_bound(e), s);
+                        e->recs_eq, req_bound(e), s, row_mask);
   }
   e->clean_partial = consume ? (const void*)e->partial() : nullptr;
   KT_HIP(e, hipGetLastError());
@@ -1509,6 +1521,30 @@ int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_
   int32_t rc = aggregate_locked(e, s);
   if (rc != KT_OK) return rc;
   return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
+}
+
+int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
+                                 const int32_t* throttle_rows, void* stream) {
+  if (!e || n < 0 || (n > 0 && !throttle_rows)) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  KT_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = pick_stream(e, stream);
+  for (int32_t i = 0; i < n; ++i)
+    if (throttle_rows[i] < 0 || throttle_rows[i] >= e->cfg.throttle_capacity)
+      return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", throttle_rows[i]);
+  int32_t rc = ensure_ready(e, s);
+  if (rc != KT_OK) return rc;
+  // the keys of this reconcile as a byte per throttle row; the other rows keep (and report) their stored status
+  std::vector<uint8_t> mask((size_t)e->thr_rows_hi + 1, 0);
+  for (int32_t i = 0; i < n; ++i)
+    if (throttle_rows[i] < e->thr_rows_hi) mask[(size_t)throttle_rows[i]] = 1;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  KT_HIP(e, e->d_row_mask.reserve(mask.size()));
+  KT_HIP(e, hipMemcpyAsync(e->d_row_mask.p, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
+  KT_HIP(e, hipStreamSynchronize(s));  // `mask` goes out of scope
+  rc = aggregate_locked(e, s);
+  if (rc != KT_OK) return rc;
+  return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental, e->d_row_mask.p);
 }
 
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {

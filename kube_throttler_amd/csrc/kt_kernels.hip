@@ -503,11 +503,12 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
                                                   const unsigned long long (&pv)[DT], const unsigned long long (&pc)[DT],
                                                   unsigned long long pods, unsigned long long errs, int64_t now_s, int32_t now_ns,
                                                   int apply, const ReconcileOut& out, CheckRec<DT>* recs, int rec_eq,
-                                                  const ReqBound& vmax) {
+                                                  const ReqBound& vmax, bool selected = true) {
   // recs (nullable): also leave the CheckRec of the throttle for the check that follows (kt_prepare_check fused in:
   // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
   const uint32_t fl = r.fl;
-  const bool live = (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
+  // selected = false: a reconcile of other keys (kt_reconcile_rows_launch) — this throttle keeps its stored status
+  const bool live = selected && (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
   const bool error = live && errs != 0;
   if (!live || error) {  // the stored status is returned unchanged
     _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
@@ -661,7 +662,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
 template <int DT>
 __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, int consume,
                                                      int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
-                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax) {
+                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
   // consume: leave the row zeroed behind (kt_reconcile_launch: the next aggregate then needs no clearing pass)
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= T) return;
@@ -678,20 +679,21 @@ __global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, un
   const unsigned long long pods = prow[2 * D], errs = prow[2 * D + 1];
   if (consume)
     for (int j = 0; j < stride; ++j) prow[j] = 0ull;
-  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax);
+  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
+                        row_mask == nullptr || row_mask[t] != 0);
 }
 
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     const ReqBound& vmax, hipStream_t s) {
+                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask) {
   if (sp.T <= 0) return;
   // one wave per 64 throttles (T is small: spread over as many CUs as possible; everything is latency)
   const dim3 g((sp.T + 63) / 64), b(64);
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
   const int eq = rec_eq ? 1 : 0;
-  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax);
-  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax);
-  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax);
+  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
+  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax, row_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -46,7 +46,8 @@ void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgr
 // consume: the kernel leaves the partial rows zeroed behind
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     const ReqBound& vmax, hipStream_t s);
+                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask = nullptr);
+// row_mask (nullable, device, T bytes): rows with 0 are not reconciled — they keep and report their stored status
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s);
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,
                         const void* recs, uint64_t* summary, uint8_t* status, hipStream_t s);

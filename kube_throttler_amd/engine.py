@@ -35,7 +35,7 @@ EXPORTS = [
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
-    "kt_comm_allreduce_partial", "kt_comm_destroy",
+    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.kt_set_reserved.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(S.KtAmounts)]
         L.kt_set_status.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(KtStatus)]
         L.kt_reconcile_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_reconcile_rows_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
         L.kt_aggregate_launch.argtypes = [C.c_void_p, C.c_void_p]
         L.kt_partial_used_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.kt_use_partial_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -233,6 +234,13 @@ class Engine:
     # ---- reconcile
     def reconcile_launch(self, now, apply=True, stream=None):
         self._ck(lib().kt_reconcile_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, stream))
+
+    def reconcile_rows(self, now, rows, apply=True) -> "ReconcileResult":
+        """Reconcile of the listed throttle rows only (one workqueue key each, throttle_controller.go:84-133)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self._ck(lib().kt_reconcile_rows_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0,
+                                                len(rows), rows.ctypes.data_as(C.c_void_p), None))
+        return self.reconcile_fetch()
 
     def aggregate_launch(self, stream=None):
         self._ck(lib().kt_aggregate_launch(self._h, stream))

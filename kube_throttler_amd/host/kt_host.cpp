@@ -1,3 +1,5 @@
+#include <mutex>
+#include <set>
 // kt_host.cpp — see kt_host.hpp.  Host-side mirror of pkg/scheduler_plugin/plugin.go over the C-ABI.
 #include "kt_host.hpp"
 
@@ -324,6 +326,9 @@ struct DenseAmount {
 }  // namespace
 
 struct KubeThrottler::Impl {
+  // PreFilter / Reserve run on the scheduling goroutine, Unreserve on binding goroutines, the event handlers on informer
+  // goroutines (plugin.go:148-257): every public method takes this lock (recursive: the methods call each other)
+  std::recursive_mutex mu;
   PluginArgs args;
   kt_engine* e = nullptr;
   int D = KT_MAX_DIMS;
@@ -461,6 +466,7 @@ std::unique_ptr<KubeThrottler> NewPlugin(const PluginArgs& args, std::string* er
 // informer feed
 // ---------------------------------------------------------------------------------------------------
 bool KubeThrottler::OnNamespaceAdd(const Namespace& ns, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const int64_t row = p.ns_rows.acquire(ns.name);
   if (row < 0) { if (err) *err = "namespace capacity exhausted"; return false; }
@@ -483,6 +489,7 @@ bool KubeThrottler::OnNamespaceAdd(const Namespace& ns, std::string* err) {
 }
 
 bool KubeThrottler::OnNamespaceDelete(const std::string& name, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const int64_t row = p.ns_rows.find(name);
   if (row < 0) return true;
@@ -503,6 +510,7 @@ bool KubeThrottler::OnNamespaceDelete(const std::string& name, std::string* err)
 }
 
 bool KubeThrottler::OnPodAdd(const Pod& pod, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   // the pod's namespace id must exist even when no Namespace object was seen (then it stays invalid)
   int64_t ns_row = p.ns_rows.find(pod.ns);
@@ -567,6 +575,7 @@ bool KubeThrottler::OnPodAdd(const Pod& pod, std::string* err) {
 }
 
 bool KubeThrottler::OnPodDelete(const std::string& key, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const int64_t row = p.pod_rows.find(key);
   if (row < 0) return true;
@@ -605,6 +614,7 @@ struct ReqPool {
 }  // namespace
 
 bool KubeThrottler::OnThrottleAdd(const Throttle& thr, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const int D = p.D;
   int64_t ns_row = 0;
@@ -737,6 +747,7 @@ bool KubeThrottler::OnThrottleAdd(const Throttle& thr, std::string* err) {
 }
 
 bool KubeThrottler::OnThrottleDelete(const std::string& key, bool cluster, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const std::string tk = (cluster ? "C:" : "T:") + key;
   const int64_t row = p.thr_rows.find(tk);
@@ -774,8 +785,8 @@ static bool check_one(KubeThrottler::Impl& p, const Pod& pod, KubeThrottler* sel
   int32_t T = 0;
   kt_throttle_rows(p.e, &T);
   row_out->assign((size_t)std::max(T, 1), 0);
-  int32_t rc = kt_check_launch(p.e, 1, &row, /*isThrottledOnEqual=*/0, KT_CHECK_STATUS_MATRIX, nullptr);
-  if (rc == KT_OK) rc = kt_check_fetch(p.e, 1, summary, row_out->data());
+  // kt_check: launch + fetch under ONE engine lock (another thread's check cannot slip in between the two)
+  int32_t rc = kt_check(p.e, 1, &row, /*isThrottledOnEqual=*/0, summary, row_out->data());
   if (rc != KT_OK) {
     if (err) *err = p.engine_error(rc);
     return false;
@@ -819,6 +830,7 @@ static std::vector<Event> block_events(const KubeThrottler::Impl& p, const uint8
 }
 
 Status KubeThrottler::PreFilter(const Pod& pod) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   Status st;
   uint64_t summary = 0;
@@ -841,6 +853,7 @@ Status KubeThrottler::PreFilter(const Pod& pod) {
 }
 
 std::string KubeThrottler::LastStatusOf(const std::string& throttle_key) const {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   for (size_t t = 0; t < p.last_status.size(); ++t)
     if (p.thr_live[t] && p.thr_by_row[t].Key() == throttle_key) return status_name(p.last_status[t]);
@@ -848,6 +861,7 @@ std::string KubeThrottler::LastStatusOf(const std::string& throttle_key) const {
 }
 
 Status KubeThrottler::Reserve(const Pod& pod) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   Status st;
   std::vector<uint8_t> row;
@@ -877,12 +891,14 @@ Status KubeThrottler::Reserve(const Pod& pod) {
 }
 
 void KubeThrottler::Unreserve(const Pod& pod) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   for (auto& kv : p.reserved)
     if (kv.second.erase(pod.Key())) p.push_reserved(kv.first, nullptr);
 }
 
 bool KubeThrottler::OnPodUpdate(const Pod& old_pod, const Pod& new_pod, std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   auto counts_in = [&](const Pod& q) { return q.schedulerName == p.args.targetSchedulerName && !q.nodeName.empty(); };
   if (old_pod.Key() != new_pod.Key() || (!counts_in(old_pod) && !counts_in(new_pod))) return OnPodAdd(new_pod, err);
@@ -920,6 +936,7 @@ bool KubeThrottler::OnPodUpdate(const Pod& old_pod, const Pod& new_pod, std::str
 // launch (kt_admit_launch) instead of 2 x n calls.  The reserved cache is updated exactly as n
 // Reserve calls would have (reserved_resource_amounts.go:66-77), so Unreserve keeps working pod by pod.
 std::vector<Status> KubeThrottler::AdmitQueue(const std::vector<std::string>& pod_keys) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   const size_t n = pod_keys.size();
   std::vector<Status> out(n);
@@ -932,39 +949,69 @@ std::vector<Status> KubeThrottler::AdmitQueue(const std::vector<std::string>& po
     }
   }
   if (n == 0) return out;
-  int32_t T = 0;
-  kt_throttle_rows(p.e, &T);
-  std::vector<uint64_t> summary(n);
-  std::vector<uint8_t> status(n * (size_t)(T > 0 ? T : 1));
-  std::vector<int64_t> req(n * (size_t)p.D);
-  std::vector<uint32_t> present(n);
-  int32_t rc = kt_admit_launch(p.e, (int64_t)n, rows.data(), /*isThrottledOnEqual=*/0, KT_ADMIT_COMMIT, nullptr);
-  if (rc == KT_OK) rc = kt_check_fetch(p.e, (int64_t)n, summary.data(), T > 0 ? status.data() : nullptr);
-  if (rc == KT_OK) rc = kt_fetch_pod_requests(p.e, (int64_t)n, rows.data(), req.data(), present.data());
-  if (rc != KT_OK) {
-    for (auto& st : out) st.code = Error, st.reasons = {p.engine_error(rc)};
-    return out;
-  }
-  for (size_t i = 0; i < n; ++i) {
-    const uint8_t* row = status.data() + i * (size_t)T;
-    const uint64_t v = KT_SUMMARY_VERDICT(summary[i]);
-    if (v == KT_VERDICT_ERROR) {
-      out[i].code = Error;
-      out[i].reasons.push_back("throttle check failed for pod " + pod_keys[i] + " (invalid selector or unknown namespace)");
-    } else if (v != KT_VERDICT_SUCCESS) {
-      out[i].code = UnschedulableAndUnresolvable;
-      out[i].reasons = block_reasons(p, row, (size_t)T);
-      out[i].events = block_events(p, row, (size_t)T);
-    } else {
-      DenseAmount amt;
-      for (int d = 0; d < p.D; ++d) amt.v[d] = req[i * (size_t)p.D + d];
-      amt.present = present[i];
-      amt.has_count = 1;
-      amt.count = 1;
-      for (int32_t t = 0; t < T; ++t)
-        if (row[t] != KT_STATUS_NOT_AFFECTED) p.reserved[t][pod_keys[i]] = amt;  // the engine already holds the totals
+  // The reservation cache is a map keyed by pod (reserved_resource_amounts.go:130-135: c[nn] = amount, idempotent): a pod
+  // that is ALREADY reserved somewhere, or named twice in the queue, must not add its amount a second time — neither to
+  // the totals nor to what the following pods are checked against.  The engine's queue walk adds every admitted pod, so
+  // such a pod ends the current engine segment and goes through the plain PreFilter + Reserve calls; everything else
+  // runs as ONE launch per segment (the whole queue in the common case).
+  auto already_reserved = [&](const std::string& key) {
+    for (auto& kv : p.reserved)
+      if (kv.second.count(key)) return true;
+    return false;
+  };
+  auto admit_segment = [&](size_t i0, size_t i1) {
+    const size_t m = i1 - i0;
+    if (m == 0) return;
+    int32_t T = 0;
+    kt_throttle_rows(p.e, &T);
+    std::vector<uint64_t> summary(m);
+    std::vector<uint8_t> status(m * (size_t)(T > 0 ? T : 1));
+    std::vector<int64_t> req(m * (size_t)p.D);
+    std::vector<uint32_t> present(m);
+    int32_t rc = kt_admit_launch(p.e, (int64_t)m, rows.data() + i0, /*isThrottledOnEqual=*/0, KT_ADMIT_COMMIT, nullptr);
+    if (rc == KT_OK) rc = kt_check_fetch(p.e, (int64_t)m, summary.data(), T > 0 ? status.data() : nullptr);
+    if (rc == KT_OK) rc = kt_fetch_pod_requests(p.e, (int64_t)m, rows.data() + i0, req.data(), present.data());
+    if (rc != KT_OK) {
+      for (size_t i = i0; i < i1; ++i) out[i].code = Error, out[i].reasons = {p.engine_error(rc)};
+      return;
     }
+    for (size_t j = 0; j < m; ++j) {
+      const size_t i = i0 + j;
+      const uint8_t* row = status.data() + j * (size_t)T;
+      const uint64_t v = KT_SUMMARY_VERDICT(summary[j]);
+      if (v == KT_VERDICT_ERROR) {
+        out[i].code = Error;
+        out[i].reasons.push_back("throttle check failed for pod " + pod_keys[i] + " (invalid selector or unknown namespace)");
+      } else if (v != KT_VERDICT_SUCCESS) {
+        out[i].code = UnschedulableAndUnresolvable;
+        out[i].reasons = block_reasons(p, row, (size_t)T);
+        out[i].events = block_events(p, row, (size_t)T);
+      } else {
+        DenseAmount amt;
+        for (int d = 0; d < p.D; ++d) amt.v[d] = req[j * (size_t)p.D + d];
+        amt.present = present[j];
+        amt.has_count = 1;
+        amt.count = 1;
+        for (int32_t t = 0; t < T; ++t)
+          if (row[t] != KT_STATUS_NOT_AFFECTED) p.reserved[t][pod_keys[i]] = amt;  // the engine already holds the totals
+      }
+    }
+  };
+  size_t seg0 = 0;
+  std::set<std::string> in_segment;
+  for (size_t i = 0; i < n; ++i) {
+    if (!in_segment.count(pod_keys[i]) && !already_reserved(pod_keys[i])) {
+      in_segment.insert(pod_keys[i]);
+      continue;
+    }
+    admit_segment(seg0, i);
+    const Pod pod = p.pods.at(pod_keys[i]);
+    out[i] = PreFilter(pod);
+    if (out[i].IsSuccess()) out[i] = Reserve(pod);
+    seg0 = i + 1;
+    in_segment.clear();
   }
+  admit_segment(seg0, n);
   return out;
 }
 
@@ -973,6 +1020,7 @@ std::vector<Status> KubeThrottler::AdmitQueue(const std::vector<std::string>& po
 // ---------------------------------------------------------------------------------------------------
 bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::string, ThrottleStatus>* out,
                                  std::string* err) {
+  std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
   int64_t now_s;
   int32_t now_ns;
@@ -1004,6 +1052,10 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
   }
   // Once status is updated, counted pods are safe to un-reserve (throttle_controller.go:135-155)
   for (auto& kv : p.reserved) {
+    // a reconcile that failed returned before unreserveAffectedPods (throttle_controller.go:103-106), and throttles of
+    // another throttler are never reconciled: their reservations stay
+    const int32_t t = kv.first;
+    if (t < 0 || t >= T || terr[(size_t)t] || !p.thr_live[(size_t)t] || p.thr_by_row[(size_t)t].throttlerName != p.args.name) continue;
     bool changed = false;
     for (auto it = kv.second.begin(); it != kv.second.end();) {
       auto pit = p.pods.find(it->first);

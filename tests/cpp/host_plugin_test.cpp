@@ -218,6 +218,28 @@ static void TestAdmitQueue() {
   EXPECT(k->PreFilter(pods[5]).IsSuccess());
 }
 
+// The reservation cache is keyed by pod (reserved_resource_amounts.go:130-135): reserving a pod twice — a queue that
+// names it twice, or a pod Reserve already holds — must leave ONE amount on the throttle, in the plugin's map and in the
+// engine's totals alike.  pod=3: after {p0, p0, p1} plus a prior Reserve(p1) two slots are taken, a third pod still fits.
+static void TestAdmitQueueIsIdempotentPerPod() {
+  auto k = Fresh();
+  std::string err;
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "t", "grp", "a", 3, "1"), &err));
+  std::vector<Pod> pods;
+  for (int i = 0; i < 4; ++i) {
+    pods.push_back(MakePod("default", "p" + std::to_string(i), "100m", {{"grp", "a"}}));
+    EXPECT(k->OnPodAdd(pods.back(), &err));
+  }
+  EXPECT(k->Reserve(pods[1]).IsSuccess());
+  std::vector<Status> st = k->AdmitQueue({pods[0].Key(), pods[0].Key(), pods[1].Key()});
+  EXPECT(st.size() == 3 && st[0].IsSuccess() && st[1].IsSuccess() && st[2].IsSuccess());
+  EXPECT(k->PreFilter(pods[2]).IsSuccess());  // 2 reserved + 1 = 3, not over pod=3 (isThrottledOnEqual = false)
+  EXPECT(k->Reserve(pods[2]).IsSuccess());
+  EXPECT(k->PreFilter(pods[3]).code == UnschedulableAndUnresolvable);  // 3 reserved: step 3 of a Throttle is >= (throttle_types.go:143)
+  k->Unreserve(pods[0]);
+  EXPECT(k->PreFilter(pods[3]).IsSuccess());
+}
+
 // temporaryThresholdOverrides: the reconcile also says when the throttle has to be looked at again
 static void TestNextOverride() {
   auto k = Fresh();
@@ -313,6 +335,7 @@ int main(int argc, char** argv) {
     TestThrottleScenarios();
     TestClusterThrottleAndReserve();
     TestAdmitQueue();
+    TestAdmitQueueIsIdempotentPerPod();
     TestNextOverride();
   }
   if (g_fail) {

@@ -480,6 +480,17 @@ def test_api_errors():
         eng.check(rows=np.array([99], dtype=np.int64))
     assert ei.value.code == -2
     eng.close()
+    # an incremental engine applies a batch row by row through delta scans: naming a row twice would apply it twice
+    inc = E.Engine(snap.D, max(snap.L, 1), 16, max(snap.n_thr, 1), max(snap.n_ns, 1), -1, E.VARIANT_INDEXED | E.VARIANT_INCREMENTAL)
+    try:
+        inc.upsert_namespaces(snap)
+        inc.upsert_throttles(snap)
+        with pytest.raises(E.EngineError) as ei:
+            inc.upsert_pods(_permute_pods(snap, np.array([0, 1, 2])), rows=np.array([3, 5, 3], dtype=np.int64))
+        assert ei.value.code == -1
+        inc.upsert_pods(_permute_pods(snap, np.array([0, 1, 2])), rows=np.array([3, 5, 4], dtype=np.int64))
+    finally:
+        inc.close()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -171,3 +171,40 @@ def test_concurrent_callers(oracle_mod):
         np.testing.assert_array_equal(sm_g, sm_w)
     finally:
         eng.close()
+
+
+def test_reconcile_of_single_keys(oracle_mod):
+    """The reference reconciles ONE throttle per workqueue key (throttle_controller.go:84-133): kt_reconcile_rows_launch
+    renews only the listed rows — the others keep their stored status — and the PreFilter that follows sees exactly the
+    mix of renewed and stored statuses the oracle sees after the same keys were written back."""
+    from test_engine_gpu import NOW, assert_reconcile_equal, responsible_rows
+    snap = W.generate(W.small(seed=61, n_pods=2500, n_thr=80, n_cluster=40))
+    T = snap.n_thr
+    o = oracle_mod.Oracle(snap)
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        resp = responsible_rows(snap)
+        keys = resp[::3]                      # every third responsible throttle is reconciled
+        want = o.reconcile(NOW, rows=keys)
+        got_all = eng.reconcile_rows(NOW, keys, apply=True)
+        got = E.ReconcileResult(len(keys), snap.D)
+        for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+            getattr(got, name)[:len(keys)] = getattr(got_all, name)[keys]
+        for tab in ("used", "calc"):
+            for f in ("v", "present", "count", "has_count"):
+                getattr(getattr(got, tab), f)[:len(keys)] = getattr(getattr(got_all, tab), f)[keys]
+        assert_reconcile_equal(got, want, len(keys))
+        # the rows that were not keys report the status they had
+        others = np.setdiff1d(np.arange(T), keys)
+        np.testing.assert_array_equal(got_all.used.v[others], snap.thr_used.v[others])
+        np.testing.assert_array_equal(got_all.used.present[others], snap.thr_used.present[others])
+        np.testing.assert_array_equal(got_all.calc_updated[others], 0)
+        # UpdateStatus of the keys on the oracle side, then PreFilter against the mixed statuses
+        snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=keys)
+        for on_equal in (False, True):
+            st_w, sm_w = o.check(on_equal=on_equal, nthreads=8)
+            st_g, sm_g = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w)
+            np.testing.assert_array_equal(sm_g, sm_w)
+    finally:
+        eng.close()
