@@ -147,6 +147,8 @@ struct kt_engine {
   DevBuf<int64_t> d_countable;                   // rows of the pods a reconcile scans (kt_compact_countable)
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
+  bool req_sums_valid = false;                   // the requests of the current pods were proven to add up inside 2^60
+  DevBuf<unsigned long long> d_req_sums;
   bool countable_valid = false;                  // d_countable describes the current pod table
   bool countable_by_ns = false;                  // ... ordered by namespace (multi-chunk index: kt_order_rows_by_ns)
   DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
@@ -794,6 +796,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_ns_cursor.release();
   e->d_slab_tag.release();
   e->d_row_mask.release();
+  e->d_req_sums.release();
   e->d_n_countable.release();
   e->d_ticket.release();
   if (e->h_small) (void)hipHostFree(e->h_small);
@@ -901,17 +904,17 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       if (sorted[(size_t)i] == sorted[(size_t)i - 1])
         return e->fail(KT_ERR_INVALID_ARGUMENT, "pod row %lld appears twice in one batch (incremental engine)", (long long)sorted[(size_t)i]);
   }
-  for (int d = 0; d < D; ++d) {
-    const unsigned __int128 m = std::max(batch_max[d], e->max_abs[d]);
-    if (m * (unsigned __int128)e->cfg.pod_capacity > kSumBound)
-      return e->fail(KT_ERR_OVERFLOW_RISK,
-                     "dimension %d: max |request| x pod_capacity exceeds 2^60; use a coarser scale for it", d);
-  }
+  // a single request beyond 2^60 is refused here; whether the requests of all pods still ADD UP inside the exact range
+  // is checked against their actual sum when a reconcile scans them (request_sums_in_range)
+  for (int d = 0; d < D; ++d)
+    if (batch_max[d] > kSumBound)
+      return e->fail(KT_ERR_OVERFLOW_RISK, "dimension %d: a pod's request exceeds 2^60 at this scale; use a coarser scale for it", d);
   for (int d = 0; d < D; ++d) {
     if (batch_max[d] > e->max_abs[d]) e->recs_valid = false;  // kRecTight was judged against the old bound
     e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
   }
   e->countable_valid = false;
+  e->req_sums_valid = false;
   e->order_all_valid = false;
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
@@ -1007,6 +1010,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
   e->countable_valid = false;
+  e->req_sums_valid = false;
   e->order_all_valid = false;
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
@@ -1258,6 +1262,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   KT_HIP(e, hipMemsetAsync(e->pods.meta, 0, (size_t)e->cfg.pod_capacity * 8, e->own_stream));
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   e->countable_valid = false;
+  e->req_sums_valid = false;
   e->order_all_valid = false;
   e->pod_rows_hi = 0;
   e->neg_seen = false;
@@ -1355,9 +1360,33 @@ static int32_t slab_tags(kt_engine* e, kt::AggScan& sc, hipStream_t s) {
   return KT_OK;
 }
 
+// resource.Quantity never overflows (it promotes to big decimals); the engine's exact range is int64.  Every sum a
+// scan, a delta scan or the exchange between GPUs forms is a sum over some of the CURRENT pods, so one exact total of
+// |request| per dimension (recomputed after pod events) proves all of them in range — or names the dimension that needs
+// a coarser scale.  2^60 per GPU leaves the headroom for up to 8 ranks' partials to meet in an all-reduce.
+static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
+  if (e->req_sums_valid) return KT_OK;
+  KT_HIP(e, e->d_req_sums.reserve(32));
+  kt::launch_sum_abs_requests(e->pods, e->pod_rows_hi, e->d_req_sums.p, s);
+  KT_HIP(e, hipGetLastError());
+  unsigned long long h[32];
+  KT_HIP(e, hipMemcpyAsync(h, e->d_req_sums.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  KT_HIP(e, hipStreamSynchronize(s));
+  for (int d = 0; d < e->D; ++d) {
+    const unsigned __int128 total = (unsigned __int128)h[2 * d] + ((unsigned __int128)h[2 * d + 1] << 32);
+    if (total > kSumBound)
+      return e->fail(KT_ERR_OVERFLOW_RISK,
+                     "dimension %d: the requests of the pods held here add up beyond 2^60 at this scale (the reference would "
+                     "promote to big decimals); use a coarser scale for it", d);
+  }
+  e->req_sums_valid = true;
+  return KT_OK;
+}
+
 static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
+  if ((rc = request_sums_in_range(e, s)) != KT_OK) return rc;
   const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
   if (e->ext_partial && (int64_t)words > e->ext_partial_words)
     return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed",

@@ -282,6 +282,46 @@ void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows
   hipLaunchKernelGGL(kt_build_scan_view, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, pods, n, rows, v_meta, v_latom, v_req);
 }
 
+// kt_sum_abs_requests — sum over the valid pod rows of |effective request| per dimension, exactly (two 32-bit limb sums
+// per dimension: out[2d] = sum of the low halves, out[2d+1] = sum of the high halves; good for 2^32 pods).  Every sum
+// the scans or the exchange between GPUs can form is a sum over a subset of these pods, so it is bounded by this total:
+// the engine refuses a reconcile only when THIS exceeds the exact range — where the reference would promote to big
+// decimals — instead of pricing every pod at the largest request ever seen.
+__global__ __launch_bounds__(256) void kt_sum_abs_requests(PodTable pods, int64_t n, unsigned long long* out) {
+  const int D = pods.D, DS = pods.DS;
+  unsigned long long lo[16], hi[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) lo[d] = 0ull, hi[d] = 0ull;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+    if (!((pods.meta[p] >> kMetaStateShift) & kPodValid)) continue;
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+      if (d < D) {
+        const int64_t v = pods.req[p * DS + d];
+        const unsigned long long a = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        lo[d] += a & 0xFFFFFFFFull, hi[d] += a >> 32;
+      }
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+    if (d < D) {
+      unsigned long long l = lo[d], h = hi[d];
+      for (int off = 32; off >= 1; off >>= 1) {
+        l += (unsigned long long)__shfl_xor((long long)l, off);
+        h += (unsigned long long)__shfl_xor((long long)h, off);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        if (l) atomicAdd(out + 2 * d, l);
+        if (h) atomicAdd(out + 2 * d + 1, h);
+      }
+    }
+}
+void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s) {
+  (void)hipMemsetAsync(out, 0, 32 * 8, s);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(kt_sum_abs_requests, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, pods, n, out);
+}
+
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {
   if (b.n <= 0) return;
   hipLaunchKernelGGL(kt_ingest_pods, dim3(grid_for(b.n)), dim3(kBlock), 0, s, pods, b);

@@ -36,6 +36,8 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
 // scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
 void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
                             int64_t* v_req, hipStream_t s);
+// exact per-dimension sums of |request| over the valid rows of [0, n): out[2d] low-half sum, out[2d+1] high-half sum (32 words)
+void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
                                 uint32_t* out_present, hipStream_t s);

@@ -458,16 +458,40 @@ def test_admit_golden_prefix(oracle_mod):
         eng.close()
 
 
-def test_overflow_guard():
-    """A dimension whose worst-case sum could leave int64 is refused at ingest, never wrapped."""
+def test_overflow_guard(oracle_mod):
+    """resource.Quantity never overflows; the engine's exact range is int64.  A single request beyond 2^60 is refused at
+    ingest; requests that only ADD UP beyond 2^60 are refused by the reconcile that would sum them (judged on their actual
+    total, not on max x capacity); large requests whose total fits are summed exactly."""
     snap = W.generate(W.small(seed=41, n_pods=4, n_thr=2, n_cluster=0, D=2))
-    snap.ctr_req[0, 0] = 1 << 59
+    snap.ctr_req[0, 0] = (1 << 60) + 1
     snap.ctr_present[0] |= 1
     eng = E.Engine(2, snap.L, 4, 2, snap.n_ns)
     with pytest.raises(E.EngineError) as ei:
         eng.load_snapshot(snap)
     assert ei.value.code == -4
     eng.close()
+    # 64 pods x 2^55 = 2^61: every pod is fine, their sum is not
+    snap = W.generate(W.small(seed=41, n_pods=64, n_thr=4, n_cluster=2, D=2))
+    nc = int(snap.pod_ctr_off[snap.n_pods])
+    snap.ctr_req[:nc, 0] = 0
+    snap.ctr_req[snap.pod_ctr_off[:snap.n_pods], 0] = 1 << 55   # first container of every pod
+    snap.ctr_present[snap.pod_ctr_off[:snap.n_pods]] |= 1
+    eng = E.Engine.for_snapshot(snap)
+    with pytest.raises(E.EngineError) as ei:
+        eng.reconcile(NOW, apply=False)
+    assert ei.value.code == -4
+    eng.close()
+    # 64 pods x 2^53 = 2^59 fits: exact sums, equal to the oracle's 128-bit arithmetic
+    snap.ctr_req[snap.pod_ctr_off[:snap.n_pods], 0] = 1 << 53
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        rows = responsible_rows(snap)
+        want = oracle_mod.Oracle(snap).reconcile(NOW, rows=rows)
+        got_all = eng.reconcile(NOW, apply=False)
+        np.testing.assert_array_equal(got_all.used.v[rows], want.used.v[:len(rows)])
+        assert int(got_all.used.v[rows].max()) >= 1 << 53
+    finally:
+        eng.close()
 
 
 def test_api_errors():
