@@ -50,6 +50,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         break;
       }
   }
+  // a throttle with more than 64 selector terms: its run of term numbers could not stay inside one 64-bit word (the scans
+  // settle "reported once" per word) — walked term by term like the throttles with unconvertible selectors
+  for (size_t t = 0; t < T; ++t) {
+    if (is_slow_thr[t] || !thr_info((uint32_t)t).live) continue;
+    if (thr_term_off[t + 1] - thr_term_off[t] > 64u) out.slow_thr.push_back((uint32_t)t), is_slow_thr[t] = 1;
+  }
   // ---- referenced atoms.  A pod label (k, v) is ONE atom: the pair (k, v) when some In / NotIn requirement names it,
   //      else the key atom of k when some Exists / DoesNotExist requirement names k (else nothing).  A key-level
   //      requirement therefore covers the key atom AND every referenced pair of that key.
@@ -362,7 +368,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       const size_t lds_hi = std::max(lds, (size_t)out.bm_max_lds);
       const size_t thr_hi = std::max((size_t)nthr, (size_t)out.bm_max_thr);
       const size_t nw_hi = std::max(nw, (size_t)out.bm_max_words);
-      const bool fits = lds_hi + nw_hi * 64 * 8 <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + thr_hi * thr_bytes + 16 <= agg_budget &&
+      const bool fits = lds_hi + nw_hi * kCheckWordLds <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + thr_hi * thr_bytes + 16 <= agg_budget &&
                         nthr < 0x8000u;
       if (!fits && w1 != 0) break;
       if (cand == W || splittable[cand]) {

@@ -40,6 +40,7 @@
 namespace kt {
 
 constexpr uint32_t kKeyAtom = 0x80000000u;
+constexpr uint32_t kCheckWordLds = 64u * 8u + 176u;  // = check_word_lds(): TermInfo[64] + WordVerdict<16> per word
 
 // term_t[] entry of a chunk image: throttle row | flags
 constexpr uint32_t kTermAdj = 0x80000000u;   // multi-term throttle: a match repeating the lane's previous throttle is dropped
@@ -142,7 +143,7 @@ struct IndexDev {
 };
 
 // LDS budgets: a chunk must satisfy
-//   check     : lds_bytes + n_words*64*8 (term info)                      <= chk_budget
+//   check     : lds_bytes + n_words*kCheckWordLds (term info + verdict masks) <= chk_budget
 //   aggregate : lds_bytes + n_words*64*2 (ranks) + n_thr * thr_bytes      <= agg_budget
 // (both kernels lay LDS out once, for the maxima over all chunks, so the maxima have to fit too).
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
@@ -168,6 +169,7 @@ struct SelProgram;
 // LDS the two scan kernels need beside the chunk image and its per-term / per-throttle tables
 uint32_t aggregate_fixed_lds();
 uint32_t check_fixed_lds();
+uint32_t check_word_lds();  // check: bytes per 64-bit word of term numbers beside the image (TermInfo + WordVerdict)
 // which pods an aggregate scan covers and how they enter the target buffer
 struct AggScan {
   int64_t n = 0;                 // pods

@@ -21,6 +21,21 @@ namespace kt {
 // ---------------------------------------------------------------------------------------------------
 
 constexpr uint32_t kListCap = 128;  // tight-match list entries per wave (512 B)
+// Per 64-bit word of term numbers, rebuilt per launch from the CheckRec flags (lean instantiation: the PreFilter sweep):
+// the pod-independent part of every term's verdict as masks, so that a lane settles ALL matches of a word that need no
+// comparison with a handful of mask operations and three popcounts — only matches of `tight` throttles are peeled.
+//   seg_lo / seg_hi : lowest / highest number of every run of one throttle's terms (a throttle with several terms is
+//                     reported once: (v ^ (v - seg_lo)) & v with v = x | seg_hi keeps the lowest match of every run; the
+//                     index never lets a run straddle a word)
+template <int DT>
+struct alignas(16) WordVerdict {
+  uint64_t seg_lo, seg_hi;
+  uint64_t tight;      // kRecTight: the request row has to be compared with thr[] / head[]
+  uint64_t exc;        // kRecExceedsByCount
+  uint64_t act;        // kRecActiveByCount
+  uint64_t ins;        // kRecInsufficientByCount
+  uint64_t act_d[DT];  // active_mask bit d: a pod that requests dimension d is `active`
+};
 // TermInfo word 0: throttle row | kTiAdj
 //          word 1: active_mask (16 bits) | counter shift when the pod requests an active dimension << 16
 //                  | counter shift otherwise << 22 | kTiTight
@@ -43,10 +58,9 @@ struct BmCheckArgs {
   const uint32_t* slow_thr;
   int64_t n;
   BmIndexArgs ix;
-  uint32_t off_cnt, off_list, off_tinfo;
+  uint32_t off_cnt, off_list, off_tinfo, off_wv;
   uint32_t n_slow;
   int32_t DS, LS, T;
-  uint32_t exp;  // KT_EXP (timing experiments only; results are wrong when set): 1 no drain, 2 no peel work, 4 no scan
   // small launches (SMALL instantiation: one workgroup per (chunk, tile), results met by atomics)
   uint32_t* ticket;        // [tiles] arrival counters, zero between launches
   uint64_t* host_summary;  // nullable: pinned host copy of the final summary words
@@ -67,19 +81,20 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
   a.sp = sp_dev, a.ns_valid = sp.ns_valid, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow;
   a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
-  static const uint32_t exp_env = getenv("KT_EXP") ? (uint32_t)atoi(getenv("KT_EXP")) : 0u;
-  a.exp = exp_env;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
   a.off_list = take((kBlockIx / kWave) * kListCap * 4);
   a.off_tinfo = take(ix.bm_max_words * 64u * 8u);
+  a.off_wv = take(ix.bm_max_words * (uint32_t)(pods.D <= 8 ? sizeof(WordVerdict<8>) : sizeof(WordVerdict<16>)));
   plan_bitmap_index(ix, a.ix, take);
   *total = o;
   return a;
 }
 
 uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
+static_assert(sizeof(WordVerdict<16>) == 176 && 64u * 8u + sizeof(WordVerdict<16>) == kCheckWordLds, "kCheckWordLds (kt_index.h) follows WordVerdict");
+uint32_t check_word_lds() { return 64u * 8u + (uint32_t)sizeof(WordVerdict<16>); }  // TermInfo + WordVerdict per 64-bit word
 
 // SMALL: a launch of a few pods (one PreFilter call, an admission queue): grid = (chunks, tiles), every workgroup scans
 //        ONE tile against ONE chunk, so that the chunks of a large program are walked side by side instead of one after
@@ -91,6 +106,12 @@ uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap
 template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;
+  // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
+  // being peeled one by one.  Pays when a pod matches several terms per word (measured: config 4's 130 matches per pod,
+  // check 1.27 -> 0.92 ms); with a match or two per pod the peel is cheaper and the masks' registers do not fit the
+  // 64-VGPR budget of the two-workgroups-per-CU instantiation (config 2: 33.6 -> 38.2 us, 56 B of scratch), which
+  // therefore keeps the peel.
+  constexpr bool WORDWISE = !FULL && WPE < 8;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
@@ -139,6 +160,28 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           ti.y = (rf.y & 0xFFFFu) | sh_act << kTiShActive | sh_idle << kTiShIdle | ((rf.x & kRecTight) ? kTiTight : 0u);
         }
         tinfo[c] = ti;
+        if (WORDWISE) {  // this wave holds the 64 numbers of word c / 64: their verdict masks by ballot
+          const uint32_t ln = c & 63u;
+          const bool real = (tt & kTermReal) != 0;
+          const uint32_t t = tt & kTermRowMask;
+          const u32x2 rf = real ? g_rflags[t] : u32x2{0u, 0u};
+          const uint32_t tp = (uint32_t)__shfl_up((int)tt, 1), tn = (uint32_t)__shfl_down((int)tt, 1);
+          const bool adj = (tt & kTermAdj) != 0;
+          const bool same_prev = ln > 0u && adj && (tp & kTermReal) && (tp & kTermAdj) && (tp & kTermRowMask) == t;
+          const bool same_next = ln < 63u && adj && (tn & kTermReal) && (tn & kTermAdj) && (tn & kTermRowMask) == t;
+          const bool xc = (rf.x & kRecExceedsByCount) != 0;
+          const uint64_t m_lo = __ballot(real && !same_prev), m_hi = __ballot(real && !same_next);
+          const uint64_t m_tight = __ballot(real && (rf.x & kRecTight) != 0), m_exc = __ballot(real && xc);
+          const uint64_t m_act = __ballot(real && (rf.x & kRecActiveByCount) != 0), m_ins = __ballot(real && (rf.x & kRecInsufficientByCount) != 0);
+          KT_LDS WordVerdict<DT>* wvp = (KT_LDS WordVerdict<DT>*)(lds + a.off_wv) + (c >> 6);
+          uint64_t mine = ln == 0u ? m_lo : ln == 1u ? m_hi : ln == 2u ? m_tight : ln == 3u ? m_exc : ln == 4u ? m_act : m_ins;
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const uint64_t m = __ballot(real && ((rf.y >> d) & 1u) != 0);
+            mine = ln == 6u + (uint32_t)d ? m : mine;
+          }
+          if (ln < 6u + (uint32_t)DT) ((KT_LDS uint64_t*)wvp)[ln] = mine;
+        }
       }
     }
     __syncthreads();
@@ -171,14 +214,15 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       uint32_t last_t = 0xFFFFFFFFu;
 
       auto drain = [&]() {
-        if (a.exp & 1u) { n_list = 0; return; }
         // ---- lane = listed (pod lane, throttle): the full comparison; pod row / non-zero mask come from the pod's
         //      lane by ds_bpermute
         for (uint32_t base = 0; base < n_list; base += kWave) {
           const uint32_t j = base + lane;
           const bool vv = j < n_list;
           const uint32_t e = list[vv ? j : 0u];
-          const uint32_t pl = e >> 20, t = e & kTermRowMask;
+          // the list holds throttle rows — or, WORDWISE, term numbers (their row is one LDS read away, taken here with
+          // every lane busy instead of in the peel)
+          const uint32_t pl = e >> 20, t = !WORDWISE ? e & kTermRowMask : tinfo[e & kTermRowMask].x & kTermRowMask;
           const uint32_t prow = (uint32_t)__shfl((int)p, (int)pl);
           const uint32_t psi = FULL ? (uint32_t)__shfl((int)si, (int)pl) : 0u;
           const uint32_t pnz = (uint32_t)__shfl((int)nz, (int)pl);
@@ -236,11 +280,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           }
       }
 
-      if (!(a.exp & 4u))
+      if (!WORDWISE) {
       scan_tile<LA, VETO, NEED>(
           bm, scan_on, ns, ro,
           [&](bool has, uint32_t c) {
-            if (a.exp & 2u) return;
             // branch-free: the term's TermInfo word carries both verdicts a non-tight throttle can give (as the bit
             // position of the class counter to bump: 4 / 24 / 44, 0 = not throttled), chosen by the pod's non-zero mask
             const u32x2 ti = tinfo[c];
@@ -259,6 +302,36 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           [&](uint32_t c) {
             return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
           });
+      } else {
+      // every match that needs no comparison is settled per WORD with mask algebra (WordVerdict), the matches of tight
+      // throttles are peeled into the list as bare term numbers
+      KT_LDS const WordVerdict<DT>* wv = (KT_LDS const WordVerdict<DT>*)(lds + a.off_wv);
+      scan_tile<LA, VETO, NEED>(
+          bm, scan_on, ns, ro,
+          [&](bool has, uint32_t c) { push(has, c); },
+          [&](uint32_t c) {
+            return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
+          },
+          [&](uint32_t w, uint64_t x) -> uint64_t {
+            KT_LDS const WordVerdict<DT>* q = wv + w;
+            const u64x2 seg = *(KT_LDS const u64x2*)&q->seg_lo;  // {seg_lo, seg_hi}
+            const u64x2 te = *(KT_LDS const u64x2*)&q->tight;    // {tight, exc}
+            const u64x2 ai = *(KT_LDS const u64x2*)&q->act;      // {act, ins}
+            // a throttle with several terms is reported once: the lowest match of every run
+            const uint64_t v = x | seg.y;
+            x &= (v ^ (v - seg.x)) & v;
+            uint64_t act = ai.x;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+              if ((nz >> d) & 1u) act |= q->act_d[d];
+            const uint64_t xf = x & ~te.x & ~te.y;  // settled here, not exceeded by count
+            const uint64_t n_exc = (uint64_t)__popcll(x & ~te.x & te.y);
+            const uint64_t n_act = (uint64_t)__popcll(xf & act);
+            const uint64_t n_ins = (uint64_t)__popcll(xf & ~act & ai.y);
+            my += n_exc << 4 | n_act << 24 | n_ins << 44;
+            return x & te.x;
+          });
+      }
       if (n_list) drain();
       // ---- lane = pod: the 8-byte summary word
       if (SMALL) {

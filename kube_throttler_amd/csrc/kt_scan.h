@@ -136,9 +136,14 @@ __device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uin
 //   match(has, c) : wave-wide call per peel step; lanes with `has` matched term number c of this chunk (c = 0 for the
 //                others).  Ascending c per lane.
 //   confirm(c) : lane-divergent — does the lane's pod satisfy ALL requirements of `slow` term number c
-template <int LA, bool VETO, int NEED, class Match, class Confirm>
+//   post(w, x) : per lane, once per advanced word: x = the matched terms of word w; returns the bits that still go
+//                through the peel (a consumer that can settle matches 64 at a time with mask algebra keeps the rest)
+struct ScanKeepAll {
+  __device__ __forceinline__ uint64_t operator()(uint32_t, uint64_t x) const { return x; }
+};
+template <int LA, bool VETO, int NEED, class Match, class Confirm, class Post = ScanKeepAll>
 __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_t ns, const uint32_t (&ro)[LA], Match&& match,
-                                          Confirm&& confirm) {
+                                          Confirm&& confirm, Post&& post = Post()) {
   uint32_t k = b.nsl_off[ns];
   const uint32_t k1 = lane_on ? b.nsl_off[ns + 1] : k;
   uint64_t x = 0;
@@ -190,7 +195,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           if (!confirm(w * 64u + bit)) xx &= ~(1ull << bit);
         }
       }
-      x = xx;
+      x = post(w, xx);
       k += adv ? 1u : 0u;
     } else {
       break;

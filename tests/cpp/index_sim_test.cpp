@@ -244,7 +244,7 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   uint32_t w = 0, rank = 0;
   std::set<uint32_t> seen_t;
   auto fits_one = [&](const BmChunk& ch) {
-    return (size_t)ch.lds_bytes + (size_t)ch.n_words * 64 * 8 <= chk_budget &&
+    return (size_t)ch.lds_bytes + (size_t)ch.n_words * kCheckWordLds <= chk_budget &&
            (size_t)ch.lds_bytes + (((size_t)ch.n_words * 128 + 15) & ~(size_t)15) + (size_t)ch.n_thr * thr_bytes + 16 <= agg_budget;
   };
   for (size_t i = 0; i < ix.bm_chunks.size(); ++i) {
@@ -280,7 +280,7 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   bool all_fit = true;
   for (const BmChunk& ch : ix.bm_chunks) all_fit &= fits_one(ch);
   if (all_fit) {
-    EXPECT((size_t)ix.bm_max_lds + (size_t)ix.bm_max_words * 64 * 8 <= chk_budget, "maxima exceed the check budget");
+    EXPECT((size_t)ix.bm_max_lds + (size_t)ix.bm_max_words * kCheckWordLds <= chk_budget, "maxima exceed the check budget");
     EXPECT((size_t)ix.bm_max_lds + (((size_t)ix.bm_max_words * 128 + 15) & ~(size_t)15) + (size_t)ix.bm_max_thr * thr_bytes + 16 <= agg_budget,
            "maxima exceed the aggregate budget");
   }
@@ -450,7 +450,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
   printf("  %u atoms, %u words, form: %s (veto %d, max need %u, slow terms %d), %u atom slots per pod\n", (uint32_t)ix.atoms.size(), ix.bm_words,
          ix.rich ? "rich {any, veto}" : "simple {any}", (int)ix.has_veto, ix.max_need, (int)ix.has_slow, ix.la);
   printf("  LDS: check %u B (image part + term info), aggregate %u B (image part + ranks + table)\n",
-         ix.bm_max_lds + ix.bm_max_words * 512 + check_fixed_lds(), ix.bm_max_lds + ix.bm_max_words * 128 + ix.bm_max_thr * thr_bytes);
+         ix.bm_max_lds + ix.bm_max_words * kCheckWordLds + check_fixed_lds(), ix.bm_max_lds + ix.bm_max_words * 128 + ix.bm_max_thr * thr_bytes);
   printf("  %ld pods: %.2f matches per pod (exact, no candidates), %.2f word steps per pod, %ld slow confirmations\n", pods,
          (double)matches / (double)pods, (double)g_word_steps / (double)pods, g_slow_confirms);
   if (tiles)
