@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/sq2_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency $*"
 i=0
 for SET in "SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES" \
            "SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM"; do
