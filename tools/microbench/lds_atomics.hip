@@ -11,7 +11,7 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k(unsigned long long* out, int iters, int active, int same, int stride8) {
   LDS unsigned long long* t64 = (LDS unsigned long long*)smem;
   LDS uint32_t* t32 = (LDS uint32_t*)smem;
-  for (int i = threadIdx.x; i < 16384; i += 1024) t64[i] = 0;
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) t64[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool on = lane < active;
@@ -57,22 +57,22 @@ static void run(const char* name, int active, int same, int stride8) {
 }
 
 template <int MODE>
-static void timed(const char* name, int active, int same, int stride8) {
+static void timed(const char* name, int active, int same, int stride8, int threads = 1024) {
   unsigned long long* d;
   hipMalloc(&d, 256 * 8);
   const int iters = 4096;
   hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(1024), 131072, 0, d, iters, active, same, stride8);
+  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 131072, 0, d, iters, active, same, stride8);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(1024), 131072, 0, d, iters, active, same, stride8);
+  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 131072, 0, d, iters, active, same, stride8);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("%-28s active=%2d same=%d stride=%2d : %7.3f ms -> %6.2f ns per wave-instruction per CU (16 waves x %d iters share one LDS)\n", name, active,
-         same, stride8, ms, ms * 1e6 / (16.0 * iters), iters);
+  printf("%-28s active=%2d same=%d stride=%2d waves=%2d : %7.3f ms -> %6.2f ns per wave-instruction per CU, %6.1f ns per instruction of one wave\n", name, active,
+         same, stride8, threads / 64, ms, ms * 1e6 / ((threads / 64.0) * iters), ms * 1e6 / iters);
   hipFree(d);
 }
 
@@ -90,5 +90,9 @@ int main() {
   timed<3>("ds_read_b64 + ds_write_b64", 64, 0, 1);
   timed<4>("ds_read_b64", 64, 0, 1);
   timed<5>("ds_bpermute_b32", 64, 0, 1);
+  for (int threads : {64, 256, 512, 1024}) {
+    timed<0>("ds_add_u64", 64, 0, 1, threads);
+    timed<4>("ds_read_b64", 64, 0, 1, threads);
+  }
   return 0;
 }
