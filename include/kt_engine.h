@@ -33,7 +33,8 @@ extern "C" {
 #define KT_ERR_INVALID_ARGUMENT (-1)
 #define KT_ERR_OUT_OF_RANGE (-2)   /* row / id / dimension outside the configured capacity */
 #define KT_ERR_DEVICE (-3)         /* HIP runtime error (message has the hipError string) */
-#define KT_ERR_OVERFLOW_RISK (-4)  /* a per-dimension sum could leave the exact int64 range: rescale the dimension */
+#define KT_ERR_OVERFLOW_RISK (-4)  /* a value beyond 2^60 (upsert), or pod requests that ADD UP beyond 2^60 in one dimension
+                                      (reconcile: where resource.Quantity would promote to big decimals): rescale it */
 #define KT_ERR_NOT_READY (-5)      /* fetch without a preceding launch */
 #define KT_ERR_NO_DEVICE (-6)      /* no gfx950 device visible: there is NO CPU fallback */
 #define KT_ERR_UNSUPPORTED (-7)    /* the request exceeds what this entry point supports (message says what) */

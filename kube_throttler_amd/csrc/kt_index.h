@@ -9,21 +9,26 @@
 // the label-count cap of the scan kernels.  A key-level requirement (Exists / DoesNotExist) is entered in the key
 // atom's row AND in the rows of all referenced pairs of that key.
 //
-// Terms.  Every term of a live throttle (valid, responsible, no unconvertible podSelector) gets a number c; terms with
-// the same namespace-admission set (a "class") are numbered contiguously — throttles ordered by the admission set of
-// their first term, the terms of a throttle kept together — and a class of <= 64 terms never straddles a 64-bit word.
+// Terms and groups.  For one namespace the terms of a live throttle that can match are those whose namespace side admits
+// it; the namespaces are partitioned by WHICH of the throttle's terms admit them ("cells").  Every cell becomes a GROUP
+// of term copies — the admitted terms, in term order, each admitting exactly the cell's namespaces — and every copy gets
+// a number c.  Groups are ordered by their admission set (a "class"), a class of <= 64 numbers never straddles a 64-bit
+// word, and neither does a group: for any pod exactly one group of a throttle is live and its copies sit side by side
+// in one word (the scans report a throttle once by keeping the lowest match of such a run), and the words are class-pure
+// even when the terms of a ClusterThrottle select different namespaces — a pod only visits words of classes that admit
+// its namespace.  A throttle with more than 64 terms cannot keep that promise and joins the slow list (below).
 // Two bitmap families over c, one row per atom:
 //     any [a] : terms with a POSITIVE requirement (In / Exists) that atom a satisfies
 //     veto[a] : terms with a NEGATIVE requirement (NotIn / DoesNotExist) that atom a violates
-// A pod carries at most one value per key, so it carries at most ONE atom of any requirement's atom set: the number
-// of rows of `any` in which a term's bit is met while OR-ing the pod's atom rows IS the number of its positive
-// requirements the pod satisfies.  With need(c) = number of positive requirements (0..3):
+// The positive requirements of a term are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S), and a pod
+// carries one atom per key: the number of rows of `any` in which a term's bit is met while OR-ing the pod's atom rows
+// IS the number of its positive keys the pod satisfies.  With need(c) = number of positive keys (0..3):
 //     match(pod)[w] = hits>=need (any / two / three accumulators, masks m2 m3) & ~OR veto & nsmask[ns][w]
-// is EXACT — no TermRec, no second-pair compare, no inline extras.  Terms outside that shape (more than three
-// positive requirements, or one atom in two positive requirements of the same term) keep only their anchor
-// requirement in `any` and are flagged in the word header's `slow` mask: their candidates are decided by the generic
-// requirement walk.  Throttles that contain an unconvertible podSelector term go to a "slow list" and are walked term
-// by term in order (error semantics of throttle_selector.go:30-42 depend on term order).
+// is EXACT — no TermRec, no second-pair compare, no inline extras.  Terms with more than three positive keys keep only
+// their anchor requirement in `any` and are flagged in the word header's `slow` mask: their candidates are decided by
+// the generic requirement walk.  Throttles that contain an unconvertible podSelector term (error semantics of
+// throttle_selector.go:30-42 depend on term order) or more than 64 terms go to a "slow list" and are walked term by
+// term in order.
 // The namespace side of every term (implicit namespace equality of a Throttle, throttle_controller.go:249;
 // namespaceSelector of a ClusterThrottle) is pre-evaluated into SelProgram::ns_term_ok and enters as per-namespace
 // (word, mask) lists.

@@ -288,38 +288,40 @@ void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows
 // the engine refuses a reconcile only when THIS exceeds the exact range — where the reference would promote to big
 // decimals — instead of pricing every pod at the largest request ever seen.
 __global__ __launch_bounds__(256) void kt_sum_abs_requests(PodTable pods, int64_t n, unsigned long long* out) {
-  const int D = pods.D, DS = pods.DS;
+  // lane = pod: its request row as 16-byte pieces (the lanes of a wave cover 64 consecutive rows: every fetched line is
+  // used in full); limb sums per dimension in registers, met per block in LDS, one atomic per block and word
+  const int D = pods.D, ppr = pods.DS / 2;  // pieces per row (<= 8)
   unsigned long long lo[16], hi[16];
 #pragma unroll
   for (int d = 0; d < 16; ++d) lo[d] = 0ull, hi[d] = 0ull;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
     if (!((pods.meta[p] >> kMetaStateShift) & kPodValid)) continue;
+    const kt_i64x2* row = (const kt_i64x2*)(pods.req + p * pods.DS);
 #pragma unroll
-    for (int d = 0; d < 16; ++d)
-      if (d < D) {
-        const int64_t v = pods.req[p * DS + d];
-        const unsigned long long a = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
-        lo[d] += a & 0xFFFFFFFFull, hi[d] += a >> 32;
+    for (int q = 0; q < 8; ++q)
+      if (q < ppr) {
+        const kt_i64x2 v = row[q];
+        const unsigned long long a = v.x < 0 ? 0ull - (unsigned long long)v.x : (unsigned long long)v.x;
+        const unsigned long long b = v.y < 0 ? 0ull - (unsigned long long)v.y : (unsigned long long)v.y;
+        lo[2 * q] += a & 0xFFFFFFFFull, hi[2 * q] += a >> 32, lo[2 * q + 1] += b & 0xFFFFFFFFull, hi[2 * q + 1] += b >> 32;
       }
   }
+  __shared__ unsigned long long acc[32];
+  if (threadIdx.x < 32) acc[threadIdx.x] = 0ull;
+  __syncthreads();
 #pragma unroll
   for (int d = 0; d < 16; ++d)
     if (d < D) {
-      unsigned long long l = lo[d], h = hi[d];
-      for (int off = 32; off >= 1; off >>= 1) {
-        l += (unsigned long long)__shfl_xor((long long)l, off);
-        h += (unsigned long long)__shfl_xor((long long)h, off);
-      }
-      if ((threadIdx.x & 63) == 0) {
-        if (l) atomicAdd(out + 2 * d, l);
-        if (h) atomicAdd(out + 2 * d + 1, h);
-      }
+      if (lo[d]) atomicAdd(&acc[2 * d], lo[d]);
+      if (hi[d]) atomicAdd(&acc[2 * d + 1], hi[d]);
     }
+  __syncthreads();
+  if (threadIdx.x < 2u * (unsigned)D && acc[threadIdx.x]) atomicAdd(out + threadIdx.x, acc[threadIdx.x]);
 }
 void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s) {
   (void)hipMemsetAsync(out, 0, 32 * 8, s);
   if (n <= 0) return;
-  hipLaunchKernelGGL(kt_sum_abs_requests, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, pods, n, out);
+  hipLaunchKernelGGL(kt_sum_abs_requests, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, pods, n, out);
 }
 
 void launch_ingest_pods(const PodTable& pods, const PodBatchDev& b, hipStream_t s) {
