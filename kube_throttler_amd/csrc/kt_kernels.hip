@@ -204,11 +204,34 @@ __device__ __forceinline__ bool order_takes(uint64_t meta, bool countable_only) 
   const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
   return !countable_only || (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
 }
+constexpr uint32_t kNsLdsKeys = 12288;      // histogram: namespaces whose u32 counters fit 48 KB of LDS
+constexpr uint32_t kNsLdsKeysScatter = 4096;  // scatter: counter + 64-bit base per namespace (12 bytes) in 48 KB
+// Both passes keep a workgroup's per-namespace counters in LDS when the namespaces fit (one global atomic per
+// (workgroup, namespace present in its 8192 rows) instead of one per row on a few hot words); more namespaces than that
+// fall back to plain global atomics.
+constexpr int kNsRowsPerBlock = 8192;
 __global__ __launch_bounds__(1024) void kt_ns_histogram(const uint64_t* meta, int64_t n, int countable_only, uint32_t n_keys,
                                                        unsigned long long* counts) {
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
-    const uint64_t m = meta[i];
-    if (order_takes(m, countable_only != 0)) atomicAdd(counts + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1ull);
+  extern __shared__ uint32_t ns_hist[];
+  const bool in_lds = n_keys <= kNsLdsKeys;
+  for (int64_t b0 = (int64_t)blockIdx.x * kNsRowsPerBlock; b0 < n; b0 += (int64_t)gridDim.x * kNsRowsPerBlock) {
+    if (in_lds) {
+      for (uint32_t k = threadIdx.x; k < n_keys; k += 1024) ns_hist[k] = 0u;
+      __syncthreads();
+    }
+    for (int64_t i = b0 + threadIdx.x; i < min(b0 + (int64_t)kNsRowsPerBlock, n); i += 1024) {
+      const uint64_t m = meta[i];
+      if (!order_takes(m, countable_only != 0)) continue;
+      const uint32_t key = min((uint32_t)(m & kMetaNsMask), n_keys - 1u);
+      if (in_lds) atomicAdd(ns_hist + key, 1u);
+      else atomicAdd(counts + key, 1ull);
+    }
+    if (in_lds) {
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < n_keys; k += 1024)
+        if (ns_hist[k]) atomicAdd(counts + k, (unsigned long long)ns_hist[k]);
+      __syncthreads();
+    }
   }
 }
 // one workgroup: counts[k] -> first position of key k (exclusive prefix sum), *total = number of listed rows
@@ -239,9 +262,39 @@ __global__ __launch_bounds__(1024) void kt_ns_scan(unsigned long long* counts, u
 }
 __global__ __launch_bounds__(1024) void kt_ns_scatter(const uint64_t* meta, int64_t n, int countable_only, uint32_t n_keys,
                                                      unsigned long long* cursor, int64_t* out_rows) {
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
-    const uint64_t m = meta[i];
-    if (order_takes(m, countable_only != 0)) out_rows[atomicAdd(cursor + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1ull)] = i;
+  extern __shared__ uint32_t ns_hist[];  // [n_keys] rows of the block per namespace, then its local cursor | [n_keys] x 2 base
+  const bool in_lds = n_keys <= kNsLdsKeysScatter;
+  unsigned long long* base = (unsigned long long*)(ns_hist + ((n_keys + 1u) & ~1u));
+  for (int64_t b0 = (int64_t)blockIdx.x * kNsRowsPerBlock; b0 < n; b0 += (int64_t)gridDim.x * kNsRowsPerBlock) {
+    const int64_t b1 = min(b0 + (int64_t)kNsRowsPerBlock, n);
+    if (!in_lds) {
+      for (int64_t i = b0 + threadIdx.x; i < b1; i += 1024) {
+        const uint64_t m = meta[i];
+        if (order_takes(m, countable_only != 0)) out_rows[atomicAdd(cursor + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1ull)] = i;
+      }
+      continue;
+    }
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 1024) ns_hist[k] = 0u;
+    __syncthreads();
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 1024) {
+      const uint64_t m = meta[i];
+      if (order_takes(m, countable_only != 0)) atomicAdd(ns_hist + min((uint32_t)(m & kMetaNsMask), n_keys - 1u), 1u);
+    }
+    __syncthreads();
+    // the block reserves its rows' range of every namespace with ONE global atomic, then hands out the slots locally
+    for (uint32_t k = threadIdx.x; k < n_keys; k += 1024) {
+      const uint32_t c = ns_hist[k];
+      base[k] = c ? atomicAdd(cursor + k, (unsigned long long)c) : 0ull;
+      ns_hist[k] = 0u;
+    }
+    __syncthreads();
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 1024) {
+      const uint64_t m = meta[i];
+      if (!order_takes(m, countable_only != 0)) continue;
+      const uint32_t key = min((uint32_t)(m & kMetaNsMask), n_keys - 1u);
+      out_rows[base[key] + atomicAdd(ns_hist + key, 1u)] = i;
+    }
+    __syncthreads();
   }
 }
 void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
@@ -251,10 +304,12 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
     (void)hipMemsetAsync(out_n, 0, 8, s);
     return;
   }
-  const dim3 g(grid_for(n, 1024, 2048)), b(1024);
-  hipLaunchKernelGGL(kt_ns_histogram, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor);
+  const dim3 g(grid_for(n, kNsRowsPerBlock, 2048)), b(1024);
+  const size_t lds_hist = n_keys <= kNsLdsKeys ? (size_t)n_keys * 4 : 0;
+  const size_t lds_scat = n_keys <= kNsLdsKeysScatter ? (size_t)((n_keys + 1u) & ~1u) * 4 + (size_t)n_keys * 8 : 0;
+  hipLaunchKernelGGL(kt_ns_histogram, g, b, lds_hist, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor);
   hipLaunchKernelGGL(kt_ns_scan, dim3(1), b, 0, s, cursor, n_keys, out_n);
-  hipLaunchKernelGGL(kt_ns_scatter, g, b, 0, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
+  hipLaunchKernelGGL(kt_ns_scatter, g, b, lds_scat, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
 }
 
 // kt_build_scan_view — the records the namespace-ordered scans stream, copied into scan order once per ordering so that
