@@ -83,7 +83,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from kube_throttler_amd import distributed as KD, engine as E, snapshot as S, workload as W
+    from kube_throttler_amd import engine as E, snapshot as S, workload as W
 
     # ---- workload: this rank's pod shard of a job with P_total = world x pods_per_gpu pods
     cfg = W.preset(args.config)
@@ -132,7 +132,7 @@ def main():
                 eng.finalize_launch(now, True, stream)
             elif world > 1:
                 eng.aggregate_launch(stream)
-                KD.allreduce_partial(partial, dist)  # RCCL over xGMI; int64 sums are order-independent
+                dist.all_reduce(partial, op=dist.ReduceOp.SUM)  # RCCL over xGMI; int64 sums are order-independent
                 eng.finalize_launch(now, True, stream)
             else:
                 eng.reconcile_launch(now, True, stream)  # one GPU: nothing to exchange between scan and finalize

@@ -1,10 +1,8 @@
-"""Row-sharding helpers for multi-GPU runs (one process per GPU, torch.distributed: nccl = RCCL on ROCm).
-
-The hot path shards by pods: rank r holds the contiguous pod rows [r*P/N, (r+1)*P/N) and a full replica of
-the throttle tables.  The only exchange is one sum all-reduce of the int64 partial-`used` buffer
-``[T][2D+2]`` (values, key-presence counts, pod count, error count) between ``kt_aggregate`` and
-``kt_finalize`` — integer sums are associative, so the result is bit-identical for any world size.
-"""
+"""Test helper: the layout of the engine's partial-`used` buffer ``[T][2D+2]`` (values, key-presence counts, pod count,
+error count) on the host — how the oracle's per-shard `used` is laid out as the buffer ranks exchange, and how a summed
+buffer reads back.  The product's exchange is `kt_comm_allreduce_partial` (RCCL inside the engine) or any collective on
+the buffer `kt_partial_used_buffer` exposes; integer sums are associative, so the result is bit-identical for any world
+size."""
 from __future__ import annotations
 
 import numpy as np
@@ -38,10 +36,3 @@ def unpack_partial(buf: np.ndarray, D: int):
     v = np.where((buf[:, D:2 * D] > 0) | (buf[:, :D] != 0), buf[:, :D], 0)
     count = buf[:, 2 * D]
     return v, present, count, count > 0, buf[:, 2 * D + 1] > 0
-
-
-def allreduce_partial(tensor, dist):
-    """One collective per reconcile: sum over ranks, in place."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
-    return tensor

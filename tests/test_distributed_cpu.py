@@ -28,17 +28,19 @@ def _free_port():
 
 def _worker(rank, world, port, n_pods, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from kube_throttler_amd import workload as W, distributed as KD
+    from kube_throttler_amd import workload as W
+    import partial_layout as KD
     from oracle import kt_oracle as O
     full_cfg = W.small(seed=77, n_pods=n_pods, n_thr=40, n_cluster=20)
     snap = W.generate(full_cfg.shard(rank, world))
     now = (full_cfg.now_s, 0)
     r = O.Oracle(snap).reconcile(now)
     buf = torch.from_numpy(KD.pack_partial(r.used.v, r.used.present, r.used.count, r.error, snap.D).copy())
-    KD.allreduce_partial(buf, dist)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     if rank == 0:
         q.put(buf.numpy().copy())
     dist.barrier()
@@ -47,7 +49,8 @@ def _worker(rank, world, port, n_pods, q):
 
 @pytest.mark.parametrize("n_pods", [2001])
 def test_two_rank_allreduce_matches_single_process(n_pods, oracle_mod):
-    from kube_throttler_amd import workload as W, distributed as KD
+    from kube_throttler_amd import workload as W
+    import partial_layout as KD
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
