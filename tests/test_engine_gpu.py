@@ -294,6 +294,67 @@ def test_incremental_event_path(budget, oracle_mod, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("budget", [None, 5000])
+def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
+    """The scan lists and scan-ordered record copies (namespace order with a multi-chunk index) are rebuilt after pod
+    events: adds, updates that move pods to other namespaces / labels / requests, deletes and a throttle change between
+    full sweeps of a NON-incremental engine — every reconcile + check equals the oracle on the pods currently held."""
+    if budget:
+        monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
+    base = W.generate(W.small(seed=73, n_pods=2600, n_thr=96, n_cluster=48))
+    P = 2200
+    rng = np.random.default_rng(73)
+    state = np.full(P, -1, dtype=np.int64)
+    state[:1500] = np.arange(1500)
+    eng = E.Engine(base.D, max(base.L, 1), P, max(base.n_thr, 1), max(base.n_ns, 1))
+    try:
+        eng.upsert_namespaces(base)
+        eng.upsert_throttles(base)
+        eng.upsert_pods(_permute_pods(base, np.arange(1500)), rows=np.arange(1500))
+
+        def sweep():
+            n = int(np.nonzero(state >= 0)[0].max()) + 1   # rows in use
+            snap = _with_pods(base, state[:n])
+            o = oracle_mod.Oracle(snap)
+            rows = responsible_rows(snap)
+            want = o.reconcile(NOW, rows=rows)
+            got_all = eng.reconcile(NOW, apply=True)
+            got = E.ReconcileResult(len(rows), snap.D)
+            for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+                getattr(got, name)[:len(rows)] = getattr(got_all, name)[rows]
+            for tab in ("used", "calc"):
+                for f in ("v", "present", "count", "has_count"):
+                    getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
+            assert_reconcile_equal(got, want, len(rows))
+            snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows)
+            st_w, sm_w = o.check(on_equal=False, nthreads=8)
+            st_g, sm_g = eng.check(n=n, on_equal=False, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w)
+            _, sm_lean = eng.check(n=n, on_equal=False, want_status=False)   # the sweep instantiation (summary words only)
+            np.testing.assert_array_equal(sm_lean, sm_w)
+            # the stored status is the engine's: keep base's copy in step for the next round's oracle
+            base.thr_used, base.thr_calc = snap.thr_used, snap.thr_calc
+            base.thr_flags, base.thr_thrl_flag, base.thr_thrl_has = snap.thr_flags, snap.thr_thrl_flag, snap.thr_thrl_has
+
+        sweep()
+        add_rows = np.arange(1500, 2100)
+        state[add_rows] = np.arange(1500, 2100)
+        eng.upsert_pods(_permute_pods(base, state[add_rows]), rows=add_rows)
+        sweep()
+        upd_rows = rng.choice(2100, 500, replace=False)
+        state[upd_rows] = rng.integers(2100, 2600, 500)      # other namespaces, labels, requests, phases
+        eng.upsert_pods(_permute_pods(base, state[upd_rows]), rows=upd_rows)
+        sweep()
+        del_rows = rng.choice(2000, 400, replace=False).astype(np.int64)
+        state[del_rows] = -1
+        eng.delete_pods(del_rows)
+        sweep()
+        eng.upsert_throttles(base)                             # program recompile: atoms re-translated, views rebuilt
+        sweep()
+    finally:
+        eng.close()
+
+
 def _permute_pods(snap, rows):
     """A pods-only batch holding snap's pods in the order given by rows."""
     rows = np.asarray(rows)
