@@ -146,3 +146,79 @@ def test_three_uneven_shards_with_selector_errors(oracle_mod):
         eng.use_partial_buffer(None, 0)
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Two real GPUs, one process each, the engine's own RCCL exchange between them (skipped on a one-GPU box)
+# ---------------------------------------------------------------------------------------------------
+def _rank_main(rank, world, uid, cfg_bytes, out_q):
+    """One rank: its shard on device `rank`, kt_aggregate_launch -> kt_comm_allreduce_partial -> kt_finalize_launch
+    (APPLY) -> the PreFilter sweep of its pods; results go back to the parent for the comparison."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from kube_throttler_amd import engine as E2, workload as W2
+    full_cfg = W2.WorkloadCfg.from_buffer_copy(cfg_bytes)
+    snap = W2.generate(full_cfg.shard(rank, world))
+    eng = E2.Engine.for_snapshot(snap, device=rank)
+    try:
+        eng.comm_init(rank, world, uid)
+        eng.aggregate_launch()
+        eng.comm_allreduce_partial()
+        eng.finalize_launch((full_cfg.now_s, 0), True)
+        rec = eng.reconcile_fetch()
+        st, sm = eng.check(n=snap.n_pods, on_equal=False, want_status=True)
+        eng.comm_destroy()
+        out_q.put((rank, rec.used.v.copy(), rec.used.present.copy(), rec.used.count.copy(), rec.thrl_flag.copy(), st, sm))
+    finally:
+        eng.close()
+
+
+def test_two_gpus_with_the_native_exchange(oracle_mod):
+    """world_size 2 on real hardware: pods row-sharded over two GPUs, partials summed by ncclAllReduce(int64, sum)
+    inside the engines (kt_comm_*), finalize replicated, check local — against the oracle on the unsharded snapshot."""
+    import multiprocessing as mp
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-GPU form of this check is test_eight_shards_*)")
+    full_cfg = W.small(seed=91, n_pods=6000, n_thr=96, n_cluster=48)
+    full = W.generate(full_cfg)
+    now = (full_cfg.now_s, 0)
+    uid = E.Engine.comm_unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, uid, bytes(full_cfg), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(2):
+            item = q.get(timeout=300)
+            got[item[0]] = item[1:]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # a rank that died leaves its peer inside the collective: do not leave it behind
+            if p.is_alive():
+                p.kill()
+    o = oracle_mod.Oracle(full)
+    rows = _responsible(full)
+    want = o.reconcile(now, rows=rows, nthreads=8)
+    for r in range(2):  # finalize ran replicated: both ranks hold the whole result
+        used_v, used_p, used_c, thrl, _, _ = got[r]
+        np.testing.assert_array_equal(used_v[rows], want.used.v[:len(rows)])
+        np.testing.assert_array_equal(used_p[rows], want.used.present[:len(rows)])
+        np.testing.assert_array_equal(used_c[rows], want.used.count[:len(rows)])
+        np.testing.assert_array_equal(thrl[rows], want.thrl_flag[:len(rows)])
+    full.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows)
+    st_w, sm_w = o.check(on_equal=False, nthreads=8)
+    begin = 0
+    for r in range(2):
+        st, sm = got[r][4], got[r][5]
+        np.testing.assert_array_equal(st, st_w[begin:begin + len(sm)])
+        np.testing.assert_array_equal(sm, sm_w[begin:begin + len(sm)])
+        begin += len(sm)
+    assert begin == full.n_pods
