@@ -427,6 +427,24 @@ def test_multi_chunk_index(seed, budget, oracle_mod, monkeypatch):
         assert (S.summary_fields(sm)[0] == S.VERDICT_ERROR).any() and rec.error.any()
 
 
+@pytest.mark.parametrize("ns_capacity", [5000, 13000])
+def test_namespace_order_with_many_namespace_rows(ns_capacity, oracle_mod, monkeypatch):
+    """The counting sort by namespace keeps a workgroup's counters in LDS while the namespace rows fit (<= 12288 for the
+    histogram, <= 4096 for the scatter) and falls back to global atomics beyond: both fallbacks, through a full parity
+    run in namespace order (forced here: the program is small enough for one chunk)."""
+    monkeypatch.setenv("KT_FORCE_NS_ORDER", "1")
+
+    def roomy(cls, snap, kernel_variant=E.VARIANT_INDEXED, device=-1, pod_capacity=None):
+        e = cls(snap.D, max(snap.L, 1), pod_capacity or max(snap.n_pods, 1), max(snap.n_thr, 1), ns_capacity, device, kernel_variant)
+        e.load_snapshot(snap)
+        return e
+
+    monkeypatch.setattr(E.Engine, "for_snapshot", classmethod(roomy))
+    snap = W.generate(W.small(seed=15, n_pods=5000, n_thr=96, n_cluster=48, n_ns=24))
+    st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED}
+
+
 def _stored_status(snap, oracle_mod):
     """Reconcile on the oracle and store the result as the snapshot's status (what UpdateStatus persists)."""
     o = oracle_mod.Oracle(snap)
