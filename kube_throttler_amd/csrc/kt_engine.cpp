@@ -166,6 +166,8 @@ struct kt_engine {
   // ---- host mirrors of the small tables
   std::vector<HostNamespace> ns;
   int32_t ns_rows_hi = 0;
+  int64_t pod_ns_hi = 0;   // 1 + highest namespace row any pod was fed with
+  size_t ns_compiled = 0;  // namespace rows the compiled program / index cover (compile_program)
   std::vector<HostThrottle> thr;
   int32_t thr_rows_hi = 0;
   bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
@@ -415,7 +417,14 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
 int32_t compile_program(kt_engine* e, hipStream_t s) {
   const int D = e->D;
   const size_t T = (size_t)e->thr_rows_hi;
-  const size_t NS = (size_t)e->cfg.namespace_capacity;
+  // namespace rows the program covers: the rows in USE (namespace objects, pods, namespaced Throttles), not the
+  // configured capacity — the per-namespace tables of the program and of every index chunk scale with this number.
+  // A pod that later arrives with a higher namespace row marks the program dirty (upsert_pods_locked).
+  size_t NS = std::max<size_t>(1, std::max<size_t>((size_t)e->ns_rows_hi, (size_t)e->pod_ns_hi));
+  for (size_t t = 0; t < T; ++t)
+    if ((e->thr[t].flags & KT_THR_VALID) && !(e->thr[t].flags & KT_THR_CLUSTER)) NS = std::max(NS, (size_t)e->thr[t].ns + 1);
+  NS = std::min(NS, (size_t)e->cfg.namespace_capacity);
+  e->ns_compiled = NS;
   std::vector<uint32_t> thr_term_off(T + 1, 0), term_thr, term_req_off{0}, req_key, req_val_off{0}, req_val;
   std::vector<uint8_t> term_flags, req_op;
   std::vector<uint32_t> ovr_off(T + 1, 0);
@@ -869,13 +878,14 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   const int64_t n = b->n_pods;
   if (n <= 0) return KT_OK;
   // ---- validation + overflow bound (host pass over the batch; the data is copied once, below)
-  int64_t hi = e->pod_rows_hi;
+  int64_t hi = e->pod_rows_hi, ns_hi = e->pod_ns_hi;
   unsigned __int128 batch_max[KT_MAX_DIMS] = {0};
   for (int64_t i = 0; i < n; ++i) {
     const int64_t row = rows ? rows[i] : i;
     if (row < 0 || row >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)row);
     if (b->pod_ns[i] >= (uint32_t)e->cfg.namespace_capacity)
       return e->fail(KT_ERR_OUT_OF_RANGE, "pod %lld: namespace id %u", (long long)i, b->pod_ns[i]);
+    ns_hi = std::max(ns_hi, (int64_t)b->pod_ns[i] + 1);
     if (b->pod_label_off[i + 1] - b->pod_label_off[i] > (uint32_t)e->L)
       return e->fail(KT_ERR_OUT_OF_RANGE, "pod %lld has %u labels, engine keeps %d", (long long)i,
                      b->pod_label_off[i + 1] - b->pod_label_off[i], e->L);
@@ -916,6 +926,8 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   e->countable_valid = false;
   e->req_sums_valid = false;
   e->order_all_valid = false;
+  e->pod_ns_hi = ns_hi;
+  if ((size_t)ns_hi > e->ns_compiled) e->program_dirty = true;  // a namespace row the compiled program does not cover yet
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
   const int64_t chunk = 1 << 20;
@@ -1265,6 +1277,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   e->req_sums_valid = false;
   e->order_all_valid = false;
   e->pod_rows_hi = 0;
+  e->pod_ns_hi = 0;
   e->neg_seen = false;
   for (auto& m : e->max_abs) m = 0;
   for (auto& n : e->ns) n = HostNamespace();
@@ -1404,8 +1417,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     KT_HIP(e, e->d_countable.reserve((size_t)e->pod_rows_hi + 1));
     KT_HIP(e, e->d_n_countable.reserve(1));
     if (by_ns) {
-      KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->cfg.namespace_capacity + 1));
-      kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/true, (uint32_t)e->cfg.namespace_capacity,
+      KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->sp.n_ns + 1));
+      kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/true, (uint32_t)e->sp.n_ns,
                                   e->d_ns_cursor.p, e->d_countable.p, e->d_n_countable.p, s);
     } else {
       KT_HIP(e, hipMemsetAsync(e->d_n_countable.p, 0, 8, s));
@@ -1692,9 +1705,9 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
       const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
       if (by_ns && !e->order_all_valid) {
         KT_HIP(e, e->d_order_all.reserve((size_t)e->pod_rows_hi + 1));
-        KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->cfg.namespace_capacity + 1));
+        KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->sp.n_ns + 1));
         KT_HIP(e, e->d_n_countable.reserve(1));
-        kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->cfg.namespace_capacity,
+        kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->sp.n_ns,
                                     e->d_ns_cursor.p, e->d_order_all.p, e->d_n_countable.p, s);
         KT_HIP(e, hipGetLastError());
         const size_t na = (size_t)e->pod_rows_hi + 1;

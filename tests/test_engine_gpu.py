@@ -427,22 +427,61 @@ def test_multi_chunk_index(seed, budget, oracle_mod, monkeypatch):
         assert (S.summary_fields(sm)[0] == S.VERDICT_ERROR).any() and rec.error.any()
 
 
-@pytest.mark.parametrize("ns_capacity", [5000, 13000])
-def test_namespace_order_with_many_namespace_rows(ns_capacity, oracle_mod, monkeypatch):
-    """The counting sort by namespace keeps a workgroup's counters in LDS while the namespace rows fit (<= 12288 for the
-    histogram, <= 4096 for the scatter) and falls back to global atomics beyond: both fallbacks, through a full parity
-    run in namespace order (forced here: the program is small enough for one chunk)."""
+def _spread_namespaces(snap, stride):
+    """The same cluster with namespace row i moved to row i * stride (rows in between hold no Namespace object)."""
+    import copy
+    out = copy.copy(snap)
+    n_new = (snap.n_ns - 1) * stride + 1
+    out.n_ns = n_new
+    out.ns_valid = np.zeros(n_new, dtype=np.uint8)
+    out.ns_valid[::stride] = snap.ns_valid[:snap.n_ns]
+    off = np.zeros(n_new + 1, dtype=np.uint32)
+    counts = np.zeros(n_new, dtype=np.uint32)
+    counts[::stride] = np.diff(snap.ns_label_off[:snap.n_ns + 1])
+    off[1:] = np.cumsum(counts)
+    out.ns_label_off = off          # the label arrays keep their order: only the rows' offsets move
+    out.pod_ns = (snap.pod_ns.astype(np.uint64) * stride).astype(np.uint32)
+    out.thr_ns = (snap.thr_ns.astype(np.uint64) * stride).astype(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("stride", [250, 600])
+def test_namespace_order_with_many_namespace_rows(stride, oracle_mod, monkeypatch):
+    """Namespace rows in use up to 5 751 / 13 801: the counting sort by namespace keeps a workgroup's counters in LDS
+    while the rows fit (<= 12288 for the histogram, <= 4096 for the scatter) and falls back to global atomics beyond —
+    both fallbacks, through a full parity run in namespace order (forced here: the program is small enough for one
+    chunk).  The program covers the rows in USE, whatever the configured capacity."""
     monkeypatch.setenv("KT_FORCE_NS_ORDER", "1")
 
     def roomy(cls, snap, kernel_variant=E.VARIANT_INDEXED, device=-1, pod_capacity=None):
-        e = cls(snap.D, max(snap.L, 1), pod_capacity or max(snap.n_pods, 1), max(snap.n_thr, 1), ns_capacity, device, kernel_variant)
+        e = cls(snap.D, max(snap.L, 1), pod_capacity or max(snap.n_pods, 1), max(snap.n_thr, 1), 100000, device, kernel_variant)
         e.load_snapshot(snap)
         return e
 
     monkeypatch.setattr(E.Engine, "for_snapshot", classmethod(roomy))
-    snap = W.generate(W.small(seed=15, n_pods=5000, n_thr=96, n_cluster=48, n_ns=24))
+    snap = _spread_namespaces(W.generate(W.small(seed=15, n_pods=5000, n_thr=96, n_cluster=48, n_ns=24)), stride)
     st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
     assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED}
+
+
+def test_pod_in_a_namespace_row_beyond_the_compiled_program(oracle_mod):
+    """The program is compiled for the namespace rows in use; a pod that arrives later in a higher row (no Namespace
+    object there yet) makes it recompile — its PreFilter is an Error (affectedClusterThrottles: Namespace lookup fails,
+    clusterthrottle_controller.go:273-276), everything else is unchanged."""
+    base = W.generate(W.small(seed=16, n_pods=600, n_thr=48, n_cluster=24, n_ns=6))
+    eng = E.Engine(base.D, max(base.L, 1), 1000, max(base.n_thr, 1), 5000)
+    try:
+        eng.load_snapshot(base)
+        st0, sm0 = eng.check(n=base.n_pods, want_status=False)
+        stray = _permute_pods(base, np.array([0]))
+        stray.pod_ns[0] = 4321
+        eng.upsert_pods(stray, rows=np.array([600], dtype=np.int64))
+        st1, sm1 = eng.check(n=601, want_status=False)
+        np.testing.assert_array_equal(sm1[:600], sm0)
+        assert S.summary_fields(sm1[600:601])[0][0] == S.VERDICT_ERROR
+        eng.reconcile(NOW, apply=False)
+    finally:
+        eng.close()
 
 
 def _stored_status(snap, oracle_mod):
