@@ -7,7 +7,7 @@ test: build
 test-gpu: build
 	python -m pytest tests -q -m gpu
 bench: build
-	python bench.py --gpus 1 --steps 20 --warmup 3
+	python bench.py --gpus 1
 resources:
 	tools/kernel_resources.sh
 clean:

@@ -52,8 +52,8 @@ def aggregate_bytes(snap, n_counted, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i], i in 1..4 (default 2)")
     ap.add_argument("--pods-per-gpu", type=int, default=0, help="override the per-GPU pod rows")
     ap.add_argument("--variant", choices=["indexed", "dense"], default="indexed")
