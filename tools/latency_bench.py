@@ -5,6 +5,8 @@ the C-ABI, engine already holding the snapshot).
   check1        kt_check(n=1): PreFilter of ONE pod (plugin.go:148-215) — H2D of the row, kernels, D2H of the summary
   check1_busy   the same while another thread runs kt_reconcile_launch + kt_reconcile_fetch in a loop (one engine lock)
   upsert_pod1   kt_upsert_pods(1): a pod informer event (stage + kt_ingest_pods + kt_translate_pods)
+  sweep         a full reconcile + PreFilter sweep in the steady state, and the first one after ONE pod event (which rebuilds
+                the scan lists, the scan-ordered record copies and the request-sum proof of the overflow guard)
   recompile     the first kt_check after ONE kt_upsert_throttles: selector program recompile + index rebuild + upload +
                 re-translation of every pod's labels (what ANY throttle / namespace event costs)
 (bench.py's cpu_baseline leg adds the CPU restatement's PreFilter of one pod on one core as the yardstick.)
@@ -70,6 +72,22 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
         eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
         ts.append(time.perf_counter() - t0)
     out["upsert_pod1"] = _pct(ts)
+    # ---- a full sweep (reconcile + PreFilter of every pod) right after ONE pod event, against the steady sweep: the event
+    #      voids the scan lists / scan-ordered record copies / request-sum proof, the next sweep rebuilds them
+    def full_sweep():
+        t0 = time.perf_counter()
+        eng.reconcile_launch(now, True)
+        eng.check_launch(P, None, False, False)
+        eng.synchronize()
+        return time.perf_counter() - t0
+    full_sweep()
+    steady = [full_sweep() for _ in range(20)]
+    after = []
+    for r in rng.integers(0, P, size=20):
+        one = snap.pod_batch(np.array([int(r)], dtype=np.int64))
+        eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
+        after.append(full_sweep())
+    out["sweep"] = {"steady_ms": round(float(np.median(steady)) * 1e3, 3), "after_pod_event_ms": round(float(np.median(after)) * 1e3, 3), "n": 20}
     # ---- one throttle event: the next call recompiles the program, rebuilds the index and re-translates the pods
     ts = []
     for k in range(5):
