@@ -547,8 +547,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
                     (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L);
     // KT_CHUNK_HALF=1 (A/B runs): keep the half-LDS chunks — more of them, but two workgroups per CU
     if (!hook && !getenv("KT_CHUNK_HALF") && e->hindex.bm_chunks.size() > 1)
-      kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
-                      (uint32_t)NS, ns_term_ok, gw, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, e->L);
+      kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes);
   }
   e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));

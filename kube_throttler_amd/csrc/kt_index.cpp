@@ -88,6 +88,18 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     std::sort(a.begin(), a.end());
     return a;
   };
+  // admission set of every term as namespace bit words, transposed from ns_term_ok by walking its SET bits (the rows
+  // are sparse: a namespace admits a few thousand of the terms)
+  const size_t G_all = term_req_off.empty() ? 0 : term_req_off.size() - 1;
+  std::vector<uint32_t> adm_all(G_all * nsw, 0u);
+  for (uint32_t n = 0; n < n_ns; ++n) {
+    const uint32_t* row = ns_term_ok.data() + (size_t)n * gw;
+    for (uint32_t wi = 0; wi < gw; ++wi)
+      for (uint32_t m = row[wi]; m; m &= m - 1) {
+        const size_t g = (size_t)wi * 32 + (size_t)__builtin_ctz(m);
+        if (g < G_all) adm_all[g * nsw + (n >> 5)] |= 1u << (n & 31);
+      }
+  }
   // ---- terms
   std::vector<BT> bts;
   std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
@@ -101,10 +113,9 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       BT b;
       b.g = g, b.t = (uint32_t)t, b.slow = false, b.need = 0;
       b.adj = thr_term_off[t + 1] - thr_term_off[t] > 1;
-      b.adm.assign(nsw, 0u);
+      b.adm.assign(adm_all.begin() + (size_t)g * nsw, adm_all.begin() + (size_t)(g + 1) * nsw);
       bool any_ns = false;
-      for (uint32_t n = 0; n < n_ns; ++n)
-        if ((ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u) b.adm[n >> 5] |= 1u << (n & 31), any_ns = true;
+      for (uint32_t wv : b.adm) any_ns |= wv != 0u;
       if (!any_ns) continue;  // admitted nowhere: can never match
       bool never = false;
       // positive requirements are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S): a pod carries
@@ -192,8 +203,11 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     } else {
       std::vector<uint64_t> pat(n_ns, 0ull);
       for (size_t q = i; q < j; ++q)
-        for (uint32_t n = 0; n < n_ns; ++n)
-          if ((bts[q].adm[n >> 5] >> (n & 31)) & 1u) pat[n] |= 1ull << (q - i);
+        for (uint32_t wi = 0; wi < nsw; ++wi)
+          for (uint32_t m = bts[q].adm[wi]; m; m &= m - 1) {
+            const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
+            if (n < n_ns) pat[n] |= 1ull << (q - i);
+          }
       std::unordered_map<uint64_t, uint32_t> cell_of;  // pattern -> group
       const size_t g0 = grps.size();
       for (uint32_t n = 0; n < n_ns; ++n) {
@@ -292,11 +306,24 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   }
   // ---- full bitmaps (host only), dense throttle ranks in term order
   const bool veto = out.rich;  // the image form follows the kernel instantiation
-  std::vector<uint64_t> any((size_t)R * W, 0ull), vet(veto ? (size_t)R * W : 0, 0ull), nsrows((size_t)n_ns * W, 0ull);
-  std::vector<WordHdr> hdr(W, WordHdr{0, 0, 0, 0});
-  std::vector<uint32_t> term_t((size_t)W * 64, 0u), term_g((size_t)W * 64, 0u), term_rank((size_t)W * 64, 0u);
-  std::vector<uint8_t> real((size_t)W * 64, 0);  // term number in use (not padding)
+  // (kept in the HostIndex: cut_chunks() lays them out as chunk images, and can do so again for other LDS budgets)
+  std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
+  any.assign((size_t)R * W, 0ull), vet.assign(veto ? (size_t)R * W : 0, 0ull), nsrows.assign((size_t)n_ns * W, 0ull);
+  std::vector<WordHdr>& hdr = out.full_hdr;
+  hdr.assign(W, WordHdr{0, 0, 0, 0});
+  std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
+  term_t.assign((size_t)W * 64, 0u), term_g.assign((size_t)W * 64, 0u), term_rank.assign((size_t)W * 64, 0u);
+  std::vector<uint8_t>& real = out.full_real;  // term number in use (not padding)
+  real.assign((size_t)W * 64, 0);
+  out.n_ns = n_ns;
   out.bm_rank_t.clear();
+  // bitmap rows of every term's atoms, resolved once (a term may have several copies)
+  std::vector<std::vector<uint32_t>> pos_rows(bts.size()), neg_rows(bts.size());
+  for (size_t q = 0; q < bts.size(); ++q) {
+    for (auto& ps : bts[q].pos)
+      for (uint32_t a : ps) pos_rows[q].push_back(row_of[a]);
+    for (uint32_t a : bts[q].neg) neg_rows[q].push_back(row_of[a]);
+  }
   {
     std::vector<uint32_t> by_num(G2, ~0u);
     for (size_t q = 0; q < tcs.size(); ++q) by_num[num[q]] = (uint32_t)q;
@@ -315,17 +342,32 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       term_t[c] = b.t | kTermReal | (b.adj ? kTermAdj : 0u);
       term_g[c] = b.g;
       if (b.pos.empty()) hdr[w].univ |= bit;
-      for (auto& ps : b.pos)
-        for (uint32_t a : ps) any[(size_t)row_of[a] * W + w] |= bit;
-      for (uint32_t a : b.neg) vet[(size_t)row_of[a] * W + w] |= bit;
+      for (uint32_t r : pos_rows[tc.bt]) any[(size_t)r * W + w] |= bit;
+      for (uint32_t r : neg_rows[tc.bt]) vet[(size_t)r * W + w] |= bit;
       if (b.need >= 2) hdr[w].m2 |= bit;
       if (b.need >= 3) hdr[w].m3 |= bit;
       if (b.slow) hdr[w].slow |= bit;
       const std::vector<uint32_t>& adm = grp_own_adm[tc.grp] ? b.adm : grps[tc.grp].adm;
-      for (uint32_t n = 0; n < n_ns; ++n)
-        if ((adm[n >> 5] >> (n & 31)) & 1u) nsrows[(size_t)n * W + w] |= bit;
+      for (uint32_t wi = 0; wi < nsw; ++wi)
+        for (uint32_t m = adm[wi]; m; m &= m - 1) {
+          const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
+          if (n < n_ns) nsrows[(size_t)n * W + w] |= bit;
+        }
     }
   }
+  cut_chunks(out, agg_budget, chk_budget, thr_bytes);
+}
+
+// Cuts the numbered bitmaps of `out` (build_index) into chunk images for the given LDS budgets; callable again with
+// other budgets without renumbering (the engine first asks for half-LDS chunks — two check workgroups per CU — and
+// re-cuts for the full LDS when the program needs several chunks anyway).
+void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
+  const uint32_t W = out.bm_words, R = out.bm_rows, n_ns = out.n_ns;
+  const bool veto = out.rich;
+  const std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
+  const std::vector<WordHdr>& hdr = out.full_hdr;
+  const std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
+  const std::vector<uint8_t>& real = out.full_real;
   // ---- chunks: word ranges whose LDS part (rows | headers | namespace word lists) plus the per-term / per-throttle
   //      tables of the kernels fit the LDS budgets; a throttle's terms never straddle a chunk
   std::vector<uint8_t> splittable(W + 1, 1);  // chunk may START at word w
@@ -347,6 +389,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   out.bm_chunks.clear();
   out.bm_images.clear();
   out.bm_chunk_ns.clear();
+  const uint32_t nsw = (n_ns + 31) / 32;
   out.ns_words = nsw ? nsw : 1u;
   out.bm_max_lds = 0, out.bm_max_thr = 0, out.bm_max_words = 0, out.bm_slab_bytes = 0;
   uint32_t w0 = 0;

@@ -117,6 +117,13 @@ struct HostIndex {
   uint32_t ns_words = 0;                   // 32-bit words per row of bm_chunk_ns
   uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
+  // the numbered program before it is cut into chunks (host only; cut_chunks reads it): full bitmap rows [rows][W],
+  // namespace rows [n_ns][W], per-word headers, per-number tables [W * 64]
+  uint32_t n_ns = 0;
+  std::vector<uint64_t> full_any, full_veto, full_nsrows;
+  std::vector<WordHdr> full_hdr;
+  std::vector<uint32_t> full_term_t, full_term_g, full_term_rank;
+  std::vector<uint8_t> full_real;
 };
 
 // One throttle's record in the aggregate's LDS table / slab (16-byte granules):
@@ -158,6 +165,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
                  int max_labels);
+// chunk images of an index build_index numbered, for other LDS budgets (no renumbering)
+void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
