@@ -183,7 +183,11 @@ def main():
     n_counted = int(((flags & need) == need).sum())
     chk_bytes, b_pod, thr_bytes = algorithmic_bytes(snap, per_gpu, L)
     agg_bytes = aggregate_bytes(snap, n_counted, L)
-    dominant = "check" if k_ms["check"] >= k_ms["aggregate"] else "aggregate"
+    # the dominant kernel = the one that carries most of the step's ALGORITHMIC bytes (what a roofline is about).  The two
+    # scans take the same time within run-to-run noise at 1M x 1k (31-32 us each), so "the slower one" would flip from
+    # run to run; SURVEY.md 8d makes the check the primary rate and the aggregation the secondary one.  Both kernels are
+    # reported in full below, and `step` prices the whole step against the roofline.
+    dominant = "check" if chk_bytes >= agg_bytes else "aggregate"
     dom_bytes = chk_bytes if dominant == "check" else agg_bytes
     achieved = dom_bytes / (k_ms[dominant] * 1e-3) / 1e9 if k_ms[dominant] > 0 else 0.0
     # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/profile.sh + tools/pmc_summary.py) is only quoted when it
@@ -220,8 +224,12 @@ def main():
         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
         "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(k_ms[dominant], 6),
         "per_kernel_ms": {k: round(v, 6) for k, v in k_ms.items()},
+        "dominant_by": "algorithmic bytes per launch",
         "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes),
         "aggregate": kernel_roofline("aggregate", E.KERNEL_AGGREGATE, agg_bytes),
+        # the whole step (both scans + slab reduction + finalize, launch gaps included) against the same roofline
+        "step": {"algorithmic_bytes": chk_bytes + agg_bytes, "ms": round(ms_per_step, 6),
+                 "frac": round((chk_bytes + agg_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms_per_step > 0 else 0.0},
     }
 
     # ---- CPU baseline: the C restatement of the reference algorithm on this box's host cores (rank 0, N=1)
