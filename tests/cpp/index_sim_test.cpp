@@ -329,7 +329,27 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
       matches += want == 1;
     }
   }
-  return (long)ix.bm_chunks.size() * 1000000L + matches % 1000000L + (ix.rich ? 0 : 500000000L);
+  const size_t chunks_first = ix.bm_chunks.size();
+  {  // cut_chunks(): the same numbering cut again for other budgets (what the engine does when the half-LDS cut needs
+     // several chunks) must describe the same matches
+    const uint32_t agg2 = agg_budget * 2, chk2 = chk_budget * 2;
+    cut_chunks(ix, agg2, chk2, thr_bytes);
+    check_structure(p, ix, agg2, chk2, thr_bytes);
+    std::mt19937 rng2(seed ^ 0x5bd1e995u);
+    for (int i = 0; i < n_pods / 4 + 1; ++i) {
+      PodLabels pod;
+      pod.ns = rng2() % n_ns;
+      for (uint32_t k = 1; k <= K; ++k)
+        if (rng2() % 100 < 55) pod.keys.push_back(k), pod.pairs.push_back(p.pair(k, rng2() % V));
+      const std::map<uint32_t, int> got = scan(p, ix, pod);
+      for (uint32_t t = 0; t < T; ++t) {
+        const auto it = got.find(t);
+        EXPECT((it == got.end() ? 0 : it->second) == brute(p, t, pod), "seed %u re-cut pod %d throttle %u", seed, i, t);
+      }
+    }
+    EXPECT(ix.bm_chunks.size() <= chunks_first, "doubling the budgets gave %zu chunks instead of %zu", ix.bm_chunks.size(), chunks_first);
+  }
+  return (long)chunks_first * 1000000L + matches % 1000000L + (ix.rich ? 0 : 500000000L);
 }
 
 // ---- file mode: the REAL selector program of a BASELINE config + a pod sample (tools/dump_program.py)
