@@ -147,7 +147,9 @@ struct kt_engine {
   DevBuf<int64_t> d_countable;                   // rows of the pods a reconcile scans (kt_compact_countable)
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
-  bool req_sums_valid = false;                   // the requests of the current pods were proven to add up inside 2^60
+  bool req_sums_valid = true;                    // the requests of the current pods are proven to add up inside 2^60
+  unsigned __int128 req_sum_bound[KT_MAX_DIMS] = {0};  // >= sum of |request| over the pods held, per dimension: the last exact
+                                                 // device total + everything fed since (overwritten / deleted pods stay in)
   DevBuf<unsigned long long> d_req_sums;
   bool countable_valid = false;                  // d_countable describes the current pod table
   bool countable_by_ns = false;                  // ... ordered by namespace (multi-chunk index: kt_order_rows_by_ns)
@@ -878,7 +880,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   if (n <= 0) return KT_OK;
   // ---- validation + overflow bound (host pass over the batch; the data is copied once, below)
   int64_t hi = e->pod_rows_hi, ns_hi = e->pod_ns_hi;
-  unsigned __int128 batch_max[KT_MAX_DIMS] = {0};
+  unsigned __int128 batch_max[KT_MAX_DIMS] = {0}, batch_total[KT_MAX_DIMS] = {0};
   for (int64_t i = 0; i < n; ++i) {
     const int64_t row = rows ? rows[i] : i;
     if (row < 0 || row >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)row);
@@ -902,7 +904,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
           sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
           if (b->pod_ovh[(size_t)i * D + d] < 0) e->neg_seen = true;
         }
-    for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]);
+    for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]), batch_total[d] += sum[d];
   }
   if (e->incremental && rows && n > 1) {
     // the delta scans remove every row's old content and add its new one, once per occurrence: a row named twice in
@@ -923,8 +925,13 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
   }
   e->countable_valid = false;
-  e->req_sums_valid = false;
   e->order_all_valid = false;
+  // the overflow guard's bound grows by what this batch brings; only when it passes 2^60 does the next reconcile count
+  // exactly on the device (request_sums_in_range), which also forgets the overwritten and deleted pods again
+  for (int d = 0; d < D; ++d) {
+    e->req_sum_bound[d] += batch_total[d];
+    if (e->req_sum_bound[d] > kSumBound) e->req_sums_valid = false;
+  }
   e->pod_ns_hi = ns_hi;
   if ((size_t)ns_hi > e->ns_compiled) e->program_dirty = true;  // a namespace row the compiled program does not cover yet
   // ---- stage + ingest in chunks
@@ -1021,7 +1028,6 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
   e->countable_valid = false;
-  e->req_sums_valid = false;
   e->order_all_valid = false;
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
@@ -1273,7 +1279,8 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   KT_HIP(e, hipMemsetAsync(e->pods.meta, 0, (size_t)e->cfg.pod_capacity * 8, e->own_stream));
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   e->countable_valid = false;
-  e->req_sums_valid = false;
+  e->req_sums_valid = true;
+  for (auto& b : e->req_sum_bound) b = 0;
   e->order_all_valid = false;
   e->pod_rows_hi = 0;
   e->pod_ns_hi = 0;
@@ -1374,8 +1381,10 @@ static int32_t slab_tags(kt_engine* e, kt::AggScan& sc, hipStream_t s) {
 
 // resource.Quantity never overflows (it promotes to big decimals); the engine's exact range is int64.  Every sum a
 // scan, a delta scan or the exchange between GPUs forms is a sum over some of the CURRENT pods, so one exact total of
-// |request| per dimension (recomputed after pod events) proves all of them in range — or names the dimension that needs
-// a coarser scale.  2^60 per GPU leaves the headroom for up to 8 ranks' partials to meet in an all-reduce.
+// |request| per dimension proves all of them in range — or names the dimension that needs a coarser scale.  The host
+// keeps an upper bound of that total (req_sum_bound: it only grows with what is fed); the exact count on the device runs
+// when the bound passes 2^60 and resets it.  2^60 per GPU leaves the headroom for up to 8 ranks' partials to meet in an
+// all-reduce.
 static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   if (e->req_sums_valid) return KT_OK;
   KT_HIP(e, e->d_req_sums.reserve(32));
@@ -1386,6 +1395,7 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   KT_HIP(e, hipStreamSynchronize(s));
   for (int d = 0; d < e->D; ++d) {
     const unsigned __int128 total = (unsigned __int128)h[2 * d] + ((unsigned __int128)h[2 * d + 1] << 32);
+    e->req_sum_bound[d] = total;
     if (total > kSumBound)
       return e->fail(KT_ERR_OVERFLOW_RISK,
                      "dimension %d: the requests of the pods held here add up beyond 2^60 at this scale (the reference would "
