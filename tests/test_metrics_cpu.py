@@ -56,3 +56,32 @@ def test_gauges_follow_the_reference_families(oracle_mod):
         assert helps[f"{prefix}_status_calculated_threshold_resourceRequests"] == \
             "calculated threshold on specific resourceRequests of the throttle"
     assert len(helps) == 16
+
+
+def test_only_throttles_of_this_throttler_are_recorded(oracle_mod):
+    """The reference records inside reconcile (throttle_controller.go:159,187), and only throttles whose
+    spec.throttlerName is this throttler's are ever enqueued (event handlers, :404-420): another throttler's throttle
+    exports nothing; nil resourceCounts export 0; a throttle no pod matches exports no `used` requests."""
+    cs = ClusterState()
+    cs.add_namespace("default", {"kubernetes.io/metadata.name": "default"})
+    sel = {"selectorTerms": [{"podSelector": {"matchLabels": {"app": "web"}}}]}
+    cs.add({"kind": "Throttle", "metadata": {"namespace": "default", "name": "mine", "uid": "u-1"},
+            "spec": {"throttlerName": "kube-throttler", "threshold": {"resourceRequests": {"cpu": "1"}}, "selector": sel}})
+    cs.add({"kind": "Throttle", "metadata": {"namespace": "default", "name": "theirs", "uid": "u-2"},
+            "spec": {"throttlerName": "someone-else", "threshold": {"resourceCounts": {"pod": 1}}, "selector": sel}})
+    cs.add({"kind": "Throttle", "metadata": {"namespace": "default", "name": "idle", "uid": "u-3"},
+            "spec": {"throttlerName": "kube-throttler", "threshold": {"resourceCounts": {"pod": 1}},
+                     "selector": {"selectorTerms": [{"podSelector": {"matchLabels": {"app": "none"}}}]}}})
+    cs.add({"kind": "Pod", "metadata": {"namespace": "default", "name": "p0", "labels": {"app": "web"}},
+            "spec": {"schedulerName": "my-scheduler", "nodeName": "node-1", "containers": [{"resources": {"requests": {"cpu": "250m"}}}]},
+            "status": {"phase": "Running"}})
+    built = cs.build()
+    rec = oracle_mod.Oracle(built.snapshot).reconcile((1767225600, 0))
+    text = MetricsRecorder().record(built, rec).exposition()
+    samples = {line.split(" ")[0]: float(line.split(" ")[1]) for line in text.splitlines() if line and line[0] != "#"}
+    assert not any('name="theirs"' in k for k in samples)
+    mine = 'name="mine",namespace="default",resource="{}",uid="u-1"'
+    assert samples["throttle_spec_threshold_resourceCounts{" + mine.format("pod") + "}"] == 0      # nil counts export 0
+    assert samples["throttle_status_used_resourceRequests{" + mine.format("cpu") + "}"] == 250
+    assert samples['throttle_status_used_resourceCounts{name="idle",namespace="default",resource="pod",uid="u-3"}'] == 0
+    assert not any(k.startswith("throttle_status_used_resourceRequests{") and 'name="idle"' in k for k in samples)
