@@ -116,8 +116,45 @@ class ClusterState:
         return manifest
 
     # ---- flattening ---------------------------------------------------------------------------
-    def build(self) -> "BuiltState":
-        return BuiltState(self)
+    def build(self, only=None) -> "BuiltState":
+        """``only``: keep just these resource names as dimensions (a page of a cluster with more than KT_MAX_DIMS of
+        them, see build_pages); every other name is ignored wherever it occurs."""
+        return BuiltState(self, only)
+
+    def resource_names(self) -> list:
+        """Every resource name that occurs in a request, an overhead, a threshold, an override, a status or a reservation."""
+        names = set()
+
+        def see(rl):
+            names.update((rl or {}).keys())
+
+        for p in self.pods:
+            spec = p.get("spec", {})
+            for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
+                see((c.get("resources") or {}).get("requests"))
+            see(spec.get("overhead"))
+        for t in self.throttles:
+            spec, st = t.get("spec", {}), t.get("status", {}) or {}
+            see((spec.get("threshold") or {}).get("resourceRequests"))
+            for o in spec.get("temporaryThresholdOverrides") or []:
+                see((o.get("threshold") or {}).get("resourceRequests"))
+            see(((st.get("calculatedThreshold") or {}).get("threshold") or {}).get("resourceRequests"))
+            see((st.get("used") or {}).get("resourceRequests"))
+            see((st.get("throttled") or {}).get("resourceRequests"))
+        for a in self.reserved.values():
+            see((a or {}).get("resourceRequests"))
+        return sorted(names)
+
+    def build_pages(self, max_dims: int = S.KT_MAX_DIMS) -> list:
+        """The reference sums ANY resource name (pkg/resourcelist/resourcelist.go:27-54); an engine holds KT_MAX_DIMS
+        dimensions.  A cluster with more names is built as several PAGES — the same pods, namespaces, throttles and
+        selectors, each page with its own <= max_dims names as dimensions — evaluated by one engine each and combined by
+        kube_throttler_amd/paging.py (every step of CheckThrottledFor / IsThrottled is an OR over resource names plus a
+        count part that every page computes alike, so the combination is exact)."""
+        names = self.resource_names()
+        if len(names) <= max_dims:
+            return [self.build()]
+        return [self.build(only=set(names[i:i + max_dims])) for i in range(0, len(names), max_dims)]
 
 
 def _amount_quantities(a: dict | None):
@@ -127,8 +164,9 @@ def _amount_quantities(a: dict | None):
 class BuiltState:
     """Flattened state: ``.snapshot`` plus the dictionaries needed to read results back."""
 
-    def __init__(self, cs: ClusterState):
+    def __init__(self, cs: ClusterState, only=None):
         self.cs = cs
+        self.only = only  # None, or the resource names this page keeps
         ns_names = [n["metadata"]["name"] for n in cs.namespaces]
         for p in cs.pods:
             ns = p["metadata"].get("namespace", "default")
@@ -153,6 +191,8 @@ class BuiltState:
 
         def see(rl):
             for name, q in (rl or {}).items():
+                if only is not None and name not in only:
+                    continue
                 v = parse_quantity(q)
                 quantities.setdefault(name, []).append(v)
                 if v != 0:
@@ -171,7 +211,8 @@ class BuiltState:
             see(((st.get("calculatedThreshold") or {}).get("threshold") or {}).get("resourceRequests"))
             see((st.get("used") or {}).get("resourceRequests"))
             for name in ((st.get("throttled") or {}).get("resourceRequests") or {}):
-                quantities.setdefault(name, [])
+                if only is None or name in only:
+                    quantities.setdefault(name, [])
         for a in cs.reserved.values():
             see((a or {}).get("resourceRequests"))
         self.dims = {name: i for i, name in enumerate(sorted(quantities))}
@@ -268,6 +309,8 @@ class BuiltState:
             if (thrl.get("resourceCounts") or {}).get("pod"):
                 f |= S.THR_THROTTLED_POD
             for name, v in (thrl.get("resourceRequests") or {}).items():
+                if name not in self.dims:
+                    continue  # another page's resource
                 snap.thr_thrl_has[i] |= np.uint32(1 << self.dims[name])
                 if v:
                     snap.thr_thrl_flag[i] |= np.uint32(1 << self.dims[name])
@@ -322,6 +365,8 @@ class BuiltState:
     # ---- helpers --------------------------------------------------------------------------------
     def _fill_row(self, v, present, i, rl):
         for name, q in (rl or {}).items():
+            if name not in self.dims:
+                continue  # another page's resource (ClusterState.build_pages)
             d = self.dims[name]
             v[i, d] = to_scaled(parse_quantity(q), self.scales[name])
             present[i] |= np.uint32(1 << d)

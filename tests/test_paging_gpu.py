@@ -1,0 +1,34 @@
+"""tests/test_paging_cpu.py with the HIP engines as the per-page evaluators (kube_throttler_amd.paging.PagedEngine)."""
+import pytest
+
+from kube_throttler_amd import paging
+from test_paging_cpu import check_against_model, wide_cluster
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 8])
+def test_paged_engines_equal_the_manifest_model(seed):
+    state = {}
+
+    def reconcile_pages(pages, now):
+        eng = paging.PagedEngine(pages)
+        try:
+            return eng.reconcile(now, apply=False)[1]
+        finally:
+            eng.close()
+
+    def check_pages(pages, on_equal):
+        eng = state.get("eng")
+        if eng is None or eng.pages is not pages:
+            if eng is not None:
+                eng.close()
+            eng = state["eng"] = paging.PagedEngine(pages)
+        n = pages[0].snapshot.n_pods
+        return [e.check(n=n, on_equal=on_equal, want_status=True)[0] for e in eng.engines]
+
+    try:
+        check_against_model(wide_cluster(seed), reconcile_pages, check_pages, f"seed {seed}")
+    finally:
+        if state.get("eng") is not None:
+            state["eng"].close()
