@@ -504,6 +504,10 @@ int main(int argc, char** argv) {
   acc(run_case(78, 3000, 1, 10, 8, 3, 2, 0.001, 60 << 10, 60 << 10, 152, 64));
   // four and five requirements per term: shapes beyond three positive requirements take the slow confirmation
   acc(run_case(79, 300, 5, 12, 3, 3, 6, 0.0, 160 << 10, 160 << 10, 72, 400));
+  // throttles with up to 150 selector terms: beyond 64 a throttle's run of numbers could not stay inside one word — it
+  // joins the slow list (walked term by term), everything else keeps the bitmaps
+  acc(run_case(80, 24, 6, 8, 3, 150, 2, 0.0, 160 << 10, 160 << 10, 72, 150));
+  acc(run_case(81, 60, 3, 6, 3, 70, 2, 0.01, 20000, 16000, 72, 150));
   if (chunks_seen < 8) ++g_fail, fprintf(stderr, "FAIL: the tight budgets never produced a multi-chunk index (%ld)\n", chunks_seen);
   if (matches < 1000) ++g_fail, fprintf(stderr, "FAIL: only %ld matches — the cases are too sparse to mean anything\n", matches);
   if (simple_seen < 10) ++g_fail, fprintf(stderr, "FAIL: only %ld programs took the simple image form\n", simple_seen);
