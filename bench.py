@@ -7,8 +7,10 @@ One "step" = one pass of the hot path over the whole synthetic snapshot resident
   + check      (kt_prepare_check + kt_check: PreFilter for EVERY pod against EVERY throttle)
 decisions per step = P_total x T  (the 5-state status of every (pod, throttle) pair is determined).
 
-Weak scaling: every rank holds `pods_per_gpu` pod rows of a job with P_total = N x pods_per_gpu pods;
-throttle tables are replicated; the only exchange is one int64 sum all-reduce of [T][2D+2] words.
+Weak scaling (default): every rank holds `pods_per_gpu` pod rows of a job with P_total = N x pods_per_gpu pods;
+`--scaling strong` fixes P_total (the config's pod count; configs[4]: 10M) and gives every rank P_total / N rows.
+Throttle tables are replicated; the only exchange is one int64 sum all-reduce of [T][2D+2] words — with N > 1 through
+the engine's own RCCL communicator (kt_comm_*: what a Go host links), `--torch-comm` runs it through torch.distributed.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -62,7 +64,10 @@ def main():
     ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-call latency leg (tools/latency_bench.py)")
     ap.add_argument("--native-comm", action="store_true",
-                    help="exchange the partials with the engine's own RCCL communicator (kt_comm_*) instead of torch.distributed")
+                    help="exchange the partials with the engine's own RCCL communicator (kt_comm_*); the default when N > 1")
+    ap.add_argument("--torch-comm", action="store_true", help="N > 1: run the exchange through torch.distributed instead")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: fixed rows per GPU (default); strong: the config's total pod count divided over the GPUs")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +92,10 @@ def main():
 
     # ---- workload: this rank's pod shard of a job with P_total = world x pods_per_gpu pods
     cfg = W.preset(args.config)
-    if args.config == 4 and not args.pods_per_gpu:
+    if args.scaling == "strong":  # total work fixed: the config's pods (or --pods-per-gpu x 1 as the total) over N ranks
+        total = args.pods_per_gpu or cfg.n_pods_total
+        per_gpu = (total + world - 1) // world
+    elif args.config == 4 and not args.pods_per_gpu:
         per_gpu = cfg.n_pods_total // 8  # the config is defined on 8 GPUs: 1.25M rows each
     else:
         per_gpu = args.pods_per_gpu or cfg.n_pods_total
@@ -118,21 +126,32 @@ def main():
     ts.synchronize()
     eng.use_partial_buffer(partial.data_ptr(), partial.numel())
 
+    if world > 1 and not args.torch_comm:
+        args.native_comm = True  # the product's own exchange is what a multi-GPU run measures
+    if world > 1 and not args.native_comm:
+        eng.set_exchange_world(world)  # the exact-range guard must cover the sum over all ranks
     if args.native_comm:  # the framework-free exchange: torch.distributed only carries the 128-byte id to the ranks
         ids = [E.Engine.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         eng.comm_init(rank, world, ids[0])
 
-    def step():
+    xchg_events = []  # (start, stop) around the exchange, recorded only in the instrumented pass
+
+    def step(timed_exchange=False):
         with torch.cuda.stream(ts):
-            if args.native_comm:
+            if args.native_comm or world > 1:
                 eng.aggregate_launch(stream)
-                eng.comm_allreduce_partial(stream)  # ncclAllReduce(int64, sum) on the kernels' stream
-                eng.finalize_launch(now, True, stream)
-            elif world > 1:
-                eng.aggregate_launch(stream)
-                dist.all_reduce(partial, op=dist.ReduceOp.SUM)  # RCCL over xGMI; int64 sums are order-independent
+                if timed_exchange:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(ts)
+                if args.native_comm:
+                    eng.comm_allreduce_partial(stream)  # ncclAllReduce(int64, sum) on the kernels' stream
+                else:
+                    dist.all_reduce(partial, op=dist.ReduceOp.SUM)  # RCCL over xGMI; int64 sums are order-independent
+                if timed_exchange:
+                    e1.record(ts)
+                    xchg_events.append((e0, e1))
                 eng.finalize_launch(now, True, stream)
             else:
                 eng.reconcile_launch(now, True, stream)  # one GPU: nothing to exchange between scan and finalize
@@ -155,17 +174,21 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed * 1e3 / args.steps]
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        all_t = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(all_t, te)
+        rank_ms = [float(t.item()) * 1e3 / args.steps for t in all_t]
+        elapsed = max(float(t.item()) for t in all_t)  # MAX over ranks
     # per-kernel durations: HIP events on the launch stream, same steps again
     eng.timing_enable(True)
     eng.timing_reset()
     for _ in range(min(args.steps, 20)):
-        step()
+        step(timed_exchange=True)
     fence()
     eng.timing_enable(False)
+    exchange_ms = (sum(a.elapsed_time(b) for a, b in xchg_events) / len(xchg_events)) if xchg_events else None
 
     k_ms = {}
     for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("reduce", E.KERNEL_REDUCE),
@@ -219,6 +242,11 @@ def main():
                 "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
                 "traffic": pmc_kernels.get(sym(kn), {}).get("hbm_bytes_per_launch")}
 
+    # reconcile = the three launches that turn pods into stored status (aggregate scan + slab reduction + finalize; the
+    # fused kernel reports all of it under `aggregate`) against the aggregation's algorithmic bytes
+    rec_ms = k_ms["aggregate"] + k_ms["reduce"] + k_ms["finalize"]
+    slowest = max(("check", "aggregate", "reduce", "finalize"), key=lambda k: k_ms[k])
+    fam_of = {"check": E.KERNEL_CHECK, "aggregate": E.KERNEL_AGGREGATE, "reduce": E.KERNEL_REDUCE, "finalize": E.KERNEL_FINALIZE}
     roofline = {
         "bound": "hbm", "kernel": dom_kernel,
         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -227,6 +255,13 @@ def main():
         "dominant_by": "algorithmic bytes per launch",
         "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes),
         "aggregate": kernel_roofline("aggregate", E.KERNEL_AGGREGATE, agg_bytes),
+        "reconcile": {"kernels": [eng.kernel_name(E.KERNEL_AGGREGATE), eng.kernel_name(E.KERNEL_REDUCE), eng.kernel_name(E.KERNEL_FINALIZE)],
+                      "ms": round(rec_ms, 6), "algorithmic_bytes": agg_bytes,
+                      "frac": round(agg_bytes / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if rec_ms > 0 else 0.0},
+        # the other reading of "dominant": the launch that takes longest (it flips between the two scans from run to run)
+        "slowest": {"kernel": eng.kernel_name(fam_of[slowest]), "family": slowest, "avg_launch_ms": round(k_ms[slowest], 6),
+                    "frac": round({"check": chk_bytes, "aggregate": agg_bytes}.get(slowest, 0) / (k_ms[slowest] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+                    if k_ms[slowest] > 0 else 0.0},
         # the whole step (both scans + slab reduction + finalize, launch gaps included) against the same roofline
         "step": {"algorithmic_bytes": chk_bytes + agg_bytes, "ms": round(ms_per_step, 6),
                  "frac": round((chk_bytes + agg_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms_per_step > 0 else 0.0},
@@ -282,18 +317,29 @@ def main():
             latency = latency_bench.measure(eng, snap, n_check=4000, n_upsert=200, now=now)
         except Exception as ex:  # never lose the bench line over the side measurement
             latency = {"error": repr(ex)}
+        if isinstance(latency, dict) and "sweep" in latency:
+            # the event-driven step: in the reference EVERY reconcile follows an event (throttle_controller.go:400-536);
+            # a sweep right after ONE pod upsert, host wall clock incl. launches, against the same roofline
+            sw = latency["sweep"]
+            roofline["step_after_event"] = {
+                "ms": sw["after_pod_event_ms"], "steady_ms": sw["steady_ms"],
+                "ratio": round(sw["after_pod_event_ms"] / sw["steady_ms"], 3) if sw["steady_ms"] > 0 else None,
+                "frac": round((chk_bytes + agg_bytes) / (sw["after_pod_event_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+                if sw["after_pod_event_ms"] > 0 else 0.0}
 
     if rank == 0:
         out = {
             "metric": "pod_throttle_decisions_per_sec", "value": value, "unit": "decisions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.config], "pods_total": P_total, "pods_per_gpu": per_gpu,
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
                        "step": "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
                        "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
+            "per_rank_ms_per_step": [round(x, 6) for x in rank_ms],
+            "exchange_ms": None if exchange_ms is None else round(exchange_ms, 6),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "latency": latency,
         }
         print(json.dumps(out))

@@ -176,8 +176,14 @@ int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t
 #define KT_COMM_ID_BYTES 128
 int32_t kt_comm_unique_id(void* out_id128);
 int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id128);
-/* in-place sum over all ranks of this engine's partial buffer (the caller's, if kt_use_partial_buffer set one) */
+/* in-place sum over all ranks of this engine's partial buffer (the caller's, if kt_use_partial_buffer set one) — exactly
+ * the words the preceding kt_aggregate_launch filled.  KT_ERR_NOT_READY when no aggregate is pending, or when throttles /
+ * namespaces changed since it ran (the ranks would disagree on the word count): aggregate again. */
 int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream);
+/* A caller that sums the partial buffers with its OWN collective (kt_partial_used_buffer / kt_use_partial_buffer) declares
+ * the number of ranks here, so that the engine's exact-range guard covers the sum over all of them (2^60 per rank up to 4
+ * ranks, 2^62 / world beyond); kt_comm_init does it by itself. */
+int32_t kt_set_exchange_world(kt_engine* e, int32_t world);
 int32_t kt_comm_destroy(kt_engine* e);
 
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */

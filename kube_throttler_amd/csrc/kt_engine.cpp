@@ -215,6 +215,12 @@ struct kt_engine {
   DevBuf<int32_t> d_out_next_ns;
   DevBuf<uint32_t> d_out_thrl_flag, d_out_thrl_has;
   bool reconcile_ready = false;
+  // the partial buffer as the last kt_aggregate_launch filled it: word count and the selector program it was scanned
+  // with — the exchange and the finalize that follow must see the same throttle set
+  bool agg_pending = false;
+  size_t agg_words = 0;
+  uint64_t program_gen = 0, agg_gen = 0;
+  int32_t exchange_world = 1;  // ranks whose partials meet in the reconcile's all-reduce (kt_comm_init / kt_set_exchange_world)
 
   // ---- check state
   DevBuf<uint8_t> d_recs;
@@ -586,6 +592,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, hipMemcpyAsync(e->d_sp.p, &e->sp, sizeof(kt::SelProgram), hipMemcpyHostToDevice, s));
   KT_HIP(e, hipStreamSynchronize(s));
   e->program_dirty = false;
+  ++e->program_gen;
   return KT_OK;
 }
 
@@ -638,6 +645,23 @@ void amount_to_table(const HostAmount& h, const kt_amounts& a, size_t i, int D) 
 }
 
 constexpr unsigned __int128 kSumBound = (unsigned __int128)1 << 60;
+// Per-rank bound of the summed |request| per dimension: the all-reduced `used` of `world` ranks must stay inside int64
+// (kt_finalize reads it as int64), so 2^60 up to 4 ranks and 2^62 / world (rounded down to a power of two) beyond.
+inline unsigned __int128 rank_sum_bound(int32_t world) {
+  unsigned __int128 b = kSumBound;
+  for (int32_t w = 4; w < world; w *= 2) b >>= 1;
+  return b;
+}
+// Between kt_aggregate_launch and the calls that consume its partials (kt_comm_allreduce_partial, kt_finalize_launch) the
+// throttle set must not change: a grown thr_rows_hi would read past the buffer the scan filled, ranks would disagree on
+// the word count, and ensure_ready would recompile and clear the buffer.
+#define KT_CHECK_PARTIALS_CURRENT(e, who)                                                                              \
+  do {                                                                                                                 \
+    if ((e)->agg_pending && ((e)->program_dirty || (e)->agg_gen != (e)->program_gen ||                                 \
+                             (e)->agg_words != (size_t)(e)->thr_rows_hi * kt::partial_stride((e)->D)))                 \
+      return (e)->fail(KT_ERR_NOT_READY, who ": throttles or namespaces changed since kt_aggregate_launch filled the "  \
+                                             "partial buffer; aggregate again");                                       \
+  } while (0)
 constexpr size_t kPinnedStageBytes = 1u << 20;
 
 // upper bound of every pod's effective request per dimension, for kRecTight (kt_device.h)
@@ -930,7 +954,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   // exactly on the device (request_sums_in_range), which also forgets the overwritten and deleted pods again
   for (int d = 0; d < D; ++d) {
     e->req_sum_bound[d] += batch_total[d];
-    if (e->req_sum_bound[d] > kSumBound) e->req_sums_valid = false;
+    if (e->req_sum_bound[d] > rank_sum_bound(e->exchange_world)) e->req_sums_valid = false;
   }
   e->pod_ns_hi = ns_hi;
   if ((size_t)ns_hi > e->ns_compiled) e->program_dirty = true;  // a namespace row the compiled program does not cover yet
@@ -1236,6 +1260,20 @@ int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id12
     return e->fail(KT_ERR_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString ? r->GetErrorString(rc) : "error");
   }
   e->comm_rank = rank, e->comm_world = world;
+  if (world > e->exchange_world) {
+    e->exchange_world = world;
+    if (world > 4) e->req_sums_valid = false;  // the per-rank bound shrinks: count again at the next reconcile
+  }
+  return KT_OK;
+}
+
+// the number of ranks whose partials the caller sums between kt_aggregate_launch and kt_finalize_launch with its OWN
+// collective (kt_partial_used_buffer / kt_use_partial_buffer); kt_comm_init sets it by itself
+int32_t kt_set_exchange_world(kt_engine* e, int32_t world) {
+  if (!e || world < 1) return KT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (world != e->exchange_world && (world > 4 || e->exchange_world > 4)) e->req_sums_valid = false;
+  e->exchange_world = world;
   return KT_OK;
 }
 
@@ -1245,9 +1283,14 @@ int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream) {
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->comm) return e->fail(KT_ERR_NOT_READY, "kt_comm_allreduce_partial before kt_comm_init");
   hipStream_t s = pick_stream(e, stream);
-  const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  if (!e->agg_pending) return e->fail(KT_ERR_NOT_READY, "kt_comm_allreduce_partial: no partials pending (kt_aggregate_launch first)");
+  KT_CHECK_PARTIALS_CURRENT(e, "kt_comm_allreduce_partial");
+  const size_t words = e->agg_words;  // what the scan filled, not what the throttle table holds now
   if (!words) return KT_OK;
   if (!e->partial()) return e->fail(KT_ERR_NOT_READY, "no partial buffer yet: kt_aggregate_launch first");
+  if (e->ext_partial && (int64_t)words > e->ext_partial_words)
+    return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed", (long long)e->ext_partial_words,
+                   (long long)words);
   Rccl* r = rccl();
   const int rc = r->AllReduce(e->partial(), e->partial(), words, kNcclInt64, kNcclSum, e->comm, s);
   if (rc != 0) return e->fail(KT_ERR_DEVICE, "ncclAllReduce: %s", r->GetErrorString ? r->GetErrorString(rc) : "error");
@@ -1396,7 +1439,7 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   for (int d = 0; d < e->D; ++d) {
     const unsigned __int128 total = (unsigned __int128)h[2 * d] + ((unsigned __int128)h[2 * d + 1] << 32);
     e->req_sum_bound[d] = total;
-    if (total > kSumBound)
+    if (total > rank_sum_bound(e->exchange_world))
       return e->fail(KT_ERR_OVERFLOW_RISK,
                      "dimension %d: the requests of the pods held here add up beyond 2^60 at this scale (the reference would "
                      "promote to big decimals); use a coarser scale for it", d);
@@ -1418,6 +1461,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     if (words) KT_HIP(e, hipMemcpyAsync(e->partial(), e->d_agg.p, words * 8, hipMemcpyDeviceToDevice, s));
     e->last_kernel[KT_KERNEL_AGGREGATE] = "(incremental: no scan)";
     e->last_stream = s;
+    e->agg_pending = true, e->agg_words = words, e->agg_gen = e->program_gen;
     return KT_OK;
   }
   // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
@@ -1481,6 +1525,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     e->agg_valid = true;
   }
   e->last_stream = s;
+  e->agg_pending = true, e->agg_words = words, e->agg_gen = e->program_gen;
   return KT_OK;
 }
 
@@ -1502,8 +1547,10 @@ static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int6
 // consume: kt_reconcile_launch — nobody reads the partials after this finalize, which leaves them zeroed for the next scan
 static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, hipStream_t s, bool consume = false,
                                const uint8_t* row_mask = nullptr) {
+  KT_CHECK_PARTIALS_CURRENT(e, "kt_finalize_launch");
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
+  e->agg_pending = false;  // consumed (or caller-provided partials: nothing was pending)
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
                        e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p, e->d_out_next_s.p, e->d_out_next_ns.p};
   const bool apply = (flags & KT_RECONCILE_APPLY) != 0;
@@ -1587,8 +1634,12 @@ int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, ui
   if (rc != KT_OK) return rc;
   // the keys of this reconcile as a byte per throttle row; the other rows keep (and report) their stored status
   std::vector<uint8_t> mask((size_t)e->thr_rows_hi + 1, 0);
-  for (int32_t i = 0; i < n; ++i)
-    if (throttle_rows[i] < e->thr_rows_hi) mask[(size_t)throttle_rows[i]] = 1;
+  for (int32_t i = 0; i < n; ++i) {
+    // a key beyond the rows in use was never upserted: silently "reconciling" it would report a stored status nobody wrote
+    if (throttle_rows[i] >= e->thr_rows_hi)
+      return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d was never upserted (rows in use: %d)", throttle_rows[i], e->thr_rows_hi);
+    mask[(size_t)throttle_rows[i]] = 1;
+  }
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   KT_HIP(e, e->d_row_mask.reserve(mask.size()));
   KT_HIP(e, hipMemcpyAsync(e->d_row_mask.p, mask.data(), mask.size(), hipMemcpyHostToDevice, s));

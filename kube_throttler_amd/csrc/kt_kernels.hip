@@ -485,6 +485,11 @@ __device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, i
 }
 
 __device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
+// used + reserved in 128 bits: the all-reduced `used` of several ranks may come close to int64's end
+__device__ __forceinline__ bool cmp_eq_sum(int64_t a0, int64_t a1, int64_t b, bool eq) {
+  const __int128 a = (__int128)a0 + (__int128)a1;
+  return eq ? a >= (__int128)b : a > (__int128)b;
+}
 
 // Everything CheckThrottledFor needs that does not depend on the pod, folded into the throttle's CheckRec
 // (effective threshold, headroom, step-2/3 bitmask, count verdicts) — see DESIGN.md "Check algebra".
@@ -504,9 +509,9 @@ __device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int 
   // step 2: stored status.throttled ; step 3: IsThrottled(used + reserved, eq3)
   uint32_t act_mask = thrl_flag & thrl_has;
   bool act_pod = (fl & kThrThrottledPod) != 0;
-  if (th_hc && (u_hc || r_hc) && cmp_eq(u_c + r_c, th_c, eq3)) act_pod = true;
+  if (th_hc && (u_hc || r_hc) && cmp_eq_sum(u_c, r_c, th_c, eq3)) act_pod = true;
   // step 4, counts: used + pod(1) + reserved always has counts
-  if (th_hc && cmp_eq(u_c + 1 + r_c, th_c, eq)) f |= kRecInsufficientByCount;
+  if (th_hc && (eq ? (__int128)u_c + 1 + r_c >= (__int128)th_c : (__int128)u_c + 1 + r_c > (__int128)th_c)) f |= kRecInsufficientByCount;
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
     int64_t thr = kInf, head = kInf;
@@ -514,7 +519,7 @@ __device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int 
       const int64_t tv = th_v[d];
       const int64_t uv = ((u_p >> d) & 1u) ? u_v[d] : 0;
       const int64_t rv = ((r_p >> d) & 1u) ? r_v[d] : 0;
-      if ((((u_p | r_p) >> d) & 1u) && cmp_eq(uv + rv, tv, eq3)) act_mask |= 1u << d;
+      if ((((u_p | r_p) >> d) & 1u) && cmp_eq_sum(uv, rv, tv, eq3)) act_mask |= 1u << d;
       thr = tv;
       __int128 h = (__int128)tv - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
       head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;

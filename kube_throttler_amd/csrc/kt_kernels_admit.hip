@@ -36,7 +36,8 @@ struct AdmitArgs {
   uint32_t off_rv, off_rc, off_rp, off_list, list_cap;
 };
 
-__device__ __forceinline__ bool admit_cmp(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
+// the sums of used + reserved (+ the pod) are formed in 128 bits: an all-reduced `used` may come close to int64's end
+__device__ __forceinline__ bool admit_cmp(__int128 a, int64_t b, bool eq) { return eq ? a >= (__int128)b : a > (__int128)b; }
 
 // The mutable state (reserved amounts of all throttles) lives in LDS when it fits; otherwise in a scratch buffer in
 // HBM that only this wave touches, read and written through L2 (agent-scope atomics: never served from a stale L1 line).
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
         const int64_t uv = ((u_p >> d) & 1u) ? tt.used.v[(size_t)t * D + d] : 0;
         const int64_t rvd = st.ld_v(t * D + d);
         if (nz && v > tv) bits |= 1u;                                                        // step 1
-        if (nz && (((u_p | r_pw) >> d) & 1u) && admit_cmp(uv + rvd, tv, eq3)) bits |= 2u;    // step 3
-        if (nz && admit_cmp(uv + v + rvd, tv, eq)) bits |= 4u;                               // step 4
+        if (nz && (((u_p | r_pw) >> d) & 1u) && admit_cmp((__int128)uv + rvd, tv, eq3)) bits |= 2u;    // step 3
+        if (nz && admit_cmp((__int128)uv + v + rvd, tv, eq)) bits |= 4u;                               // step 4
       }
       if (vv && nz && ((tt.thrl_flag[t] & tt.thrl_has[t]) >> d) & 1u) bits |= 2u;            // step 2
       if (vv && d == 0) {  // resourceCounts.pod
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(kWave) void kt_admit_sequential(const AdmitArgs a) 
         const bool u_hc = tt.used.has_count[t] != 0, r_hc = (r_pw >> 31) != 0;
         const int64_t u_c = u_hc ? tt.used.count[t] : 0, r_c = st.ld_c(t);
         if (th_hc && 1 > th_c) bits |= 1u;
-        if ((tf & kThrThrottledPod) || (th_hc && (u_hc || r_hc) && admit_cmp(u_c + r_c, th_c, eq3))) bits |= 2u;
-        if (th_hc && admit_cmp(u_c + 1 + r_c, th_c, eq)) bits |= 4u;
+        if ((tf & kThrThrottledPod) || (th_hc && (u_hc || r_hc) && admit_cmp((__int128)u_c + r_c, th_c, eq3))) bits |= 2u;
+        if (th_hc && admit_cmp((__int128)u_c + 1 + r_c, th_c, eq)) bits |= 4u;
       }
 #pragma unroll
       for (int o = DT / 2; o >= 1; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o);

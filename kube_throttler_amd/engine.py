@@ -35,7 +35,7 @@ EXPORTS = [
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
-    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch",
+    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.kt_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.kt_comm_allreduce_partial.argtypes = [C.c_void_p, C.c_void_p]
         L.kt_comm_destroy.argtypes = [C.c_void_p]
+        L.kt_set_exchange_world.argtypes = [C.c_void_p, C.c_int32]
         L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.kt_fetch_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -270,6 +271,10 @@ class Engine:
 
     def comm_destroy(self):
         self._ck(lib().kt_comm_destroy(self._h))
+
+    def set_exchange_world(self, world: int):
+        """Ranks whose partials the CALLER sums with its own collective (kt_comm_init declares it by itself)."""
+        self._ck(lib().kt_set_exchange_world(self._h, world))
 
     def partial_words(self) -> int:
         return self.throttle_rows() * (2 * self.D + 2)
