@@ -209,6 +209,11 @@ int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* 
  * matrix is produced then).  This is the form a PreFilter shim calls when other threads use the engine concurrently
  * (Unreserve from binding goroutines plugin.go:240-257, reconcile workers controller.go:52-122): results of a
  * separate launch / fetch pair may be replaced by another thread's launch in between. */
+/* With n <= 8 and out_status == NULL (one PreFilter call: the verdict; the status row is only needed to word the reasons
+ * of a blocked pod) the call takes the few-pod path: it holds the engine lock SHARED, launches one wave per index chunk
+ * on a high-priority stream of its own and spins on a sequence number the kernel writes to pinned host memory behind
+ * the summary words — no copy, no stream synchronisation, and no waiting for the kernels of a reconcile another thread
+ * launched (while those run it sees the status as stored before that reconcile: the CheckRecs are double-buffered). */
 int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary,
                  uint8_t* out_status);
 /* ---- sequential admission with reservation: for i = 0..n-1 IN ORDER,
@@ -253,6 +258,9 @@ int32_t kt_timing_reset(kt_engine* e);
 int32_t kt_synchronize(kt_engine* e, void* stream);
 /* symbol of the HIP kernel LAST dispatched for a family (to match rocprofv3 kernel-trace rows) */
 const char* kt_kernel_name(kt_engine* e, int32_t kernel);
+/* event counters (-1: unknown counter) */
+#define KT_COUNTER_FEW_CHECKS 0 /* kt_check calls served by the few-pod path (shared lock, no copy, no stream sync) */
+int64_t kt_counter(kt_engine* e, int32_t which);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -131,7 +133,23 @@ struct TimingFamily {
 
 struct kt_engine {
   kt_config cfg{};
-  std::mutex mu;
+  // writers (state feed, launches, fetches) hold it exclusively for the duration of the call; the single-pod PreFilter
+  // path (kt_check with n <= 8, summaries only) holds it SHARED: it reads device tables nobody may rewrite meanwhile,
+  // but it does not queue behind the kernels a reconcile launch left running (controller.go:52-62: PreFilter reads
+  // RW-safe caches while the reconcile workers run)
+  std::shared_mutex mu;
+  std::mutex small_mu;  // serialises the few-pod callers among themselves (one scratch / pinned slot)
+  // Every call except the few-pod check takes op_mu first: among themselves those calls are serialised exactly as under
+  // the single mutex of rounds 1-2 (every interleaving equals some serial order).  What they take of `mu` depends on what
+  // they do to the state a few-pod check reads (pod tables, selector program + index, namespace table, CheckRecs):
+  //   state feed (upserts, deletes, snapshots, status / reserved amounts)      -> exclusive
+  //   launches, fetches, timing — they only enqueue kernels and move results   -> shared (exclusive when the first call
+  //                                                                              after a state change has to recompile /
+  //                                                                              re-upload: ensure_ready)
+  // so a PreFilter call waits for a pod informer event, not for a reconcile worker's launch or fetch.
+  std::mutex op_mu;
+  std::mutex recs_mu;  // the CheckRec bookkeeping below (launches update it under the shared lock, the few-pod path reads it)
+  std::mutex err_mu;
   std::string err;
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -223,7 +241,23 @@ struct kt_engine {
   int32_t exchange_world = 1;  // ranks whose partials meet in the reconcile's all-reduce (kt_comm_init / kt_set_exchange_world)
 
   // ---- check state
-  DevBuf<uint8_t> d_recs;
+  // CheckRecs, double-buffered: a reconcile with APPLY writes the NEW generation into the other buffer and records an
+  // event behind it; until that event has completed, a concurrent single-pod check reads the previous generation (a
+  // consistent status: the one before the reconcile) instead of waiting for — or racing with — kt_finalize
+  DevBuf<uint8_t> d_recs2[2];
+  int recs_cur = 0;
+  hipEvent_t recs_ev[2] = {nullptr, nullptr};
+  bool recs_ev_pending[2] = {false, false};
+  bool recs_prev_valid = false;  // the other buffer holds complete records of the same (program, on_equal, DT)
+  uint8_t* recs_ptr() { return d_recs2[recs_cur].p; }
+  // ---- few-pod check path (kt_kernels_few.hip)
+  hipStream_t small_stream = nullptr;  // high priority: its one-wave workgroups start beside a running sweep
+  DevBuf<unsigned long long> d_few_acc;
+  DevBuf<uint32_t> d_few_ticket;
+  uint64_t* h_few = nullptr;  // pinned: [8] summary words, [8] = sequence number
+  uint64_t few_seq = 0;
+  std::atomic<bool> few_ready{false};
+  std::atomic<int64_t> few_served{0};
   DevBuf<uint64_t> d_summary;
   DevBuf<uint8_t> d_status;
   DevBuf<int64_t> d_rows;
@@ -256,7 +290,10 @@ struct kt_engine {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    err = buf;
+    {
+      std::lock_guard<std::mutex> g(err_mu);
+      err = buf;
+    }
     return code;
   }
 };
@@ -268,6 +305,34 @@ struct kt_engine {
   } while (0)
 
 namespace {
+
+// state feed: nobody else inside
+struct StateLock {
+  std::unique_lock<std::mutex> op;
+  std::unique_lock<std::shared_mutex> ex;
+  explicit StateLock(kt_engine* e) : op(e->op_mu), ex(e->mu) {}
+};
+// launches / fetches: serialised among themselves (op_mu), beside few-pod checks (shared) — unless this call will have to
+// recompile or re-upload state those checks read (the dirty flags are only written under op_mu + exclusive mu, so reading
+// them with op_mu held is safe)
+struct LaunchLock {
+  std::unique_lock<std::mutex> op;
+  std::unique_lock<std::shared_mutex> ex;
+  std::shared_lock<std::shared_mutex> sh;
+  explicit LaunchLock(kt_engine* e, bool force_exclusive = false) : op(e->op_mu) {
+    if (force_exclusive || e->program_dirty || e->status_host_dirty) ex = std::unique_lock<std::shared_mutex>(e->mu);
+    else sh = std::shared_lock<std::shared_mutex>(e->mu);
+  }
+};
+// CheckRecs about to be rewritten IN PLACE: no few-pod check may start on them (recs_valid = false under recs_mu) and
+// the one in flight, if any, has to finish first (it holds small_mu from launch to completion)
+void recs_invalidate_and_drain(kt_engine* e) {
+  {
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    e->recs_valid = false;
+  }
+  if (e->few_ready) std::lock_guard<std::mutex> drain(e->small_mu);
+}
 
 hipStream_t pick_stream(kt_engine* e, void* s) { return s ? (hipStream_t)s : e->own_stream; }
 
@@ -531,7 +596,9 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_out_next_ns.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_flag.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_has.reserve(T + 1));
-  KT_HIP(e, e->d_recs.reserve(kt::recs_bytes((int)T)));
+  KT_HIP(e, e->d_recs2[0].reserve(kt::recs_bytes((int)T)));
+  KT_HIP(e, e->d_recs2[1].reserve(kt::recs_bytes((int)T)));
+  e->recs_prev_valid = false;
   // index for the work ~ (pods + matches) kernels
   {
     auto thr_info = [&](uint32_t t) {
@@ -834,13 +901,19 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_n_countable.release();
   e->d_ticket.release();
   if (e->h_small) (void)hipHostFree(e->h_small);
+  if (e->h_few) (void)hipHostFree(e->h_few);
+  e->d_few_acc.release();
+  e->d_few_ticket.release();
+  for (auto& ev : e->recs_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->small_stream) (void)hipStreamDestroy(e->small_stream);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
   for (auto* b : u32s) b->release();
   DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
-                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs, &e->d_status, &e->d_stage, &e->d_slab, &e->d_admit};
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_status, &e->d_stage, &e->d_slab, &e->d_admit};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
@@ -867,7 +940,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
 // ---------------------------------------------------------------------------------------------------
 int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* b, const int32_t* rows) {
   if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   for (int32_t i = 0; i < b->n_ns; ++i) {
     const int32_t row = rows ? rows[i] : i;
     if (row < 0 || row >= e->cfg.namespace_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "namespace row %d", row);
@@ -886,7 +959,7 @@ int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* b, const int32_t* 
 
 int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* rows) {
   if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   for (int32_t i = 0; i < n; ++i) {
     if (rows[i] < 0 || rows[i] >= e->cfg.namespace_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "namespace row %d", rows[i]);
     e->ns[(size_t)rows[i]] = HostNamespace();
@@ -1035,7 +1108,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
 
 int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
   if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   return upsert_pods_locked(e, b, rows);
@@ -1043,7 +1116,7 @@ int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* b, const int64_t* rows) 
 
 int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   for (int64_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)rows[i]);
@@ -1124,14 +1197,14 @@ static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const
 
 int32_t kt_upsert_throttles(kt_engine* e, const kt_snapshot* b, const int32_t* rows) {
   if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return upsert_throttles_locked(e, b, rows);
 }
 
 int32_t kt_delete_throttles(kt_engine* e, int32_t n, const int32_t* rows) {
   if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   for (int32_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->cfg.throttle_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
@@ -1247,7 +1320,7 @@ int32_t kt_comm_unique_id(void* out_id128) {
 
 int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id128) {
   if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   Rccl* r = rccl();
   if (!r->err.empty()) return e->fail(KT_ERR_UNSUPPORTED, "%s", r->err.c_str());
@@ -1271,7 +1344,7 @@ int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id12
 // collective (kt_partial_used_buffer / kt_use_partial_buffer); kt_comm_init sets it by itself
 int32_t kt_set_exchange_world(kt_engine* e, int32_t world) {
   if (!e || world < 1) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   if (world != e->exchange_world && (world > 4 || e->exchange_world > 4)) e->req_sums_valid = false;
   e->exchange_world = world;
   return KT_OK;
@@ -1279,7 +1352,7 @@ int32_t kt_set_exchange_world(kt_engine* e, int32_t world) {
 
 int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->comm) return e->fail(KT_ERR_NOT_READY, "kt_comm_allreduce_partial before kt_comm_init");
   hipStream_t s = pick_stream(e, stream);
@@ -1300,7 +1373,7 @@ int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream) {
 
 int32_t kt_comm_destroy(kt_engine* e) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->comm) return KT_OK;
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
@@ -1312,7 +1385,7 @@ int32_t kt_comm_destroy(kt_engine* e) {
 
 int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   if (!e || !s) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (s->n_ns > e->cfg.namespace_capacity || s->n_pods > e->cfg.pod_capacity || s->n_thr > e->cfg.throttle_capacity)
     return e->fail(KT_ERR_OUT_OF_RANGE, "snapshot larger than the configured capacity");
@@ -1352,7 +1425,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
 
 int32_t kt_set_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt_amounts* reserved) {
   if (!e || !reserved || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   for (int32_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
@@ -1370,7 +1443,7 @@ int32_t kt_set_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt_a
 
 int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* rows, const kt_status* st) {
   if (!e || !st || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   for (int32_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
@@ -1557,18 +1630,33 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   // with APPLY the stored status changes: leave the CheckRecs of the new status behind (kt_prepare_check fused in),
   // built for the isThrottledOnEqual value the last check used (PreFilter: false)
   const int rec_DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
+  // the new generation of CheckRecs goes into the OTHER buffer when the current one is worth keeping for concurrent
+  // single-pod checks (valid records of the same shape); otherwise it is rewritten in place, behind the checks in flight
+  bool keep_prev;
+  int wbuf;
+  {
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    keep_prev = apply && e->recs_valid && e->recs_DT == rec_DT && e->few_ready;
+    wbuf = keep_prev ? 1 - e->recs_cur : e->recs_cur;
+  }
+  if (apply && !keep_prev) recs_invalidate_and_drain(e);
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
-    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs.p : nullptr, rec_DT,
+    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT,
                         e->recs_eq, req_bound(e), s, row_mask);
   }
-  e->clean_partial = consume ? (const void*)e->partial() : nullptr;
-  KT_HIP(e, hipGetLastError());
   if (apply) {
-    e->status_dev_newer = true;
+    if (e->few_ready) KT_HIP(e, hipEventRecord(e->recs_ev[wbuf], s));
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    e->recs_ev_pending[wbuf] = e->few_ready;
+    e->recs_prev_valid = keep_prev;
+    e->recs_cur = wbuf;
     e->recs_valid = true;  // e->recs_eq unchanged
     e->recs_DT = rec_DT;
   }
+  e->clean_partial = consume ? (const void*)e->partial() : nullptr;
+  KT_HIP(e, hipGetLastError());
+  if (apply) e->status_dev_newer = true;
   e->reconcile_ready = true;
   e->reconcile_T = e->thr_rows_hi;
   e->last_stream = s;
@@ -1577,14 +1665,14 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
 
 int32_t kt_aggregate_launch(kt_engine* e, void* stream) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return aggregate_locked(e, pick_stream(e, stream));
 }
 
 int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64) {
   if (!e || !device_ptr || !n_int64) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   int32_t rc = ensure_ready(e, e->own_stream);
   if (rc != KT_OK) return rc;
@@ -1595,7 +1683,7 @@ int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64
 
 int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64) {
   if (!e || (device_ptr && n_int64 <= 0)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  StateLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   e->ext_partial = (unsigned long long*)device_ptr;
@@ -1606,14 +1694,14 @@ int32_t kt_use_partial_buffer(kt_engine* e, void* device_ptr, int64_t n_int64) {
 
 int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return finalize_locked(e, now_s, now_ns, flags, pick_stream(e, stream));
 }
 
 int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, void* stream) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   hipStream_t s = pick_stream(e, stream);
   int32_t rc = aggregate_locked(e, s);
@@ -1624,7 +1712,7 @@ int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_
 int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
                                  const int32_t* throttle_rows, void* stream) {
   if (!e || n < 0 || (n > 0 && !throttle_rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   hipStream_t s = pick_stream(e, stream);
   for (int32_t i = 0; i < n; ++i)
@@ -1651,7 +1739,7 @@ int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, ui
 
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
   if (!e || !out) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch before a reconcile launch");
   if (n < 0 || n > e->reconcile_T) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows of the last reconcile=%d", n, e->reconcile_T);
@@ -1682,7 +1770,7 @@ int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
 // NextOverrideHappensIn of the last reconcile, as instants (has = 0: nothing ahead / row not reconciled)
 int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_s, int32_t* next_ns, uint8_t* has) {
   if (!e || !next_s || !next_ns || !has) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch_next_override before a reconcile launch");
   if (n < 0 || n > e->reconcile_T) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows of the last reconcile=%d", n, e->reconcile_T);
@@ -1748,8 +1836,15 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   // the CheckRecs only depend on (stored status, reserved amounts, isThrottledOnEqual): rebuilt when one of them
   // changed since they were last built (by kt_prepare_check or by kt_finalize with APPLY)
   if (!(e->recs_valid && e->recs_eq == (on_equal != 0) && e->recs_DT == DT)) {
-    TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
-    kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->d_recs.p, req_bound(e), s);
+    recs_invalidate_and_drain(e);  // rebuilt in place
+    {
+      TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
+      kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->recs_ptr(), req_bound(e), s);
+    }
+    if (e->few_ready) KT_HIP(e, hipEventRecord(e->recs_ev[e->recs_cur], s));
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    e->recs_ev_pending[e->recs_cur] = e->few_ready;
+    e->recs_prev_valid = false;  // records of an older status / other on_equal: not a substitute any more
     e->recs_valid = true;
     e->recs_eq = on_equal != 0;
     e->recs_DT = DT;
@@ -1757,7 +1852,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   {
     TimedLaunch tl(e, KT_KERNEL_CHECK, s);
     if (e->cfg.kernel_variant == 1)
-      kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->d_recs.p,
+      kt::launch_check_dense(e->pods, n, pod_rows ? e->d_rows.p : nullptr, e->sp, e->uses_keys, e->recs_ptr(),
                              e->d_summary.p, want_status ? e->d_status.p : nullptr, s),
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
@@ -1780,7 +1875,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
       }
       const kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
       const char* k = kt::launch_check_indexed(e->pods, n, by_ns ? e->d_order_all.p : pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
-                                               e->d_recs.p, e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
+                                               e->recs_ptr(), e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
                                                small ? &sm : nullptr, e->n_overflow != 0, by_ns ? &view : nullptr);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "%d throttle rows exceed the indexed check kernel's LDS budget (use kernel_variant 1)", e->thr_rows_hi);
       e->last_kernel[KT_KERNEL_CHECK] = k;
@@ -1798,7 +1893,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
 
 int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
   if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return check_launch_locked(e, n, pod_rows, on_equal, flags, pick_stream(e, stream));
 }
@@ -1808,7 +1903,7 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
 // ---------------------------------------------------------------------------------------------------
 int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags, void* stream) {
   if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   hipStream_t s = pick_stream(e, stream);
   if ((double)n * (double)e->thr_rows_hi > 2147483648.0)
@@ -1824,13 +1919,17 @@ int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
                         e->d_status.p, e->d_summary.p, e->d_admit.p, force_global, s))
     return e->fail(KT_ERR_UNSUPPORTED, "admit queue: %d throttle rows exceed the kernel's LDS list", e->thr_rows_hi);
   KT_HIP(e, hipGetLastError());
-  if (commit) e->reserved_dev_newer = true, e->recs_valid = false;
+  if (commit) {
+    e->reserved_dev_newer = true;
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    e->recs_valid = false;
+  }
   return KT_OK;
 }
 
 int32_t kt_fetch_reserved(kt_engine* e, int32_t n, const int32_t* rows, const kt_amounts* out) {
   if (!e || !out || n < 0 || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   for (int32_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->thr_rows_hi) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", rows[i]);
@@ -1844,17 +1943,102 @@ static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary
 
 int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return check_fetch_locked(e, n, out_summary, out_status);
+}
+
+// ---- the few-pod path: what the scheduler's PreFilter actually calls (one pod per call, plugin.go:148-215)
+static int32_t few_setup(kt_engine* e) {  // under the exclusive lock
+  if (e->few_ready) return KT_OK;
+  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));  // CheckRecs written so far carry no event: let them land
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+  KT_HIP(e, hipStreamCreateWithPriority(&e->small_stream, hipStreamNonBlocking, hi));
+  for (auto& ev : e->recs_ev) KT_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  KT_HIP(e, e->d_few_acc.reserve(8));
+  KT_HIP(e, e->d_few_ticket.reserve(4));
+  KT_HIP(e, hipMemsetAsync(e->d_few_acc.p, 0, 8 * 8, e->small_stream));
+  KT_HIP(e, hipMemsetAsync(e->d_few_ticket.p, 0, 4 * 4, e->small_stream));
+  KT_HIP(e, hipHostMalloc((void**)&e->h_few, 16 * 8, hipHostMallocMapped));
+  memset(e->h_few, 0, 16 * 8);
+  KT_HIP(e, hipStreamSynchronize(e->small_stream));
+  e->few_ready = true;
+  return KT_OK;
+}
+
+static inline bool few_shape_ok(const kt_engine* e, int64_t n, const int64_t* pod_rows, const uint64_t* out_summary, const uint8_t* out_status) {
+  static const bool disabled = getenv("KT_NO_FEW") != nullptr;  // A/B runs: every kt_check through the staged small launch
+  return !disabled && n >= 1 && n <= 8 && pod_rows && out_summary && !out_status && e->cfg.kernel_variant == 0;
+}
+
+// Under the SHARED lock (+ small_mu): nothing of the engine's host state is modified except the fields only this path
+// touches.  Returns 1 when served, 0 when the caller has to take the exclusive path, < 0 on error.
+static int32_t check_few_shared(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary) {
+  if (!e->few_ready || e->program_dirty || e->status_host_dirty || e->hindex.has_slow || e->dindex.n_slow != 0 || e->n_overflow != 0 ||
+      e->thr_rows_hi <= 0 || e->dindex.n_chunks == 0)
+    return 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (pod_rows[i] < 0 || pod_rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)pod_rows[i]);
+  // which generation of CheckRecs: the current one once the kernel that writes it has completed, else the previous one
+  int b;
+  bool wait_cur = false;
+  {
+    std::lock_guard<std::mutex> g(e->recs_mu);
+    if (!e->recs_valid || e->recs_eq != (on_equal != 0) || e->recs_DT != kt::dt_bucket_ix(e->D)) return 0;
+    b = e->recs_cur;
+    if (e->recs_ev_pending[b] && hipEventQuery(e->recs_ev[b]) == hipSuccess) e->recs_ev_pending[b] = false;
+    if (e->recs_ev_pending[b]) {
+      const int pb = 1 - b;
+      if (e->recs_prev_valid && e->recs_ev_pending[pb] && hipEventQuery(e->recs_ev[pb]) == hipSuccess) e->recs_ev_pending[pb] = false;
+      if (e->recs_prev_valid && !e->recs_ev_pending[pb]) b = pb;
+      else wait_cur = true;  // two reconciles in flight: wait for the newer one
+    }
+  }
+  if (wait_cur) KT_HIP(e, hipStreamWaitEvent(e->small_stream, e->recs_ev[b], 0));
+  const uint64_t seq = ++e->few_seq;
+  if (!kt::launch_check_few(e->pods, (int)n, pod_rows, e->sp, e->dindex, e->d_recs2[b].p, e->d_few_acc.p, e->d_few_ticket.p, e->h_few, e->h_few + 8,
+                            seq, e->small_stream))
+    return 0;
+  KT_HIP(e, hipGetLastError());
+  // the last workgroup writes the words and then the sequence number into pinned memory: spin on it
+  volatile uint64_t* seqp = (volatile uint64_t*)(e->h_few + 8);
+  bool done = false;
+  for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+    if (*seqp == seq) {
+      done = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!done) {  // far beyond any plausible latency: let the runtime report what happened
+    KT_HIP(e, hipStreamSynchronize(e->small_stream));
+    if (*seqp != seq) return e->fail(KT_ERR_DEVICE, "kt_check_few: no completion signal");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int64_t i = 0; i < n; ++i) out_summary[i] = e->h_few[i];
+  e->few_served.fetch_add(1, std::memory_order_relaxed);
+  return 1;
 }
 
 // launch + fetch as ONE critical section: what a caller needs when other threads use the engine at the same time
 // (Unreserve from binding goroutines, reconcile workers) — a kt_check_launch / kt_check_fetch pair can be interleaved
 int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary, uint8_t* out_status) {
   if (!e || n < 0) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  const bool few = few_shape_ok(e, n, pod_rows, out_summary, out_status);
+  if (few) {
+    std::shared_lock<std::shared_mutex> rd(e->mu);
+    std::lock_guard<std::mutex> sl(e->small_mu);
+    KT_HIP(e, hipSetDevice(e->device));
+    const int32_t rc = check_few_shared(e, n, pod_rows, on_equal, out_summary);
+    if (rc != 0) return rc < 0 ? rc : KT_OK;
+  }
+  LaunchLock lk(e, few && !e->few_ready);  // the one-time set-up of the few-pod path changes what those checks read
   KT_HIP(e, hipSetDevice(e->device));
+  if (few && !e->few_ready) {
+    int32_t rc0 = few_setup(e);
+    if (rc0 != KT_OK) return rc0;
+  }
   int32_t rc = check_launch_locked(e, n, pod_rows, on_equal, out_status ? KT_CHECK_STATUS_MATRIX : 0u, e->own_stream);
   if (rc != KT_OK) return rc;
   return check_fetch_locked(e, n, out_summary, out_status);
@@ -1876,14 +2060,14 @@ static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary
 
 int32_t kt_throttle_rows(kt_engine* e, int32_t* out_rows) {
   if (!e || !out_rows) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   *out_rows = e->thr_rows_hi;
   return KT_OK;
 }
 
 int32_t kt_check_device_summary(kt_engine* e, void** device_ptr) {
   if (!e || !device_ptr) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   if (!e->check_ready) return e->fail(KT_ERR_NOT_READY, "no check launched yet");
   *device_ptr = e->d_summary.p;
   return KT_OK;
@@ -1891,7 +2075,7 @@ int32_t kt_check_device_summary(kt_engine* e, void** device_ptr) {
 
 int32_t kt_fetch_pod_requests(kt_engine* e, int64_t n, const int64_t* pod_rows, int64_t* out_v, uint32_t* out_present) {
   if (!e || n < 0 || !out_v || !out_present) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (n == 0) return KT_OK;
   if (!pod_rows && n > e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "n > pod_capacity");
@@ -1919,14 +2103,14 @@ int32_t kt_fetch_pod_requests(kt_engine* e, int64_t n, const int64_t* pod_rows, 
 // ---------------------------------------------------------------------------------------------------
 int32_t kt_timing_enable(kt_engine* e, int32_t on) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   e->timing = on != 0;
   return KT_OK;
 }
 
 int32_t kt_timing_reset(kt_engine* e) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   for (auto& f : e->fam) f.used = 0;
@@ -1935,7 +2119,7 @@ int32_t kt_timing_reset(kt_engine* e) {
 
 int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* launches) {
   if (!e || kernel < 0 || kernel >= KT_KERNEL_COUNT || !total_ms || !launches) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   double tot = 0;
@@ -1952,10 +2136,18 @@ int32_t kt_timing_read(kt_engine* e, int32_t kernel, double* total_ms, int64_t* 
 
 int32_t kt_synchronize(kt_engine* e, void* stream) {
   if (!e) return KT_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
+  LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   KT_HIP(e, hipStreamSynchronize(pick_stream(e, stream)));
   return KT_OK;
+}
+
+int64_t kt_counter(kt_engine* e, int32_t which) {
+  if (!e) return -1;
+  switch (which) {
+    case KT_COUNTER_FEW_CHECKS: return e->few_served.load(std::memory_order_relaxed);
+    default: return -1;
+  }
 }
 
 const char* kt_kernel_name(kt_engine* e, int32_t kernel) {

@@ -226,6 +226,11 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,
                           const CheckByNs* by_ns = nullptr);
+// PreFilter of n <= 8 pods without staging, copies or a stream synchronisation (kt_kernels_few.hip): one wave per index
+// chunk, summaries + sequence number to pinned host memory.  false: not dispatched (slow-list throttles; the caller
+// also keeps programs with `slow` term shapes and overflow pods away).
+bool launch_check_few(const PodTable& pods, int n, const int64_t* rows_host, const SelProgram& sp, const IndexDev& ix, const void* recs,
+                      unsigned long long* acc, uint32_t* ticket, uint64_t* host_summary, uint64_t* host_seq, uint64_t seq, hipStream_t s);
 // by_ns: rows_dev lists ALL n pod rows ordered by namespace (launch_order_rows_by_ns); summary / status are then
 // indexed by POD ROW (as a launch without a row list would), the scan runs in namespace order
 // labels -> atom ids for pod rows [row0, row0+n) or rows[0..n) (after ingest / after a program change)

@@ -35,7 +35,7 @@ EXPORTS = [
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
-    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world",
+    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
         L.kt_comm_allreduce_partial.argtypes = [C.c_void_p, C.c_void_p]
         L.kt_comm_destroy.argtypes = [C.c_void_p]
         L.kt_set_exchange_world.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_counter.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_counter.restype = C.c_int64
         L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.kt_fetch_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -272,6 +274,10 @@ class Engine:
     def comm_destroy(self):
         self._ck(lib().kt_comm_destroy(self._h))
 
+    def few_checks_served(self) -> int:
+        """kt_check calls that took the few-pod path (kt_kernels_few.hip) so far."""
+        return int(lib().kt_counter(self._h, 0))
+
     def set_exchange_world(self, world: int):
         """Ranks whose partials the CALLER sums with its own collective (kt_comm_init declares it by itself)."""
         self._ck(lib().kt_set_exchange_world(self._h, world))
@@ -332,6 +338,20 @@ class Engine:
         self._ck(lib().kt_check(self._h, n, p, int(on_equal), summary.ctypes.data,
                                 None if status is None else status.ctypes.data))
         return (None if status is None else status[:n, :T]), summary[:n]
+
+    def checker(self, n: int, on_equal=False):
+        """Pre-bound kt_check(n pods, summaries only) for latency-sensitive callers: (rows, summary, call) — fill rows[:],
+        call(), read summary[:]; no per-call allocation or argument marshalling beyond the foreign call itself."""
+        rows = np.zeros(n, np.int64)
+        summary = np.zeros(n, np.uint64)
+        fn, h = lib().kt_check, self._h
+        rp, sp, eq = C.c_void_p(rows.ctypes.data), C.c_void_p(summary.ctypes.data), int(on_equal)
+
+        def call():
+            rc = fn(h, n, rp, eq, sp, None)
+            if rc != KT_OK:
+                self._ck(rc)
+        return rows, summary, call
 
     # ---- sequential admission with reservation (N1): results are read like a check's
     def admit(self, rows=None, n=None, on_equal=False, commit=False, want_status=True):

@@ -348,6 +348,7 @@ struct KubeThrottler::Impl {
   // reserved cache: throttle row -> pod key -> amount of the pod (reserved_resource_amounts.go:32-41)
   std::map<int32_t, std::map<std::string, DenseAmount>> reserved;
   std::vector<uint8_t> last_status;
+  int64_t last_row_pending = -1;  // pod row whose status row LastStatusOf still has to fetch (PreFilter allowed it on the summary)
 
   uint32_t key_id(const std::string& k) { return key_ids.emplace(k, (uint32_t)key_ids.size() + 1).first->second; }
   uint32_t pair_id(const std::string& k, const std::string& v) {
@@ -778,15 +779,22 @@ const char* status_name(uint8_t s) {
 }
 }  // namespace
 
+// row_always: the caller needs the status row even of an allowed pod (Reserve: which throttles the pod affects)
 static bool check_one(KubeThrottler::Impl& p, const Pod& pod, KubeThrottler* self, std::vector<uint8_t>* row_out,
-                      uint64_t* summary, std::string* err) {
+                      uint64_t* summary, std::string* err, bool row_always = true) {
   if (!self->OnPodAdd(pod, err)) return false;  // the engine evaluates what the informer cache would hold
   const int64_t row = p.pod_rows.find(pod.Key());
   int32_t T = 0;
   kt_throttle_rows(p.e, &T);
   row_out->assign((size_t)std::max(T, 1), 0);
-  // kt_check: launch + fetch under ONE engine lock (another thread's check cannot slip in between the two)
-  int32_t rc = kt_check(p.e, 1, &row, /*isThrottledOnEqual=*/0, summary, row_out->data());
+  // the verdict first: one pod, summary word only = the engine's few-pod path (no copy, no stream synchronisation, not
+  // queued behind a running reconcile); the status row is only needed to word the reasons of a pod that is not allowed
+  int32_t rc = row_always ? KT_OK : kt_check(p.e, 1, &row, /*isThrottledOnEqual=*/0, summary, nullptr);
+  p.last_row_pending = -1;
+  if (rc == KT_OK && (row_always || *summary != 0))  // blocked or Error: launch + fetch of the row under ONE engine lock
+    rc = kt_check(p.e, 1, &row, /*isThrottledOnEqual=*/0, summary, row_out->data());
+  else if (rc == KT_OK && row_out == &p.last_status)
+    p.last_row_pending = row;
   if (rc != KT_OK) {
     if (err) *err = p.engine_error(rc);
     return false;
@@ -835,7 +843,7 @@ Status KubeThrottler::PreFilter(const Pod& pod) {
   Status st;
   uint64_t summary = 0;
   std::string err;
-  if (!check_one(p, pod, this, &p.last_status, &summary, &err)) {
+  if (!check_one(p, pod, this, &p.last_status, &summary, &err, /*row_always=*/false)) {
     st.code = Error;
     st.reasons.push_back(err);
     return st;
@@ -855,6 +863,16 @@ Status KubeThrottler::PreFilter(const Pod& pod) {
 std::string KubeThrottler::LastStatusOf(const std::string& throttle_key) const {
   std::lock_guard<std::recursive_mutex> lk(p_->mu);
   auto& p = *p_;
+  if (p.last_row_pending >= 0) {  // the last PreFilter allowed the pod on the summary word alone: fetch its row now
+    uint64_t summary = 0;
+    int64_t row = p.last_row_pending;
+    int32_t T = 0;
+    kt_throttle_rows(p.e, &T);
+    p.last_status.assign((size_t)std::max(T, 1), 0);
+    if (kt_check(p.e, 1, &row, 0, &summary, p.last_status.data()) != KT_OK) p.last_status.assign(p.last_status.size(), 0);
+    p.last_status.resize((size_t)T);
+    p.last_row_pending = -1;
+  }
   for (size_t t = 0; t < p.last_status.size(); ++t)
     if (p.thr_live[t] && p.thr_by_row[t].Key() == throttle_key) return status_name(p.last_status[t]);
   return "";
@@ -867,7 +885,7 @@ Status KubeThrottler::Reserve(const Pod& pod) {
   std::vector<uint8_t> row;
   uint64_t summary = 0;
   std::string err;
-  if (!check_one(p, pod, this, &row, &summary, &err) || KT_SUMMARY_VERDICT(summary) == KT_VERDICT_ERROR) {
+  if (!check_one(p, pod, this, &row, &summary, &err, /*row_always=*/true) || KT_SUMMARY_VERDICT(summary) == KT_VERDICT_ERROR) {
     st.code = Error;  // plugin.go:223-233
     st.reasons.push_back("Failed to reserve pod=" + pod.Key() + (err.empty() ? "" : ": " + err));
     return st;

