@@ -159,6 +159,9 @@ struct kt_engine {
   kt::PodTable pods{};
   int64_t pod_rows_hi = 0;             // 1 + highest row ever upserted
   unsigned __int128 max_abs[KT_MAX_DIMS] = {0};  // max |effective request| bound per dimension
+  uint64_t or_abs[KT_MAX_DIMS] = {0};            // OR of every |request| fed: its trailing zero bits are common to all of them
+  kt::PackPlan pack;                             // packed fold of the current scan view (nw == 0: plain fold)
+  DevBuf<uint64_t> d_vc_pk;                      // packed request words of the countable list, scan order
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
   unsigned long long n_overflow = 0;
@@ -893,7 +896,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_countable.release();
   e->d_order_all.release();
   e->d_vc_meta.release(); e->d_va_meta.release(); e->d_carry.release();
-  e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release();
+  e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release(); e->d_vc_pk.release();
   e->d_ns_cursor.release();
   e->d_slab_tag.release();
   e->d_row_mask.release();
@@ -993,12 +996,14 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       for (int d = 0; d < D; ++d)
         if ((b->ctr_present[k] >> d) & 1u) {
           sum[d] += uabs(b->ctr_req[(size_t)k * D + d]);
+          e->or_abs[d] |= (uint64_t)uabs(b->ctr_req[(size_t)k * D + d]);
           if (b->ctr_req[(size_t)k * D + d] < 0) e->neg_seen = true;
         }
     if (b->pod_ovh_present[i] >> 31)
       for (int d = 0; d < D; ++d)
         if ((b->pod_ovh_present[i] >> d) & 1u) {
           sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
+          e->or_abs[d] |= (uint64_t)uabs(b->pod_ovh[(size_t)i * D + d]);
           if (b->pod_ovh[(size_t)i * D + d] < 0) e->neg_seen = true;
         }
     for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]), batch_total[d] += sum[d];
@@ -1402,6 +1407,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   e->pod_ns_hi = 0;
   e->neg_seen = false;
   for (auto& m : e->max_abs) m = 0;
+  for (auto& m : e->or_abs) m = 0;
   for (auto& n : e->ns) n = HostNamespace();
   for (auto& t : e->thr) t = HostThrottle();
   e->ns_rows_hi = 0;
@@ -1480,7 +1486,7 @@ static bool getenv_flag(const char* name) {
 // every aggregate launch gets an epoch; a workgroup stamps the slabs it spills with it (kt_reduce_bitmap_slabs then
 // leaves alone what a namespace-ordered scan did not write)
 static int32_t slab_tags(kt_engine* e, kt::AggScan& sc, hipStream_t s) {
-  const size_t need = (size_t)e->dindex.n_chunks * 256 + 1;
+  const size_t need = (size_t)e->dindex.n_chunks * kt::kSlabTagStride + 1;
   if (e->d_slab_tag.cap < need) {
     if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
     KT_HIP(e, e->d_slab_tag.reserve(need));
@@ -1554,14 +1560,24 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
+    e->pack = kt::PackPlan();
     if (!getenv_flag("KT_NO_SCAN_VIEW")) {
       // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
       // (namespace order for a multi-chunk index, ascending rows otherwise)
       const size_t nc = (size_t)e->n_countable + 1;
+      // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
+      // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
+      if (!e->incremental && !getenv_flag("KT_NO_PACK")) {
+        const uint64_t slab_pods = kt::aggregate_slab_pods((int64_t)e->n_countable, kt::aggregate_blocks((int64_t)e->n_countable, false));
+        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, !getenv_flag("KT_PK_NOPAD"));
+        if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
+      }
       KT_HIP(e, e->d_vc_meta.reserve(nc));
       KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
-      KT_HIP(e, e->d_vc_req.reserve(nc * (size_t)e->pods.DS));
-      kt::launch_build_scan_view(e->pods, (int64_t)e->n_countable, e->d_countable.p, e->d_vc_meta.p, e->d_vc_latom.p, e->d_vc_req.p, s);
+      if (e->pack.nw) KT_HIP(e, e->d_vc_pk.reserve(nc * (size_t)e->pack.stride));
+      else KT_HIP(e, e->d_vc_req.reserve(nc * (size_t)e->pods.DS));
+      kt::launch_build_scan_view(e->pods, (int64_t)e->n_countable, e->d_countable.p, e->d_vc_meta.p, e->d_vc_latom.p,
+                                 e->pack.nw ? nullptr : e->d_vc_req.p, s, e->pack.nw ? &e->pack : nullptr, e->d_vc_pk.p);
       KT_HIP(e, hipGetLastError());
     }
     e->countable_valid = true;
@@ -1584,7 +1600,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       sc.overflow_pods = e->n_overflow != 0;
       // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
       sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
-      if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->d_vc_req.p;
+      if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
+      if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
       if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");

@@ -482,7 +482,8 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
     }
     ch.img_off = (uint32_t)img0, ch.img_bytes = (uint32_t)o;
     ch.slab_off = (uint32_t)(slab_run / 16);  // one table per (chunk, workgroup), 256 workgroups at most
-    slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull);
+    // ... or 512 workgroups with packed records of half the size (PackPlan): their rounding to 16 bytes needs the slack
+    slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull) + 8192ull;
     out.bm_max_lds = std::max(out.bm_max_lds, ch.lds_bytes);
     out.bm_max_thr = std::max(out.bm_max_thr, ch.n_thr);
     out.bm_max_words = std::max(out.bm_max_words, ch.n_words);
@@ -542,6 +543,34 @@ void release_index(IndexDev& d) {
   if (d.bm_chunk_ns) (void)hipFree(d.bm_chunk_ns);
   if (d.atom_table) (void)hipFree(d.atom_table);
   d = IndexDev();
+}
+
+PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd) {
+  PackPlan pk;
+  if (neg_seen || D < 1 || D > 16 || n_slab_pods == 0) return pk;
+  auto bitlen = [](unsigned __int128 x) { int b = 0; while (x) ++b, x >>= 1; return b; };
+  uint32_t fill[4] = {0, 0, 0, 0};
+  pk.cnt_width = (uint8_t)bitlen(n_slab_pods);
+  fill[0] = pk.cnt_width;
+  uint32_t nw = 1;
+  for (int d = 0; d < D; ++d) {
+    if (max_abs[d] == 0) continue;  // no pod carries a non-zero value here: no field
+    const int sh = or_abs[d] ? __builtin_ctzll(or_abs[d]) : 0;
+    const int w = bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods);
+    if (w > 64) return PackPlan();
+    int k = 0;
+    while (k < 4 && fill[k] + (uint32_t)w > 64u) ++k;
+    if (k == 4) return PackPlan();
+    pk.word[d] = (uint8_t)k, pk.pos[d] = (uint8_t)fill[k], pk.width[d] = (uint8_t)w, pk.shift[d] = (uint8_t)sh;
+    fill[k] += (uint32_t)w;
+    nw = std::max(nw, (uint32_t)k + 1u);
+  }
+  pk.nw = nw;
+  pk.stride = nw <= 2 ? 2u : 4u;
+  uint32_t units = nw + 1u;
+  if (pad_odd && !(units & 1u)) ++units;
+  pk.rec_bytes = units * 8u;
+  return pk;
 }
 
 }  // namespace kt

@@ -133,6 +133,26 @@ __host__ __device__ inline uint32_t agg_rec_bytes(int D, bool counts) {
   return (uint32_t)(((size_t)D * 8 + (counts ? (size_t)D * 4 + 4 : 8) + 15) & ~(size_t)15);
 }
 
+// Packed request words (round 3).  The aggregate's fold costs one LDS atomic INSTRUCTION per non-zero dimension and match
+// whatever the number of active lanes (4.8 ns each per CU: `profiles/r02_lds_atomics_microbench.txt`), and that is what
+// bounds it on dense programs.  When no pod carries a negative request, a pod's contribution to a throttle is D small
+// non-negative numbers and a count of one; per launch the host proves how large the sum of any field over the pods ONE
+// workgroup scans can get (largest request >> common trailing zero bits, times the pods per workgroup) and lays the
+// fields out in 1..4 64-bit words: the pod's words are built once (kt_build_scan_view), the fold adds whole words — the
+// pod count and the two everyday resources (cpu, memory) normally share word 0, so a match costs ONE atomic — and the
+// slab reduction takes the fields apart again.  No field can carry into its neighbour: sum <= n_slab_pods * max < 2^width.
+struct PackPlan {
+  uint32_t nw = 0;         // 64-bit words per pod; 0: the requests of this engine do not pack (negative values, > 4 words)
+  uint32_t stride = 0;     // words per pod in the scan view (2 or 4: whole 16-byte loads)
+  uint32_t rec_bytes = 0;  // record of the LDS table / slab: nw words, then one word whose low half is the OR of the
+                           // request-key masks of pods that carry a key with the value 0 (+ padding)
+  uint8_t word[16] = {0}, pos[16] = {0}, width[16] = {0}, shift[16] = {0};
+  uint8_t cnt_width = 0;   // the pod count sits in word 0 from bit 0
+};
+// or_abs[d]: OR of every |request| fed for dimension d (its trailing zeros are common to all of them);
+// pad_odd: pad the record to an odd number of 8-byte words (LDS bank spread) instead of the smallest size
+PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd);
+
 // slot of an atom in an open-addressing table of 2^k entries (linear probing)
 __host__ __device__ inline uint32_t atom_slot(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 7) & mask; }
 
@@ -198,9 +218,16 @@ struct AggScan {
   const uint64_t* v_meta = nullptr;   // by_ns: scan-ordered copies of the listed pods' meta words, atom rows and request
   const uint16_t* v_latom = nullptr;  //        rows (launch_build_scan_view) — record j belongs to pod rows[j]
   const int64_t* v_req = nullptr;
-  uint32_t* slab_tag = nullptr;  // [chunks][256] epoch of the last launch that spilled this (chunk, workgroup) slab
+  uint32_t* slab_tag = nullptr;  // [chunks][kSlabTagStride] epoch of the last launch that spilled this (chunk, workgroup) slab
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
+  const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
+  const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
 };
+constexpr uint32_t kSlabTagStride = 512;  // workgroups an aggregate launch may have (two per CU)
+// workgroups of an aggregate launch over n listed pods, and the most pods one of them scans (the packed fields are sized
+// for it)
+int aggregate_blocks(int64_t n_rows, bool two_per_cu);
+uint64_t aggregate_slab_pods(int64_t n_rows, int blocks);
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
 // does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued
 // and before the slab reduction kernel — the engine uses it to bracket the two kernels with separate timing events.

@@ -316,7 +316,7 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
 // a tile reads 64 consecutive records instead of gathering them through the row list on every chunk visit:
 // meta word, atom row, and (aggregate view) the request row of every listed pod.
 __global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t n, const int64_t* rows, uint64_t* v_meta,
-                                                         uint16_t* v_latom, int64_t* v_req) {
+                                                         uint16_t* v_latom, int64_t* v_req, const PackPlan pk, uint64_t* v_pk) {
   const int LA = pods.LA, DS = pods.DS;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
     const int64_t p = rows[j];
@@ -329,12 +329,27 @@ __global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t
       u128* rd = (u128*)(v_req + j * DS);
       for (int q = 0; q < DS / 2; ++q) rd[q] = rs[q];
     }
+    if (v_pk) {
+      // ResourceAmountOfPod as packed words (PackPlan, kt_index.h): pod count 1 from bit 0 of word 0, every non-zero
+      // request as its field; the plan proved that no value of this engine needs more bits than its field has
+      uint64_t w[4] = {1ull, 0ull, 0ull, 0ull};
+      for (int d = 0; d < pods.D; ++d) {
+        const uint64_t f = (uint64_t)pods.req[p * DS + d] >> pk.shift[d];
+        const uint64_t piece = pk.width[d] ? f << pk.pos[d] : 0ull;
+        const uint32_t k = pk.word[d];
+        w[0] |= k == 0u ? piece : 0ull, w[1] |= k == 1u ? piece : 0ull, w[2] |= k == 2u ? piece : 0ull, w[3] |= k == 3u ? piece : 0ull;
+      }
+      uint64_t* o = v_pk + j * pk.stride;
+      o[0] = w[0], o[1] = w[1];
+      if (pk.stride > 2u) o[2] = w[2], o[3] = w[3];
+    }
   }
 }
 void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
-                            int64_t* v_req, hipStream_t s) {
+                            int64_t* v_req, hipStream_t s, const PackPlan* pk, uint64_t* v_pk) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(kt_build_scan_view, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, pods, n, rows, v_meta, v_latom, v_req);
+  hipLaunchKernelGGL(kt_build_scan_view, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, pods, n, rows, v_meta, v_latom, v_req,
+                     pk ? *pk : PackPlan(), pk ? v_pk : nullptr);
 }
 
 // kt_sum_abs_requests — sum over the valid pod rows of |effective request| per dimension, exactly (two 32-bit limb sums

@@ -32,8 +32,10 @@ struct BmAggArgs {
   const uint64_t* v_meta;  // namespace order (ix.by_ns): scan-ordered copies, record j belongs to pod rows[j]
   const uint16_t* v_latom;
   const int64_t* v_req;
-  uint32_t* slab_tag;    // [chunks][256]: epoch of the launch that last spilled the (chunk, workgroup) slab
+  uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
+  PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
+  const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
 };
 
 static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const SelProgram& sp, const SelProgram* sp_dev,
@@ -45,12 +47,14 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   a.slab_tag = sc.slab_tag, a.epoch = sc.epoch;
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
+  const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
+  if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
-  a.off_tab = take(agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
+  a.off_tab = take(packed ? ix.bm_max_thr * a.pk.rec_bytes : agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
   plan_bitmap_index(ix, a.ix, take);
-  a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && sc.v_req) ? 1u : 0u;
+  a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && (sc.v_req || packed)) ? 1u : 0u;
   *total = o;
   return a;
 }
@@ -65,8 +69,13 @@ uint32_t aggregate_fixed_lds() { return 64; }
 // of the LDS table (v i64[D] | presence mask u32 | pods u32) for every term scan_tile reports (ds_add_u64 per non-zero dimension) — then the table is spilled to this
 // (chunk, workgroup)'s slab; kt_reduce_bitmap_slabs sums the slabs into the partial buffer.
 // No global atomics except for throttles with unconvertible selectors (the "slow" list).
-template <int DT, int LA, bool VETO, int NEED>
-__global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
+// PK: the packed fold — the lane holds its pod's contribution as 1..4 packed words (PackPlan) and adds whole words: one
+//     ds_add_u64 where the plain fold issues one per non-zero dimension plus the pod count; the record is nw words + the
+//     OR of the key masks of pods that carry a key with the value 0.  Full scans over the scan view only (no counts mode,
+//     no negative requests, sign +1).
+// WPE: waves per SIMD the register allocation leaves room for (8: two workgroups per CU when two LDS footprints fit)
+template <int DT, int LA, bool VETO, int NEED, bool PK, int WPE>
+__global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const int pstride = partial_stride(D);
@@ -94,8 +103,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
     const BmChunk ch = a.ix.chunks[ci];
     const uint32_t n_thr = ch.n_thr;
-    const uint32_t tab_bytes = agg_tab_bytes(n_thr, D, counts);
-    const uint32_t rec = agg_rec_bytes(D, counts);
+    const uint32_t rec = PK ? a.pk.rec_bytes : agg_rec_bytes(D, counts);
+    const uint32_t tab_bytes = (n_thr * rec + 15u) & ~15u;
     KT_LDS unsigned char* tab = lds + a.off_tab;
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
@@ -123,11 +132,27 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
       // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
       const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
-      // ResourceAmountOfPod: the request row, for counted pods only (exec-masked 128-bit loads)
-      int64_t v[DT];
+      // ResourceAmountOfPod: the request row (or its packed words), for counted pods only (exec-masked 128-bit loads)
+      int64_t v[DT];             // plain fold (dead in the PK instantiations)
+      unsigned long long pw[4];  // packed fold (dead in the others)
 #pragma unroll
       for (int d = 0; d < DT; ++d) v[d] = 0;
-      if (counted) load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : p, v);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pw[k] = 0ull;
+      if constexpr (!PK) {
+        if (counted) load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : p, v);
+      } else {
+        if (counted) {
+          const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
+          const u64x2 q0 = q[0];
+          pw[0] = q0.x, pw[1] = q0.y;
+          if (a.pk.stride > 2u) {
+            const u64x2 q1 = q[1];
+            pw[2] = q1.x, pw[3] = q1.y;
+          }
+        }
+      }
+      const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
       uint32_t ro[LA];
       atom_row_offsets<LA>(raw, bm.row_bytes, ro);
 
@@ -170,6 +195,13 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
               last_r = r;
               KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
               lds_u64wp tv = (lds_u64wp)rp;
+              if constexpr (PK) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (pw[k] != 0ull) lds_add64(tv + k, pw[k]);  // words past pk.nw hold 0
+                if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+              }
               lds_u32wp tu = (lds_u32wp)(rp + (uint32_t)D * 8);
 #pragma unroll
               for (int d = 0; d < DT; ++d)
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
     lds_u4p src = (lds_u4p)(lds + a.off_tab);
     for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
-    if (threadIdx.x == 0) a.slab_tag[ci * 256u + blockIdx.x] = a.epoch;  // the reduction skips slabs this launch left alone
+    if (threadIdx.x == 0) a.slab_tag[ci * kSlabTagStride + blockIdx.x] = a.epoch;  // the reduction skips slabs this launch left alone
   }
 }
 
@@ -230,7 +262,7 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
   unsigned long long acc[4] = {0, 0, 0, 0};
   const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)(in ? pi : 0u) * 16;
   const int step = G * kSlabSplits;
-  const uint32_t* tag = slab_tag + blockIdx.y * 256u;
+  const uint32_t* tag = slab_tag + blockIdx.y * kSlabTagStride;
 #pragma unroll 8
   for (int b = (int)(blockIdx.z * G + g); b < n_slabs; b += step) {
     if (tag[b] != epoch) continue;  // that workgroup had no pods for this chunk (namespace-ordered scans)
@@ -274,16 +306,100 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
   }
 }
 
+// kt_reduce_packed_slabs — the same for slabs of PACKED records (PackPlan).  One WAVE per record, lane = slab: every lane
+// takes the record of its workgroups' slabs apart into its fields (the pod count, one per dimension) in 64-bit
+// accumulators, the wave adds them up across its lanes, and lane 0 adds the sums to the partial buffer — a dozen atomics
+// per record (several groups of one throttle meet there), no cross-block reduction, every CU streaming.
+// check_tags = 0: every workgroup spilled every chunk (single-chunk programs) — no tag reads.
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    v += (unsigned long long)lo | (unsigned long long)hi << 32;
+  }
+  return v;
+}
+constexpr int kPackedWaves = 4;  // records per block
+__global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(const unsigned char* slab, const BmChunk* chunks, const uint32_t* rank_t,
+                                                                           int n_slabs, int D, const PackPlan pk, const uint32_t* slab_tag, uint32_t epoch,
+                                                                           int check_tags, unsigned long long* partial) {
+  const BmChunk ch = chunks[blockIdx.y];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t r = blockIdx.x * kPackedWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (r >= ch.n_thr) return;  // wave-uniform
+  const uint32_t rec = pk.rec_bytes, nw = pk.nw;
+  const size_t pitch = ((size_t)ch.n_thr * rec + 15u) & ~(size_t)15u;
+  const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)r * rec;
+  const uint32_t* tag = slab_tag + blockIdx.y * kSlabTagStride;
+  unsigned long long acc[16], pods = 0;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) acc[d] = 0ull;
+  uint32_t zero_keys = 0;
+  const unsigned long long cnt_mask = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
+  for (int b = (int)lane; b < n_slabs; b += 64) {
+    if (check_tags && tag[b] != epoch) continue;  // that workgroup had no pods for this chunk (namespace-ordered scans)
+    const unsigned long long* q = (const unsigned long long*)(base + (size_t)b * pitch);
+    const unsigned long long w0 = q[0];
+    if (w0 == 0ull) continue;  // nobody of that workgroup matched this throttle
+    const unsigned long long w1 = nw > 1u ? q[1] : 0ull, w2 = nw > 2u ? q[2] : 0ull, w3 = nw > 3u ? q[3] : 0ull;
+    zero_keys |= (uint32_t)q[nw];
+    pods += w0 & cnt_mask;
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+      if (d < D && pk.width[d]) {
+        const uint32_t k = pk.word[d];
+        const unsigned long long ww = k == 0u ? w0 : k == 1u ? w1 : k == 2u ? w2 : w3;
+        const unsigned long long m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
+        acc[d] += (ww >> pk.pos[d]) & m;
+      }
+  }
+  pods = wave_sum64(pods);
+  if (pods == 0ull) return;  // wave-uniform after the sum
+  uint32_t zk = zero_keys;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) zk |= (uint32_t)__shfl_xor((int)zk, o);
+  const int stride = partial_stride(D);
+  unsigned long long* prow = partial + (size_t)rank_t[ch.rank0 + r] * stride;
+  if (lane == 0) atomicAdd(prow + 2 * D, pods);
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+    if (d < D) {
+      const unsigned long long sum = pk.width[d] ? wave_sum64(acc[d]) : 0ull;
+      if (lane == 0) {
+        if (sum) atomicAdd(prow + d, sum << pk.shift[d]);
+        // key seen: a non-zero sum says so by itself (kt_finalize); a key only ever carried with the value 0 is marked here
+        if ((zk >> d) & 1u) atomicAdd(prow + D + d, 1ull);
+      }
+    }
+}
+
 #define KT_AGG_BM_CASE(DT_, LA_, VETO_, NEED_)                                                                \
   {                                                                                                           \
-    auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_>;                                                   \
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
-    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                      \
+    if (!packed) {                                                                                            \
+      auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_, false, 4>;                                       \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
+      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
+    } else if (two_per_cu) {                                                                                  \
+      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true, 8>;                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
+      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
+    } else {                                                                                                  \
+      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true, 4>;                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
+      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
+    }                                                                                                         \
   }
 
-static inline int agg_blocks(int64_t n_rows) {
+int aggregate_blocks(int64_t n_rows, bool two_per_cu) {
   int64_t b = (n_rows + kBlockIx - 1) / kBlockIx;
-  return (int)(b < 1 ? 1 : b > kCUs ? kCUs : b);
+  const int64_t cap = two_per_cu ? 2 * kCUs : kCUs;
+  return (int)(b < 1 ? 1 : b > cap ? cap : b);
+}
+// the most pods one workgroup of an aggregate launch scans: contiguous tile ranges (scan view) or a stride over the tiles
+uint64_t aggregate_slab_pods(int64_t n_rows, int blocks) {
+  const int64_t tiles = (n_rows + kWave - 1) / kWave;
+  const int64_t per_wg = (tiles + blocks - 1) / blocks + (kBlockIx / kWave);  // either assignment, rounded up generously
+  return (uint64_t)per_wg * kWave;
 }
 
 // `partial` must be zeroed by the caller.  Returns the dispatched scan kernel's symbol, nullptr when a chunk of the
@@ -295,14 +411,24 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   if (n_rows <= 0 || sp.T <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   unsigned char* slab = (unsigned char*)slab_;
-  const int nb = agg_blocks(n_rows);
-  dim3 g_(nb), b_(kBlockIx);
   uint32_t bm_total = 0;
-  const BmAggArgs bm_args = make_bm_agg_args(pods, sc, sp, sp_dev, ix, partial, slab, &bm_total);
+  BmAggArgs bm_args = make_bm_agg_args(pods, sc, sp, sp_dev, ix, partial, slab, &bm_total);
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
+  // the packed fold: full scans over the scan view, records no larger than the plain ones (the slab areas were sized for those)
+  const bool packed = bm_args.v_pk != nullptr && bm_args.ix.by_ns && !sc.counts && sc.sign == 1 && sc.nonneg &&
+                      bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false);
+  if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
+  static const int force_wgs = getenv("KT_AGG_WGS_PER_CU") ? atoi(getenv("KT_AGG_WGS_PER_CU")) : 0;  // A/B runs
+  // two workgroups per CU when two LDS footprints fit and the slab areas (sized for 256 plain records per chunk) hold 512 packed ones
+  const bool two_per_cu = packed && 2 * bm_total <= (uint32_t)kMaxLds && 2 * bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false) &&
+                          force_wgs == 2 && sc.n > (int64_t)kCUs * kBlockIx;  // measured (r03d): 33 vs 24 us at 1M x 1k — opt-in for A/B runs
+  const int nb = aggregate_blocks(n_rows, two_per_cu);
+  dim3 g_(nb), b_(kBlockIx);
   const size_t lds_bm = bm_total;
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
-  if (dbg_lds) fprintf(stderr, "kt_aggregate_bitmap: lds=%u chunks=%u largest LDS part=%u max thr=%u T=%d\n", bm_total, ix.n_chunks, ix.bm_max_lds, ix.bm_max_thr, sp.T);
+  if (dbg_lds)
+    fprintf(stderr, "kt_aggregate_bitmap: lds=%u (%d per CU) chunks=%u largest LDS part=%u max thr=%u T=%d packed=%d nw=%u rec=%u\n", bm_total,
+            two_per_cu ? 2 : 1, ix.n_chunks, ix.bm_max_lds, ix.bm_max_thr, sp.T, packed ? 1 : 0, bm_args.pk.nw, bm_args.pk.rec_bytes);
 #ifdef KT_FAST_BUILD
   KT_AGG_BM_CASE(8, 8, false, 2)
 #else
@@ -312,11 +438,18 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 3) else KT_AGG_BM_CASE(16, 32, true, 3) }
 #endif
   if (after_scan) after_scan();
-  const uint32_t max_pieces = ix.bm_max_thr * (agg_rec_bytes(pods.D, sc.counts) / 16u);
-  if (max_pieces > 0)
-    hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_pieces + 63) / 64, ix.n_chunks, kSlabSplits), dim3(256), 0, s, slab,
-                       ix.bm_chunks, ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, sc.slab_tag, sc.epoch, partial);
-  return ix.n_chunks == 1 ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_chunked";
+  if (packed) {
+    if (ix.bm_max_thr > 0)
+      hipLaunchKernelGGL(kt_reduce_packed_slabs, dim3((ix.bm_max_thr + kPackedWaves - 1) / kPackedWaves, ix.n_chunks), dim3(64 * kPackedWaves), 0, s, slab,
+                         ix.bm_chunks, ix.bm_rank_t, nb, pods.D, bm_args.pk, sc.slab_tag, sc.epoch, ix.n_chunks > 1 ? 1 : 0, partial);
+  } else {
+    const uint32_t max_pieces = ix.bm_max_thr * (agg_rec_bytes(pods.D, sc.counts) / 16u);
+    if (max_pieces > 0)
+      hipLaunchKernelGGL(kt_reduce_bitmap_slabs, dim3((max_pieces + 63) / 64, ix.n_chunks, kSlabSplits), dim3(256), 0, s, slab,
+                         ix.bm_chunks, ix.bm_rank_t, nb, pods.D, sc.counts ? 1 : 0, sc.sign, sc.slab_tag, sc.epoch, partial);
+  }
+  return packed ? (ix.n_chunks == 1 ? "kt_aggregate_bitmap_packed" : "kt_aggregate_bitmap_packed_chunked")
+                : (ix.n_chunks == 1 ? "kt_aggregate_bitmap" : "kt_aggregate_bitmap_chunked");
 }
 
 }  // namespace kt

@@ -34,8 +34,10 @@ void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows
 void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
                              int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
 // scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
+struct PackPlan;  // kt_index.h
+// pk + v_pk (nullable): also the packed request words of every listed pod
 void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
-                            int64_t* v_req, hipStream_t s);
+                            int64_t* v_req, hipStream_t s, const PackPlan* pk = nullptr, uint64_t* v_pk = nullptr);
 // exact per-dimension sums of |request| over the valid rows of [0, n): out[2d] low-half sum, out[2d+1] high-half sum (32 words)
 void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
