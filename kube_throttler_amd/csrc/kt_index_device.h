@@ -84,6 +84,67 @@ __device__ inline uint32_t walk_slow_mem(const SelProgram& sp, int t, const uint
   return res;
 }
 
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    v += (unsigned long long)lo | (unsigned long long)hi << 32;
+  }
+  return v;
+}
+
+// One record of the packed slabs (PackPlan) summed over the workgroups' slabs by ONE wave, lane = slab: every lane takes
+// the record of its slabs apart into fields (the pod count, one per dimension) in 64-bit accumulators — four slabs per
+// lane and trip with all their loads in flight — and the wave adds the accumulators up across its lanes.  On return every
+// lane holds the totals: pods, acc[d] in field units (value = acc[d] << pk.shift[d]), zero_keys = OR of the key masks of
+// pods that carry a key with the value 0.  check_tags = 0: every workgroup spilled this chunk (single-chunk programs).
+struct PackedSums {
+  unsigned long long acc[16], pods;
+  uint32_t zero_keys;
+};
+__device__ __forceinline__ void packed_record_sums(const unsigned char* base, size_t pitch, int n_slabs, const PackPlan& pk, int D,
+                                                   const uint32_t* tag, uint32_t epoch, int check_tags, uint32_t lane, PackedSums& o) {
+  const uint32_t nw = pk.nw;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) o.acc[d] = 0ull;
+  o.pods = 0ull, o.zero_keys = 0u;
+  const unsigned long long cnt_mask = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
+  for (int b0 = (int)lane; b0 < n_slabs; b0 += 256) {
+    bool on[4];
+    unsigned long long w[4][4];
+    uint32_t zk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = min(b0 + 64 * u, n_slabs - 1);
+      on[u] = b0 + 64 * u < n_slabs && (!check_tags || tag[b] == epoch);  // a stale slab is read and ignored
+      const unsigned long long* q = (const unsigned long long*)(base + (size_t)b * pitch);
+      w[u][0] = q[0], w[u][1] = q[nw > 1u ? 1 : 0], w[u][2] = q[nw > 2u ? 2 : 0], w[u][3] = q[nw > 3u ? 3 : 0];
+      zk[u] = (uint32_t)q[nw];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!on[u] || w[u][0] == 0ull) continue;  // nobody of that workgroup matched this throttle
+      o.pods += w[u][0] & cnt_mask;
+      o.zero_keys |= zk[u];
+#pragma unroll
+      for (int d = 0; d < 16; ++d)
+        if (d < D && pk.width[d]) {
+          const uint32_t k = pk.word[d];
+          const unsigned long long ww = k == 0u ? w[u][0] : k == 1u ? w[u][1] : k == 2u ? w[u][2] : w[u][3];
+          const unsigned long long m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
+          o.acc[d] += (ww >> pk.pos[d]) & m;
+        }
+    }
+  }
+  o.pods = wave_sum64(o.pods);
+  if (o.pods == 0ull) return;  // wave-uniform
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) o.zero_keys |= (uint32_t)__shfl_xor((int)o.zero_keys, s);
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+    if (d < D && pk.width[d]) o.acc[d] = wave_sum64(o.acc[d]);
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char kt_smem[];
 
 }  // namespace kt

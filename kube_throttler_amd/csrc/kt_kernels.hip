@@ -493,7 +493,15 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int6
 // (throttle_types.go:65-106, temporary_threshold_override.go:57-70), replace-only-if-changed
 // (throttle_controller.go:122-132, Semantic.DeepEqual by value) and
 // throttled = calculatedThreshold.IsThrottled(used, true) (:133, resource_amount.go:127-159).
-// One thread per throttle (T is 10^3..10^4: a few waves; latency-bound, negligible next to the scans).
+//
+// lane = (throttle, DIMENSION): a throttle is a group of DT consecutive lanes (8 throttles per wave at DT = 8), every
+// lane holds ONE dimension of every amount.  Rounds 1-2 ran one thread per throttle: every load and store of a wave then
+// touched 64 cache lines, and the D-unrolled logic was a 5 000-instruction serial stream per wave (13 us for 1000
+// throttles, all of it latency).  Here a group's lanes read one 64-byte row together, the per-dimension work (used,
+// first-wins override merge, changed-by-value, flags, the 128-bit headroom of the CheckRec) is one lane's scalar work,
+// and every per-throttle BITMASK (presence, flags, active / tight dimensions) is the group's slice of a wave ballot.
+// Per-throttle scalars (counts, flags, message fingerprints) are loaded by every lane of the group (one address: a
+// broadcast) and stored by the lane of dimension 0.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, int32_t bn) {
   return as != bs ? (as < bs ? -1 : 1) : (an != bn ? (an < bn ? -1 : 1) : 0);
@@ -506,84 +514,73 @@ __device__ __forceinline__ bool cmp_eq_sum(int64_t a0, int64_t a1, int64_t b, bo
   return eq ? a >= (__int128)b : a > (__int128)b;
 }
 
+// the DT-bit slice of a wave ballot that belongs to this lane's throttle: bit d = the predicate of dimension d.
+// Control flow is uniform within a group (all its lanes share the throttle), so a ballot taken inside a branch still
+// carries every lane of the groups that took it.
+template <int DT>
+__device__ __forceinline__ uint32_t group_bits(bool b) {
+  const uint32_t lane = threadIdx.x & 63u;
+  return (uint32_t)(__ballot(b) >> (lane & ~(uint32_t)(DT - 1))) & ((1u << DT) - 1u);
+}
+
 // Everything CheckThrottledFor needs that does not depend on the pod, folded into the throttle's CheckRec
-// (effective threshold, headroom, step-2/3 bitmask, count verdicts) — see DESIGN.md "Check algebra".
+// (effective threshold, headroom, step-2/3 bitmask, count verdicts) — see DESIGN.md "Check algebra".  This lane's
+// dimension d: th_v / u_v / r_v are ITS values, the masks and counts are the throttle's.
 // fl: the throttle's flags as stored AFTER this point (kThrCalcAtNonzero already decided the threshold passed in).
 template <int DT>
-__device__ __forceinline__ void build_check_rec(const ThrTables& tt, int t, int T, int D, uint32_t fl, const int64_t (&th_v)[DT],
-                                                uint32_t th_p, bool th_hc, int64_t th_c, const int64_t (&u_v)[DT], uint32_t u_p,
-                                                bool u_hc, int64_t u_c_, const int64_t (&r_v)[DT], uint32_t r_p, bool r_hc,
-                                                int64_t r_c_, uint32_t thrl_flag, uint32_t thrl_has, bool eq,
-                                                const ReqBound& vmax, CheckRec<DT>* recs) {
+__device__ __forceinline__ void build_check_rec(int t, int T, int D, int d, bool valid, uint32_t fl, int64_t th_v, uint32_t th_p, bool th_hc,
+                                                int64_t th_c, int64_t u_v, uint32_t u_p, bool u_hc, int64_t u_c_, int64_t r_v, uint32_t r_p,
+                                                bool r_hc, int64_t r_c_, uint32_t thrl_flag, uint32_t thrl_has, bool eq, const ReqBound& vmax,
+                                                CheckRec<DT>* recs) {
   const int64_t u_c = u_hc ? u_c_ : 0, r_c = r_hc ? r_c_ : 0;
   const bool eq3 = (fl & kThrCluster) ? eq : true;  // throttle_types.go:143 vs clusterthrottle_types.go:45
-  CheckRec<DT> rec;
   uint32_t f = 0;
   // step 1, counts: IsThrottled(podAmount{pod:1}, false).pod
   if (th_hc && 1 > th_c) f |= kRecExceedsByCount;
   // step 2: stored status.throttled ; step 3: IsThrottled(used + reserved, eq3)
-  uint32_t act_mask = thrl_flag & thrl_has;
   bool act_pod = (fl & kThrThrottledPod) != 0;
   if (th_hc && (u_hc || r_hc) && cmp_eq_sum(u_c, r_c, th_c, eq3)) act_pod = true;
   // step 4, counts: used + pod(1) + reserved always has counts
   if (th_hc && (eq ? (__int128)u_c + 1 + r_c >= (__int128)th_c : (__int128)u_c + 1 + r_c > (__int128)th_c)) f |= kRecInsufficientByCount;
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    int64_t thr = kInf, head = kInf;
-    if (d < D && ((th_p >> d) & 1u)) {
-      const int64_t tv = th_v[d];
-      const int64_t uv = ((u_p >> d) & 1u) ? u_v[d] : 0;
-      const int64_t rv = ((r_p >> d) & 1u) ? r_v[d] : 0;
-      if ((((u_p | r_p) >> d) & 1u) && cmp_eq_sum(uv, rv, tv, eq3)) act_mask |= 1u << d;
-      thr = tv;
-      __int128 h = (__int128)tv - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
-      head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
-    }
-    rec.thr[d] = thr;
-    rec.head[d] = head;
-    // could ANY pod of this engine exceed the threshold in this dimension — or the headroom, where that can still
-    // change the verdict (a pod that requests an already-active dimension is `active` whatever the headroom says)
-    if (d < D && (vmax.v[d] > thr || (!act_pod && !((act_mask >> d) & 1u) && vmax.v[d] > head))) f |= kRecTight;
+  int64_t thr = kInf, head = kInf;
+  bool act_d = false;
+  const bool in_d = valid && d < D;
+  if (in_d && ((th_p >> d) & 1u)) {
+    const int64_t uv = ((u_p >> d) & 1u) ? u_v : 0;
+    const int64_t rv = ((r_p >> d) & 1u) ? r_v : 0;
+    act_d = (((u_p | r_p) >> d) & 1u) && cmp_eq_sum(uv, rv, th_v, eq3);
+    thr = th_v;
+    const __int128 h = (__int128)th_v - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
+    head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
   }
+  const uint32_t act_mask = (thrl_flag & thrl_has) | group_bits<DT>(act_d);
+  // could ANY pod of this engine exceed the threshold in this dimension — or the headroom, where that can still
+  // change the verdict (a pod that requests an already-active dimension is `active` whatever the headroom says)
+  const int64_t vm = vmax.v[d < 16 ? d : 15];
+  const bool tight_d = in_d && (vm > thr || (!act_pod && !((act_mask >> d) & 1u) && vm > head));
+  if (group_bits<DT>(tight_d) != 0u) f |= kRecTight;
   if (act_pod) f |= kRecActiveByCount;
-  rec.flags = f;
-  rec.active_mask = act_mask;
-  recs[t] = rec;
-  rec_flags<DT>(recs, T)[t] = RecFlags{f, act_mask};
-}
-
-// the CheckRec of throttle t from the status as stored in the tables
-template <int DT>
-__device__ __forceinline__ void build_check_rec_stored(const ThrTables& tt, int t, int T, int D, bool eq, const ReqBound& vmax,
-                                                       CheckRec<DT>* recs) {
-  const uint32_t fl = tt.flags[t];
-  // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
-  const AmountTab& th = (fl & kThrCalcAtNonzero) ? tt.calc : tt.spec;
-  int64_t th_v[DT], u_v[DT], r_v[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    th_v[d] = d < D ? th.v[(size_t)t * D + d] : 0;
-    u_v[d] = d < D ? tt.used.v[(size_t)t * D + d] : 0;
-    r_v[d] = d < D ? tt.reserved.v[(size_t)t * D + d] : 0;
+  if (!valid) return;
+  recs[t].thr[d] = thr;
+  recs[t].head[d] = head;
+  if (d == 0) {
+    recs[t].flags = f;
+    recs[t].active_mask = act_mask;
+    rec_flags<DT>(recs, T)[t] = RecFlags{f, act_mask};
   }
-  build_check_rec<DT>(tt, t, T, D, fl, th_v, th.present[t], th.has_count[t] != 0, th.count[t], u_v, tt.used.present[t],
-                      tt.used.has_count[t] != 0, tt.used.count[t], r_v, tt.reserved.present[t],
-                      tt.reserved.has_count[t] != 0, tt.reserved.count[t], tt.thrl_flag[t], tt.thrl_has[t], eq, vmax, recs);
 }
 
-// Everything kt_finalize needs of one throttle's stored state, requested as ONE batch of independent loads (the
+// One throttle's stored state as the lane of dimension d sees it, requested as ONE batch of independent loads (the
 // kernel is a latency chain: every load that waits for a branch outcome is another round trip).
-template <int DT>
-struct ThrRegs {
+struct ThrLane {
   uint32_t fl, thrl_flag, thrl_has, ovr0, ovr1;
   uint64_t status_fp, spec_fp;
-  int64_t calc_v[DT], used_v[DT], spec_v[DT], res_v[DT];
+  int64_t calc_v, used_v, spec_v, res_v;  // this lane's dimension; 0 for padding dimensions
   uint32_t calc_p, used_p, spec_p, res_p;
   int64_t calc_c, used_c, spec_c, res_c;
   bool calc_hc, used_hc, spec_hc, res_hc;
 };
-template <int DT>
-__device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, ThrRegs<DT>& r) {
+__device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, int d, ThrLane& r) {
   r.fl = tt.flags[t], r.thrl_flag = tt.thrl_flag[t], r.thrl_has = tt.thrl_has[t];
   r.ovr0 = tt.ovr_off[t], r.ovr1 = tt.ovr_off[t + 1];
   r.status_fp = tt.status_msgs_fp[t], r.spec_fp = tt.spec_msgs_fp[t];
@@ -591,80 +588,72 @@ __device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, ThrR
   r.calc_c = tt.calc.count[t], r.used_c = tt.used.count[t], r.spec_c = tt.spec.count[t], r.res_c = tt.reserved.count[t];
   r.calc_hc = tt.calc.has_count[t] != 0, r.used_hc = tt.used.has_count[t] != 0, r.spec_hc = tt.spec.has_count[t] != 0,
   r.res_hc = tt.reserved.has_count[t] != 0;
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    const size_t i = (size_t)t * D + (d < D ? d : 0);
-    const int64_t c = tt.calc.v[i], u = tt.used.v[i], sp = tt.spec.v[i], rs = tt.reserved.v[i];
-    r.calc_v[d] = d < D ? c : 0, r.used_v[d] = d < D ? u : 0, r.spec_v[d] = d < D ? sp : 0, r.res_v[d] = d < D ? rs : 0;
-  }
+  const size_t i = (size_t)t * D + (d < D ? d : 0);
+  const int64_t c = tt.calc.v[i], u = tt.used.v[i], sp = tt.spec.v[i], rs = tt.reserved.v[i];
+  r.calc_v = d < D ? c : 0, r.used_v = d < D ? u : 0, r.spec_v = d < D ? sp : 0, r.res_v = d < D ? rs : 0;
 }
 
-// the CheckRec of throttle t from the stored status held in registers
+// the CheckRec of throttle t from the status as held in the lane registers (stored status unchanged)
 template <int DT>
-__device__ __forceinline__ void build_check_rec_regs(const ThrTables& tt, int t, int T, int D, const ThrRegs<DT>& r, bool eq,
-                                                     const ReqBound& vmax, CheckRec<DT>* recs) {
+__device__ __forceinline__ void build_check_rec_regs(int t, int T, int D, int d, bool valid, const ThrLane& r, bool eq, const ReqBound& vmax,
+                                                     CheckRec<DT>* recs) {
   // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
   const bool calc = (r.fl & kThrCalcAtNonzero) != 0;
-  int64_t th_v[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d) th_v[d] = calc ? r.calc_v[d] : r.spec_v[d];
-  build_check_rec<DT>(tt, t, T, D, r.fl, th_v, calc ? r.calc_p : r.spec_p, calc ? r.calc_hc : r.spec_hc, calc ? r.calc_c : r.spec_c,
-                      r.used_v, r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag, r.thrl_has, eq, vmax,
-                      recs);
+  build_check_rec<DT>(t, T, D, d, valid, r.fl, calc ? r.calc_v : r.spec_v, calc ? r.calc_p : r.spec_p, calc ? r.calc_hc : r.spec_hc,
+                      calc ? r.calc_c : r.spec_c, r.used_v, r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag,
+                      r.thrl_has, eq, vmax, recs);
 }
 
-// One throttle of kt_finalize.  pv / pc / pods / errs: its row of the partial buffer (values, per-key contributor
-// counts, pod count, error count).
+// One throttle of kt_finalize, the lane of dimension d.  pv / pc: its words of the partial row (value, per-key
+// contributor count); pods / errs: the row's pod count and error count.
 template <int DT>
-__device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, int T, int D, const ThrRegs<DT>& r,
-                                                  const unsigned long long (&pv)[DT], const unsigned long long (&pc)[DT],
-                                                  unsigned long long pods, unsigned long long errs, int64_t now_s, int32_t now_ns,
-                                                  int apply, const ReconcileOut& out, CheckRec<DT>* recs, int rec_eq,
-                                                  const ReqBound& vmax, bool selected = true) {
+__device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, int T, int D, int d, bool valid, const ThrLane& r,
+                                                  unsigned long long pv, unsigned long long pc, unsigned long long pods,
+                                                  unsigned long long errs, int64_t now_s, int32_t now_ns, int apply, const ReconcileOut& out,
+                                                  CheckRec<DT>* recs, int rec_eq, const ReqBound& vmax, bool selected) {
   // recs (nullable): also leave the CheckRec of the throttle for the check that follows (kt_prepare_check fused in:
   // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
   const uint32_t fl = r.fl;
+  const bool in_d = valid && d < D, lead = valid && d == 0;
+  const size_t vi = (size_t)t * D + (d < D ? d : 0);
   // selected = false: a reconcile of other keys (kt_reconcile_rows_launch) — this throttle keeps its stored status
   const bool live = selected && (fl & (kThrValid | kThrResponsible)) == (kThrValid | kThrResponsible);
   const bool error = live && errs != 0;
   if (!live || error) {  // the stored status is returned unchanged
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-      out.used.v[(size_t)t * D + d] = r.used_v[d];
-      out.calc.v[(size_t)t * D + d] = r.calc_v[d];
+    if (in_d) {
+      out.used.v[vi] = r.used_v;
+      out.calc.v[vi] = r.calc_v;
     }
-    out.used.present[t] = r.used_p;
-    out.used.count[t] = r.used_c;
-    out.used.has_count[t] = r.used_hc;
-    out.calc.present[t] = r.calc_p;
-    out.calc.count[t] = r.calc_c;
-    out.calc.has_count[t] = r.calc_hc;
-    out.calc_updated[t] = 0;
-    out.thrl_flag[t] = r.thrl_flag;
-    out.thrl_has[t] = r.thrl_has;
-    out.thrl_pod[t] = (fl & kThrThrottledPod) ? 1 : 0;
-    out.error[t] = error ? 1 : 0;
-    out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
-    out.next_ns[t] = 0;
-    if (recs) build_check_rec_regs<DT>(tt, t, T, D, r, rec_eq != 0, vmax, recs);
+    if (lead) {
+      out.used.present[t] = r.used_p;
+      out.used.count[t] = r.used_c;
+      out.used.has_count[t] = r.used_hc;
+      out.calc.present[t] = r.calc_p;
+      out.calc.count[t] = r.calc_c;
+      out.calc.has_count[t] = r.calc_hc;
+      out.calc_updated[t] = 0;
+      out.thrl_flag[t] = r.thrl_flag;
+      out.thrl_has[t] = r.thrl_has;
+      out.thrl_pod[t] = (fl & kThrThrottledPod) ? 1 : 0;
+      out.error[t] = error ? 1 : 0;
+      out.next_s[t] = INT64_MAX;  // reconcile returns before NextOverrideHappensIn (throttle_controller.go:103-111)
+      out.next_ns[t] = 0;
+    }
+    if (recs) build_check_rec_regs<DT>(t, T, D, d, valid, r, rec_eq != 0, vmax, recs);
     return;
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
-  int64_t u_v[DT];
-  uint32_t u_p = 0;
+  // a key is present when some counted pod carried it: the contributor count says so, and so does a non-zero sum
+  const bool u_pr = in_d && (pc != 0 || pv != 0);
+  const uint32_t u_p = group_bits<DT>(u_pr);
+  const int64_t u_v = u_pr ? (int64_t)pv : 0;
   const int64_t u_c = (int64_t)pods;
   const bool u_hc = u_c > 0;
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) {
-    // a key is present when some counted pod carried it: the contributor count says so, and so does a non-zero sum
-    const bool pr = d < D && (pc[d] != 0 || pv[d] != 0);
-    u_p |= (pr ? 1u : 0u) << d;
-    u_v[d] = pr ? (int64_t)pv[d] : 0;
-  }
   // ---- CalculateThreshold(now)
-  int64_t c_v[DT];
-  uint32_t c_p = 0;
+  int64_t c_v = 0;
+  bool c_pd = false;  // this dimension of the merged override
   bool c_hc = false, active_found = false, any_err = false;
   int64_t c_c = 0;
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = 0;
   // NextOverrideHappensIn (throttle_types.go:37-63): earliest begin / end instant strictly after now
   int64_t nx_s = INT64_MAX;
   int32_t nx_ns = 0;
@@ -679,8 +668,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
     const bool o_hc = tt.ovr_thr.has_count[o] != 0;
     const int64_t o_c = tt.ovr_thr.count[o];
     const uint32_t op = tt.ovr_thr.present[o];
-    int64_t o_v[DT];
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) o_v[d] = tt.ovr_thr.v[(size_t)o * D + (d < D ? d : 0)];
+    const int64_t o_v = tt.ovr_thr.v[(size_t)o * D + (d < D ? d : 0)];
     if (of & kOvrParseError) {
       any_err = true;
       if (of & kOvrBeginParsed) sooner(ob_s, ob_ns);  // only `end` is bad
@@ -697,106 +685,110 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
       c_hc = true;
       c_c = o_c;
     }
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
-      if (((op >> d) & 1u) && !((c_p >> d) & 1u)) {
-        c_p |= 1u << d;
-        c_v[d] = o_v[d];
-      }
+    if (in_d && ((op >> d) & 1u) && !c_pd) {
+      c_pd = true;
+      c_v = o_v;
+    }
   }
   if (!active_found) {  // no active override: spec.threshold; otherwise the merged override REPLACES it
-    c_p = r.spec_p;
+    c_pd = in_d && ((r.spec_p >> d) & 1u);
     c_hc = r.spec_hc;
     c_c = r.spec_c;
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = ((c_p >> d) & 1u) ? r.spec_v[d] : 0;
+    c_v = c_pd ? r.spec_v : 0;
   }
+  uint32_t c_p = group_bits<DT>(c_pd);
   const uint64_t c_fp = any_err ? r.spec_fp : 0ull;
   // ---- replace the stored calculatedThreshold only if threshold or messages differ by value
-  bool same = (c_hc == r.calc_hc) && (!c_hc || c_c == r.calc_c) && (c_p == r.calc_p);
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
-    if ((c_p >> d) & 1u) same &= c_v[d] == r.calc_v[d];
+  const bool differs_d = c_pd && c_v != r.calc_v;
+  const bool same = (c_hc == r.calc_hc) && (!c_hc || c_c == r.calc_c) && (c_p == r.calc_p) && group_bits<DT>(differs_d) == 0u;
   const bool replace = !same || r.status_fp != c_fp;
   if (!replace) {
     c_p = r.calc_p;
     c_hc = r.calc_hc;
     c_c = r.calc_c;
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) c_v[d] = r.calc_v[d];
+    c_v = r.calc_v;
+    c_pd = in_d && ((c_p >> d) & 1u);
   }
   // ---- throttled = calculatedThreshold.IsThrottled(used, onEqual = true)
   const bool th_pod = c_hc && u_hc && u_c >= c_c;
-  uint32_t th_flag = 0;
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D)
-    if (((c_p >> d) & 1u) && ((u_p >> d) & 1u) && u_v[d] >= c_v[d]) th_flag |= 1u << d;
+  const uint32_t th_flag = group_bits<DT>(c_pd && u_pr && u_v >= c_v);
   // ---- outputs
-  _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-    out.used.v[(size_t)t * D + d] = u_v[d];
-    out.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
+  const int64_t c_out = c_pd ? c_v : 0;
+  if (in_d) {
+    out.used.v[vi] = u_v;
+    out.calc.v[vi] = c_out;
   }
-  out.used.present[t] = u_p;
-  out.used.count[t] = u_hc ? u_c : 0;
-  out.used.has_count[t] = u_hc;
-  out.calc.present[t] = c_p;
-  out.calc.count[t] = c_hc ? c_c : 0;
-  out.calc.has_count[t] = c_hc;
-  out.calc_updated[t] = replace;
-  out.thrl_flag[t] = th_flag;
-  out.thrl_has[t] = c_p;
-  out.thrl_pod[t] = th_pod;
-  out.error[t] = 0;
-  out.next_s[t] = nx_s;
-  out.next_ns[t] = nx_ns;
+  if (lead) {
+    out.used.present[t] = u_p;
+    out.used.count[t] = u_hc ? u_c : 0;
+    out.used.has_count[t] = u_hc;
+    out.calc.present[t] = c_p;
+    out.calc.count[t] = c_hc ? c_c : 0;
+    out.calc.has_count[t] = c_hc;
+    out.calc_updated[t] = replace;
+    out.thrl_flag[t] = th_flag;
+    out.thrl_has[t] = c_p;
+    out.thrl_pod[t] = th_pod;
+    out.error[t] = 0;
+    out.next_s[t] = nx_s;
+    out.next_ns[t] = nx_ns;
+  }
   if (apply) {  // UpdateStatus: the result becomes the stored status the next check reads
-    _Pragma("unroll") for (int d = 0; d < DT; ++d) if (d < D) {
-      tt.used.v[(size_t)t * D + d] = u_v[d];
-      if (replace) tt.calc.v[(size_t)t * D + d] = ((c_p >> d) & 1u) ? c_v[d] : 0;
+    if (in_d) {
+      tt.used.v[vi] = u_v;
+      if (replace) tt.calc.v[vi] = c_out;
     }
-    tt.used.present[t] = u_p;
-    tt.used.count[t] = u_hc ? u_c : 0;
-    tt.used.has_count[t] = u_hc;
     uint32_t nf = fl & ~kThrThrottledPod;
     if (th_pod) nf |= kThrThrottledPod;
-    if (replace) {
-      tt.calc.present[t] = c_p;
-      tt.calc.count[t] = c_hc ? c_c : 0;
-      tt.calc.has_count[t] = c_hc;
-      tt.status_msgs_fp[t] = c_fp;
-      nf |= kThrCalcAtNonzero;
+    if (replace) nf |= kThrCalcAtNonzero;
+    if (lead) {
+      tt.used.present[t] = u_p;
+      tt.used.count[t] = u_hc ? u_c : 0;
+      tt.used.has_count[t] = u_hc;
+      if (replace) {
+        tt.calc.present[t] = c_p;
+        tt.calc.count[t] = c_hc ? c_c : 0;
+        tt.calc.has_count[t] = c_hc;
+        tt.status_msgs_fp[t] = c_fp;
+      }
+      tt.flags[t] = nf;
+      tt.thrl_flag[t] = th_flag;
+      tt.thrl_has[t] = c_p;
     }
-    tt.flags[t] = nf;
-    tt.thrl_flag[t] = th_flag;
-    tt.thrl_has[t] = c_p;
-    if (recs) {  // from the registers that were just stored (no re-read of this thread's own writes)
+    if (recs) {  // from the registers that were just stored (no re-read of this lane's own writes)
       const bool calc = (nf & kThrCalcAtNonzero) != 0;  // calculatedAt still zero: spec.threshold
-      int64_t th_v[DT];
-      _Pragma("unroll") for (int d = 0; d < DT; ++d) th_v[d] = calc ? c_v[d] : r.spec_v[d];
-      build_check_rec<DT>(tt, t, T, D, nf, th_v, calc ? c_p : r.spec_p, calc ? c_hc : r.spec_hc, calc ? c_c : r.spec_c, u_v, u_p, u_hc,
-                          u_c, r.res_v, r.res_p, r.res_hc, r.res_c, th_flag, c_p, rec_eq != 0, vmax, recs);
+      build_check_rec<DT>(t, T, D, d, valid, nf, calc ? c_out : r.spec_v, calc ? c_p : r.spec_p, calc ? c_hc : r.spec_hc, calc ? c_c : r.spec_c,
+                          u_v, u_p, u_hc, u_c, r.res_v, r.res_p, r.res_hc, r.res_c, th_flag, c_p, rec_eq != 0, vmax, recs);
     }
   } else if (recs) {
-    build_check_rec_regs<DT>(tt, t, T, D, r, rec_eq != 0, vmax, recs);
+    build_check_rec_regs<DT>(t, T, D, d, valid, r, rec_eq != 0, vmax, recs);
   }
 }
 
+constexpr int kFinalizeBlock = 64;  // one wave: 64 / DT throttles
 template <int DT>
-__global__ __launch_bounds__(64) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, int consume,
-                                                     int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
-                                                     CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
+__global__ __launch_bounds__(kFinalizeBlock) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, int consume,
+                                                                int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+                                                                CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
   // consume: leave the row zeroed behind (kt_reconcile_launch: the next aggregate then needs no clearing pass)
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= T) return;
+  const int d = (int)(threadIdx.x & (DT - 1));
+  const int tq = (int)((blockIdx.x * kFinalizeBlock + threadIdx.x) / DT);
+  const bool valid = tq < T;
+  const int t = valid ? tq : T - 1;  // lanes past the end shadow the last throttle (every lane takes part in the ballots) and store nothing
   const int stride = partial_stride(D);
-  ThrRegs<DT> r;
-  load_thr<DT>(tt, t, D, r);
+  ThrLane r;
+  load_thr(tt, t, D, d, r);
   unsigned long long* prow = partial + (size_t)t * stride;
-  unsigned long long pv[DT], pc[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    const unsigned long long a = prow[d < D ? d : 0], b = prow[D + (d < D ? d : 0)];
-    pv[d] = d < D ? a : 0ull, pc[d] = d < D ? b : 0ull;
-  }
+  const int dd = d < D ? d : 0;
+  const unsigned long long a = prow[dd], b = prow[D + dd];
+  const unsigned long long pv = d < D ? a : 0ull, pc = d < D ? b : 0ull;
   const unsigned long long pods = prow[2 * D], errs = prow[2 * D + 1];
-  if (consume)
-    for (int j = 0; j < stride; ++j) prow[j] = 0ull;
-  finalize_throttle<DT>(tt, t, T, D, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
+  if (consume && valid) {
+    // the group's lanes clear the row between them: words d, d + DT, ... (every word was read above by some lane of the
+    // group before any lane of it stores: the loads complete before dependent code, the stores follow the ballots below)
+    for (int j = d; j < stride; j += DT) prow[j] = 0ull;
+  }
+  finalize_throttle<DT>(tt, t, T, D, d, valid, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
                         row_mask == nullptr || row_mask[t] != 0);
 }
 
@@ -804,9 +796,9 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned 
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
                      const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask) {
   if (sp.T <= 0) return;
-  // one wave per 64 throttles (T is small: spread over as many CUs as possible; everything is latency)
-  const dim3 g((sp.T + 63) / 64), b(64);
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
+  // one wave per 64 / DT throttles (T is small: spread over as many CUs as possible; everything is latency)
+  const dim3 g((unsigned)(((size_t)sp.T * DT + kFinalizeBlock - 1) / kFinalizeBlock)), b(kFinalizeBlock);
   const int eq = rec_eq ? 1 : 0;
   if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
   else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);
@@ -815,18 +807,23 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned 
 
 // ---------------------------------------------------------------------------------------------------
 // kt_prepare_check — per throttle: fold everything CheckThrottledFor needs that does not depend on
-// the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts).
+// the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts); lane = (throttle,
+// dimension) like kt_finalize.
 // ---------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(64) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs, const ReqBound vmax) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= T) return;
-  build_check_rec_stored<DT>(tt, t, T, D, on_equal != 0, vmax, recs);
+__global__ __launch_bounds__(kFinalizeBlock) void kt_prepare_check(ThrTables tt, int T, int D, int on_equal, CheckRec<DT>* recs, const ReqBound vmax) {
+  const int d = (int)(threadIdx.x & (DT - 1));
+  const int tq = (int)((blockIdx.x * kFinalizeBlock + threadIdx.x) / DT);
+  const bool valid = tq < T;
+  const int t = valid ? tq : T - 1;
+  ThrLane r;
+  load_thr(tt, t, D, d, r);
+  build_check_rec_regs<DT>(t, T, D, d, valid, r, on_equal != 0, vmax, recs);
 }
 
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s) {
   if (T <= 0) return;
-  dim3 g((T + 63) / 64), b(64);
+  dim3 g((unsigned)(((size_t)T * DT + kFinalizeBlock - 1) / kFinalizeBlock)), b(kFinalizeBlock);
   if (DT == 4) hipLaunchKernelGGL(kt_prepare_check<4>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<4>*)recs, vmax);
   else if (DT == 8) hipLaunchKernelGGL(kt_prepare_check<8>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<8>*)recs, vmax);
   else hipLaunchKernelGGL(kt_prepare_check<16>, g, b, 0, s, tt, T, D, on_equal ? 1 : 0, (CheckRec<16>*)recs, vmax);

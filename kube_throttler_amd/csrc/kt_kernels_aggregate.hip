@@ -311,14 +311,6 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
 // accumulators, the wave adds them up across its lanes, and lane 0 adds the sums to the partial buffer — a dozen atomics
 // per record (several groups of one throttle meet there), no cross-block reduction, every CU streaming.
 // check_tags = 0: every workgroup spilled every chunk (single-chunk programs) — no tag reads.
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
-    v += (unsigned long long)lo | (unsigned long long)hi << 32;
-  }
-  return v;
-}
 constexpr int kPackedWaves = 4;  // records per block
 __global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(const unsigned char* slab, const BmChunk* chunks, const uint32_t* rank_t,
                                                                            int n_slabs, int D, const PackPlan pk, const uint32_t* slab_tag, uint32_t epoch,
@@ -327,50 +319,24 @@ __global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(cons
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t r = blockIdx.x * kPackedWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (r >= ch.n_thr) return;  // wave-uniform
-  const uint32_t rec = pk.rec_bytes, nw = pk.nw;
+  const uint32_t rec = pk.rec_bytes;
   const size_t pitch = ((size_t)ch.n_thr * rec + 15u) & ~(size_t)15u;
   const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)r * rec;
-  const uint32_t* tag = slab_tag + blockIdx.y * kSlabTagStride;
-  unsigned long long acc[16], pods = 0;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) acc[d] = 0ull;
-  uint32_t zero_keys = 0;
-  const unsigned long long cnt_mask = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
-  for (int b = (int)lane; b < n_slabs; b += 64) {
-    if (check_tags && tag[b] != epoch) continue;  // that workgroup had no pods for this chunk (namespace-ordered scans)
-    const unsigned long long* q = (const unsigned long long*)(base + (size_t)b * pitch);
-    const unsigned long long w0 = q[0];
-    if (w0 == 0ull) continue;  // nobody of that workgroup matched this throttle
-    const unsigned long long w1 = nw > 1u ? q[1] : 0ull, w2 = nw > 2u ? q[2] : 0ull, w3 = nw > 3u ? q[3] : 0ull;
-    zero_keys |= (uint32_t)q[nw];
-    pods += w0 & cnt_mask;
-#pragma unroll
-    for (int d = 0; d < 16; ++d)
-      if (d < D && pk.width[d]) {
-        const uint32_t k = pk.word[d];
-        const unsigned long long ww = k == 0u ? w0 : k == 1u ? w1 : k == 2u ? w2 : w3;
-        const unsigned long long m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
-        acc[d] += (ww >> pk.pos[d]) & m;
-      }
-  }
-  pods = wave_sum64(pods);
-  if (pods == 0ull) return;  // wave-uniform after the sum
-  uint32_t zk = zero_keys;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) zk |= (uint32_t)__shfl_xor((int)zk, o);
+  PackedSums sm;
+  packed_record_sums(base, pitch, n_slabs, pk, D, slab_tag + blockIdx.y * kSlabTagStride, epoch, check_tags, lane, sm);
+  if (sm.pods == 0ull) return;  // wave-uniform
   const int stride = partial_stride(D);
   unsigned long long* prow = partial + (size_t)rank_t[ch.rank0 + r] * stride;
-  if (lane == 0) atomicAdd(prow + 2 * D, pods);
+  if (lane == 0) {
+    atomicAdd(prow + 2 * D, sm.pods);
 #pragma unroll
-  for (int d = 0; d < 16; ++d)
-    if (d < D) {
-      const unsigned long long sum = pk.width[d] ? wave_sum64(acc[d]) : 0ull;
-      if (lane == 0) {
-        if (sum) atomicAdd(prow + d, sum << pk.shift[d]);
+    for (int d = 0; d < 16; ++d)
+      if (d < D) {
+        if (pk.width[d] && sm.acc[d]) atomicAdd(prow + d, sm.acc[d] << pk.shift[d]);
         // key seen: a non-zero sum says so by itself (kt_finalize); a key only ever carried with the value 0 is marked here
-        if ((zk >> d) & 1u) atomicAdd(prow + D + d, 1ull);
+        if ((sm.zero_keys >> d) & 1u) atomicAdd(prow + D + d, 1ull);
       }
-    }
+  }
 }
 
 #define KT_AGG_BM_CASE(DT_, LA_, VETO_, NEED_)                                                                \
