@@ -239,6 +239,11 @@ struct kt_engine {
   // the partial buffer as the last kt_aggregate_launch filled it: word count and the selector program it was scanned
   // with — the exchange and the finalize that follow must see the same throttle set
   bool agg_pending = false;
+  // a packed scan whose slabs still wait for kt_reduce_finalize_packed (kt_reconcile_launch: nothing can come between the
+  // scan and the finalize, so the slab reduction and kt_finalize are ONE launch): workgroups of the scan, its slab epoch
+  bool fused_pending = false;
+  int fused_nb = 0;
+  uint32_t fused_epoch = 0;
   size_t agg_words = 0;
   uint64_t program_gen = 0, agg_gen = 0;
   int32_t exchange_world = 1;  // ranks whose partials meet in the reconcile's all-reduce (kt_comm_init / kt_set_exchange_world)
@@ -627,6 +632,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     if (!hook && !getenv("KT_CHUNK_HALF") && e->hindex.bm_chunks.size() > 1)
       kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes);
   }
+  kt::index_group_counts(e->hindex, (uint32_t)T);
   e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
@@ -1527,7 +1533,8 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   return KT_OK;
 }
 
-static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
+static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = false) {
+  e->fused_pending = false;
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   if ((rc = request_sums_in_range(e, s)) != KT_OK) return rc;
@@ -1587,9 +1594,13 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
   {
     TimedLaunch tl(e, KT_KERNEL_AGGREGATE, s);
     std::unique_ptr<TimedLaunch> tr;
+    // reconcile in one call: the slab reduction of a packed scan is done by kt_reduce_finalize_packed
+    // (single-chunk programs: with a chunked index most slabs are skipped and most throttles have several groups that meet
+    // in the partial rows anyway — measured on the configs[4] shard: 111 us fused against 72 + 9 us)
+    const bool defer = allow_fused && !e->incremental && e->dindex.n_chunks == 1 && !getenv_flag("KT_NO_FUSED");
     auto after_scan = [&]() {  // the slab reduction is its own kernel: time it as its own family
       tl.stop_now();
-      tr.reset(new TimedLaunch(e, KT_KERNEL_REDUCE, s));
+      if (!(defer && e->pack.nw)) tr.reset(new TimedLaunch(e, KT_KERNEL_REDUCE, s));
     };
     if (e->cfg.kernel_variant == 1)
       kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
@@ -1603,9 +1614,12 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s) {
       if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
       if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
       if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
+      sc.defer_reduce = defer && sc.pk != nullptr;
       const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
       if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
       e->last_kernel[KT_KERNEL_AGGREGATE] = k;
+      if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch;
+      e->last_kernel[KT_KERNEL_REDUCE] = e->fused_pending ? "(in kt_reduce_finalize_packed)" : sc.launched_packed ? "kt_reduce_packed_slabs" : "kt_reduce_bitmap_slabs";
     }
   }
   KT_HIP(e, hipGetLastError());
@@ -1659,8 +1673,17 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   if (apply && !keep_prev) recs_invalidate_and_drain(e);
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
-    kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT,
-                        e->recs_eq, req_bound(e), s, row_mask);
+    if (e->fused_pending) {
+      kt::launch_reduce_finalize_packed(e->tt, e->sp, e->D, e->dindex, e->pack, e->d_slab.p, e->fused_nb, e->d_slab_tag.p, e->fused_epoch, e->partial(),
+                                        consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT, e->recs_eq, req_bound(e), s,
+                                        row_mask, e->dindex.n_slow != 0 || e->n_overflow != 0);
+      e->last_kernel[KT_KERNEL_FINALIZE] = "kt_reduce_finalize_packed";
+    } else {
+      kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT,
+                          e->recs_eq, req_bound(e), s, row_mask);
+      e->last_kernel[KT_KERNEL_FINALIZE] = "kt_finalize";
+    }
+    e->fused_pending = false;
   }
   if (apply) {
     if (e->few_ready) KT_HIP(e, hipEventRecord(e->recs_ev[wbuf], s));
@@ -1713,6 +1736,7 @@ int32_t kt_finalize_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t
   if (!e) return KT_ERR_INVALID_ARGUMENT;
   LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
+  e->fused_pending = false;  // a finalize of its own reads the partial buffer (kt_aggregate_launch reduced the slabs into it)
   return finalize_locked(e, now_s, now_ns, flags, pick_stream(e, stream));
 }
 
@@ -1721,7 +1745,7 @@ int32_t kt_reconcile_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_
   LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   hipStream_t s = pick_stream(e, stream);
-  int32_t rc = aggregate_locked(e, s);
+  int32_t rc = aggregate_locked(e, s, /*allow_fused=*/true);
   if (rc != KT_OK) return rc;
   return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
 }
@@ -1749,7 +1773,7 @@ int32_t kt_reconcile_rows_launch(kt_engine* e, int64_t now_s, int32_t now_ns, ui
   KT_HIP(e, e->d_row_mask.reserve(mask.size()));
   KT_HIP(e, hipMemcpyAsync(e->d_row_mask.p, mask.data(), mask.size(), hipMemcpyHostToDevice, s));
   KT_HIP(e, hipStreamSynchronize(s));  // `mask` goes out of scope
-  rc = aggregate_locked(e, s);
+  rc = aggregate_locked(e, s, /*allow_fused=*/true);
   if (rc != KT_OK) return rc;
   return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental, e->d_row_mask.p);
 }

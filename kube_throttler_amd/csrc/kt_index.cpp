@@ -509,8 +509,25 @@ static hipError_t up(T*& dev, size_t& cap, const std::vector<T>& h, hipStream_t 
   return hipSuccess;
 }
 
+void index_group_counts(HostIndex& h, uint32_t T) {
+  h.thr_ngrp.assign(T, 0u);
+  for (uint32_t t : h.bm_rank_t)
+    if (t < T) ++h.thr_ngrp[t];
+  h.nogroup.clear();
+  for (uint32_t t = 0; t < T; ++t)
+    if (!h.thr_ngrp[t]) h.nogroup.push_back(t);
+}
+
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   hipError_t e;
+  if ((e = up(d.thr_ngrp, d.cap_thr_ngrp, h.thr_ngrp, s)) != hipSuccess) return e;
+  if ((e = up(d.nogroup, d.cap_nogroup, h.nogroup, s)) != hipSuccess) return e;
+  d.n_nogroup = (uint32_t)h.nogroup.size();
+  {
+    const std::vector<uint32_t> zeros(h.thr_ngrp.size() + 1, 0u);
+    if ((e = up(d.grp_arrive, d.cap_grp_arrive, zeros, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;  // `zeros` goes out of scope
+  }
   if ((e = up(d.slow_thr, d.cap_slow, h.slow_thr, s)) != hipSuccess) return e;
   d.n_slow = (uint32_t)h.slow_thr.size();
   if ((e = up(d.bm_blob, d.cap_bm_blob, h.bm_images, s)) != hipSuccess) return e;
@@ -540,6 +557,9 @@ void release_index(IndexDev& d) {
   if (d.bm_blob) (void)hipFree(d.bm_blob);
   if (d.bm_chunks) (void)hipFree(d.bm_chunks);
   if (d.bm_rank_t) (void)hipFree(d.bm_rank_t);
+  if (d.thr_ngrp) (void)hipFree(d.thr_ngrp);
+  if (d.nogroup) (void)hipFree(d.nogroup);
+  if (d.grp_arrive) (void)hipFree(d.grp_arrive);
   if (d.bm_chunk_ns) (void)hipFree(d.bm_chunk_ns);
   if (d.atom_table) (void)hipFree(d.atom_table);
   d = IndexDev();

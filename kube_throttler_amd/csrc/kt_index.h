@@ -113,6 +113,8 @@ struct HostIndex {
   std::vector<BmChunk> bm_chunks;
   std::vector<unsigned char> bm_images;    // chunk images back to back
   std::vector<uint32_t> bm_rank_t;         // dense rank (one per group, number order) -> throttle row
+  std::vector<uint32_t> thr_ngrp;          // [T] groups (= ranks = slab records) of every throttle row (index_group_counts)
+  std::vector<uint32_t> nogroup;           // throttle rows without any group: not live, or on the slow list
   std::vector<uint32_t> bm_chunk_ns;       // [chunks][ns_words] bit n: namespace n has words in the chunk
   uint32_t ns_words = 0;                   // 32-bit words per row of bm_chunk_ns
   uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
@@ -162,6 +164,11 @@ struct IndexDev {
   unsigned char* bm_blob = nullptr;  // chunk images
   BmChunk* bm_chunks = nullptr;
   uint32_t* bm_rank_t = nullptr;
+  uint32_t* thr_ngrp = nullptr;   // [T]
+  uint32_t* nogroup = nullptr;    // [n_nogroup]
+  uint32_t* grp_arrive = nullptr; // [T] arrival counters of kt_reduce_finalize_packed (zero between launches)
+  uint32_t n_nogroup = 0;
+  size_t cap_thr_ngrp = 0, cap_nogroup = 0, cap_grp_arrive = 0;
   uint32_t* bm_chunk_ns = nullptr;
   uint32_t ns_words = 0;
   uint64_t* atom_table = nullptr;
@@ -187,6 +194,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  int max_labels);
 // chunk images of an index build_index numbered, for other LDS budgets (no renumbering)
 void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
+// groups per throttle row and the rows without any, from bm_rank_t (after the final cut)
+void index_group_counts(HostIndex& h, uint32_t T);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
 void release_index(IndexDev& d);
 
@@ -222,6 +231,9 @@ struct AggScan {
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
   const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
   const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
+  bool defer_reduce = false;     // packed scans: leave the slabs as they are — kt_reduce_finalize_packed takes them from there
+  mutable int launched_blocks = 0;  // out: workgroups (= slabs per chunk) of the scan launch
+  mutable bool launched_packed = false;
 };
 constexpr uint32_t kSlabTagStride = 512;  // workgroups an aggregate launch may have (two per CU)
 // workgroups of an aggregate launch over n listed pods, and the most pods one of them scans (the packed fields are sized
@@ -234,6 +246,14 @@ uint64_t aggregate_slab_pods(int64_t n_rows, int blocks);
 const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& scan, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, unsigned long long* partial, void* slab, hipStream_t s,
                               const std::function<void()>& after_scan = nullptr);
+// the slab reduction of a packed scan + kt_finalize as one launch (kt_kernels.hip: kt_reduce_finalize_packed); one GPU
+struct ThrTables;
+struct ReconcileOut;
+struct ReqBound;
+void launch_reduce_finalize_packed(const ThrTables& tt, const SelProgram& sp, int D, const IndexDev& ix, const PackPlan& pk, const void* slab,
+                                   int n_slabs, const uint32_t* slab_tag, uint32_t epoch, unsigned long long* partial, bool consume, int64_t now_s,
+                                   int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq, const ReqBound& vmax,
+                                   hipStream_t s, const uint8_t* row_mask, bool scan_adds_rows);
 // small launches (n <= kCheckSmallMax): one workgroup per (chunk, tile); see kt_check_bitmap's SMALL instantiation
 constexpr int64_t kCheckSmallMax = 256;
 struct CheckSmall {

@@ -113,13 +113,25 @@ __device__ __forceinline__ void packed_record_sums(const unsigned char* base, si
     bool on[4];
     unsigned long long w[4][4];
     uint32_t zk[4];
+    // which of this lane's four slabs this launch wrote (namespace-ordered scans leave most (chunk, workgroup) slabs alone):
+    // the four tags as one batch of loads, then the records of the live slabs only
+#pragma unroll
+    for (int u = 0; u < 4; ++u) on[u] = b0 + 64 * u < n_slabs;
+    if (check_tags) {
+      uint32_t tg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tg[u] = tag[min(b0 + 64 * u, n_slabs - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) on[u] = on[u] && tg[u] == epoch;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int b = min(b0 + 64 * u, n_slabs - 1);
-      on[u] = b0 + 64 * u < n_slabs && (!check_tags || tag[b] == epoch);  // a stale slab is read and ignored
-      const unsigned long long* q = (const unsigned long long*)(base + (size_t)b * pitch);
-      w[u][0] = q[0], w[u][1] = q[nw > 1u ? 1 : 0], w[u][2] = q[nw > 2u ? 2 : 0], w[u][3] = q[nw > 3u ? 3 : 0];
-      zk[u] = (uint32_t)q[nw];
+      w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0ull, zk[u] = 0u;
+      if (on[u]) {
+        const unsigned long long* q = (const unsigned long long*)(base + (size_t)(b0 + 64 * u) * pitch);
+        w[u][0] = q[0], w[u][1] = q[nw > 1u ? 1 : 0], w[u][2] = q[nw > 2u ? 2 : 0], w[u][3] = q[nw > 3u ? 3 : 0];
+        zk[u] = (uint32_t)q[nw];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

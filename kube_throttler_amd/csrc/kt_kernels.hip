@@ -805,6 +805,135 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned 
   else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax, row_mask);
 }
 
+// kt_reduce_finalize_packed — the slab reduction of a packed scan (kt_aggregate_bitmap PK) and kt_finalize as ONE
+// launch, one WAVE per slab record: the wave sums its record over the workgroups' slabs (packed_record_sums: lane =
+// slab) and — the record being the throttle's only group — goes straight on to finalize that throttle from the sums in
+// its registers, lanes 0..DT-1 as the throttle's dimension group (finalize_throttle above; the other lanes shadow the
+// group and store nothing).  Two dependent launches (a reduction that funnels 10 MB into 140 KB through atomics, then a
+// latency chain over the tables) become one, and the sums never travel through the partial buffer.
+//   * a throttle with several groups (namespace cells): every wave adds its sums to the throttle's partial row and takes
+//     a ticket; the last to arrive finalizes from the row (and leaves row and ticket zeroed);
+//   * what the scan kernel itself added to the partial buffer (slow-list throttles, overflow pods, selector errors) is
+//     read from the row and added; throttles without any group get a wave of their own (blockIdx.y = chunks).
+// kt_reconcile_launch only: with several ranks the partial rows cross the all-reduce between reduction and kt_finalize
+// (kt_aggregate_launch -> exchange -> kt_finalize_launch keep the separate kernels).
+struct FusedReduceArgs {
+  const unsigned char* slab;
+  const BmChunk* chunks;
+  const uint32_t* rank_t;
+  const uint32_t* thr_ngrp;
+  const uint32_t* nogroup;
+  uint32_t* arrive;
+  const uint32_t* slab_tag;
+  uint32_t n_chunks, n_nogroup, epoch;
+  int32_t n_slabs, check_tags;
+  int32_t scan_adds_rows;  // the scan kernel itself may have added to partial rows (slow-list throttles, overflow pods)
+  PackPlan pk;
+  BmChunk ch0;             // n_chunks == 1: the chunk's descriptor by value (one dependent load less)
+};
+template <int DT>
+__global__ __launch_bounds__(256) void kt_reduce_finalize_packed(const FusedReduceArgs f, ThrTables tt, int T, int D, unsigned long long* partial,
+                                                                 int consume, int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+                                                                 CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int d = (int)(lane & (DT - 1));
+  const bool valid = lane < (uint32_t)DT;  // the throttle's dimension group
+  const int stride = partial_stride(D);
+  unsigned long long pv = 0, pc = 0, pods = 0, errs = 0;
+  uint32_t t;
+  bool from_row = f.scan_adds_rows != 0;  // (part of) the sums are in the throttle's partial row ...
+  bool met = false;                       // ... put there by other waves of this launch (several groups)
+  ThrLane r;
+  if (blockIdx.y < f.n_chunks) {
+    const BmChunk ch = f.n_chunks == 1u ? f.ch0 : f.chunks[blockIdx.y];
+    if (wv >= ch.n_thr) return;  // wave-uniform
+    t = f.rank_t[ch.rank0 + wv];
+    // the throttle's stored state is requested BEFORE the slab records: both batches of loads are in flight together
+    load_thr(tt, (int)t, D, d, r);
+    const uint32_t ngrp = f.thr_ngrp[t];
+    const size_t pitch = ((size_t)ch.n_thr * f.pk.rec_bytes + 15u) & ~(size_t)15u;
+    PackedSums sm;
+    packed_record_sums(f.slab + (size_t)ch.slab_off * 16 + (size_t)wv * f.pk.rec_bytes, pitch, f.n_slabs, f.pk, D,
+                       f.slab_tag + blockIdx.y * kSlabTagStride, f.epoch, f.check_tags, lane, sm);
+    if (ngrp > 1u) {
+      // several groups: meet in the partial row, the last wave to arrive goes on
+      unsigned long long* prow = partial + (size_t)t * stride;
+      uint32_t arrived = 0;
+      if (lane == 0) {
+        // RETURNING atomics: their results feed the ticket's operand, so the ticket is issued after every add has been
+        // performed at the device's coherence point — ordering by data dependence instead of a release fence (an
+        // agent-scope fence writes back and invalidates the XCD's whole L2: 20 000 waves doing that serialised the
+        // configs[4] launch into 0.9 ms)
+        unsigned long long seen = 0;
+        if (sm.pods) {
+          seen |= atomicAdd(prow + 2 * D, sm.pods);
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (k < D) {
+              if (f.pk.width[k] && sm.acc[k]) seen |= atomicAdd(prow + k, sm.acc[k] << f.pk.shift[k]);
+              if ((sm.zero_keys >> k) & 1u) seen |= atomicAdd(prow + D + k, 1ull);
+            }
+        }
+        // (the previous values are sums far below 2^64: the comparison is false, but only the hardware knows)
+        const uint32_t one = 1u + (uint32_t)(seen == ~0ull);
+        arrived = __hip_atomic_fetch_add(f.arrive + t, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      arrived = __builtin_amdgcn_readfirstlane(arrived);
+      if (arrived + 1u != ngrp) return;
+      if (lane == 0) __hip_atomic_store(f.arrive + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      from_row = met = true;
+    } else if (sm.pods) {
+      pods = sm.pods;
+      // every lane holds all the totals: the lane of dimension d picks its own
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < D && f.pk.width[k]) mine = d == k ? sm.acc[k] << f.pk.shift[k] : mine;
+      pv = d < D ? mine : 0ull;
+      pc = d < D ? (sm.zero_keys >> d) & 1u : 0u;  // a non-zero sum marks the key by itself
+    }
+  } else {
+    if (wv >= f.n_nogroup) return;
+    t = f.nogroup[wv];
+    load_thr(tt, (int)t, D, d, r);
+  }
+  // ---- what the scan kernel added to the row by itself (slow list, overflow pods, errors) and, for a throttle of
+  //      several groups, the sums of all its records
+  if (from_row) {
+    unsigned long long* prow = partial + (size_t)t * stride;
+    // rows other waves of THIS launch added to are read past the caches; rows only the scan kernel wrote are plain data
+    auto ld = [&](int j) { return met ? __hip_atomic_load(prow + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : prow[j]; };
+    const int dd = d < D ? d : 0;
+    const unsigned long long a = ld(dd), b = ld(D + dd), pp = ld(2 * D), ee = ld(2 * D + 1);
+    pv += d < D ? a : 0ull, pc += d < D ? b : 0ull, pods += pp, errs += ee;
+    if (consume && valid)
+      for (int j = d; j < stride; j += DT) prow[j] = 0ull;
+  }
+  finalize_throttle<DT>(tt, (int)t, T, D, d, valid, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
+                        row_mask == nullptr || row_mask[t] != 0);
+}
+
+void launch_reduce_finalize_packed(const ThrTables& tt, const SelProgram& sp, int D, const IndexDev& ix, const PackPlan& pk, const void* slab,
+                                   int n_slabs, const uint32_t* slab_tag, uint32_t epoch, unsigned long long* partial, bool consume, int64_t now_s,
+                                   int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq, const ReqBound& vmax,
+                                   hipStream_t s, const uint8_t* row_mask, bool scan_adds_rows) {
+  if (sp.T <= 0) return;
+  FusedReduceArgs f{};
+  f.slab = (const unsigned char*)slab, f.chunks = ix.bm_chunks, f.rank_t = ix.bm_rank_t, f.thr_ngrp = ix.thr_ngrp, f.nogroup = ix.nogroup;
+  f.arrive = ix.grp_arrive, f.slab_tag = slab_tag, f.n_chunks = ix.n_chunks, f.n_nogroup = ix.n_nogroup, f.epoch = epoch;
+  f.n_slabs = n_slabs, f.check_tags = ix.n_chunks > 1 ? 1 : 0, f.pk = pk;
+  f.scan_adds_rows = scan_adds_rows ? 1 : 0;
+  if (ix.n_chunks == 1 && !ix.h_chunks.empty()) f.ch0 = ix.h_chunks[0];
+  const uint32_t gx = (std::max(ix.bm_max_thr, ix.n_nogroup) + 3u) / 4u;
+  const dim3 g(gx ? gx : 1u, ix.n_chunks + 1u), b(256);
+  const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);
+  const int eq = rec_eq ? 1 : 0;
+  if (DT == 4) hipLaunchKernelGGL(kt_reduce_finalize_packed<4>, g, b, 0, s, f, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
+  else if (DT == 8) hipLaunchKernelGGL(kt_reduce_finalize_packed<8>, g, b, 0, s, f, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);
+  else hipLaunchKernelGGL(kt_reduce_finalize_packed<16>, g, b, 0, s, f, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax, row_mask);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kt_prepare_check — per throttle: fold everything CheckThrottledFor needs that does not depend on
 // the pod into a CheckRec (effective threshold, headroom, step-2/3 bitmask, count verdicts); lane = (throttle,

@@ -34,6 +34,7 @@ struct BmAggArgs {
   const int64_t* v_req;
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
+  uint32_t exp;          // TEMPORARY measurement switches (KT_EXP): 8 = no fold (scan only)
   PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
   const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
 };
@@ -49,6 +50,7 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
   const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
   if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
+  a.exp = getenv("KT_EXP") ? (uint32_t)atoi(getenv("KT_EXP")) : 0u;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAgg
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
             // a throttle with several terms is counted once
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
-            if (ok) {
+            if (ok && !(a.exp & 8u)) {
               last_r = r;
               KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
               lds_u64wp tv = (lds_u64wp)rp;
@@ -404,7 +406,10 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 3) else KT_AGG_BM_CASE(16, 32, true, 3) }
 #endif
   if (after_scan) after_scan();
-  if (packed) {
+  sc.launched_blocks = nb, sc.launched_packed = packed;
+  if (packed && sc.defer_reduce) {
+    // the caller goes on with kt_reduce_finalize_packed
+  } else if (packed) {
     if (ix.bm_max_thr > 0)
       hipLaunchKernelGGL(kt_reduce_packed_slabs, dim3((ix.bm_max_thr + kPackedWaves - 1) / kPackedWaves, ix.n_chunks), dim3(64 * kPackedWaves), 0, s, slab,
                          ix.bm_chunks, ix.bm_rank_t, nb, pods.D, bm_args.pk, sc.slab_tag, sc.epoch, ix.n_chunks > 1 ? 1 : 0, partial);
