@@ -172,6 +172,16 @@ struct kt_engine {
   unsigned __int128 req_sum_bound[KT_MAX_DIMS] = {0};  // >= sum of |request| over the pods held, per dimension: the last exact
                                                  // device total + everything fed since (overwritten / deleted pods stay in)
   DevBuf<unsigned long long> d_req_sums;
+  // Pod events are applied to the scan lists / views IN PLACE (kt_patch_scan_views) as long as they fit what the views were
+  // built for; d_pos_c / d_pos_a map a pod row to its record.  view_cap_c: records the countable view holds; view_extra:
+  // upper bound of the records appended since it was built (the scan covers n_countable + view_extra records: what was
+  // not really appended is zero = not countable); view_check_dirty: a namespace-ordered view was patched — the kernel
+  // raises d_view_dirty when an entry would have had to move, read before the next scan
+  DevBuf<int32_t> d_pos_c, d_pos_a;
+  DevBuf<uint32_t> d_view_dirty;
+  DevBuf<unsigned long long> d_n_all;
+  int64_t view_cap_c = 0, view_extra = 0, view_rows_a = 0;
+  bool view_check_dirty = false;
   bool countable_valid = false;                  // d_countable describes the current pod table
   bool countable_by_ns = false;                  // ... ordered by namespace (multi-chunk index: kt_order_rows_by_ns)
   DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
@@ -903,6 +913,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_order_all.release();
   e->d_vc_meta.release(); e->d_va_meta.release(); e->d_carry.release();
   e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release(); e->d_vc_pk.release();
+  e->d_pos_c.release(); e->d_pos_a.release(); e->d_view_dirty.release(); e->d_n_all.release();
   e->d_ns_cursor.release();
   e->d_slab_tag.release();
   e->d_row_mask.release();
@@ -979,6 +990,61 @@ int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* rows) {
 
 static int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, int sign, hipStream_t s);
 
+// ---- pod events applied to the scan views in place
+constexpr int64_t kPatchBatchMax = 65536;
+// can a batch of n pod rows (largest |request| per dimension batch_max, OR of the values batch_or, a negative value seen)
+// be applied to the current views?  The packed request words only hold what their plan was proved for.
+static bool views_patchable(const kt_engine* e, int64_t n, const unsigned __int128* batch_max, const uint64_t* batch_or, bool batch_neg) {
+  if (e->incremental || e->cfg.kernel_variant != 0 || e->program_dirty || n > kPatchBatchMax) return false;
+  if (!e->countable_valid && !e->order_all_valid) return false;  // nothing to patch: the next scan builds anyway
+  if (getenv("KT_NO_VIEW_PATCH")) return false;
+  if (e->countable_valid) {
+    if (e->d_vc_meta.p == nullptr || e->d_pos_c.p == nullptr) return false;
+    if (e->view_extra + n > e->view_cap_c - (int64_t)e->n_countable) return false;
+    if (e->pack.nw) {
+      if (batch_neg) return false;
+      for (int d = 0; d < e->D; ++d) {
+        if (batch_max[d] > e->max_abs[d]) return false;  // a field may be too narrow
+        if (e->pack.shift[d] && (batch_or[d] & ((1ull << e->pack.shift[d]) - 1ull))) return false;  // fewer common trailing zeros
+      }
+    } else if (!e->neg_seen && !batch_neg) {
+      // unpacked view of an engine that could pack: a rebuild decides again
+    }
+  }
+  return true;
+}
+static int32_t patch_views(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, hipStream_t s) {
+  kt::ViewPatch v{};
+  if (e->countable_valid) {
+    v.vc_meta = e->d_vc_meta.p, v.vc_latom = e->d_vc_latom.p, v.vc_req = e->pack.nw ? nullptr : e->d_vc_req.p, v.vc_pk = e->pack.nw ? e->d_vc_pk.p : nullptr;
+    v.vc_rows = e->d_countable.p, v.pos_c = e->d_pos_c.p, v.n_c = e->d_n_countable.p, v.cap_c = e->view_cap_c;
+    v.by_ns = e->countable_by_ns ? 1u : 0u;
+    v.pk = e->pack;
+    if (!e->countable_by_ns) e->view_extra += n;  // at most n appended
+  }
+  if (e->order_all_valid) {
+    v.va_meta = e->d_va_meta.p, v.va_latom = e->d_va_latom.p, v.pos_a = e->d_pos_a.p, v.rows_a = e->view_rows_a;
+  }
+  v.dirty = e->d_view_dirty.p;
+  if ((e->countable_valid && e->countable_by_ns) || e->order_all_valid) e->view_check_dirty = true;
+  kt::launch_patch_scan_views(e->pods, n, rows_dev, row0, v, s);
+  KT_HIP(e, hipGetLastError());
+  return KT_OK;
+}
+// before a scan uses a namespace-ordered view that was patched: did an entry have to move?
+static int32_t settle_view_patches(kt_engine* e, hipStream_t s) {
+  if (!e->view_check_dirty) return KT_OK;
+  uint32_t dirty = 0;
+  KT_HIP(e, hipMemcpyAsync(&dirty, e->d_view_dirty.p, 4, hipMemcpyDeviceToHost, s));
+  KT_HIP(e, hipStreamSynchronize(s));
+  if (dirty) {
+    e->countable_valid = false, e->order_all_valid = false;
+    KT_HIP(e, hipMemsetAsync(e->d_view_dirty.p, 0, 4, s));
+  }
+  e->view_check_dirty = false;
+  return KT_OK;
+}
+
 static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
   const int D = e->D;
   if (b->D != D) return e->fail(KT_ERR_INVALID_ARGUMENT, "batch D=%d, engine D=%d", b->D, D);
@@ -987,6 +1053,8 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   // ---- validation + overflow bound (host pass over the batch; the data is copied once, below)
   int64_t hi = e->pod_rows_hi, ns_hi = e->pod_ns_hi;
   unsigned __int128 batch_max[KT_MAX_DIMS] = {0}, batch_total[KT_MAX_DIMS] = {0};
+  uint64_t batch_or[KT_MAX_DIMS] = {0};
+  const bool neg_before = e->neg_seen;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t row = rows ? rows[i] : i;
     if (row < 0 || row >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)row);
@@ -1002,14 +1070,14 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       for (int d = 0; d < D; ++d)
         if ((b->ctr_present[k] >> d) & 1u) {
           sum[d] += uabs(b->ctr_req[(size_t)k * D + d]);
-          e->or_abs[d] |= (uint64_t)uabs(b->ctr_req[(size_t)k * D + d]);
+          batch_or[d] |= (uint64_t)uabs(b->ctr_req[(size_t)k * D + d]);
           if (b->ctr_req[(size_t)k * D + d] < 0) e->neg_seen = true;
         }
     if (b->pod_ovh_present[i] >> 31)
       for (int d = 0; d < D; ++d)
         if ((b->pod_ovh_present[i] >> d) & 1u) {
           sum[d] += uabs(b->pod_ovh[(size_t)i * D + d]);
-          e->or_abs[d] |= (uint64_t)uabs(b->pod_ovh[(size_t)i * D + d]);
+          batch_or[d] |= (uint64_t)uabs(b->pod_ovh[(size_t)i * D + d]);
           if (b->pod_ovh[(size_t)i * D + d] < 0) e->neg_seen = true;
         }
     for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]), batch_total[d] += sum[d];
@@ -1028,12 +1096,17 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   for (int d = 0; d < D; ++d)
     if (batch_max[d] > kSumBound)
       return e->fail(KT_ERR_OVERFLOW_RISK, "dimension %d: a pod's request exceeds 2^60 at this scale; use a coarser scale for it", d);
+  // the scan lists / views: patched in place when the batch fits what they were built for, else rebuilt by the next scan
+  const bool patch = views_patchable(e, n, batch_max, batch_or, e->neg_seen && !neg_before);
   for (int d = 0; d < D; ++d) {
     if (batch_max[d] > e->max_abs[d]) e->recs_valid = false;  // kRecTight was judged against the old bound
     e->max_abs[d] = std::max(batch_max[d], e->max_abs[d]);
+    e->or_abs[d] |= batch_or[d];
   }
-  e->countable_valid = false;
-  e->order_all_valid = false;
+  if (!patch) {
+    e->countable_valid = false;
+    e->order_all_valid = false;
+  }
   // the overflow guard's bound grows by what this batch brings; only when it passes 2^60 does the next reconcile count
   // exactly on the device (request_sums_in_range), which also forgets the overwritten and deleted pods again
   for (int d = 0; d < D; ++d) {
@@ -1111,6 +1184,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
     }
     if ((drc = delta_scan(e, cn, pb.rows, pb.row0, +1, s)) != KT_OK) return drc;
+    if (patch && (drc = patch_views(e, cn, pb.rows, pb.row0, s)) != KT_OK) return drc;
     KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
   }
   e->pod_rows_hi = hi;
@@ -1135,14 +1209,23 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   KT_HIP(e, e->d_rows.reserve((size_t)n));
   KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
-  e->countable_valid = false;
-  e->order_all_valid = false;
+  const unsigned __int128 no_max[KT_MAX_DIMS] = {0};
+  const uint64_t no_or[KT_MAX_DIMS] = {0};
+  const bool patch = views_patchable(e, n, no_max, no_or, false);
+  if (!patch) {
+    e->countable_valid = false;
+    e->order_all_valid = false;
+  }
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
     int32_t drc = delta_scan(e, n, e->d_rows.p, 0, -1, e->own_stream);
     if (drc != KT_OK) return drc;
   }
   kt::launch_delete_pods(e->pods, n, e->d_rows.p, e->own_stream);
+  if (patch) {  // the rows' meta words are 0 now: their records stop counting
+    int32_t prc = patch_views(e, n, e->d_rows.p, 0, e->own_stream);
+    if (prc != KT_OK) return prc;
+  }
   KT_HIP(e, hipStreamSynchronize(e->own_stream));
   return KT_OK;
 }
@@ -1552,8 +1635,10 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
   }
   // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
   const bool by_ns = (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
+  if ((rc = settle_view_patches(e, s)) != KT_OK) return rc;
   if (e->cfg.kernel_variant != 1 && (!e->countable_valid || e->countable_by_ns != by_ns)) {  // pods changed since the last scan: which rows does a reconcile look at
-    KT_HIP(e, e->d_countable.reserve((size_t)e->pod_rows_hi + 1));
+    if (e->last_stream && e->last_stream != s) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+    KT_HIP(e, e->d_countable.reserve((size_t)e->cfg.pod_capacity + 1));
     KT_HIP(e, e->d_n_countable.reserve(1));
     if (by_ns) {
       KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->sp.n_ns + 1));
@@ -1571,11 +1656,15 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     if (!getenv_flag("KT_NO_SCAN_VIEW")) {
       // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
       // (namespace order for a multi-chunk index, ascending rows otherwise)
-      const size_t nc = (size_t)e->n_countable + 1;
+      // room for the pods that become countable before the next rebuild (kt_patch_scan_views appends them)
+      const int64_t headroom = std::min<int64_t>(std::max<int64_t>(65536, (int64_t)e->n_countable / 16), e->cfg.pod_capacity - (int64_t)e->n_countable);
+      e->view_cap_c = (int64_t)e->n_countable + headroom;
+      e->view_extra = 0;
+      const size_t nc = (size_t)e->view_cap_c + 1;
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
       if (!e->incremental && !getenv_flag("KT_NO_PACK")) {
-        const uint64_t slab_pods = kt::aggregate_slab_pods((int64_t)e->n_countable, kt::aggregate_blocks((int64_t)e->n_countable, false));
+        const uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c, false));
         e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, !getenv_flag("KT_PK_NOPAD"));
         if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
       }
@@ -1583,8 +1672,15 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
       if (e->pack.nw) KT_HIP(e, e->d_vc_pk.reserve(nc * (size_t)e->pack.stride));
       else KT_HIP(e, e->d_vc_req.reserve(nc * (size_t)e->pods.DS));
+      KT_HIP(e, e->d_pos_c.reserve((size_t)e->cfg.pod_capacity + 1));
+      KT_HIP(e, e->d_view_dirty.reserve(4));
+      KT_HIP(e, hipMemsetAsync(e->d_pos_c.p, 0xFF, ((size_t)e->cfg.pod_capacity + 1) * 4, s));
+      // the records past the listed ones are "no pod" until something is appended there
+      KT_HIP(e, hipMemsetAsync(e->d_vc_meta.p + e->n_countable, 0, (size_t)(headroom + 1) * 8, s));
+      KT_HIP(e, hipMemsetAsync(e->d_countable.p + e->n_countable, 0, (size_t)(headroom + 1) * 8, s));
+      if (!e->view_check_dirty) KT_HIP(e, hipMemsetAsync(e->d_view_dirty.p, 0, 4, s));
       kt::launch_build_scan_view(e->pods, (int64_t)e->n_countable, e->d_countable.p, e->d_vc_meta.p, e->d_vc_latom.p,
-                                 e->pack.nw ? nullptr : e->d_vc_req.p, s, e->pack.nw ? &e->pack : nullptr, e->d_vc_pk.p);
+                                 e->pack.nw ? nullptr : e->d_vc_req.p, s, e->pack.nw ? &e->pack : nullptr, e->d_vc_pk.p, e->d_pos_c.p);
       KT_HIP(e, hipGetLastError());
     }
     e->countable_valid = true;
@@ -1607,7 +1703,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
           e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
     else {
       kt::AggScan sc;
-      sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
+      sc.n = (int64_t)e->n_countable + (getenv_flag("KT_NO_SCAN_VIEW") ? 0 : e->view_extra), sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
       sc.overflow_pods = e->n_overflow != 0;
       // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
       sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
@@ -1899,19 +1995,25 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
     else {
       // a sweep over every row of a multi-chunk index runs in namespace order (results stay indexed by pod row)
       const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
-      if (by_ns && !e->order_all_valid) {
+      if (by_ns && (rc = settle_view_patches(e, s)) != KT_OK) return rc;
+      if (by_ns && (!e->order_all_valid || e->view_rows_a != e->pod_rows_hi)) {
         KT_HIP(e, e->d_order_all.reserve((size_t)e->pod_rows_hi + 1));
         KT_HIP(e, e->d_ns_cursor.reserve((size_t)e->sp.n_ns + 1));
-        KT_HIP(e, e->d_n_countable.reserve(1));
+        KT_HIP(e, e->d_n_all.reserve(1));
         kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->sp.n_ns,
-                                    e->d_ns_cursor.p, e->d_order_all.p, e->d_n_countable.p, s);
+                                    e->d_ns_cursor.p, e->d_order_all.p, e->d_n_all.p, s);
         KT_HIP(e, hipGetLastError());
         const size_t na = (size_t)e->pod_rows_hi + 1;
         KT_HIP(e, e->d_va_meta.reserve(na));
         KT_HIP(e, e->d_va_latom.reserve(na * (size_t)e->pods.LA));
         KT_HIP(e, e->d_carry.reserve(na));
-        kt::launch_build_scan_view(e->pods, e->pod_rows_hi, e->d_order_all.p, e->d_va_meta.p, e->d_va_latom.p, nullptr, s);
+        KT_HIP(e, e->d_pos_a.reserve(na));
+        KT_HIP(e, e->d_view_dirty.reserve(4));
+        if (!e->view_check_dirty) KT_HIP(e, hipMemsetAsync(e->d_view_dirty.p, 0, 4, s));
+        KT_HIP(e, hipMemsetAsync(e->d_pos_a.p, 0xFF, na * 4, s));
+        kt::launch_build_scan_view(e->pods, e->pod_rows_hi, e->d_order_all.p, e->d_va_meta.p, e->d_va_latom.p, nullptr, s, nullptr, nullptr, e->d_pos_a.p);
         KT_HIP(e, hipGetLastError());
+        e->view_rows_a = e->pod_rows_hi;
         e->order_all_valid = true;
       }
       const kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};

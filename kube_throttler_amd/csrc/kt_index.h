@@ -155,6 +155,25 @@ struct PackPlan {
 // pad_odd: pad the record to an odd number of 8-byte words (LDS bank spread) instead of the smallest size
 PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd);
 
+// what kt_patch_scan_views (kt_kernels.hip) needs of the scan views a pod event batch is applied to in place
+struct ViewPatch {
+  uint64_t* vc_meta;  // the aggregate's view of the countable pods (nullable)
+  uint16_t* vc_latom;
+  int64_t* vc_req;
+  uint64_t* vc_pk;
+  int64_t* vc_rows;
+  int32_t* pos_c;
+  unsigned long long* n_c;  // device counter of listed rows
+  int64_t cap_c;
+  uint64_t* va_meta;  // the check sweep's view of all rows (namespace-ordered programs; nullable)
+  uint16_t* va_latom;
+  int32_t* pos_a;
+  int64_t rows_a;     // rows the all-rows list covers
+  uint32_t by_ns;
+  uint32_t* dirty;
+  PackPlan pk;
+};
+
 // slot of an atom in an open-addressing table of 2^k entries (linear probing)
 __host__ __device__ inline uint32_t atom_slot(uint32_t atom, uint32_t mask) { return ((atom * 0x9E3779B1u) >> 7) & mask; }
 

@@ -315,41 +315,99 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
 // kt_build_scan_view — the records the namespace-ordered scans stream, copied into scan order once per ordering so that
 // a tile reads 64 consecutive records instead of gathering them through the row list on every chunk visit:
 // meta word, atom row, and (aggregate view) the request row of every listed pod.
-__global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t n, const int64_t* rows, uint64_t* v_meta,
-                                                         uint16_t* v_latom, int64_t* v_req, const PackPlan pk, uint64_t* v_pk) {
+// One pod's record of a scan view (meta word, atom row, request row and / or packed request words) at position j
+__device__ __forceinline__ void write_view_record(const PodTable& pods, int64_t p, int64_t j, uint64_t meta, uint64_t* v_meta, uint16_t* v_latom,
+                                                  int64_t* v_req, const PackPlan& pk, uint64_t* v_pk) {
   const int LA = pods.LA, DS = pods.DS;
+  v_meta[j] = meta;
+  const u128* src = (const u128*)(pods.latom + p * LA);
+  u128* dst = (u128*)(v_latom + j * LA);
+  for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
+  if (v_req) {
+    const u128* rs = (const u128*)(pods.req + p * DS);
+    u128* rd = (u128*)(v_req + j * DS);
+    for (int q = 0; q < DS / 2; ++q) rd[q] = rs[q];
+  }
+  if (v_pk) {
+    // ResourceAmountOfPod as packed words (PackPlan, kt_index.h): pod count 1 from bit 0 of word 0, every non-zero
+    // request as its field; the plan proved that no value of this engine needs more bits than its field has
+    uint64_t w[4] = {1ull, 0ull, 0ull, 0ull};
+    for (int d = 0; d < pods.D; ++d) {
+      const uint64_t f = (uint64_t)pods.req[p * DS + d] >> pk.shift[d];
+      const uint64_t piece = pk.width[d] ? f << pk.pos[d] : 0ull;
+      const uint32_t k = pk.word[d];
+      w[0] |= k == 0u ? piece : 0ull, w[1] |= k == 1u ? piece : 0ull, w[2] |= k == 2u ? piece : 0ull, w[3] |= k == 3u ? piece : 0ull;
+    }
+    uint64_t* o = v_pk + j * pk.stride;
+    o[0] = w[0], o[1] = w[1];
+    if (pk.stride > 2u) o[2] = w[2], o[3] = w[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t n, const int64_t* rows, uint64_t* v_meta,
+                                                         uint16_t* v_latom, int64_t* v_req, const PackPlan pk, uint64_t* v_pk, int32_t* pos) {
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
     const int64_t p = rows[j];
-    v_meta[j] = pods.meta[p];
-    const u128* src = (const u128*)(pods.latom + p * LA);
-    u128* dst = (u128*)(v_latom + j * LA);
-    for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
-    if (v_req) {
-      const u128* rs = (const u128*)(pods.req + p * DS);
-      u128* rd = (u128*)(v_req + j * DS);
-      for (int q = 0; q < DS / 2; ++q) rd[q] = rs[q];
-    }
-    if (v_pk) {
-      // ResourceAmountOfPod as packed words (PackPlan, kt_index.h): pod count 1 from bit 0 of word 0, every non-zero
-      // request as its field; the plan proved that no value of this engine needs more bits than its field has
-      uint64_t w[4] = {1ull, 0ull, 0ull, 0ull};
-      for (int d = 0; d < pods.D; ++d) {
-        const uint64_t f = (uint64_t)pods.req[p * DS + d] >> pk.shift[d];
-        const uint64_t piece = pk.width[d] ? f << pk.pos[d] : 0ull;
-        const uint32_t k = pk.word[d];
-        w[0] |= k == 0u ? piece : 0ull, w[1] |= k == 1u ? piece : 0ull, w[2] |= k == 2u ? piece : 0ull, w[3] |= k == 3u ? piece : 0ull;
+    if (pos) pos[p] = (int32_t)j;  // where a later pod event finds the record (kt_patch_scan_views)
+    write_view_record(pods, p, j, pods.meta[p], v_meta, v_latom, v_req, pk, v_pk);
+  }
+}
+
+// kt_patch_scan_views — a pod event batch (upserts: the rows hold their NEW content; deletes: their meta word is 0)
+// applied to the scan views in place instead of voiding them (every reconcile of the reference follows an event,
+// throttle_controller.go:400-536; rebuilding lists and views costs a full pass over the pod tables per event):
+//   * a pod that has a record keeps its position and gets its record rewritten — a pod that stopped being countable
+//     stays as a record whose meta word says so (the scan's own `countable` test skips it);
+//   * a newly countable pod is appended (row-ordered list) — or, in a namespace-ordered list, raises `dirty`: the
+//     next scan then rebuilds (so does a pod that moved to another namespace).
+__global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = rows ? rows[i] : row0 + i;
+  const uint64_t meta = pods.meta[p];
+  const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
+  const bool countable = (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+  if (v.vc_meta) {
+    int64_t pos = v.pos_c[p];
+    if (pos < 0 && countable) {
+      if (v.by_ns) {
+        *v.dirty = 1u;  // has to be sorted in
+      } else {
+        pos = (int64_t)atomicAdd(v.n_c, 1ull);
+        if (pos >= v.cap_c) {
+          *v.dirty = 1u;
+          pos = -1;
+        } else {
+          v.pos_c[p] = (int32_t)pos;
+          v.vc_rows[pos] = p;
+        }
       }
-      uint64_t* o = v_pk + j * pk.stride;
-      o[0] = w[0], o[1] = w[1];
-      if (pk.stride > 2u) o[2] = w[2], o[3] = w[3];
+    }
+    if (pos >= 0) {
+      if (v.by_ns && countable && ((v.vc_meta[pos] ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;  // moved to another namespace
+      write_view_record(pods, p, pos, meta, v.vc_meta, v.vc_latom, v.vc_req, v.pk, v.vc_pk);
+    }
+  }
+  if (v.va_meta) {
+    const int64_t pos = p < v.rows_a ? (int64_t)v.pos_a[p] : -1;
+    if (pos < 0) {
+      *v.dirty = 1u;  // a row the list does not cover yet
+    } else {
+      if ((st & kPodValid) && ((v.va_meta[pos] ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;
+      write_view_record(pods, p, pos, meta, v.va_meta, v.va_latom, nullptr, v.pk, nullptr);
     }
   }
 }
+void launch_patch_scan_views(const PodTable& pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch& v, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(kt_patch_scan_views, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pods, n, rows, row0, v);
+}
+
 void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
-                            int64_t* v_req, hipStream_t s, const PackPlan* pk, uint64_t* v_pk) {
+                            int64_t* v_req, hipStream_t s, const PackPlan* pk, uint64_t* v_pk, int32_t* pos) {
   if (n <= 0) return;
   hipLaunchKernelGGL(kt_build_scan_view, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, pods, n, rows, v_meta, v_latom, v_req,
-                     pk ? *pk : PackPlan(), pk ? v_pk : nullptr);
+                     pk ? *pk : PackPlan(), pk ? v_pk : nullptr, pos);
 }
 
 // kt_sum_abs_requests — sum over the valid pod rows of |effective request| per dimension, exactly (two 32-bit limb sums

@@ -36,8 +36,12 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
 // scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
 struct PackPlan;  // kt_index.h
 // pk + v_pk (nullable): also the packed request words of every listed pod
+// pos (nullable, one int32 per pod row, -1 = not listed): pos[row] = the record's position in the view
 void launch_build_scan_view(const PodTable& pods, int64_t n, const int64_t* rows, uint64_t* v_meta, uint16_t* v_latom,
-                            int64_t* v_req, hipStream_t s, const PackPlan* pk = nullptr, uint64_t* v_pk = nullptr);
+                            int64_t* v_req, hipStream_t s, const PackPlan* pk = nullptr, uint64_t* v_pk = nullptr, int32_t* pos = nullptr);
+// a pod event batch applied to the scan views in place (kt_kernels.hip: kt_patch_scan_views)
+struct ViewPatch;  // kt_index.h
+void launch_patch_scan_views(const PodTable& pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch& v, hipStream_t s);
 // exact per-dimension sums of |request| over the valid rows of [0, n): out[2d] low-half sum, out[2d+1] high-half sum (32 words)
 void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);

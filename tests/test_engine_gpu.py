@@ -304,6 +304,11 @@ def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
     if budget:
         monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
     base = W.generate(W.small(seed=73, n_pods=2600, n_thr=96, n_cluster=48))
+    # pod 2599 carries a cpu request larger than every other and with odd low bits: when it arrives, the packed request
+    # words of the scan view (PackPlan: field widths / common trailing zeros proved per view) no longer hold — rebuild
+    k99 = int(base.pod_ctr_off[2599])
+    base.ctr_req[k99, 0] = 3_000_001
+    base.ctr_present[k99] |= 1
     P = 2200
     rng = np.random.default_rng(73)
     state = np.full(P, -1, dtype=np.int64)
@@ -350,6 +355,24 @@ def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
         del_rows = rng.choice(2000, 400, replace=False).astype(np.int64)
         state[del_rows] = -1
         eng.delete_pods(del_rows)
+        sweep()
+        # single-pod events: the scan lists / views are patched in place (records rewritten, appended, left behind as
+        # "not countable") instead of being rebuilt — kt_patch_scan_views
+        for k in range(60):
+            r = int(rng.integers(0, 2200))
+            if rng.random() < .25 and state[r] >= 0:
+                state[r] = -1
+                eng.delete_pods(np.array([r], dtype=np.int64))
+            else:
+                state[r] = int(rng.integers(0, 2599))
+                eng.upsert_pods(_permute_pods(base, state[[r]]), rows=np.array([r]))
+            if k % 12 == 11:
+                sweep()
+        state[7] = 2599                                        # does not fit the packed fields: the views are rebuilt
+        eng.upsert_pods(_permute_pods(base, state[[7]]), rows=np.array([7]))
+        sweep()
+        state[8] = 11
+        eng.upsert_pods(_permute_pods(base, state[[8]]), rows=np.array([8]))
         sweep()
         eng.upsert_throttles(base)                             # program recompile: atoms re-translated, views rebuilt
         sweep()
