@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -56,6 +57,11 @@ struct HostThrottle {
   uint64_t status_fp = 0, spec_fp = 0;
   std::vector<Override> ovr;
   std::vector<Term> terms;
+  // namespace side of the terms, evaluated once per (throttle, namespace generation): bit n of row k = term k can apply
+  // to pods of namespace n.  A throttle event then costs the evaluation of ONE throttle's namespaceSelectors, not of all
+  std::vector<uint32_t> adm;
+  uint64_t adm_gen = 0;
+  uint32_t adm_ns = 0;
 };
 struct HostNamespace {
   bool valid = false;
@@ -198,6 +204,7 @@ struct kt_engine {
 
   // ---- host mirrors of the small tables
   std::vector<HostNamespace> ns;
+  uint64_t ns_gen = 1;  // bumped by every namespace event (HostThrottle::adm is keyed by it)
   int32_t ns_rows_hi = 0;
   int64_t pod_ns_hi = 0;   // 1 + highest namespace row any pod was fed with
   size_t ns_compiled = 0;  // namespace rows the compiled program / index cover (compile_program)
@@ -506,6 +513,14 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
 
 // Compile throttles + namespaces into the device selector program, spec tables and index.
 int32_t compile_program(kt_engine* e, hipStream_t s) {
+  static const bool dbg_time = getenv("KT_DEBUG_COMPILE") != nullptr;  // phase times of a recompile on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_time) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "compile_program: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   const int D = e->D;
   const size_t T = (size_t)e->thr_rows_hi;
   // namespace rows the program covers: the rows in USE (namespace objects, pods, namespaced Throttles), not the
@@ -558,28 +573,51 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
       }
     thr_term_off[t + 1] = (uint32_t)term_thr.size();
   }
+  lap("flatten throttles");
   const size_t G = term_thr.size();
   const uint32_t gw = (uint32_t)((G + 31) / 32 + 1);
-  // ns x term applicability bitmap
-  std::vector<uint32_t> ns_term_ok(NS * gw, 0u);
+  // ns x term applicability: the namespace side of every term, cached per throttle (HostThrottle::adm) and re-evaluated
+  // only for throttles that changed since — or for all of them, on several host threads, after a namespace event
+  const uint32_t nsw = (uint32_t)((NS + 31) / 32);
   std::vector<uint8_t> ns_valid(NS, 0);
   for (size_t n = 0; n < NS; ++n) ns_valid[n] = n < e->ns.size() && e->ns[n].valid;
+  {
+    std::vector<uint32_t> stale;
+    for (size_t t = 0; t < T; ++t) {
+      const HostThrottle& h = e->thr[t];
+      if ((h.flags & KT_THR_VALID) && (h.adm_gen != e->ns_gen || h.adm_ns != (uint32_t)NS || h.adm.size() != h.terms.size() * nsw)) stale.push_back((uint32_t)t);
+    }
+    kt::parallel_for(stale.size(), 64, [&](size_t b0, size_t b1, size_t) {
+      for (size_t q = b0; q < b1; ++q) {
+        HostThrottle& h = e->thr[stale[q]];
+        h.adm.assign(h.terms.size() * nsw, 0u);
+        h.adm_gen = e->ns_gen, h.adm_ns = (uint32_t)NS;
+        const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
+        if ((h.flags & need) != need) continue;
+        for (size_t k = 0; k < h.terms.size(); ++k) {
+          const Term& tm = h.terms[k];
+          uint32_t* row = h.adm.data() + k * nsw;
+          if (!(h.flags & KT_THR_CLUSTER)) {
+            // Throttles(pod.Namespace).List: implicit namespace equality, no Namespace object needed
+            if (h.ns < NS) row[h.ns >> 5] |= 1u << (h.ns & 31);
+          } else {
+            if (tm.flags & KT_TERM_NS_SEL_INVALID) continue;  // swallowed to "no match" (clusterthrottle_selector.go:63-69)
+            for (size_t n = 0; n < NS && n < e->ns.size(); ++n)
+              if (e->ns[n].valid && ns_selector_matches(tm.nreq, e->ns[n])) row[n >> 5] |= 1u << (n & 31);
+          }
+        }
+      }
+    }, nullptr);
+  }
+  std::vector<uint32_t> adm_all(G * nsw, 0u);  // [term][namespace words]: what the index build wants
   for (size_t t = 0; t < T; ++t) {
     const HostThrottle& h = e->thr[t];
-    const uint32_t need = KT_THR_VALID | KT_THR_RESPONSIBLE;
-    if ((h.flags & need) != need) continue;
-    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
-      const Term& tm = h.terms[g - thr_term_off[t]];
-      if (!(h.flags & KT_THR_CLUSTER)) {
-        // Throttles(pod.Namespace).List: implicit namespace equality, no Namespace object needed
-        if (h.ns < NS) ns_term_ok[(size_t)h.ns * gw + (g >> 5)] |= 1u << (g & 31);
-      } else {
-        if (tm.flags & KT_TERM_NS_SEL_INVALID) continue;  // swallowed to "no match" (clusterthrottle_selector.go:63-69)
-        for (size_t n = 0; n < NS && n < e->ns.size(); ++n)
-          if (e->ns[n].valid && ns_selector_matches(tm.nreq, e->ns[n])) ns_term_ok[n * gw + (g >> 5)] |= 1u << (g & 31);
-      }
-    }
+    if (!(h.flags & KT_THR_VALID) || h.terms.empty()) continue;
+    memcpy(adm_all.data() + (size_t)thr_term_off[t] * nsw, h.adm.data(), h.adm.size() * 4);
   }
+  std::vector<uint32_t> ns_term_ok;  // [namespace][term words]: what the kernels' rare paths and the dense variant read
+  kt::transpose_term_ns_bits(adm_all, G, nsw, (uint32_t)NS, gw, ns_term_ok);
+  lap("namespace side of the terms");
   int32_t rc;
 #define UP(dev, host) if ((rc = upload(e, e->dev, host, s)) != KT_OK) return rc
   UP(d_thr_term_off, thr_term_off);
@@ -617,6 +655,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_recs2[0].reserve(kt::recs_bytes((int)T)));
   KT_HIP(e, e->d_recs2[1].reserve(kt::recs_bytes((int)T)));
   e->recs_prev_valid = false;
+  lap("uploads + buffers");
   // index for the work ~ (pods + matches) kernels
   {
     auto thr_info = [&](uint32_t t) {
@@ -636,11 +675,16 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();
-    kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
-                    (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L);
     // KT_CHUNK_HALF=1 (A/B runs): keep the half-LDS chunks — more of them, but two workgroups per CU
-    if (!hook && !getenv("KT_CHUNK_HALF") && e->hindex.bm_chunks.size() > 1)
+    const bool full_when_chunked = !hook && !getenv("KT_CHUNK_HALF");
+    kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
+                    (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L, &adm_all,
+                    full_when_chunked ? lds_all - kt::check_fixed_lds() : 0u);
+    lap("build_index");
+    // a program that fits half the LDS as rows but still came out in several chunks (per-term tables): larger chunks
+    if (full_when_chunked && e->hindex.bm_chunks.size() > 1 && e->hindex.cut_chk_budget != lds_all - kt::check_fixed_lds())
       kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes);
+    lap("cut_chunks (full LDS)");
   }
   kt::index_group_counts(e->hindex, (uint32_t)T);
   e->agg_valid = false;  // a new selector program: the maintained partials are void
@@ -649,6 +693,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     hipError_t he = kt::upload_index(e->hindex, e->dindex, s);
     if (he != hipSuccess) return e->fail(KT_ERR_DEVICE, "upload_index: %s", hipGetErrorString(he));
   }
+  lap("upload_index");
   // the pods' labels as atom ids of THIS program (labels no selector mentions drop out here)
   e->pods.LA = (int32_t)e->hindex.la;
   KT_HIP(e, e->d_latom.reserve((size_t)e->cfg.pod_capacity * (size_t)e->pods.LA + 64));
@@ -677,6 +722,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   KT_HIP(e, e->d_sp.reserve(1));
   KT_HIP(e, hipMemcpyAsync(e->d_sp.p, &e->sp, sizeof(kt::SelProgram), hipMemcpyHostToDevice, s));
   KT_HIP(e, hipStreamSynchronize(s));
+  lap("translate pods + sync");
   e->program_dirty = false;
   ++e->program_gen;
   return KT_OK;
@@ -973,7 +1019,7 @@ int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* b, const int32_t* 
       n.labels.emplace_back(b->ns_label_key[k], b->ns_label_pair[k]);
     e->ns_rows_hi = std::max(e->ns_rows_hi, (rows ? rows[i] : i) + 1);
   }
-  if (b->n_ns > 0) e->program_dirty = true;
+  if (b->n_ns > 0) e->program_dirty = true, ++e->ns_gen;
   return KT_OK;
 }
 
@@ -984,7 +1030,7 @@ int32_t kt_delete_namespaces(kt_engine* e, int32_t n, const int32_t* rows) {
     if (rows[i] < 0 || rows[i] >= e->cfg.namespace_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "namespace row %d", rows[i]);
     e->ns[(size_t)rows[i]] = HostNamespace();
   }
-  if (n > 0) e->program_dirty = true;
+  if (n > 0) e->program_dirty = true, ++e->ns_gen;
   return KT_OK;
 }
 
@@ -1498,6 +1544,7 @@ int32_t kt_load_snapshot(kt_engine* e, const kt_snapshot* s) {
   for (auto& m : e->max_abs) m = 0;
   for (auto& m : e->or_abs) m = 0;
   for (auto& n : e->ns) n = HostNamespace();
+  ++e->ns_gen;
   for (auto& t : e->thr) t = HostThrottle();
   e->ns_rows_hi = 0;
   e->thr_rows_hi = 0;

@@ -2,9 +2,11 @@
 #include "kt_index.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -28,15 +30,74 @@ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace
 
+// f(begin, end, part) over [0, n) on up to 16 host threads (a recompile after a throttle event is on the scheduler's
+// critical path: 10k throttles / 30k terms are 25 ms of single-threaded index construction)
+void parallel_for(size_t n, size_t min_per_part, const std::function<void(size_t, size_t, size_t)>& f, size_t* parts_out) {
+  size_t parts = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, n / std::max<size_t>(1, min_per_part)));
+  if (getenv("KT_INDEX_THREADS")) parts = std::max(1, atoi(getenv("KT_INDEX_THREADS")));
+  if (parts_out) *parts_out = parts;
+  if (parts <= 1) {
+    f(0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < parts; ++k) th.emplace_back([&, k] { f(n * k / parts, n * (k + 1) / parts, k); });
+  for (auto& t : th) t.join();
+}
+size_t parallel_parts(size_t n, size_t min_per_part) {
+  size_t parts = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, n / std::max<size_t>(1, min_per_part)));
+  if (getenv("KT_INDEX_THREADS")) parts = std::max(1, atoi(getenv("KT_INDEX_THREADS")));
+  return parts;
+}
+
+// out[n][gw] (bit g of row n) = in[g][nsw] (bit n of row g): 32 x 32 bit blocks (Hacker's Delight 7-3)
+void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t nsw, uint32_t n_ns, uint32_t gw, std::vector<uint32_t>& out) {
+  out.assign((size_t)n_ns * gw, 0u);
+  const size_t gb = (G + 31) / 32;
+  parallel_for(gb, 64, [&](size_t b0, size_t b1, size_t) {
+    for (size_t bg = b0; bg < b1; ++bg)
+      for (uint32_t bn = 0; bn < nsw; ++bn) {
+        uint32_t a[32];
+        bool any = false;
+        for (uint32_t k = 0; k < 32; ++k) {
+          const size_t g = bg * 32 + k;
+          a[k] = g < G ? in[g * nsw + bn] : 0u;
+          any |= a[k] != 0u;
+        }
+        if (!any) continue;
+        // a[k] bit j  ->  t[j] bit k
+        uint32_t m = 0x0000FFFFu;
+        for (uint32_t j = 16; j != 0; j >>= 1, m ^= m << j)
+          for (uint32_t k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = (a[k] ^ (a[k + j] << j)) & ~m;  // (lsb-first variant of the classic step)
+            a[k] ^= t;
+            a[k + j] ^= t >> j;
+          }
+        for (uint32_t j = 0; j < 32; ++j) {
+          const uint32_t n = bn * 32 + j;
+          if (n < n_ns && a[j]) out[(size_t)n * gw + bg] = a[j];
+        }
+      }
+  }, nullptr);
+}
+
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
                  const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
-                 int max_labels) {
+                 int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full) {
   out = HostIndex();
   (void)term_thr;
+  static const bool dbg_time = getenv("KT_DEBUG_COMPILE") != nullptr;  // phase times on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_time) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  build_index: %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
   // a reachable unconvertible podSelector makes term ORDER matter: these throttles are walked term by term
   std::vector<uint8_t> is_slow_thr(T, 0);
@@ -91,19 +152,30 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // admission set of every term as namespace bit words, transposed from ns_term_ok by walking its SET bits (the rows
   // are sparse: a namespace admits a few thousand of the terms)
   const size_t G_all = term_req_off.empty() ? 0 : term_req_off.size() - 1;
-  std::vector<uint32_t> adm_all(G_all * nsw, 0u);
-  for (uint32_t n = 0; n < n_ns; ++n) {
-    const uint32_t* row = ns_term_ok.data() + (size_t)n * gw;
-    for (uint32_t wi = 0; wi < gw; ++wi)
-      for (uint32_t m = row[wi]; m; m &= m - 1) {
-        const size_t g = (size_t)wi * 32 + (size_t)__builtin_ctz(m);
-        if (g < G_all) adm_all[g * nsw + (n >> 5)] |= 1u << (n & 31);
-      }
+  std::vector<uint32_t> adm_own;
+  if (!adm_in || adm_in->size() != G_all * nsw) {
+    adm_own.assign(G_all * nsw, 0u);
+    for (uint32_t n = 0; n < n_ns; ++n) {
+      const uint32_t* row = ns_term_ok.data() + (size_t)n * gw;
+      for (uint32_t wi = 0; wi < gw; ++wi)
+        for (uint32_t m = row[wi]; m; m &= m - 1) {
+          const size_t g = (size_t)wi * 32 + (size_t)__builtin_ctz(m);
+          if (g < G_all) adm_own[g * nsw + (n >> 5)] |= 1u << (n & 31);
+        }
+    }
   }
-  // ---- terms
+  const std::vector<uint32_t>& adm_all = adm_own.empty() && adm_in ? *adm_in : adm_own;  // the caller may hold the per-term sets already
+  lap("atoms + admission transpose");
+  // ---- terms (throttles are independent: built by ranges on several host threads, joined in throttle order)
   std::vector<BT> bts;
   std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
-  for (size_t t = 0; t < T; ++t) {
+  const size_t term_parts = parallel_parts(T, 512);
+  std::vector<std::vector<BT>> bts_part(term_parts);
+  std::vector<std::vector<uint32_t>> first_part(term_parts);
+  parallel_for(T, 512, [&](size_t t_begin, size_t t_end, size_t part) {
+  std::vector<BT>& bts = bts_part[part];
+  std::vector<uint32_t>& first_of = first_part[part];
+  for (size_t t = t_begin; t < t_end; ++t) {
     const ThrInfo ti = thr_info((uint32_t)t);
     if (!ti.live || is_slow_thr[t]) continue;
     const size_t first = bts.size();
@@ -171,6 +243,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       bts.push_back(std::move(b));
     }
   }
+  }, nullptr);
+  for (size_t k = 0; k < term_parts; ++k) {
+    const uint32_t off = (uint32_t)bts.size();
+    for (uint32_t f : first_part[k]) first_of.push_back(f + off);
+    for (BT& b : bts_part[k]) bts.push_back(std::move(b));
+  }
+  lap("terms");
   out.n_pair_keys = (uint32_t)pair_keys.size();
   out.n_key_atoms = (uint32_t)key_atoms.size();
   {
@@ -228,6 +307,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     i = j;
   }
+  lap("groups (cells)");
   std::vector<uint8_t> grp_own_adm(grps.size(), 0);  // group of a >64-term throttle: copies use the term's own set
   {
     std::vector<uint32_t> cnt(grps.size(), 0u);
@@ -245,6 +325,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     if (x != y) return x < y;
     return tcs[a].grp < tcs[b].grp;
   });
+  lap("sort by admission set");
   // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
   // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
   const uint32_t gran = tcs.size() <= 4096 ? 64u : 128u;
@@ -304,6 +385,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       out.atom_table[s] = (uint64_t)ai.atom | (uint64_t)ai.id << 32;
     }
   }
+  lap("numbering + atom ids");
   // ---- full bitmaps (host only), dense throttle ranks in term order
   const bool veto = out.rich;  // the image form follows the kernel instantiation
   // (kept in the HostIndex: cut_chunks() lays them out as chunk images, and can do so again for other LDS budgets)
@@ -327,41 +409,55 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   {
     std::vector<uint32_t> by_num(G2, ~0u);
     for (size_t q = 0; q < tcs.size(); ++q) by_num[num[q]] = (uint32_t)q;
+    // dense ranks: one per GROUP in number order (a throttle with several cells has several; the slab reduction adds
+    // them all into the throttle's row) — the one sequential pass
     uint32_t last_g = ~0u;
     for (uint32_t c = 0; c < G2; ++c) {
       if (by_num[c] == ~0u) continue;  // padding
       const TC& tc = tcs[by_num[c]];
-      const BT& b = bts[tc.bt];
-      // dense ranks: one per GROUP in number order (a throttle with several cells has several; the slab reduction
-      // adds them all into the throttle's row)
-      if (tc.grp != last_g) out.bm_rank_t.push_back(b.t), last_g = tc.grp;
+      if (tc.grp != last_g) out.bm_rank_t.push_back(bts[tc.bt].t), last_g = tc.grp;
       term_rank[c] = (uint32_t)out.bm_rank_t.size() - 1;
-      real[c] = 1;
-      const uint64_t bit = 1ull << (c & 63);
-      const size_t w = c >> 6;
-      term_t[c] = b.t | kTermReal | (b.adj ? kTermAdj : 0u);
-      term_g[c] = b.g;
-      if (b.pos.empty()) hdr[w].univ |= bit;
-      for (uint32_t r : pos_rows[tc.bt]) any[(size_t)r * W + w] |= bit;
-      for (uint32_t r : neg_rows[tc.bt]) vet[(size_t)r * W + w] |= bit;
-      if (b.need >= 2) hdr[w].m2 |= bit;
-      if (b.need >= 3) hdr[w].m3 |= bit;
-      if (b.slow) hdr[w].slow |= bit;
-      const std::vector<uint32_t>& adm = grp_own_adm[tc.grp] ? b.adm : grps[tc.grp].adm;
-      for (uint32_t wi = 0; wi < nsw; ++wi)
-        for (uint32_t m = adm[wi]; m; m &= m - 1) {
-          const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
-          if (n < n_ns) nsrows[(size_t)n * W + w] |= bit;
-        }
     }
+    // the bits: every 64-bit word column of the bitmaps belongs to one range of term numbers — ranges on several threads
+    parallel_for(W, 32, [&](size_t w_begin, size_t w_end, size_t) {
+      for (uint32_t c = (uint32_t)w_begin * 64u; c < std::min<uint32_t>((uint32_t)w_end * 64u, G2); ++c) {
+        if (by_num[c] == ~0u) continue;  // padding
+        const TC& tc = tcs[by_num[c]];
+        const BT& b = bts[tc.bt];
+        real[c] = 1;
+        const uint64_t bit = 1ull << (c & 63);
+        const size_t w = c >> 6;
+        term_t[c] = b.t | kTermReal | (b.adj ? kTermAdj : 0u);
+        term_g[c] = b.g;
+        if (b.pos.empty()) hdr[w].univ |= bit;
+        for (uint32_t r : pos_rows[tc.bt]) any[(size_t)r * W + w] |= bit;
+        for (uint32_t r : neg_rows[tc.bt]) vet[(size_t)r * W + w] |= bit;
+        if (b.need >= 2) hdr[w].m2 |= bit;
+        if (b.need >= 3) hdr[w].m3 |= bit;
+        if (b.slow) hdr[w].slow |= bit;
+        const std::vector<uint32_t>& adm = grp_own_adm[tc.grp] ? b.adm : grps[tc.grp].adm;
+        for (uint32_t wi = 0; wi < nsw; ++wi)
+          for (uint32_t m = adm[wi]; m; m &= m - 1) {
+            const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
+            if (n < n_ns) nsrows[(size_t)n * W + w] |= bit;
+          }
+      }
+    }, nullptr);
   }
-  cut_chunks(out, agg_budget, chk_budget, thr_bytes);
+  lap("full bitmaps");
+  // chunks for chk_budget (two check workgroups per CU) — unless the caller wants larger chunks when the program needs
+  // several anyway (chk_budget_full) and it plainly does: then only that cut is made
+  const size_t rows_bytes = (size_t)R * W * 8u * (veto ? 2u : 1u);
+  if (chk_budget_full && rows_bytes > (size_t)chk_budget) cut_chunks(out, agg_budget, chk_budget_full, thr_bytes);
+  else cut_chunks(out, agg_budget, chk_budget, thr_bytes);
+  lap("cut_chunks");
 }
 
 // Cuts the numbered bitmaps of `out` (build_index) into chunk images for the given LDS budgets; callable again with
 // other budgets without renumbering (the engine first asks for half-LDS chunks — two check workgroups per CU — and
 // re-cuts for the full LDS when the program needs several chunks anyway).
 void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
+  out.cut_chk_budget = chk_budget;
   const uint32_t W = out.bm_words, R = out.bm_rows, n_ns = out.n_ns;
   const bool veto = out.rich;
   const std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;

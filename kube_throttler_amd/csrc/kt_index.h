@@ -119,6 +119,7 @@ struct HostIndex {
   uint32_t ns_words = 0;                   // 32-bit words per row of bm_chunk_ns
   uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
+  uint32_t cut_chk_budget = 0; // the check budget the chunks were last cut for
   // the numbered program before it is cut into chunks (host only; cut_chunks reads it): full bitmap rows [rows][W],
   // namespace rows [n_ns][W], per-word headers, per-number tables [W * 64]
   uint32_t n_ns = 0;
@@ -210,7 +211,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
-                 int max_labels);
+                 int max_labels, const std::vector<uint32_t>* adm_in = nullptr, uint32_t chk_budget_full = 0);
+// adm_in (optional): the namespace admission set of every term as bit words [terms][(n_ns + 31) / 32] (= ns_term_ok
+// transposed), when the caller holds it already; chk_budget_full (optional): the check budget to cut for when the
+// program needs several chunks anyway (one cut instead of two)
+// out[n][gw] (bit g of row n) = in[g][nsw] (bit n of row g)
+void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t nsw, uint32_t n_ns, uint32_t gw, std::vector<uint32_t>& out);
+void parallel_for(size_t n, size_t min_per_part, const std::function<void(size_t, size_t, size_t)>& f, size_t* parts_out);
 // chunk images of an index build_index numbered, for other LDS budgets (no renumbering)
 void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
 // groups per throttle row and the rows without any, from bm_rank_t (after the final cut)
