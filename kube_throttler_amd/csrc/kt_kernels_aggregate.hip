@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAgg
       }
 
       uint32_t last_r = 0xFFFFFFFFu;
-      scan_tile<LA, VETO, NEED>(
+      scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
           bm, scan_counted, ns, ro,
           [&](bool has, uint32_t c) {
             const uint32_t tr = trank[c];

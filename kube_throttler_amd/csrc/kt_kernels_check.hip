@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
 
       if (!WORDWISE) {
-      scan_tile<LA, VETO, NEED>(
+      scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
           bm, scan_on, ns, ro,
           [&](bool has, uint32_t c) {
             // branch-free: the term's TermInfo word carries both verdicts a non-tight throttle can give (as the bit
@@ -308,31 +308,44 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       // every match that needs no comparison is settled per WORD with mask algebra (WordVerdict), the matches of tight
       // throttles are peeled into the list as bare term numbers
       KT_LDS const WordVerdict<DT>* wv = (KT_LDS const WordVerdict<DT>*)(lds + a.off_wv);
-      scan_tile<LA, VETO, NEED>(
+      // the word's verdict masks are requested as soon as the word is known (pre), so that they arrive with the atom rows
+      struct VerdictRegs {
+        u64x2 seg, te, ai;
+        u64x2 ad[DT / 2];
+      };
+      scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
           bm, scan_on, ns, ro,
           [&](bool has, uint32_t c) { if (!(a.exp & 4u)) push(has, c); },
           [&](uint32_t c) {
             return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
           },
-          [&](uint32_t w, uint64_t x) -> uint64_t {
+          [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
             if (a.exp & 2u) return x;
-            KT_LDS const WordVerdict<DT>* q = wv + w;
-            const u64x2 seg = *(KT_LDS const u64x2*)&q->seg_lo;  // {seg_lo, seg_hi}
-            const u64x2 te = *(KT_LDS const u64x2*)&q->tight;    // {tight, exc}
-            const u64x2 ai = *(KT_LDS const u64x2*)&q->act;      // {act, ins}
             // a throttle with several terms is reported once: the lowest match of every run
-            const uint64_t v = x | seg.y;
-            x &= (v ^ (v - seg.x)) & v;
-            uint64_t act = ai.x;
+            const uint64_t v = x | q.seg.y;
+            x &= (v ^ (v - q.seg.x)) & v;
+            uint64_t act = q.ai.x;
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
-              if ((nz >> d) & 1u) act |= q->act_d[d];
-            const uint64_t xf = x & ~te.x & ~te.y;  // settled here, not exceeded by count
-            const uint64_t n_exc = (uint64_t)__popcll(x & ~te.x & te.y);
+            for (int d = 0; d < DT; ++d) {
+              const uint64_t m = 0ull - (uint64_t)((nz >> d) & 1u);  // all ones when the pod requests dimension d
+              act |= ((d & 1) ? q.ad[d / 2].y : q.ad[d / 2].x) & m;
+            }
+            const uint64_t xf = x & ~q.te.x & ~q.te.y;  // settled here, not exceeded by count
+            const uint64_t n_exc = (uint64_t)__popcll(x & ~q.te.x & q.te.y);
             const uint64_t n_act = (uint64_t)__popcll(xf & act);
-            const uint64_t n_ins = (uint64_t)__popcll(xf & ~act & ai.y);
+            const uint64_t n_ins = (uint64_t)__popcll(xf & ~act & q.ai.y);
             my += n_exc << 4 | n_act << 24 | n_ins << 44;
-            return x & te.x;
+            return x & q.te.x;
+          },
+          [&](uint32_t w) -> VerdictRegs {
+            KT_LDS const WordVerdict<DT>* q = wv + w;
+            VerdictRegs r;
+            r.seg = *(KT_LDS const u64x2*)&q->seg_lo;  // {seg_lo, seg_hi}
+            r.te = *(KT_LDS const u64x2*)&q->tight;    // {tight, exc}
+            r.ai = *(KT_LDS const u64x2*)&q->act;      // {act, ins}
+#pragma unroll
+            for (int d = 0; d < DT / 2; ++d) r.ad[d] = *(KT_LDS const u64x2*)&q->act_d[2 * d];
+            return r;
           });
       }
       if (n_list) drain();

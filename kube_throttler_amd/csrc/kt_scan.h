@@ -139,15 +139,26 @@ __device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uin
 //   post(w, x) : per lane, once per advanced word: x = the matched terms of word w; returns the bits that still go
 //                through the peel (a consumer that can settle matches 64 at a time with mask algebra keeps the rest)
 struct ScanKeepAll {
-  __device__ __forceinline__ uint64_t operator()(uint32_t, uint64_t x) const { return x; }
+  __device__ __forceinline__ uint64_t operator()(uint32_t, uint64_t x, int) const { return x; }
 };
-template <int LA, bool VETO, int NEED, class Match, class Confirm, class Post = ScanKeepAll>
+struct ScanNoPrefetch {
+  __device__ __forceinline__ int operator()(uint32_t) const { return 0; }
+};
+//   pre(w)      : per lane, called as soon as the word of an advance is known — BEFORE the atom rows are consumed: what the
+//                 consumer's post() will need of word w (its reads then travel with the row reads instead of starting a
+//                 round trip of their own after the accumulation); its result is handed to post(w, x, pre(w))
+//   PIPE        : the list entry of the NEXT advance is requested during this one (one LDS round trip less per word: the
+//                 configs[4] check went from 926 to 824 us with it and pre()); on in the rich instantiations with room
+//                 for its four registers (not the 64-VGPR ones, and no gain measured on single-chunk simple programs)
+template <int LA, bool VETO, int NEED, bool PIPE = true, class Match, class Confirm, class Post = ScanKeepAll, class Pre = ScanNoPrefetch>
 __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_t ns, const uint32_t (&ro)[LA], Match&& match,
-                                          Confirm&& confirm, Post&& post = Post()) {
+                                          Confirm&& confirm, Post&& post = Post(), Pre&& pre = Pre()) {
   uint32_t k = b.nsl_off[ns];
   const uint32_t k1 = lane_on ? b.nsl_off[ns + 1] : k;
   uint64_t x = 0;
   uint32_t w = 0;
+  u32x4 e_next = {0u, 0u, 0u, 0u};
+  if (PIPE) e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));
   for (;;) {
     const bool has = x != 0;
     if (__ballot(has) != 0ull) {
@@ -158,45 +169,86 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
     } else if (__ballot(k < k1) != 0ull) {
       // ---- advance: next word of every lane that still has one
       const bool adv = k < k1;
-      const u32x4 e = *(lds_u4p)(b.nsl + (adv ? k : 0u));  // {w, -, mask lo, mask hi}
+      u32x4 e;  // {w, -, mask lo, mask hi}
+      if (PIPE) {
+        e = e_next;
+        k += adv ? 1u : 0u;
+        e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));  // the entry of the next advance, in flight behind this word's reads
+      } else {
+        e = *(lds_u4p)(b.nsl + (adv ? k : 0u));
+        k += adv ? 1u : 0u;
+      }
       w = e.x;
       const u64x2 h0 = *(KT_LDS const u64x2*)(b.hdr + w);  // {univ, m2}
-      uint64_t any = h0.x, two = 0, three = 0, vet = 0;
+      const auto pf = pre(w);
       KT_LDS const unsigned char* col = b.rows + w * (VETO ? 16u : 8u);
+      uint64_t xx, vet = 0;
+      if (NEED >= 3) {
+        // hits per term as a 2-bit counter (c1 c0): a pod carries at most one atom of any requirement and an exactly
+        // indexed term has at most three positive keys, so the count never passes 3 — three 64-bit operations per atom
+        // where the any / two / three accumulators took five
+        uint64_t c0 = 0, c1 = 0;
 #pragma unroll
-      for (int l = 0; l < LA; ++l) {
-        uint64_t r;
-        if (VETO) {
-          const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
-          r = rv.x;
-          vet |= rv.y;
-        } else {
-          r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+        for (int l = 0; l < LA; ++l) {
+          uint64_t r;
+          if (VETO) {
+            const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
+            r = rv.x;
+            vet |= rv.y;
+          } else {
+            r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+          }
+          c1 ^= c0 & r;
+          c0 ^= r;
         }
-        if (NEED >= 3) three |= two & r;
-        if (NEED >= 2) two |= any & r;
-        any |= r;
-      }
-      uint64_t xx = any;
-      if (NEED >= 2) xx = (any & ~h0.y) | (two & h0.y);
-      uint64_t slow = 0;
-      if (NEED >= 3 || VETO) {  // the rich instantiation also serves programs with `slow` shapes
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
-        if (NEED >= 3) xx = (xx & ~h1.x) | (three & h1.x);
-        slow = h1.y;
-      }
-      xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
-      xx = adv ? xx : 0ull;
-      if ((NEED >= 3 || VETO) && b.has_slow) {
-        uint64_t sl = xx & slow;
-        while (sl) {  // rare shapes: every requirement through the generic walk (lane-divergent)
-          const uint32_t bit = (uint32_t)__ffsll((unsigned long long)sl) - 1u;
-          sl &= sl - 1ull;
-          if (!confirm(w * 64u + bit)) xx &= ~(1ull << bit);
+        const uint64_t any = h0.x | c0 | c1, two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
+        xx = (any & ~h0.y) | (two & h0.y);
+        xx = (xx & ~h1.x) | (three & h1.x);
+        xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
+        xx = adv ? xx : 0ull;
+        if (b.has_slow) {
+          uint64_t sl = xx & h1.y;
+          while (sl) {  // rare shapes: every requirement through the generic walk (lane-divergent)
+            const uint32_t bit = (uint32_t)__ffsll((unsigned long long)sl) - 1u;
+            sl &= sl - 1ull;
+            if (!confirm(w * 64u + bit)) xx &= ~(1ull << bit);
+          }
+        }
+      } else {
+        uint64_t any = h0.x, two = 0;
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+          uint64_t r;
+          if (VETO) {
+            const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
+            r = rv.x;
+            vet |= rv.y;
+          } else {
+            r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+          }
+          if (NEED >= 2) two |= any & r;
+          any |= r;
+        }
+        xx = any;
+        if (NEED >= 2) xx = (any & ~h0.y) | (two & h0.y);
+        uint64_t slow = 0;
+        if (VETO) {  // the rich instantiation also serves programs with `slow` shapes
+          const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
+          slow = h1.y;
+        }
+        xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
+        xx = adv ? xx : 0ull;
+        if (VETO && b.has_slow) {
+          uint64_t sl = xx & slow;
+          while (sl) {
+            const uint32_t bit = (uint32_t)__ffsll((unsigned long long)sl) - 1u;
+            sl &= sl - 1ull;
+            if (!confirm(w * 64u + bit)) xx &= ~(1ull << bit);
+          }
         }
       }
-      x = post(w, xx);
-      k += adv ? 1u : 0u;
+      x = post(w, xx, pf);
     } else {
       break;
     }
