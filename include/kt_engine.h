@@ -188,6 +188,15 @@ int32_t kt_comm_destroy(kt_engine* e);
 
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
 int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out);
+/* resource.Quantity never overflows (Add promotes to big decimals, pkg/resourcelist/resourcelist.go:48-54).  When the
+ * requests of the pods an engine holds add up beyond int64 at the scale they were fed with, the reconcile sums their
+ * low 32-bit limbs and the rest separately (two scans, both blocks cross the exchange: kt_partial_used_buffer then
+ * reports twice the words) and kt_finalize joins them in 128 bits: `used`, the throttled flags and the check that
+ * follows are exact up to 2^124.  kt_reconcile_fetch returns the LOW 64 bits of every value, this call the HIGH 64 bits
+ * of rows [0, n) x n_dims (two's complement; out_any_wide, nullable: some value really left int64).  A status fed back
+ * through kt_set_status / kt_upsert_throttles is int64.  Not available to KT_VARIANT_INCREMENTAL engines and
+ * kt_admit_launch (KT_ERR_OVERFLOW_RISK / KT_ERR_UNSUPPORTED there). */
+int32_t kt_reconcile_fetch_used_hi(kt_engine* e, int32_t n, int64_t* out_hi, int32_t* out_any_wide);
 /* ThrottleSpecBase.NextOverrideHappensIn(now) (throttle_types.go:37-63) of the last reconcile for throttle rows
  * [0, n), as the INSTANT of the next override boundary (the controller's enqueueAfter delay is instant - now,
  * throttle_controller.go:201-208); has[i] = 0 when nothing lies ahead or the row was not reconciled. Synchronises. */

@@ -80,6 +80,9 @@ struct SelProgram {
 struct ThrTables {
   uint32_t* flags;  // kThr*
   AmountTab spec, calc, used, reserved;
+  // status.used beyond int64 (resource.Quantity never overflows, resourcelist.go:48-54): the HIGH 64 bits of every value,
+  // used.v holding the low 64 (two's complement); nullptr = every value is in range (sign extension of used.v)
+  int64_t* used_hi;
   uint32_t* thrl_flag;
   uint32_t* thrl_has;
   uint64_t* status_msgs_fp;
@@ -96,6 +99,7 @@ struct ThrTables {
 // Result of one reconcile pass (device), T rows.
 struct ReconcileOut {
   AmountTab used, calc;
+  int64_t* used_hi;  // nullable: high 64 bits of used.v (wide sums)
   uint8_t* calc_updated;
   uint32_t* thrl_flag;
   uint32_t* thrl_has;
@@ -134,6 +138,13 @@ struct RecFlags {
 template <int DT>
 __host__ __device__ inline RecFlags* rec_flags(void* recs, int T) { return (RecFlags*)((CheckRec<DT>*)recs + T); }
 inline size_t recs_bytes(int T) { return (size_t)(T + 1) * (sizeof(CheckRec<16>) + sizeof(RecFlags)); }
+
+// Wide sums: when the requests of the pods held add up beyond int64, a reconcile scans twice — once adding the low 32-bit
+// limb of every request (limb 1), once the rest (limb 2: request >> 32, arithmetic) — and kt_finalize puts the two sums
+// together in 128 bits.  limb 0 = the request itself.
+__host__ __device__ inline int64_t limb_of(int64_t v, int limb) {
+  return limb == 1 ? (int64_t)((uint64_t)v & 0xFFFFFFFFull) : limb == 2 ? (v >> 32) : v;
+}
 
 // layout of one throttle's row in the partial-used buffer (int64 words): v[D], present_count[D], pods, errors
 __host__ __device__ inline int partial_stride(int D) { return 2 * D + 2; }

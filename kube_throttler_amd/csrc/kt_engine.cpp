@@ -39,6 +39,7 @@ struct Term {
 };
 struct HostAmount {
   int64_t v[KT_MAX_DIMS] = {0};
+  int64_t v_hi[KT_MAX_DIMS] = {0};  // status.used only: high 64 bits of a sum beyond int64 (else the sign extension of v)
   uint32_t present = 0;
   int64_t count = 0;
   uint8_t has_count = 0;
@@ -248,6 +249,11 @@ struct kt_engine {
   unsigned long long* partial() { return ext_partial ? ext_partial : d_partial.p; }
   const void* clean_partial = nullptr;  // the partial buffer known to hold zeros (left behind by a consuming finalize)
   AmountDev d_out_used, d_out_calc;
+  // wide sums: when the requests of the pods held add up beyond int64 a reconcile scans twice (low 32-bit limbs, the rest)
+  // and kt_finalize joins the sums in 128 bits; the high words of `used` live beside the int64 tables
+  bool wide = false;          // decided by request_sums_in_range
+  bool agg_wide = false;      // the pending partials are limb sums: [2][T][2D+2]
+  DevBuf<int64_t> d_used_hi, d_out_used_hi;
   DevBuf<uint8_t> d_out_calc_updated, d_out_thrl_pod, d_out_error;
   DevBuf<int64_t> d_out_next_s;
   DevBuf<int32_t> d_out_next_ns;
@@ -453,7 +459,9 @@ int32_t sync_status_to_host(kt_engine* e) {
   AmountHostFlat used, calc;
   std::vector<uint32_t> flags(T), tf(T), th(T);
   std::vector<uint64_t> fp(T);
+  std::vector<int64_t> used_hi(T * D + 1, 0);
   int32_t rc;
+  if (T && e->d_used_hi.p) KT_HIP(e, hipMemcpyAsync(used_hi.data(), e->d_used_hi.p, T * D * 8, hipMemcpyDeviceToHost, s));
   if ((rc = download_amounts(e, e->d_used, used, T, D, s)) != KT_OK) return rc;
   if ((rc = download_amounts(e, e->d_calc, calc, T, D, s)) != KT_OK) return rc;
   if (T) {
@@ -467,6 +475,7 @@ int32_t sync_status_to_host(kt_engine* e) {
     HostThrottle& h = e->thr[t];
     if (!(h.flags & KT_THR_VALID)) continue;
     used.get(t, D, h.used);
+    for (int d = 0; d < D; ++d) h.used.v_hi[d] = e->d_used_hi.p ? used_hi[t * D + d] : (h.used.v[d] < 0 ? -1 : 0);
     calc.get(t, D, h.calc);
     h.flags = flags[t];
     h.thrl_flag = tf[t];
@@ -487,10 +496,12 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
   res.resize(T, D);
   std::vector<uint32_t> flags(T), tf(T), th(T);
   std::vector<uint64_t> fp(T);
+  std::vector<int64_t> used_hi(T * D + 1, 0);
   for (size_t t = 0; t < T; ++t) {
     const HostThrottle& h = e->thr[t];
     calc.set(t, D, h.calc);
     used.set(t, D, h.used);
+    for (int d = 0; d < D; ++d) used_hi[t * D + d] = ((h.used.present >> d) & 1u) ? h.used.v_hi[d] : 0;
     res.set(t, D, h.reserved);
     flags[t] = h.flags;
     tf[t] = h.thrl_flag;
@@ -500,6 +511,7 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
   int32_t rc;
   if ((rc = upload_amounts(e, e->d_calc, calc, T, D, s)) != KT_OK) return rc;
   if ((rc = upload_amounts(e, e->d_used, used, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload(e, e->d_used_hi, used_hi, s)) != KT_OK) return rc;
   if ((rc = upload_amounts(e, e->d_reserved, res, T, D, s)) != KT_OK) return rc;
   if ((rc = upload(e, e->d_thr_flags, flags, s)) != KT_OK) return rc;
   if ((rc = upload(e, e->d_thrl_flag, tf, s)) != KT_OK) return rc;
@@ -641,9 +653,10 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   if ((rc = upload_amounts(e, e->d_spec, spec, T, D, s)) != KT_OK) return rc;
   if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
   // result / scratch buffers sized by T
-  KT_HIP(e, e->d_partial.reserve(T * kt::partial_stride(D) + 1));
+  KT_HIP(e, e->d_partial.reserve(2 * T * kt::partial_stride(D) + 1));  // room for the two limb-sum blocks of a wide reconcile
   e->clean_partial = nullptr;
   KT_HIP(e, e->d_out_used.reserve(T + 1, D));
+  KT_HIP(e, e->d_out_used_hi.reserve((T + 1) * (size_t)D));
   KT_HIP(e, e->d_out_calc.reserve(T + 1, D));
   KT_HIP(e, e->d_out_calc_updated.reserve(T + 1));
   KT_HIP(e, e->d_out_thrl_pod.reserve(T + 1));
@@ -746,6 +759,7 @@ int32_t ensure_ready(kt_engine* e, hipStream_t s) {
   e->tt.spec = e->d_spec.tab();
   e->tt.calc = e->d_calc.tab();
   e->tt.used = e->d_used.tab();
+  e->tt.used_hi = e->d_used_hi.p;
   e->tt.reserved = e->d_reserved.tab();
   e->tt.thrl_flag = e->d_thrl_flag.p;
   e->tt.thrl_has = e->d_thrl_has.p;
@@ -765,6 +779,7 @@ int32_t ensure_ready(kt_engine* e, hipStream_t s) {
 void amount_from_table(const kt_amounts& a, size_t i, int D, HostAmount& h) {
   h.present = a.present ? a.present[i] & ((1u << D) - 1u) : 0;
   for (int d = 0; d < D; ++d) h.v[d] = ((h.present >> d) & 1u) ? a.v[i * D + d] : 0;
+  for (int d = 0; d < D; ++d) h.v_hi[d] = h.v[d] < 0 ? -1 : 0;
   h.has_count = a.has_count ? (a.has_count[i] != 0) : 0;
   h.count = h.has_count ? a.count[i] : 0;
 }
@@ -790,7 +805,7 @@ inline unsigned __int128 rank_sum_bound(int32_t world) {
 #define KT_CHECK_PARTIALS_CURRENT(e, who)                                                                              \
   do {                                                                                                                 \
     if ((e)->agg_pending && ((e)->program_dirty || (e)->agg_gen != (e)->program_gen ||                                 \
-                             (e)->agg_words != (size_t)(e)->thr_rows_hi * kt::partial_stride((e)->D)))                 \
+                             (e)->agg_words != (size_t)(e)->thr_rows_hi * kt::partial_stride((e)->D) * ((e)->agg_wide ? 2u : 1u)))                 \
       return (e)->fail(KT_ERR_NOT_READY, who ": throttles or namespaces changed since kt_aggregate_launch filled the "  \
                                              "partial buffer; aggregate again");                                       \
   } while (0)
@@ -982,6 +997,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
                             &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_status, &e->d_stage, &e->d_slab, &e->d_admit};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
+  e->d_used_hi.release(); e->d_out_used_hi.release();
   e->d_ovr_begin_s.release(); e->d_ovr_end_s.release(); e->d_ovr_begin_ns.release(); e->d_ovr_end_ns.release();
   e->d_partial.release();
   e->d_out_next_s.release();
@@ -1651,14 +1667,24 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   unsigned long long h[32];
   KT_HIP(e, hipMemcpyAsync(h, e->d_req_sums.p, sizeof(h), hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));
+  bool wide = false;
   for (int d = 0; d < e->D; ++d) {
     const unsigned __int128 total = (unsigned __int128)h[2 * d] + ((unsigned __int128)h[2 * d + 1] << 32);
     e->req_sum_bound[d] = total;
-    if (total > rank_sum_bound(e->exchange_world))
-      return e->fail(KT_ERR_OVERFLOW_RISK,
-                     "dimension %d: the requests of the pods held here add up beyond 2^60 at this scale (the reference would "
-                     "promote to big decimals); use a coarser scale for it", d);
+    if (total > rank_sum_bound(e->exchange_world)) {
+      // where the reference would promote to big decimals (resourcelist.go:48-54): two limb sums per dimension, joined in
+      // 128 bits by kt_finalize — for engines that rescan (the maintained partials of an incremental engine are int64)
+      if (e->incremental)
+        return e->fail(KT_ERR_OVERFLOW_RISK,
+                       "dimension %d: the requests of the pods held here add up beyond 2^60 at this scale (the reference would "
+                       "promote to big decimals); an incremental engine needs a coarser scale for it", d);
+      if ((unsigned __int128)e->pod_rows_hi * (unsigned __int128)e->exchange_world > ((unsigned __int128)1 << 30))
+        return e->fail(KT_ERR_OVERFLOW_RISK, "dimension %d: wide sums hold for up to 2^30 pods over all ranks", d);
+      wide = true;
+    }
   }
+  if (wide != e->wide) e->countable_valid = false;  // packed request words only exist for sums inside int64
+  e->wide = wide;
   e->req_sums_valid = true;
   return KT_OK;
 }
@@ -1668,7 +1694,9 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   if ((rc = request_sums_in_range(e, s)) != KT_OK) return rc;
-  const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  const size_t block_words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  const size_t words = block_words * (e->wide ? 2 : 1);  // wide: the low-limb sums, then the high-part sums
+  e->agg_wide = e->wide;
   if (e->ext_partial && (int64_t)words > e->ext_partial_words)
     return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed",
                    (long long)e->ext_partial_words, (long long)words);
@@ -1710,7 +1738,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       const size_t nc = (size_t)e->view_cap_c + 1;
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
-      if (!e->incremental && !getenv_flag("KT_NO_PACK")) {
+      if (!e->incremental && !e->wide && !getenv_flag("KT_NO_PACK")) {
         const uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c, false));
         e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, !getenv_flag("KT_PK_NOPAD"));
         if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
@@ -1740,29 +1768,37 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     // reconcile in one call: the slab reduction of a packed scan is done by kt_reduce_finalize_packed
     // (single-chunk programs: with a chunked index most slabs are skipped and most throttles have several groups that meet
     // in the partial rows anyway — measured on the configs[4] shard: 111 us fused against 72 + 9 us)
-    const bool defer = allow_fused && !e->incremental && e->dindex.n_chunks == 1 && !getenv_flag("KT_NO_FUSED");
+    const bool defer = allow_fused && !e->incremental && !e->wide && e->dindex.n_chunks == 1 && !getenv_flag("KT_NO_FUSED");
     auto after_scan = [&]() {  // the slab reduction is its own kernel: time it as its own family
       tl.stop_now();
       if (!(defer && e->pack.nw)) tr.reset(new TimedLaunch(e, KT_KERNEL_REDUCE, s));
     };
-    if (e->cfg.kernel_variant == 1)
-      kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, e->partial(), s),
-          e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
-    else {
-      kt::AggScan sc;
-      sc.n = (int64_t)e->n_countable + (getenv_flag("KT_NO_SCAN_VIEW") ? 0 : e->view_extra), sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
-      sc.overflow_pods = e->n_overflow != 0;
-      // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
-      sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
-      if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
-      if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
-      if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
-      sc.defer_reduce = defer && sc.pk != nullptr;
-      const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->partial(), e->d_slab.p, s, after_scan);
-      if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
-      e->last_kernel[KT_KERNEL_AGGREGATE] = k;
-      if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch;
-      e->last_kernel[KT_KERNEL_REDUCE] = e->fused_pending ? "(in kt_reduce_finalize_packed)" : sc.launched_packed ? "kt_reduce_packed_slabs" : "kt_reduce_bitmap_slabs";
+    // wide sums: two scans, the low 32-bit limb of every request into the first block, the rest into the second
+    const int n_pass = e->wide ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const int limb = e->wide ? pass + 1 : 0;
+      unsigned long long* target = e->partial() + (size_t)pass * block_words;
+      if (e->cfg.kernel_variant == 1) {
+        kt::launch_aggregate_dense(e->pods, e->pod_rows_hi, e->sp, e->uses_keys, target, s, limb);
+        e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
+      } else {
+        kt::AggScan sc;
+        sc.n = (int64_t)e->n_countable + (getenv_flag("KT_NO_SCAN_VIEW") ? 0 : e->view_extra), sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
+        sc.overflow_pods = e->n_overflow != 0;
+        sc.limb = limb;
+        // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
+        sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
+        if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
+        if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
+        if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
+        sc.defer_reduce = defer && sc.pk != nullptr;
+        const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, target, e->d_slab.p, s,
+                                                     pass == 0 ? std::function<void()>(after_scan) : std::function<void()>());
+        if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
+        e->last_kernel[KT_KERNEL_AGGREGATE] = k;
+        if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch;
+        e->last_kernel[KT_KERNEL_REDUCE] = e->fused_pending ? "(in kt_reduce_finalize_packed)" : sc.launched_packed ? "kt_reduce_packed_slabs" : "kt_reduce_bitmap_slabs";
+      }
     }
   }
   KT_HIP(e, hipGetLastError());
@@ -1798,7 +1834,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
   e->agg_pending = false;  // consumed (or caller-provided partials: nothing was pending)
-  kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
+  kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_used_hi.p, e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
                        e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p, e->d_out_next_s.p, e->d_out_next_ns.p};
   const bool apply = (flags & KT_RECONCILE_APPLY) != 0;
   // with APPLY the stored status changes: leave the CheckRecs of the new status behind (kt_prepare_check fused in),
@@ -1823,7 +1859,8 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
       e->last_kernel[KT_KERNEL_FINALIZE] = "kt_reduce_finalize_packed";
     } else {
       kt::launch_finalize(e->tt, e->sp, e->D, e->partial(), consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT,
-                          e->recs_eq, req_bound(e), s, row_mask);
+                          e->recs_eq, req_bound(e), s, row_mask,
+                          e->agg_wide ? e->partial() + (size_t)e->thr_rows_hi * kt::partial_stride(e->D) : nullptr);
       e->last_kernel[KT_KERNEL_FINALIZE] = "kt_finalize";
     }
     e->fused_pending = false;
@@ -1860,7 +1897,7 @@ int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64
   int32_t rc = ensure_ready(e, e->own_stream);
   if (rc != KT_OK) return rc;
   *device_ptr = e->partial();
-  *n_int64 = (int64_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  *n_int64 = (int64_t)e->thr_rows_hi * kt::partial_stride(e->D) * (e->wide ? 2 : 1);
   return KT_OK;
 }
 
@@ -1948,6 +1985,29 @@ int32_t kt_reconcile_fetch(kt_engine* e, int32_t n, const kt_status* out) {
 #undef DL
   }
   KT_HIP(e, hipStreamSynchronize(s));
+  return KT_OK;
+}
+
+// High 64 bits of the last reconcile's `used` values (rows [0, n) x n_dims): all of them the sign extension of
+// kt_reconcile_fetch's used.v unless the requests of the pods held add up beyond int64 (resource.Quantity never overflows,
+// resourcelist.go:48-54: the engine then sums 32-bit limbs and joins them in 128 bits) — out_any_wide says whether any differs
+int32_t kt_reconcile_fetch_used_hi(kt_engine* e, int32_t n, int64_t* out_hi, int32_t* out_any_wide) {
+  if (!e || !out_hi) return KT_ERR_INVALID_ARGUMENT;
+  LaunchLock lk(e);
+  KT_HIP(e, hipSetDevice(e->device));
+  if (!e->reconcile_ready) return e->fail(KT_ERR_NOT_READY, "kt_reconcile_fetch_used_hi before a reconcile launch");
+  if (n < 0 || n > e->reconcile_T) return e->fail(KT_ERR_OUT_OF_RANGE, "n=%d, throttle rows of the last reconcile=%d", n, e->reconcile_T);
+  hipStream_t s = e->last_stream ? e->last_stream : e->own_stream;
+  const size_t N = (size_t)n * (size_t)e->D;
+  std::vector<int64_t> lo(N + 1);
+  if (N) {
+    KT_HIP(e, hipMemcpyAsync(out_hi, e->d_out_used_hi.p, N * 8, hipMemcpyDeviceToHost, s));
+    KT_HIP(e, hipMemcpyAsync(lo.data(), e->d_out_used.v.p, N * 8, hipMemcpyDeviceToHost, s));
+  }
+  KT_HIP(e, hipStreamSynchronize(s));
+  int32_t any = 0;
+  for (size_t i = 0; i < N; ++i) any |= out_hi[i] != (lo[i] < 0 ? -1 : 0);
+  if (out_any_wide) *out_any_wide = any;
   return KT_OK;
 }
 
@@ -2096,6 +2156,8 @@ int32_t kt_admit_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   hipStream_t s = pick_stream(e, stream);
+  if (e->wide)
+    return e->fail(KT_ERR_UNSUPPORTED, "admit queue: the stored `used` of this engine is wider than int64 (kt_admit_sequential reads int64 tables)");
   if ((double)n * (double)e->thr_rows_hi > 2147483648.0)
     return e->fail(KT_ERR_OUT_OF_RANGE, "admit queue: n x throttle_rows = %lld x %d exceeds 2^31 matrix bytes", (long long)n, e->thr_rows_hi);
   // (a) who affects whom, for the whole queue in parallel (statuses against the current reserved amounts)

@@ -257,6 +257,7 @@ struct AggScan {
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
   const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
   const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
+  int limb = 0;                  // wide sums: the limb of every request this scan adds (limb_of, kt_device.h)
   bool defer_reduce = false;     // packed scans: leave the slabs as they are — kt_reduce_finalize_packed takes them from there
   mutable int launched_blocks = 0;  // out: workgroups (= slabs per chunk) of the scan launch
   mutable bool launched_packed = false;

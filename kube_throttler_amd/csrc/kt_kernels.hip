@@ -384,8 +384,12 @@ __global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_
       }
     }
     if (pos >= 0) {
-      if (v.by_ns && countable && ((v.vc_meta[pos] ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;  // moved to another namespace
-      write_view_record(pods, p, pos, meta, v.vc_meta, v.vc_latom, v.vc_req, v.pk, v.vc_pk);
+      const uint64_t old = v.vc_meta[pos];
+      if (v.by_ns && countable && ((old ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;  // moved to another namespace
+      // a record that stops counting keeps its place in its namespace's run: the scans read the namespace range of a
+      // workgroup off the first and last record of its tiles
+      const uint64_t meta_w = countable ? meta : (meta & ~kMetaNsMask) | (old & kMetaNsMask);
+      write_view_record(pods, p, pos, meta_w, v.vc_meta, v.vc_latom, v.vc_req, v.pk, v.vc_pk);
     }
   }
   if (v.va_meta) {
@@ -393,8 +397,10 @@ __global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_
     if (pos < 0) {
       *v.dirty = 1u;  // a row the list does not cover yet
     } else {
-      if ((st & kPodValid) && ((v.va_meta[pos] ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;
-      write_view_record(pods, p, pos, meta, v.va_meta, v.va_latom, nullptr, v.pk, nullptr);
+      const uint64_t old = v.va_meta[pos];
+      if ((st & kPodValid) && ((old ^ meta) & kMetaNsMask) != 0) *v.dirty = 1u;
+      const uint64_t meta_w = (st & kPodValid) ? meta : (meta & ~kMetaNsMask) | (old & kMetaNsMask);
+      write_view_record(pods, p, pos, meta_w, v.va_meta, v.va_latom, nullptr, v.pk, nullptr);
     }
   }
 }
@@ -506,7 +512,7 @@ __device__ __forceinline__ void walk_terms(const SelProgram& sp, int t, const ui
 // ---------------------------------------------------------------------------------------------------
 template <int DT, int LT, bool KEYS>
 __global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int64_t n_rows, SelProgram sp,
-                                                            unsigned long long* partial) {
+                                                            unsigned long long* partial, int limb) {
   const int D = pods.D, stride = partial_stride(D);
   const int64_t n_round = (n_rows + kWave - 1) / kWave * kWave;
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_round; p += (int64_t)gridDim.x * kBlock) {
@@ -524,6 +530,8 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int6
 #pragma unroll
       for (int d = 0; d < DT; ++d) r.v[d] = 0;
     }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) r.v[d] = limb_of(r.v[d], limb);
     const uint32_t present = fl >> kPresentShift;
     const bool not_finished = !(fl & kPodFinished);  // isNotFinished (pod_util.go:26-28)
     const uint32_t* ns_row = sp.ns_term_ok + (size_t)r.ns * sp.gw;
@@ -567,9 +575,13 @@ __device__ __forceinline__ int instant_cmp(int64_t as, int32_t an, int64_t bs, i
 
 __device__ __forceinline__ bool cmp_eq(int64_t a, int64_t b, bool eq) { return eq ? a >= b : a > b; }
 // used + reserved in 128 bits: the all-reduced `used` of several ranks may come close to int64's end
-__device__ __forceinline__ bool cmp_eq_sum(int64_t a0, int64_t a1, int64_t b, bool eq) {
-  const __int128 a = (__int128)a0 + (__int128)a1;
+__device__ __forceinline__ bool cmp_eq_sum(__int128 a0, int64_t a1, int64_t b, bool eq) {
+  const __int128 a = a0 + (__int128)a1;
   return eq ? a >= (__int128)b : a > (__int128)b;
+}
+// a `used` value from its two words (hi_valid = false: in int64 range, the sign extension of lo)
+__device__ __forceinline__ __int128 wide_value(int64_t lo, int64_t hi, bool hi_valid) {
+  return hi_valid ? (__int128)(((unsigned __int128)(uint64_t)hi << 64) | (unsigned __int128)(uint64_t)lo) : (__int128)lo;
 }
 
 // the DT-bit slice of a wave ballot that belongs to this lane's throttle: bit d = the predicate of dimension d.
@@ -587,7 +599,7 @@ __device__ __forceinline__ uint32_t group_bits(bool b) {
 // fl: the throttle's flags as stored AFTER this point (kThrCalcAtNonzero already decided the threshold passed in).
 template <int DT>
 __device__ __forceinline__ void build_check_rec(int t, int T, int D, int d, bool valid, uint32_t fl, int64_t th_v, uint32_t th_p, bool th_hc,
-                                                int64_t th_c, int64_t u_v, uint32_t u_p, bool u_hc, int64_t u_c_, int64_t r_v, uint32_t r_p,
+                                                int64_t th_c, __int128 u_v, uint32_t u_p, bool u_hc, int64_t u_c_, int64_t r_v, uint32_t r_p,
                                                 bool r_hc, int64_t r_c_, uint32_t thrl_flag, uint32_t thrl_has, bool eq, const ReqBound& vmax,
                                                 CheckRec<DT>* recs) {
   const int64_t u_c = u_hc ? u_c_ : 0, r_c = r_hc ? r_c_ : 0;
@@ -604,11 +616,11 @@ __device__ __forceinline__ void build_check_rec(int t, int T, int D, int d, bool
   bool act_d = false;
   const bool in_d = valid && d < D;
   if (in_d && ((th_p >> d) & 1u)) {
-    const int64_t uv = ((u_p >> d) & 1u) ? u_v : 0;
+    const __int128 uv = ((u_p >> d) & 1u) ? u_v : (__int128)0;
     const int64_t rv = ((r_p >> d) & 1u) ? r_v : 0;
     act_d = (((u_p | r_p) >> d) & 1u) && cmp_eq_sum(uv, rv, th_v, eq3);
     thr = th_v;
-    const __int128 h = (__int128)th_v - (__int128)uv - (__int128)rv - (eq ? 1 : 0);
+    const __int128 h = (__int128)th_v - uv - (__int128)rv - (eq ? 1 : 0);  // |uv| < 2^125: no 128-bit overflow
     head = h >= (__int128)INT64_MAX ? kInf : h <= (__int128)INT64_MIN ? INT64_MIN : (int64_t)h;
   }
   const uint32_t act_mask = (thrl_flag & thrl_has) | group_bits<DT>(act_d);
@@ -634,6 +646,7 @@ struct ThrLane {
   uint32_t fl, thrl_flag, thrl_has, ovr0, ovr1;
   uint64_t status_fp, spec_fp;
   int64_t calc_v, used_v, spec_v, res_v;  // this lane's dimension; 0 for padding dimensions
+  int64_t used_hi;                        // high word of used_v (tt.used_hi; sign extension when the table is absent)
   uint32_t calc_p, used_p, spec_p, res_p;
   int64_t calc_c, used_c, spec_c, res_c;
   bool calc_hc, used_hc, spec_hc, res_hc;
@@ -648,7 +661,9 @@ __device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, int 
   r.res_hc = tt.reserved.has_count[t] != 0;
   const size_t i = (size_t)t * D + (d < D ? d : 0);
   const int64_t c = tt.calc.v[i], u = tt.used.v[i], sp = tt.spec.v[i], rs = tt.reserved.v[i];
+  const int64_t uh = tt.used_hi ? tt.used_hi[i] : (u < 0 ? -1 : 0);
   r.calc_v = d < D ? c : 0, r.used_v = d < D ? u : 0, r.spec_v = d < D ? sp : 0, r.res_v = d < D ? rs : 0;
+  r.used_hi = d < D ? uh : 0;
 }
 
 // the CheckRec of throttle t from the status as held in the lane registers (stored status unchanged)
@@ -658,7 +673,7 @@ __device__ __forceinline__ void build_check_rec_regs(int t, int T, int D, int d,
   // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
   const bool calc = (r.fl & kThrCalcAtNonzero) != 0;
   build_check_rec<DT>(t, T, D, d, valid, r.fl, calc ? r.calc_v : r.spec_v, calc ? r.calc_p : r.spec_p, calc ? r.calc_hc : r.spec_hc,
-                      calc ? r.calc_c : r.spec_c, r.used_v, r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag,
+                      calc ? r.calc_c : r.spec_c, wide_value(r.used_v, r.used_hi, true), r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag,
                       r.thrl_has, eq, vmax, recs);
 }
 
@@ -668,7 +683,10 @@ template <int DT>
 __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, int T, int D, int d, bool valid, const ThrLane& r,
                                                   unsigned long long pv, unsigned long long pc, unsigned long long pods,
                                                   unsigned long long errs, int64_t now_s, int32_t now_ns, int apply, const ReconcileOut& out,
-                                                  CheckRec<DT>* recs, int rec_eq, const ReqBound& vmax, bool selected) {
+                                                  CheckRec<DT>* recs, int rec_eq, const ReqBound& vmax, bool selected, bool wide = false,
+                                                  unsigned long long pv_hi = 0) {
+  // wide: the sums came as two limb sums — pv = sum of the low 32 bits of every request, pv_hi = sum of request >> 32
+  // (arithmetic) — because their total leaves int64 (resource.Quantity would have promoted, resourcelist.go:48-54)
   // recs (nullable): also leave the CheckRec of the throttle for the check that follows (kt_prepare_check fused in:
   // saves one dependent launch per reconcile + check step); rec_eq = the isThrottledOnEqual value it is built for
   const uint32_t fl = r.fl;
@@ -680,6 +698,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
   if (!live || error) {  // the stored status is returned unchanged
     if (in_d) {
       out.used.v[vi] = r.used_v;
+      if (out.used_hi) out.used_hi[vi] = r.used_hi;
       out.calc.v[vi] = r.calc_v;
     }
     if (lead) {
@@ -702,9 +721,10 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
   }
   // ---- used = fold Add over counted pods (zero matches => ResourceAmount{}: counts nil, requests nil)
   // a key is present when some counted pod carried it: the contributor count says so, and so does a non-zero sum
-  const bool u_pr = in_d && (pc != 0 || pv != 0);
+  const bool u_pr = in_d && (pc != 0 || pv != 0 || pv_hi != 0);
   const uint32_t u_p = group_bits<DT>(u_pr);
-  const int64_t u_v = u_pr ? (int64_t)pv : 0;
+  const __int128 u_w = !u_pr ? (__int128)0 : wide ? (__int128)(unsigned __int128)pv + (__int128)(int64_t)pv_hi * ((__int128)1 << 32) : (__int128)(int64_t)pv;
+  const int64_t u_v = (int64_t)(uint64_t)u_w, u_hi = (int64_t)(u_w >> 64);
   const int64_t u_c = (int64_t)pods;
   const bool u_hc = u_c > 0;
   // ---- CalculateThreshold(now)
@@ -769,11 +789,12 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
   }
   // ---- throttled = calculatedThreshold.IsThrottled(used, onEqual = true)
   const bool th_pod = c_hc && u_hc && u_c >= c_c;
-  const uint32_t th_flag = group_bits<DT>(c_pd && u_pr && u_v >= c_v);
+  const uint32_t th_flag = group_bits<DT>(c_pd && u_pr && u_w >= (__int128)c_v);
   // ---- outputs
   const int64_t c_out = c_pd ? c_v : 0;
   if (in_d) {
     out.used.v[vi] = u_v;
+    if (out.used_hi) out.used_hi[vi] = u_hi;
     out.calc.v[vi] = c_out;
   }
   if (lead) {
@@ -794,6 +815,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
   if (apply) {  // UpdateStatus: the result becomes the stored status the next check reads
     if (in_d) {
       tt.used.v[vi] = u_v;
+      if (tt.used_hi) tt.used_hi[vi] = u_hi;
       if (replace) tt.calc.v[vi] = c_out;
     }
     uint32_t nf = fl & ~kThrThrottledPod;
@@ -816,7 +838,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
     if (recs) {  // from the registers that were just stored (no re-read of this lane's own writes)
       const bool calc = (nf & kThrCalcAtNonzero) != 0;  // calculatedAt still zero: spec.threshold
       build_check_rec<DT>(t, T, D, d, valid, nf, calc ? c_out : r.spec_v, calc ? c_p : r.spec_p, calc ? c_hc : r.spec_hc, calc ? c_c : r.spec_c,
-                          u_v, u_p, u_hc, u_c, r.res_v, r.res_p, r.res_hc, r.res_c, th_flag, c_p, rec_eq != 0, vmax, recs);
+                          u_w, u_p, u_hc, u_c, r.res_v, r.res_p, r.res_hc, r.res_c, th_flag, c_p, rec_eq != 0, vmax, recs);
     }
   } else if (recs) {
     build_check_rec_regs<DT>(t, T, D, d, valid, r, rec_eq != 0, vmax, recs);
@@ -824,9 +846,11 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
 }
 
 constexpr int kFinalizeBlock = 64;  // one wave: 64 / DT throttles
+// partial_hi (nullable): wide sums — `partial` then holds the sums of the requests' low 32-bit limbs and partial_hi (same
+// layout; only its value words matter) the sums of their high parts
 template <int DT>
-__global__ __launch_bounds__(kFinalizeBlock) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, int consume,
-                                                                int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+__global__ __launch_bounds__(kFinalizeBlock) void kt_finalize(ThrTables tt, int T, int D, unsigned long long* partial, unsigned long long* partial_hi,
+                                                                int consume, int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
                                                                 CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
   // consume: leave the row zeroed behind (kt_reconcile_launch: the next aggregate then needs no clearing pass)
   const int d = (int)(threadIdx.x & (DT - 1));
@@ -841,26 +865,33 @@ __global__ __launch_bounds__(kFinalizeBlock) void kt_finalize(ThrTables tt, int 
   const unsigned long long a = prow[dd], b = prow[D + dd];
   const unsigned long long pv = d < D ? a : 0ull, pc = d < D ? b : 0ull;
   const unsigned long long pods = prow[2 * D], errs = prow[2 * D + 1];
+  unsigned long long pv_hi = 0;
+  if (partial_hi) {
+    const unsigned long long h = partial_hi[(size_t)t * stride + dd];
+    pv_hi = d < D ? h : 0ull;
+  }
   if (consume && valid) {
     // the group's lanes clear the row between them: words d, d + DT, ... (every word was read above by some lane of the
     // group before any lane of it stores: the loads complete before dependent code, the stores follow the ballots below)
     for (int j = d; j < stride; j += DT) prow[j] = 0ull;
+    if (partial_hi)
+      for (int j = d; j < stride; j += DT) partial_hi[(size_t)t * stride + j] = 0ull;
   }
   finalize_throttle<DT>(tt, t, T, D, d, valid, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
-                        row_mask == nullptr || row_mask[t] != 0);
+                        row_mask == nullptr || row_mask[t] != 0, partial_hi != nullptr, pv_hi);
 }
 
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask) {
+                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask, unsigned long long* partial_hi) {
   if (sp.T <= 0) return;
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);  // the CheckRec layout follows the check kernel
   // one wave per 64 / DT throttles (T is small: spread over as many CUs as possible; everything is latency)
   const dim3 g((unsigned)(((size_t)sp.T * DT + kFinalizeBlock - 1) / kFinalizeBlock)), b(kFinalizeBlock);
   const int eq = rec_eq ? 1 : 0;
-  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
-  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);
-  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax, row_mask);
+  if (DT == 4) hipLaunchKernelGGL(kt_finalize<4>, g, b, 0, s, tt, sp.T, D, partial, partial_hi, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
+  else if (DT == 8) hipLaunchKernelGGL(kt_finalize<8>, g, b, 0, s, tt, sp.T, D, partial, partial_hi, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);
+  else hipLaunchKernelGGL(kt_finalize<16>, g, b, 0, s, tt, sp.T, D, partial, partial_hi, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<16>*)recs, eq, vmax, row_mask);
 }
 
 // kt_reduce_finalize_packed — the slab reduction of a packed scan (kt_aggregate_bitmap PK) and kt_finalize as ONE
@@ -1065,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void kt_check_dense(PodTable pods, int64_t 
 // row from HBM (walk_slow_mem) instead of holding it in registers.
 // ---------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(kBlock) void kt_aggregate_dense_mem(PodTable pods, int64_t n_rows, SelProgram sp, unsigned long long* partial) {
+__global__ __launch_bounds__(kBlock) void kt_aggregate_dense_mem(PodTable pods, int64_t n_rows, SelProgram sp, unsigned long long* partial, int limb) {
   const int D = pods.D, stride = partial_stride(D);
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * kBlock) {
     const uint32_t fl = pods.flags[p];
@@ -1073,6 +1104,8 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense_mem(PodTable pods, 
     if (!countable) continue;
     int64_t v[DT];
     load_requests<DT>(pods.req, pods.DS, p, v);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) v[d] = limb_of(v[d], limb);
     const uint32_t present = fl >> kPresentShift;
     const bool not_finished = !(fl & kPodFinished);
     const uint32_t* ns_row = sp.ns_term_ok + (size_t)pods.ns[p] * sp.gw;
@@ -1149,16 +1182,16 @@ __global__ __launch_bounds__(kBlock) void kt_check_dense_mem(PodTable pods, int6
   } while (0)
 
 void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgram& sp, bool keys,
-                            unsigned long long* partial, hipStream_t s) {
+                            unsigned long long* partial, hipStream_t s, int limb) {
   if (n_rows <= 0 || sp.T <= 0) return;
   const int DT = dt_bucket(pods.D), LT = lt_bucket(pods.L);
   if (pods.LS > 16) {  // wide label rows: walked from HBM
-    if (DT == 4) hipLaunchKernelGGL(kt_aggregate_dense_mem<4>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
-    else if (DT == 8) hipLaunchKernelGGL(kt_aggregate_dense_mem<8>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
-    else hipLaunchKernelGGL(kt_aggregate_dense_mem<16>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+    if (DT == 4) hipLaunchKernelGGL(kt_aggregate_dense_mem<4>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial, limb);
+    else if (DT == 8) hipLaunchKernelGGL(kt_aggregate_dense_mem<8>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial, limb);
+    else hipLaunchKernelGGL(kt_aggregate_dense_mem<16>, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial, limb);
     return;
   }
-  KT_DISPATCH(kt_aggregate_dense, DT, LT, keys, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial);
+  KT_DISPATCH(kt_aggregate_dense, DT, LT, keys, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, pods, n_rows, sp, partial, limb);
 }
 
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,

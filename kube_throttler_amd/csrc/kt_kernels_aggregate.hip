@@ -34,6 +34,7 @@ struct BmAggArgs {
   const int64_t* v_req;
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
+  int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
   uint32_t exp;          // TEMPORARY measurement switches (KT_EXP): 8 = no fold (scan only)
   PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
   const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
@@ -46,7 +47,7 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.sp = sp_dev, a.slow_thr = ix.slow_thr, a.n_slow = ix.n_slow, a.partial = partial, a.slab = slab;
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
-  a.slab_tag = sc.slab_tag, a.epoch = sc.epoch;
+  a.slab_tag = sc.slab_tag, a.epoch = sc.epoch, a.limb = sc.limb;
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
   const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
   if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
@@ -143,6 +144,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAgg
       for (int k = 0; k < 4; ++k) pw[k] = 0ull;
       if constexpr (!PK) {
         if (counted) load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : p, v);
+        if (a.limb) {
+#pragma unroll
+          for (int d = 0; d < DT; ++d) v[d] = limb_of(v[d], a.limb);
+        }
       } else {
         if (counted) {
           const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAgg
           if ((res & kSlowMatched) && counted) {
             for (int d = 0; d < D; ++d)
               if ((present >> d) & 1u) {
-                const int64_t vd = a.req[(uint64_t)p * (uint32_t)DS + d];
+                const int64_t vd = limb_of(a.req[(uint64_t)p * (uint32_t)DS + d], a.limb);
                 if (vd != 0) atomicAdd(pr + d, (unsigned long long)(a.sign * vd));
                 atomicAdd(pr + D + d, (unsigned long long)(long long)a.sign);
               }

@@ -49,12 +49,13 @@ void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* 
                                 uint32_t* out_present, hipStream_t s);
 
 void launch_aggregate_dense(const PodTable& pods, int64_t n_rows, const SelProgram& sp, bool keys,
-                            unsigned long long* partial, hipStream_t s);
+                            unsigned long long* partial, hipStream_t s, int limb = 0);
 // recs (nullable): also build the CheckRec<rec_DT> of every throttle for isThrottledOnEqual = rec_eq
 // consume: the kernel leaves the partial rows zeroed behind
 void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned long long* partial, bool consume,
                      int64_t now_s, int32_t now_ns, bool apply, const ReconcileOut& out, void* recs, int rec_DT, bool rec_eq,
-                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask = nullptr);
+                     const ReqBound& vmax, hipStream_t s, const uint8_t* row_mask = nullptr, unsigned long long* partial_hi = nullptr);
+// partial_hi (nullable): wide sums — partial = sums of the requests' low 32-bit limbs, partial_hi = sums of their high parts
 // row_mask (nullable, device, T bytes): rows with 0 are not reconciled — they keep and report their stored status
 void launch_prepare_check(const ThrTables& tt, int T, int D, int DT, bool on_equal, void* recs, const ReqBound& vmax, hipStream_t s);
 void launch_check_dense(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp, bool keys,

@@ -35,7 +35,7 @@ EXPORTS = [
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
-    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter",
+    "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter", "kt_reconcile_fetch_used_hi",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.kt_comm_destroy.argtypes = [C.c_void_p]
         L.kt_set_exchange_world.argtypes = [C.c_void_p, C.c_int32]
         L.kt_counter.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_reconcile_fetch_used_hi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_counter.restype = C.c_int64
         L.kt_throttle_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_check_device_summary.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -273,6 +274,14 @@ class Engine:
 
     def comm_destroy(self):
         self._ck(lib().kt_comm_destroy(self._h))
+
+    def reconcile_fetch_used_hi(self, n=None):
+        """High 64 bits of the last reconcile's `used` values -> (int64 [n][D], any value beyond int64?)."""
+        n = self.throttle_rows() if n is None else n
+        hi = np.zeros((max(n, 1), self.D), np.int64)
+        anyw = C.c_int32()
+        self._ck(lib().kt_reconcile_fetch_used_hi(self._h, n, hi.ctypes.data_as(C.c_void_p), C.byref(anyw)))
+        return hi[:n], bool(anyw.value)
 
     def few_checks_served(self) -> int:
         """kt_check calls that took the few-pod path (kt_kernels_few.hip) so far."""

@@ -430,7 +430,10 @@ static irat_t stored_throttled(const kt_snapshot* s, int32_t t) {
   return f;
 }
 
-static int check_throttled_for(const kt_snapshot* s, int32_t t, pod_t pod, const ra_t* reserved, bool on_equal) {
+struct kto_ctx;
+static void status_used_of(const struct kto_ctx* c, int32_t t, ra_t* a);
+
+static int check_throttled_for(const struct kto_ctx* c, const kt_snapshot* s, int32_t t, pod_t pod, const ra_t* reserved, bool on_equal) {
   const bool is_cluster = (s->thr_flags[t] & KT_THR_CLUSTER) != 0;
   ra_t threshold;
   ra_from_row(&threshold, &s->thr_spec, t, s->D);
@@ -444,7 +447,7 @@ static int check_throttled_for(const kt_snapshot* s, int32_t t, pod_t pod, const
   if (irat_is_throttled_for(&st, pod)) return KTO_ACTIVE;
 
   ra_t status_used;
-  ra_from_row(&status_used, &s->thr_used, t, s->D);
+  status_used_of(c, t, &status_used);
   ra_t zero;
   ra_zero(&zero);
   ra_t already_used = ra_add(ra_add(zero, &status_used), reserved);
@@ -473,7 +476,30 @@ struct kto_ctx {
   int32_t* cluster_thr; /* ClusterThrottle rows */
   uint64_t* ns_pod_off; /* [n_ns+1] pod rows by namespace */
   int64_t* ns_pod;
+  /* resource.Quantity never overflows (resourcelist.go:48-54): a status.used beyond int64 keeps its high 64 bits here
+   * ([n_thr][D], two's complement with thr_used.v as the low words; NULL = every value is the int64 in thr_used.v), and
+   * kto_reconcile writes the high words of what it computes there when asked to (both set by kto_set_wide). */
+  const int64_t* status_used_hi;
+  int64_t* out_used_hi; /* [n][D] by output position */
 };
+
+void kto_set_wide(kto_ctx* c, const int64_t* status_used_hi, int64_t* out_used_hi) {
+  c->status_used_hi = status_used_hi;
+  c->out_used_hi = out_used_hi;
+}
+
+
+
+static void status_used_of(const kto_ctx* c, int32_t t, ra_t* a) {
+  const kt_snapshot* s = c->s;
+  ra_from_row(a, &s->thr_used, t, s->D);
+  if (c->status_used_hi)
+    for (int k = 0; k < a->req.n; ++k) {
+      const int d = a->req.name[k];
+      a->req.q[k] = (q_t)(((unsigned __int128)(uint64_t)c->status_used_hi[(int64_t)t * s->D + d] << 64) |
+                          (unsigned __int128)(uint64_t)s->thr_used.v[(int64_t)t * s->D + d]);
+    }
+}
 
 kto_ctx* kto_create(const kt_snapshot* s) {
   kto_ctx* c = (kto_ctx*)calloc(1, sizeof(kto_ctx));
@@ -578,13 +604,13 @@ static bool check_throttled(kto_ctx* c, pod_t pod, bool cluster, bool on_equal, 
     int32_t t = cand[i];
     if (row[t] != KTO_NOT_THROTTLED) continue;
     ra_t reserved = reserved_now ? reserved_now[t] : reserved_resource_amount(s, t);
-    row[t] = (uint8_t)check_throttled_for(s, t, pod, &reserved, on_equal);
+    row[t] = (uint8_t)check_throttled_for(c, s, t, pod, &reserved, on_equal);
     if (mimic_log_args) {
       /* klog.V(3).InfoS arguments are evaluated even when V(3) is off (throttle_controller.go:376-386):
        * one more ResourceAmountOfPod and ResourceAmount{}.Add(used).Add(pod).Add(reserved). */
       ra_t pa = resource_amount_of_pod(pod);
       ra_t su, zero;
-      ra_from_row(&su, &s->thr_used, t, s->D);
+      status_used_of(c, t, &su);
       ra_zero(&zero);
       ra_t chk = ra_add(ra_add(ra_add(zero, &su), &pa), &reserved);
       g_log_sink += (int64_t)chk.req.n + chk.pod;
@@ -797,6 +823,11 @@ static bool reconcile_one(kto_ctx* c, int32_t t, int64_t now_s, int32_t now_ns, 
   irat_t thrl = ra_is_throttled(&new_calc, &used, true);
   bool overflow = false;
   ra_to_row(&used, &out->used, i, D, &overflow);
+  if (c->out_used_hi) {  /* the caller takes `used` as 128-bit values: low words in out->used.v, high words here */
+    overflow = false;
+    for (int d = 0; d < D; ++d) c->out_used_hi[(int64_t)i * D + d] = 0;
+    for (int k = 0; k < used.req.n; ++k) c->out_used_hi[(int64_t)i * D + used.req.name[k]] = (int64_t)(used.req.q[k] >> 64);
+  }
   ra_to_row(&new_calc, &out->calc, i, D, &overflow);
   out->calc_updated[i] = replace;
   uint32_t has = 0, flag = 0;

@@ -76,6 +76,11 @@ typedef struct kto_reconcile_out {
 int kto_reconcile(kto_ctx* c, int32_t n, const int32_t* rows, int64_t now_s, int32_t now_ns,
                   kto_reconcile_out* out, int nthreads);
 
+/* resource.Quantity never overflows: status_used_hi (nullable, [n_thr][D]) = high 64 bits of the snapshot's status.used
+ * values (thr_used.v are the low words); out_used_hi (nullable, [n][D] by output position) receives the high words of what
+ * kto_reconcile computes — its error flag then no longer reports sums beyond int64.  The oracle keeps the pointers. */
+void kto_set_wide(kto_ctx* c, const int64_t* status_used_hi, int64_t* out_used_hi);
+
 /* ThrottleSpecBase.NextOverrideHappensIn for n throttles (rows NULL => 0..n-1), as the instant (has = 0: none). */
 int kto_next_override(kto_ctx* c, int32_t n, const int32_t* rows, int64_t now_s, int32_t now_ns, int64_t* out_s,
                       int32_t* out_ns, uint8_t* out_has);

@@ -45,6 +45,7 @@ def lib():
         _LIB.kto_pod_requests.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.kto_reconcile.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                        C.POINTER(_ReconcileOut), C.c_int]
+        _LIB.kto_set_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _LIB
 
 
@@ -118,10 +119,21 @@ class Oracle:
                         status.ctypes.data, summary.ctypes.data, C.byref(st))
         return status[:n, :T], summary[:n], reserved
 
-    def reconcile(self, now=(0, 0), rows=None, nthreads=1) -> ReconcileResult:
+    def set_status_used_hi(self, hi):
+        """status.used beyond int64 (resource.Quantity never overflows): hi [n_thr][D] = the high 64 bits of the snapshot's
+        thr_used.v values; None = every value is the int64 the snapshot holds."""
+        self._status_hi = None if hi is None else np.ascontiguousarray(hi, dtype=np.int64)
+        lib().kto_set_wide(self._ctx, None if self._status_hi is None else self._status_hi.ctypes.data, None)
+
+    def reconcile(self, now=(0, 0), rows=None, nthreads=1, wide=False) -> ReconcileResult:
+        """wide: `used` as 128-bit values — result.used.v holds the low words, result.used_hi the high words."""
         n = self.snap.n_thr if rows is None else len(rows)
         rows_a = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
         r = ReconcileResult(n, self.snap.D)
+        st_hi = getattr(self, "_status_hi", None)
+        if wide:
+            r.used_hi = np.zeros((max(n, 1), self.snap.D), np.int64)
+            lib().kto_set_wide(self._ctx, None if st_hi is None else st_hi.ctypes.data, r.used_hi.ctypes.data)
         out = _ReconcileOut(r.used.as_struct(), r.calc.as_struct(),
                             r.calc_updated.ctypes.data_as(C.POINTER(C.c_uint8)),
                             r.thrl_flag.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -130,6 +142,8 @@ class Oracle:
                             r.error.ctypes.data_as(C.POINTER(C.c_uint8)))
         lib().kto_reconcile(self._ctx, n, None if rows_a is None else rows_a.ctypes.data, int(now[0]), int(now[1]),
                             C.byref(out), nthreads)
+        if wide:
+            lib().kto_set_wide(self._ctx, None if st_hi is None else st_hi.ctypes.data, None)
         return r
 
 

@@ -613,13 +613,14 @@ def test_overflow_guard(oracle_mod):
         eng.load_snapshot(snap)
     assert ei.value.code == -4
     eng.close()
-    # 64 pods x 2^55 = 2^61: every pod is fine, their sum is not
+    # 64 pods x 2^55 = 2^61: every pod is fine, their sum leaves the range the int64 partials are proved for — an
+    # incremental engine (it maintains int64 partials) refuses; a rescanning engine sums limbs (test_wide_sums)
     snap = W.generate(W.small(seed=41, n_pods=64, n_thr=4, n_cluster=2, D=2))
     nc = int(snap.pod_ctr_off[snap.n_pods])
     snap.ctr_req[:nc, 0] = 0
     snap.ctr_req[snap.pod_ctr_off[:snap.n_pods], 0] = 1 << 55   # first container of every pod
     snap.ctr_present[snap.pod_ctr_off[:snap.n_pods]] |= 1
-    eng = E.Engine.for_snapshot(snap)
+    eng = E.Engine.for_snapshot(snap, E.VARIANT_INDEXED | E.VARIANT_INCREMENTAL)
     with pytest.raises(E.EngineError) as ei:
         eng.reconcile(NOW, apply=False)
     assert ei.value.code == -4
@@ -635,6 +636,73 @@ def test_overflow_guard(oracle_mod):
         assert int(got_all.used.v[rows].max()) >= 1 << 53
     finally:
         eng.close()
+
+
+def _wide_parity(snap, oracle_mod, variant):
+    """reconcile + check of a snapshot whose `used` sums leave int64, against the oracle's 128-bit arithmetic"""
+    P, T, D = snap.n_pods, snap.n_thr, snap.D
+    eng = E.Engine.for_snapshot(snap, variant)
+    try:
+        o = oracle_mod.Oracle(snap)
+        rows = responsible_rows(snap)
+        want = o.reconcile(NOW, rows=rows, nthreads=8, wide=True)
+        assert not want.error[:len(rows)].any()
+        got = eng.reconcile(NOW, apply=True)
+        hi, any_wide = eng.reconcile_fetch_used_hi()
+        assert any_wide and (want.used_hi[:len(rows)] != (want.used.v[:len(rows)] < 0) * -1).any(), "the case must leave int64"
+        np.testing.assert_array_equal(got.used.v[rows], want.used.v[:len(rows)], err_msg="used, low words")
+        np.testing.assert_array_equal(hi[rows], want.used_hi[:len(rows)], err_msg="used, high words")
+        for f in ("present", "count", "has_count"):
+            np.testing.assert_array_equal(getattr(got.used, f)[rows], getattr(want.used, f)[:len(rows)], err_msg=f"used.{f}")
+        np.testing.assert_array_equal(got.thrl_flag[rows], want.thrl_flag[:len(rows)])
+        np.testing.assert_array_equal(got.thrl_pod[rows], want.thrl_pod[:len(rows)])
+        # the check that follows reads the wide status: the oracle gets the same 128-bit values
+        snap.apply_status(got.used, got.calc, got.calc_updated, got.thrl_flag, got.thrl_has, got.thrl_pod, got.error)
+        o.set_status_used_hi(hi[:T])
+        sample = np.unique(np.linspace(0, P - 1, min(P, 4096)).astype(np.int64))
+        for on_equal in (False, True):
+            st_w, sm_w = o.check(rows=sample, on_equal=on_equal, nthreads=8)
+            st_g, sm_g = eng.check(rows=sample, on_equal=on_equal, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w)
+            np.testing.assert_array_equal(sm_g, sm_w)
+        # a second reconcile (the stored wide status is its input) changes nothing
+        again = eng.reconcile(NOW, apply=True)
+        hi2, _ = eng.reconcile_fetch_used_hi()
+        np.testing.assert_array_equal(again.used.v[:T], got.used.v[:T])
+        np.testing.assert_array_equal(hi2, hi)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("variant", [E.VARIANT_INDEXED, E.VARIANT_DENSE], ids=["indexed", "dense"])
+def test_wide_sums(variant, oracle_mod):
+    """resource.Quantity never overflows (Add promotes to big decimals, pkg/resourcelist/resourcelist.go:48-54).  When the
+    requests held add up beyond int64 the reconcile sums 32-bit limbs in two scans and kt_finalize joins them in 128 bits:
+    `used` (low + high words), the throttled flags and every CheckThrottledFor status equal the oracle's __int128
+    arithmetic.  64 pods x 2^59 of one resource, negative requests on another (the sums cancel below int64 again)."""
+    snap = W.generate(W.small(seed=45, n_pods=64, n_thr=6, n_cluster=3, D=3))
+    first = snap.pod_ctr_off[:snap.n_pods]
+    nc = int(snap.pod_ctr_off[snap.n_pods])
+    snap.ctr_req[:nc, 0] = 0
+    snap.ctr_req[first, 0] = 1 << 59
+    snap.ctr_req[first[::2], 1] = -(1 << 59)                 # every other pod: negative, the sums stay wide and signed
+    snap.ctr_req[first[1::2], 1] = (1 << 59) + 12345
+    snap.ctr_present[first] |= 3
+    snap.thr_spec.v[:snap.n_thr, 0] = (1 << 62) + 7            # thresholds the wide sums are compared with
+    snap.thr_spec.present[:snap.n_thr] |= 1
+    _wide_parity(snap, oracle_mod, variant)
+
+
+def test_wide_sums_ten_million_pods(oracle_mod):
+    """SURVEY.md 7, hard part 1: 10^7 pods with byte-sized requests at milli scale.  8 Gi = 8.6e12 milli-bytes per pod; the
+    ~1.5e6 pods a throttle counts add up to 1.3e19 > 2^63 — exact in the engine (limb sums) and in the oracle."""
+    snap = W.generate(W.small(seed=44, n_pods=10_000_000, n_thr=6, n_cluster=3, D=2, n_ns=4, K=4, V=2, L=2, terms=(1, 1), reqs=(0, 1),
+                              rich_ops=0, overrides=0))
+    first = snap.pod_ctr_off[:snap.n_pods]
+    snap.ctr_req[:, :] = 0
+    snap.ctr_req[first, 1] = (8 << 30) * 1000
+    snap.ctr_present[first] |= 2
+    _wide_parity(snap, oracle_mod, E.VARIANT_INDEXED)
 
 
 def test_api_errors():
