@@ -230,7 +230,8 @@ def main():
         except Exception:
             pmc_kernels = {}
     dom_kernel = eng.kernel_name(E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE)
-    sym = lambda k: k.replace("_chunked", "")  # "..._chunked" is the same kernel symbol walking several index chunks
+    # "..._chunked" / "..._packed" are the same kernel symbol (several index chunks / the packed fold instantiation)
+    sym = lambda k: k.replace("_chunked", "").replace("_packed", "") if k.startswith("kt_aggregate") or k.startswith("kt_check") else k
     if sym(dom_kernel) in pmc_kernels:
         traffic = pmc_kernels[sym(dom_kernel)].get("hbm_bytes_per_launch")
 

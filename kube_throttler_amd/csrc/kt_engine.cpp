@@ -1739,8 +1739,8 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
       if (!e->incremental && !e->wide && !getenv_flag("KT_NO_PACK")) {
-        const uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c, false));
-        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, !getenv_flag("KT_PK_NOPAD"));
+        const uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
+        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true);
         if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
       }
       KT_HIP(e, e->d_vc_meta.reserve(nc));

@@ -262,10 +262,10 @@ struct AggScan {
   mutable int launched_blocks = 0;  // out: workgroups (= slabs per chunk) of the scan launch
   mutable bool launched_packed = false;
 };
-constexpr uint32_t kSlabTagStride = 512;  // workgroups an aggregate launch may have (two per CU)
+constexpr uint32_t kSlabTagStride = 256;  // workgroups an aggregate launch may have (one per CU)
 // workgroups of an aggregate launch over n listed pods, and the most pods one of them scans (the packed fields are sized
 // for it)
-int aggregate_blocks(int64_t n_rows, bool two_per_cu);
+int aggregate_blocks(int64_t n_rows);
 uint64_t aggregate_slab_pods(int64_t n_rows, int blocks);
 // sp_dev: device-resident copy of sp.  Both return the symbol of the scan kernel they dispatched, nullptr when a chunk
 // does not fit the kernel's LDS.  after_scan (nullable) is invoked on the host right after the scan kernel is enqueued

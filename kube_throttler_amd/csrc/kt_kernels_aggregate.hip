@@ -35,7 +35,6 @@ struct BmAggArgs {
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
   int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
-  uint32_t exp;          // TEMPORARY measurement switches (KT_EXP): 8 = no fold (scan only)
   PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
   const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
 };
@@ -51,7 +50,6 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
   const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
   if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
-  a.exp = getenv("KT_EXP") ? (uint32_t)atoi(getenv("KT_EXP")) : 0u;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
@@ -76,9 +74,10 @@ uint32_t aggregate_fixed_lds() { return 64; }
 //     ds_add_u64 where the plain fold issues one per non-zero dimension plus the pod count; the record is nw words + the
 //     OR of the key masks of pods that carry a key with the value 0.  Full scans over the scan view only (no counts mode,
 //     no negative requests, sign +1).
-// WPE: waves per SIMD the register allocation leaves room for (8: two workgroups per CU when two LDS footprints fit)
-template <int DT, int LA, bool VETO, int NEED, bool PK, int WPE>
-__global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAggArgs a) {
+// (One workgroup per CU: two packed ones fit when the record is squeezed to 32 bytes, but the 64-VGPR form spills and the
+//  32-byte stride lands 8 records on one bank group — measured 33 us against 24 us at 1M x 1k.)
+template <int DT, int LA, bool VETO, int NEED, bool PK>
+__global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const int pstride = partial_stride(D);
@@ -191,14 +190,14 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_aggregate_bitmap(const BmAgg
       }
 
       uint32_t last_r = 0xFFFFFFFFu;
-      scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
+      scan_tile<LA, VETO, NEED, VETO>(
           bm, scan_counted, ns, ro,
           [&](bool has, uint32_t c) {
             const uint32_t tr = trank[c];
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
             // a throttle with several terms is counted once
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
-            if (ok && !(a.exp & 8u)) {
+            if (ok) {
               last_r = r;
               KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
               lds_u64wp tv = (lds_u64wp)rp;
@@ -349,24 +348,19 @@ __global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(cons
 #define KT_AGG_BM_CASE(DT_, LA_, VETO_, NEED_)                                                                \
   {                                                                                                           \
     if (!packed) {                                                                                            \
-      auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_, false, 4>;                                       \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
-      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
-    } else if (two_per_cu) {                                                                                  \
-      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true, 8>;                                          \
+      auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_, false>;                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
       hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
     } else {                                                                                                  \
-      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true, 4>;                                          \
+      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true>;                                             \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
       hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
     }                                                                                                         \
   }
 
-int aggregate_blocks(int64_t n_rows, bool two_per_cu) {
+int aggregate_blocks(int64_t n_rows) {
   int64_t b = (n_rows + kBlockIx - 1) / kBlockIx;
-  const int64_t cap = two_per_cu ? 2 * kCUs : kCUs;
-  return (int)(b < 1 ? 1 : b > cap ? cap : b);
+  return (int)(b < 1 ? 1 : b > kCUs ? kCUs : b);
 }
 // the most pods one workgroup of an aggregate launch scans: contiguous tile ranges (scan view) or a stride over the tiles
 uint64_t aggregate_slab_pods(int64_t n_rows, int blocks) {
@@ -391,17 +385,13 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   const bool packed = bm_args.v_pk != nullptr && bm_args.ix.by_ns && !sc.counts && sc.sign == 1 && sc.nonneg &&
                       bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false);
   if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
-  static const int force_wgs = getenv("KT_AGG_WGS_PER_CU") ? atoi(getenv("KT_AGG_WGS_PER_CU")) : 0;  // A/B runs
-  // two workgroups per CU when two LDS footprints fit and the slab areas (sized for 256 plain records per chunk) hold 512 packed ones
-  const bool two_per_cu = packed && 2 * bm_total <= (uint32_t)kMaxLds && 2 * bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false) &&
-                          force_wgs == 2 && sc.n > (int64_t)kCUs * kBlockIx;  // measured (r03d): 33 vs 24 us at 1M x 1k — opt-in for A/B runs
-  const int nb = aggregate_blocks(n_rows, two_per_cu);
+  const int nb = aggregate_blocks(n_rows);
   dim3 g_(nb), b_(kBlockIx);
   const size_t lds_bm = bm_total;
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds)
-    fprintf(stderr, "kt_aggregate_bitmap: lds=%u (%d per CU) chunks=%u largest LDS part=%u max thr=%u T=%d packed=%d nw=%u rec=%u\n", bm_total,
-            two_per_cu ? 2 : 1, ix.n_chunks, ix.bm_max_lds, ix.bm_max_thr, sp.T, packed ? 1 : 0, bm_args.pk.nw, bm_args.pk.rec_bytes);
+    fprintf(stderr, "kt_aggregate_bitmap: lds=%u chunks=%u largest LDS part=%u max thr=%u T=%d packed=%d nw=%u rec=%u\n", bm_total, ix.n_chunks,
+            ix.bm_max_lds, ix.bm_max_thr, sp.T, packed ? 1 : 0, bm_args.pk.nw, bm_args.pk.rec_bytes);
 #ifdef KT_FAST_BUILD
   KT_AGG_BM_CASE(8, 8, false, 2)
 #else

@@ -69,7 +69,6 @@ struct BmCheckArgs {
   const uint64_t* v_meta;
   const uint16_t* v_latom;
   uint64_t* carry;         // [n] class counters between chunks
-  uint32_t exp;            // TEMPORARY measurement switches (KT_EXP): 1 = no drain, 2 = no wordwise settle, 4 = no peel
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
 };
@@ -215,7 +214,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       uint32_t last_t = 0xFFFFFFFFu;
 
       auto drain = [&]() {
-        if (a.exp & 1u) { n_list = 0; return; }
         // ---- lane = listed (pod lane, throttle): the full comparison; pod row / non-zero mask come from the pod's
         //      lane by ds_bpermute
         for (uint32_t base = 0; base < n_list; base += kWave) {
@@ -315,12 +313,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       };
       scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
           bm, scan_on, ns, ro,
-          [&](bool has, uint32_t c) { if (!(a.exp & 4u)) push(has, c); },
+          [&](bool has, uint32_t c) { push(has, c); },
           [&](uint32_t c) {
             return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
           },
           [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
-            if (a.exp & 2u) return x;
             // a throttle with several terms is reported once: the lowest match of every run
             const uint64_t v = x | q.seg.y;
             x &= (v ^ (v - q.seg.x)) & v;
@@ -423,7 +420,6 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     for (int k = 0; k < 8; ++k) bm_args.inline_rows[k] = sm->inline_rows[k];
   }
   bm_args.has_overflow = overflow_pods ? 1u : 0u;
-  bm_args.exp = getenv("KT_EXP") ? (uint32_t)atoi(getenv("KT_EXP")) : 0u;
   if (by_ns && !small && rows_dev) {
     bm_args.ix.by_ns = 1u;
     bm_args.v_meta = by_ns->v_meta, bm_args.v_latom = by_ns->v_latom, bm_args.carry = by_ns->carry;
