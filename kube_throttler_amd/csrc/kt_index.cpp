@@ -21,8 +21,13 @@ struct BT {  // one indexed term
   bool adj;                                 // owner has several terms
   bool slow;                                // needs the generic walk to confirm a candidate
   uint32_t need;                            // positive requirements (exact terms); 1 for slow terms with an anchor
-  std::vector<std::vector<uint32_t>> pos;   // atom sets of the positive requirements that enter `any`
-  std::vector<uint32_t> neg;                // atoms of all negative requirements
+  // positive requirements that enter `any`, one per key: an explicit set of pair atoms (pos_key < 0), or — Exists, not
+  // narrowed by an In on the same key — EVERY atom a pod carrying that key can show up with (pos_key = the key; pos[i]
+  // stays empty: the atoms are those of whole_key(key), expanded only where rows are set)
+  std::vector<std::vector<uint32_t>> pos;
+  std::vector<int64_t> pos_key;
+  std::vector<uint32_t> neg;                // pair atoms of the NotIn requirements
+  std::vector<uint32_t> neg_keys;           // keys of the DoesNotExist requirements (all atoms of the key)
   std::vector<uint32_t> adm;                // namespace admission set as words
 };
 
@@ -192,7 +197,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       bool never = false;
       // positive requirements are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S): a pod carries
       // one atom per key, so the number of rows in which the term's bit is met is the number of satisfied positive keys
-      std::vector<std::pair<uint32_t, std::vector<uint32_t>>> pos_by_key;  // key -> atom set (sorted)
+      struct PosReq {
+        uint32_t key;
+        std::vector<uint32_t> atoms;  // sorted pair atoms
+        bool whole;                   // every atom of the key (Exists)
+      };
+      std::vector<PosReq> pos_by_key;
       for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
         const bool pair_op = req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN;
         std::vector<uint32_t> atoms;
@@ -200,26 +210,30 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
           atoms.assign(req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
           std::sort(atoms.begin(), atoms.end());
           atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
-        } else {
-          atoms = whole_key(req_key[r]);
         }
         if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_EXISTS) {
           size_t q = 0;
-          while (q < pos_by_key.size() && pos_by_key[q].first != req_key[r]) ++q;
+          while (q < pos_by_key.size() && pos_by_key[q].key != req_key[r]) ++q;
           if (q == pos_by_key.size()) {
-            pos_by_key.emplace_back(req_key[r], std::move(atoms));
-          } else {
+            pos_by_key.push_back(PosReq{req_key[r], std::move(atoms), !pair_op});
+          } else if (pos_by_key[q].whole) {
+            // Exists and In S = In S ; Exists and Exists = Exists
+            pos_by_key[q].atoms = std::move(atoms), pos_by_key[q].whole = !pair_op;
+          } else if (pair_op) {
             std::vector<uint32_t> both;
-            std::set_intersection(pos_by_key[q].second.begin(), pos_by_key[q].second.end(), atoms.begin(), atoms.end(), std::back_inserter(both));
-            pos_by_key[q].second = std::move(both);
-          }
-        } else {
+            std::set_intersection(pos_by_key[q].atoms.begin(), pos_by_key[q].atoms.end(), atoms.begin(), atoms.end(), std::back_inserter(both));
+            pos_by_key[q].atoms = std::move(both);
+          }  // In S and Exists = In S: nothing to do
+        } else if (pair_op) {
           for (uint32_t a : atoms) b.neg.push_back(a);  // NotIn with no values: always satisfied
+        } else {
+          b.neg_keys.push_back(req_key[r]);
         }
       }
       for (auto& pk : pos_by_key) {
-        if (pk.second.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
-        b.pos.push_back(std::move(pk.second));
+        if (!pk.whole && pk.atoms.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
+        b.pos.push_back(std::move(pk.atoms));
+        b.pos_key.push_back(pk.whole ? (int64_t)pk.key : -1);
       }
       if (never) continue;
       // exact shape: <= 3 positive keys (their atom sets are disjoint by construction)
@@ -227,15 +241,22 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       if (exact) {
         b.need = (uint32_t)b.pos.size();
       } else {
-        // candidates through the requirement with the fewest atoms (Exists last), confirmed by the generic walk
+        // candidates through the requirement with the fewest atoms (a bare key atom last), confirmed by the generic walk
         size_t best = 0, best_cost = ~(size_t)0;
         for (size_t i = 0; i < b.pos.size(); ++i) {
-          const size_t cost = (b.pos[i].size() == 1 && (b.pos[i][0] & kKeyAtom)) ? ((size_t)1 << 20) : b.pos[i].size();
+          size_t cost = b.pos[i].size();
+          if (b.pos_key[i] >= 0) {
+            auto it = pairs_of_key.find((uint32_t)b.pos_key[i]);
+            const size_t n_atoms = (it == pairs_of_key.end() ? 0 : it->second.size()) + 1;  // its pairs + the key atom
+            cost = n_atoms == 1 ? ((size_t)1 << 20) : n_atoms;
+          }
           if (cost < best_cost) best_cost = cost, best = i;
         }
         std::vector<uint32_t> anchor = b.pos[best];
-        b.pos.clear();
+        const int64_t anchor_key = b.pos_key[best];
+        b.pos.clear(), b.pos_key.clear();
         b.pos.push_back(std::move(anchor));
+        b.pos_key.push_back(anchor_key);
         b.need = 1;
         b.slow = true;
       }
@@ -269,6 +290,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   struct Grp { uint32_t t; std::vector<uint32_t> adm; };
   std::vector<TC> tcs;
   std::vector<Grp> grps;
+  std::vector<uint64_t> pat(n_ns, 0ull), cell_pat;
+  std::vector<uint32_t> uni;
   for (size_t i = 0; i < bts.size();) {
     size_t j = i;
     while (j < bts.size() && first_of[j] == first_of[i]) ++j;
@@ -280,30 +303,36 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       grps.push_back(Grp{bts[i].t, bts[i].adm});
       for (size_t q = i; q < j; ++q) tcs.push_back(TC{(uint32_t)q, (uint32_t)grps.size() - 1});
     } else {
-      std::vector<uint64_t> pat(n_ns, 0ull);
+      // (a throttle has a handful of cells at most: linear search over its patterns; `pat` is one buffer for all throttles,
+      //  only the entries a throttle touched are cleared again)
+      uni.assign(nsw, 0u);
       for (size_t q = i; q < j; ++q)
-        for (uint32_t wi = 0; wi < nsw; ++wi)
+        for (uint32_t wi = 0; wi < nsw; ++wi) {
+          uni[wi] |= bts[q].adm[wi];
           for (uint32_t m = bts[q].adm[wi]; m; m &= m - 1) {
             const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
             if (n < n_ns) pat[n] |= 1ull << (q - i);
           }
-      std::unordered_map<uint64_t, uint32_t> cell_of;  // pattern -> group
-      const size_t g0 = grps.size();
-      for (uint32_t n = 0; n < n_ns; ++n) {
-        if (!pat[n]) continue;
-        auto it = cell_of.find(pat[n]);
-        if (it == cell_of.end()) {
-          it = cell_of.emplace(pat[n], (uint32_t)grps.size()).first;
-          grps.push_back(Grp{bts[i].t, std::vector<uint32_t>(nsw, 0u)});
         }
-        grps[it->second].adm[n >> 5] |= 1u << (n & 31);
-      }
-      // copies in group order, term order inside a group (cell_of iterates in no particular order: walk the groups)
-      std::vector<uint64_t> pat_of(grps.size() - g0, 0ull);
-      for (auto& kv : cell_of) pat_of[kv.second - g0] = kv.first;
+      const size_t g0 = grps.size();
+      cell_pat.clear();
+      for (uint32_t wi = 0; wi < nsw; ++wi)  // cells are created in namespace order
+        for (uint32_t m = uni[wi]; m; m &= m - 1) {
+          const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
+          if (n >= n_ns) continue;
+          size_t c = 0;
+          while (c < cell_pat.size() && cell_pat[c] != pat[n]) ++c;
+          if (c == cell_pat.size()) {
+            cell_pat.push_back(pat[n]);
+            grps.push_back(Grp{bts[i].t, std::vector<uint32_t>(nsw, 0u)});
+          }
+          grps[g0 + c].adm[n >> 5] |= 1u << (n & 31);
+          pat[n] = 0ull;
+        }
+      // copies in group order, term order inside a group
       for (size_t g = g0; g < grps.size(); ++g)
         for (size_t q = i; q < j; ++q)
-          if ((pat_of[g - g0] >> (q - i)) & 1ull) tcs.push_back(TC{(uint32_t)q, (uint32_t)g});
+          if ((cell_pat[g - g0] >> (q - i)) & 1ull) tcs.push_back(TC{(uint32_t)q, (uint32_t)g});
     }
     i = j;
   }
@@ -329,11 +358,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
   // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
   const uint32_t gran = tcs.size() <= 4096 ? 64u : 128u;
-  std::vector<uint32_t> num(tcs.size());
-  uint32_t pos = 0;
+  std::vector<uint32_t> num(tcs.size()), cls(tcs.size());  // term number and class (= admission set) of every copy
+  uint32_t pos = 0, n_cls = 0;
   for (size_t i = 0; i < order.size();) {
     size_t j = i;
     while (j < order.size() && grps[tcs[order[j]].grp].adm == grps[tcs[order[i]].grp].adm) ++j;
+    for (size_t q = i; q < j; ++q) cls[order[q]] = n_cls;
+    ++n_cls;
     const uint32_t sz = (uint32_t)(j - i);
     if ((pos & (gran - 1)) != 0 && ((pos & (gran - 1)) + sz > gran)) pos = (pos + gran - 1) & ~(gran - 1);
     for (size_t q = i; q < j;) {
@@ -353,14 +384,20 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // ---- atoms -> ids (= bitmap rows; row 0 = no atom)
   {
     std::vector<uint32_t> atoms;
+    std::unordered_set<uint32_t> whole_keys;  // keys some kept term names at key level
     for (auto& b : bts) {
-      for (auto& ps : b.pos)
-        for (uint32_t a : ps) atoms.push_back(a);
+      for (size_t i = 0; i < b.pos.size(); ++i) {
+        if (b.pos_key[i] >= 0) whole_keys.insert((uint32_t)b.pos_key[i]);
+        for (uint32_t a : b.pos[i]) atoms.push_back(a);
+      }
       for (uint32_t a : b.neg) atoms.push_back(a);
-      out.has_veto |= !b.neg.empty();
+      for (uint32_t k : b.neg_keys) whole_keys.insert(k);
+      out.has_veto |= !b.neg.empty() || !b.neg_keys.empty();
       out.has_slow |= b.slow;
       if (!b.slow) out.max_need = std::max(out.max_need, b.need);
     }
+    for (uint32_t k : whole_keys)
+      for (uint32_t a : whole_key(k)) atoms.push_back(a);
     out.la = atom_slots(out.n_keys, max_labels);
     // the simple instantiation <8 atoms, no veto family, need <= 2> covers matchLabels-style programs; everything else
     // takes the rich one, whose images carry {any, veto} pairs
@@ -399,13 +436,23 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   real.assign((size_t)W * 64, 0);
   out.n_ns = n_ns;
   out.bm_rank_t.clear();
-  // bitmap rows of every term's atoms, resolved once (a term may have several copies)
-  std::vector<std::vector<uint32_t>> pos_rows(bts.size()), neg_rows(bts.size());
-  for (size_t q = 0; q < bts.size(); ++q) {
-    for (auto& ps : bts[q].pos)
-      for (uint32_t a : ps) pos_rows[q].push_back(row_of[a]);
-    for (uint32_t a : bts[q].neg) neg_rows[q].push_back(row_of[a]);
+  // bitmap rows: of every key named at key level (all its atoms), and of every term's pair atoms
+  std::unordered_map<uint32_t, std::vector<uint32_t>> rows_of_key;
+  for (auto& b : bts) {
+    for (int64_t k : b.pos_key)
+      if (k >= 0) rows_of_key.emplace((uint32_t)k, std::vector<uint32_t>());
+    for (uint32_t k : b.neg_keys) rows_of_key.emplace(k, std::vector<uint32_t>());
   }
+  for (auto& kv : rows_of_key)
+    for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
+  std::vector<std::vector<uint32_t>> pos_rows(bts.size()), neg_rows(bts.size());  // pair atoms only
+  parallel_for(bts.size(), 2048, [&](size_t q0, size_t q1, size_t) {
+    for (size_t q = q0; q < q1; ++q) {
+      for (auto& ps : bts[q].pos)
+        for (uint32_t a : ps) pos_rows[q].push_back(row_of.find(a)->second);
+      for (uint32_t a : bts[q].neg) neg_rows[q].push_back(row_of.find(a)->second);
+    }
+  }, nullptr);
   {
     std::vector<uint32_t> by_num(G2, ~0u);
     for (size_t q = 0; q < tcs.size(); ++q) by_num[num[q]] = (uint32_t)q;
@@ -420,9 +467,26 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     // the bits: every 64-bit word column of the bitmaps belongs to one range of term numbers — ranges on several threads
     parallel_for(W, 32, [&](size_t w_begin, size_t w_end, size_t) {
+      // the namespace rows are set once per RUN of copies of one class inside a word (they share the admission set)
+      // instead of once per copy
+      uint32_t run_cls = ~0u;
+      uint64_t run_bits = 0;
+      size_t run_w = 0;
+      const std::vector<uint32_t>* run_adm = nullptr;
+      auto flush = [&]() {
+        if (run_bits && run_adm)
+          for (uint32_t wi = 0; wi < nsw; ++wi)
+            for (uint32_t m = (*run_adm)[wi]; m; m &= m - 1) {
+              const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
+              if (n < n_ns) nsrows[(size_t)n * W + run_w] |= run_bits;
+            }
+        run_bits = 0, run_cls = ~0u, run_adm = nullptr;
+      };
       for (uint32_t c = (uint32_t)w_begin * 64u; c < std::min<uint32_t>((uint32_t)w_end * 64u, G2); ++c) {
+        if ((c & 63u) == 0u) flush();
         if (by_num[c] == ~0u) continue;  // padding
-        const TC& tc = tcs[by_num[c]];
+        const uint32_t qi = by_num[c];
+        const TC& tc = tcs[qi];
         const BT& b = bts[tc.bt];
         real[c] = 1;
         const uint64_t bit = 1ull << (c & 63);
@@ -432,19 +496,42 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         if (b.pos.empty()) hdr[w].univ |= bit;
         for (uint32_t r : pos_rows[tc.bt]) any[(size_t)r * W + w] |= bit;
         for (uint32_t r : neg_rows[tc.bt]) vet[(size_t)r * W + w] |= bit;
+        for (int64_t k : b.pos_key)
+          if (k >= 0)
+            for (uint32_t r : rows_of_key.find((uint32_t)k)->second) any[(size_t)r * W + w] |= bit;
+        for (uint32_t k : b.neg_keys)
+          for (uint32_t r : rows_of_key.find(k)->second) vet[(size_t)r * W + w] |= bit;
         if (b.need >= 2) hdr[w].m2 |= bit;
         if (b.need >= 3) hdr[w].m3 |= bit;
         if (b.slow) hdr[w].slow |= bit;
-        const std::vector<uint32_t>& adm = grp_own_adm[tc.grp] ? b.adm : grps[tc.grp].adm;
-        for (uint32_t wi = 0; wi < nsw; ++wi)
-          for (uint32_t m = adm[wi]; m; m &= m - 1) {
-            const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
-            if (n < n_ns) nsrows[(size_t)n * W + w] |= bit;
-          }
+        if (grp_own_adm[tc.grp]) {  // a copy of a >64-term throttle: its own admission set
+          flush();
+          run_adm = &b.adm, run_w = w, run_bits = bit;
+          flush();
+        } else {
+          if (cls[qi] != run_cls) flush();
+          run_cls = cls[qi], run_adm = &grps[tc.grp].adm, run_w = w, run_bits |= bit;
+        }
       }
+      flush();
     }, nullptr);
   }
   lap("full bitmaps");
+  {
+    // the construction's own containers (tens of thousands of small vectors) are handed to a helper thread to be freed: a
+    // recompile is on the scheduler's critical path, their destructors alone were a third of it
+    struct Trash {
+      std::vector<BT> bts;
+      std::vector<std::vector<BT>> bts_part;
+      std::vector<Grp> grps;
+      std::vector<std::vector<uint32_t>> pos_rows, neg_rows;
+      std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key, rows_of_key;
+    };
+    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(grps), std::move(pos_rows), std::move(neg_rows), std::move(pairs_of_key),
+                             std::move(rows_of_key)};
+    std::thread([trash] { delete trash; }).detach();
+  }
+  lap("hand-off of the scratch containers");
   // chunks for chk_budget (two check workgroups per CU) — unless the caller wants larger chunks when the program needs
   // several anyway (chk_budget_full) and it plainly does: then only that cut is made
   const size_t rows_bytes = (size_t)R * W * 8u * (veto ? 2u : 1u);
