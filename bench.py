@@ -224,6 +224,8 @@ def main():
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
             key = f"config{args.config}_{args.variant}"
+            if args.pods_per_gpu:  # e.g. config2_indexed_4M: the point past the 256 MiB Infinity Cache
+                key += "_%dM" % (args.pods_per_gpu // 1000000) if args.pods_per_gpu % 1000000 == 0 else "_%d" % args.pods_per_gpu
             src = pmc.get("_source", {}).get(key)
             if isinstance(src, dict) and src.get("engine_version") == engine_version:
                 pmc_kernels = pmc.get(key, {})
