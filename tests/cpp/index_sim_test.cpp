@@ -164,7 +164,7 @@ static std::vector<uint32_t> translate(const HostIndex& ix, const PodLabels& pod
 }
 
 // replays scan_tile (kt_scan.h) for one pod -> per-throttle result (1 match / 2 error), checks "reported once"
-static long g_matches_exact = 0, g_slow_confirms = 0, g_word_steps = 0;
+static long g_matches_exact = 0, g_slow_confirms = 0, g_word_steps = 0, g_admitted = 0;
 static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const PodLabels& pod) {
   std::map<uint32_t, int> out;
   bool overflow = false;
@@ -187,6 +187,7 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       EXPECT(prev_w == ~0u || w > prev_w, "word list of ns %u not ascending", pod.ns);
       prev_w = w;
       ++g_word_steps;
+      g_admitted += __builtin_popcountll(nsl[k].mask);
       uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0;
       for (uint32_t id : ids) {
         EXPECT(id < ix.bm_rows, "row %u of %u", id, ix.bm_rows);
@@ -471,8 +472,8 @@ static int run_file(const char* path, uint32_t chk_budget) {
          ix.rich ? "rich {any, veto}" : "simple {any}", (int)ix.has_veto, ix.max_need, (int)ix.has_slow, ix.la);
   printf("  LDS: check %u B (image part + term info), aggregate %u B (image part + ranks + table)\n",
          ix.bm_max_lds + ix.bm_max_words * kCheckWordLds + check_fixed_lds(), ix.bm_max_lds + ix.bm_max_words * 128 + ix.bm_max_thr * thr_bytes);
-  printf("  %ld pods: %.2f matches per pod (exact, no candidates), %.2f word steps per pod, %ld slow confirmations\n", pods,
-         (double)matches / (double)pods, (double)g_word_steps / (double)pods, g_slow_confirms);
+  printf("  %ld pods: %.2f matches per pod (exact, no candidates), %.2f word steps per pod (%.1f admitted term copies per visited word), %ld slow confirmations\n", pods,
+         (double)matches / (double)pods, (double)g_word_steps / (double)pods, (double)g_admitted / (double)std::max(1L, g_word_steps), g_slow_confirms);
   if (tiles)
     printf("  per 64-pod tile (all chunks): %.1f advance rounds, %.1f peel steps at %.1f %% busy lanes\n", (double)adv_rounds / tiles,
            (double)peel_steps / tiles, peel_steps ? 100.0 * (double)peel_busy / (64.0 * (double)peel_steps) : 0.0);
@@ -481,8 +482,96 @@ static int run_file(const char* path, uint32_t chk_budget) {
   return g_fail ? 1 : 0;
 }
 
+// ---- packed request words (PackPlan, kt_index.h): the host mirror of write_view_record (kt_kernels.hip), the fold of
+// the aggregate kernel (whole-word adds per matching pod) and packed_record_sums (kt_index_device.h).  For random
+// request populations: fields must not overlap or cross a word, a slab of n_slab pods carrying the maxima must not carry
+// out of its field, and the unpacked sums must be the plain sums.
+static void pack_plan_cases() {
+  std::mt19937_64 rng(4242);
+  int packed = 0, refused = 0;
+  for (int it = 0; it < 4000; ++it) {
+    const int D = 1 + (int)(rng() % 16);
+    const uint64_t n_slab = 1 + rng() % (it % 3 == 0 ? 5000 : 70000);
+    const int n = (int)std::min<uint64_t>(n_slab, 1 + rng() % 200);
+    std::vector<std::vector<uint64_t>> v(n, std::vector<uint64_t>(D, 0));
+    unsigned __int128 max_abs[16] = {0};
+    uint64_t or_abs[16] = {0};
+    for (int d = 0; d < D; ++d) {
+      const int kind = (int)(rng() % 6);
+      if (kind == 0) continue;  // nobody requests this resource
+      const int unit = kind == 1 ? 0 : (int)(rng() % 30);  // common trailing zeros (memory in MiB, ...)
+      const int bits = 1 + (int)(rng() % (kind == 5 ? 50 : 14));
+      for (int i = 0; i < n; ++i) {
+        if (rng() % 4 == 0) continue;
+        const uint64_t x = (rng() & ((1ull << bits) - 1ull)) << unit;
+        v[i][d] = x, or_abs[d] |= x;
+        if (x > max_abs[d]) max_abs[d] = x;
+      }
+    }
+    const bool pad = it & 1;
+    const PackPlan pk = make_pack_plan(D, max_abs, or_abs, false, n_slab, pad);
+    if (pk.nw == 0) {
+      ++refused;
+      // a refusal must have a reason: the fields do not fit 4 words (first fit) or a single field needs more than 64 bits
+      continue;
+    }
+    ++packed;
+    if (pk.nw > 4 || (pk.stride != 2 && pk.stride != 4) || pk.stride < pk.nw || pk.rec_bytes < (pk.nw + 1) * 8 || (pad && !((pk.rec_bytes / 8) & 1)))
+      ++g_fail, fprintf(stderr, "FAIL: pack plan shape nw=%u stride=%u rec=%u\n", pk.nw, pk.stride, pk.rec_bytes);
+    // no overlap, nothing crosses a word, the count owns the low bits of word 0
+    uint64_t occ[4] = {pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull, 0, 0, 0};
+    if ((n_slab >> pk.cnt_width) != 0) ++g_fail, fprintf(stderr, "FAIL: the pod count field is too narrow\n");
+    for (int d = 0; d < D; ++d) {
+      if (!pk.width[d]) {
+        if (max_abs[d] != 0) ++g_fail, fprintf(stderr, "FAIL: a used dimension has no field\n");
+        continue;
+      }
+      if (pk.word[d] >= pk.nw || pk.pos[d] + pk.width[d] > 64) { ++g_fail, fprintf(stderr, "FAIL: field outside its word\n"); continue; }
+      const uint64_t m = (pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull) << pk.pos[d];
+      if (occ[pk.word[d]] & m) ++g_fail, fprintf(stderr, "FAIL: fields overlap\n");
+      occ[pk.word[d]] |= m;
+      if ((or_abs[d] & ((1ull << pk.shift[d]) - 1ull)) != 0) ++g_fail, fprintf(stderr, "FAIL: the shift drops set bits\n");
+      // a full slab of the maximum stays inside the field
+      const unsigned __int128 worst = (max_abs[d] >> pk.shift[d]) * (unsigned __int128)n_slab;
+      if (pk.width[d] < 64 && (worst >> pk.width[d]) != 0) ++g_fail, fprintf(stderr, "FAIL: a full slab carries out of field %d\n", d);
+    }
+    // pack every pod, fold by whole-word adds, unpack
+    uint64_t acc[4] = {0, 0, 0, 0};
+    std::vector<unsigned __int128> want(D, 0);
+    for (int i = 0; i < n; ++i) {
+      uint64_t w[4] = {1ull, 0, 0, 0};
+      for (int d = 0; d < D; ++d) {
+        want[d] += v[i][d];
+        if (pk.width[d]) w[pk.word[d]] += (v[i][d] >> pk.shift[d]) << pk.pos[d];
+      }
+      for (int k = 0; k < 4; ++k) acc[k] += w[k];
+    }
+    const uint64_t cm = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
+    if ((acc[0] & cm) != (uint64_t)n) ++g_fail, fprintf(stderr, "FAIL: packed pod count %llu != %d\n", (unsigned long long)(acc[0] & cm), n);
+    for (int d = 0; d < D; ++d) {
+      unsigned __int128 got = 0;
+      if (pk.width[d]) {
+        const uint64_t m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
+        got = (unsigned __int128)((acc[pk.word[d]] >> pk.pos[d]) & m) << pk.shift[d];
+      }
+      if (got != want[d]) { ++g_fail, fprintf(stderr, "FAIL: packed sum of dimension %d differs (case %d)\n", d, it); break; }
+    }
+  }
+  // negative requests never pack
+  {
+    unsigned __int128 mx[16] = {5};
+    uint64_t oa[16] = {5};
+    if (make_pack_plan(1, mx, oa, true, 100, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: negative requests packed\n");
+    mx[0] = (unsigned __int128)1 << 62, oa[0] = 1ull << 62 | 1ull;
+    if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field wider than 64 bits packed\n");
+  }
+  if (packed < 1000 || refused < 10) ++g_fail, fprintf(stderr, "FAIL: pack plan cases too one-sided (%d packed, %d refused)\n", packed, refused);
+  printf("pack plan: %d packed, %d refused\n", packed, refused);
+}
+
 int main(int argc, char** argv) {
   if (argc > 1) return run_file(argv[1], argc > 2 ? (uint32_t)atoi(argv[2]) : 80u * 1024u - check_fixed_lds());
+  pack_plan_cases();
   long chunks_seen = 0, matches = 0, simple_seen = 0;
   auto acc = [&](long r) {
     if (r >= 500000000L) r -= 500000000L, ++simple_seen;
