@@ -752,20 +752,26 @@ PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t*
   PackPlan pk;
   if (neg_seen || D < 1 || D > 16 || n_slab_pods == 0) return pk;
   auto bitlen = [](unsigned __int128 x) { int b = 0; while (x) ++b, x >>= 1; return b; };
-  uint32_t fill[4] = {0, 0, 0, 0};
-  pk.cnt_width = (uint8_t)bitlen(n_slab_pods);
-  fill[0] = pk.cnt_width;
+  constexpr uint32_t H = (uint32_t)kPackHeadroomBits, kTop = 64u - H;  // every word keeps H free bits above its last field
+  uint32_t fill[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0};
+  pk.cnt_width = (uint8_t)std::max(bitlen(n_slab_pods), (int)H);
+  if (pk.cnt_width > kTop) return PackPlan();
+  fill[0] = pk.cnt_width, count[0] = 1;
+  pk.even[0] = (1ull << pk.cnt_width) - 1ull;  // the pod count is the first field of word 0
   uint32_t nw = 1;
   for (int d = 0; d < D; ++d) {
     if (max_abs[d] == 0) continue;  // no pod carries a non-zero value here: no field
     const int sh = or_abs[d] ? __builtin_ctzll(or_abs[d]) : 0;
-    const int w = bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods);
-    if (w > 64) return PackPlan();
+    const int w = std::max(bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods), (int)H);
+    if ((uint32_t)w > kTop) return PackPlan();
     int k = 0;
-    while (k < 4 && fill[k] + (uint32_t)w > 64u) ++k;
+    while (k < 4 && fill[k] + (uint32_t)w > kTop) ++k;
     if (k == 4) return PackPlan();
+    const uint32_t cls = count[k] & 1u;
     pk.word[d] = (uint8_t)k, pk.pos[d] = (uint8_t)fill[k], pk.width[d] = (uint8_t)w, pk.shift[d] = (uint8_t)sh;
-    fill[k] += (uint32_t)w;
+    pk.desc[d] = pack_desc((uint32_t)k, cls, fill[k], (uint32_t)w + H, (uint32_t)sh);
+    if (!cls) pk.even[k] |= ((1ull << w) - 1ull) << fill[k];
+    fill[k] += (uint32_t)w, ++count[k];
     nw = std::max(nw, (uint32_t)k + 1u);
   }
   pk.nw = nw;

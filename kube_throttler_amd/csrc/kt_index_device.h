@@ -84,77 +84,130 @@ __device__ inline uint32_t walk_slow_mem(const SelProgram& sp, int t, const uint
   return res;
 }
 
+// Wave-wide sums by DPP (no LDS round trips: ds_bpermute costs ~100 cycles a step, these kernels are latency chains):
+// an inclusive scan inside every row of 16 lanes (row_shr 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3
+// (row_bcast:15), lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the total, read back as a scalar.  Lanes without
+// a source take 0 (old = 0).  Must be called with every lane of the wave active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_add64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+  return v + ((unsigned long long)lo | (unsigned long long)hi << 32);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or32(uint32_t v) {
+  return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
-    v += (unsigned long long)lo | (unsigned long long)hi << 32;
-  }
-  return v;
+  v = dpp_add64<kDppRowShr1, 0xF>(v);
+  v = dpp_add64<kDppRowShr2, 0xF>(v);
+  v = dpp_add64<kDppRowShr4, 0xF>(v);
+  v = dpp_add64<kDppRowShr8, 0xF>(v);
+  v = dpp_add64<kDppRowBcast15, 0xA>(v);
+  v = dpp_add64<kDppRowBcast31, 0xC>(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return (unsigned long long)lo | (unsigned long long)hi << 32;
+}
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
+  v = dpp_or32<kDppRowShr1, 0xF>(v);
+  v = dpp_or32<kDppRowShr2, 0xF>(v);
+  v = dpp_or32<kDppRowShr4, 0xF>(v);
+  v = dpp_or32<kDppRowShr8, 0xF>(v);
+  v = dpp_or32<kDppRowBcast15, 0xA>(v);
+  v = dpp_or32<kDppRowBcast31, 0xC>(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// One record of the packed slabs (PackPlan) summed over the workgroups' slabs by ONE wave, lane = slab: every lane takes
-// the record of its slabs apart into fields (the pod count, one per dimension) in 64-bit accumulators — four slabs per
-// lane and trip with all their loads in flight — and the wave adds the accumulators up across its lanes.  On return every
-// lane holds the totals: pods, acc[d] in field units (value = acc[d] << pk.shift[d]), zero_keys = OR of the key masks of
-// pods that carry a key with the value 0.  check_tags = 0: every workgroup spilled this chunk (single-chunk programs).
-struct PackedSums {
-  unsigned long long acc[16], pods;
-  uint32_t zero_keys;
+// The packed slabs (PackPlan) of one chunk summed over the workgroups' slabs, one BLOCK of 16 waves per tile of
+// kRecTileUnits 8-byte units of the chunk's row of records (whole records: 64 / units of them).
+//   * lane = unit, wave = slab class: wave w reads the tile out of slabs w, w + 16, ... (at most 256 slabs: sixteen loads
+//     per lane, issued as one batch) — every load instruction of a wave covers 512 contiguous bytes, the slab area is read
+//     exactly once and fully coalesced (one wave per record with lane = slab, the first version of this reduction, moved
+//     a cache line per 8-byte word: ~80 MB through L2 for 10 MB of slabs);
+//   * the words are never taken apart per slab: every word is split into its two field classes (PackPlan::even — every
+//     field then has kPackHeadroomBits of zeros above it) and summed whole; the unit behind the words is the OR of the
+//     key masks of pods that carry a key with the value 0;
+//   * the sixteen waves meet in LDS: tot[unit][class].
+// Slabs a namespace-ordered scan left alone (multi-chunk programs: most of them) are skipped by their tags, wave-uniformly.
+// packed_field() then lets the lane of (record, dimension) cut its total out of tot — no loop over dimensions anywhere.
+constexpr int kRecBlock = 1024, kRecWaves = kRecBlock / 64, kRecTileUnits = 64;
+constexpr int kMaxSlabsPerRecord = 1 << kPackHeadroomBits;
+static_assert(kMaxSlabsPerRecord == 16 * kRecWaves, "sixteen slabs per wave");
+struct RecSumsLds {
+  unsigned long long red[kRecWaves][kRecTileUnits][2];
+  unsigned long long tot[kRecTileUnits][2];
 };
-__device__ __forceinline__ void packed_record_sums(const unsigned char* base, size_t pitch, int n_slabs, const PackPlan& pk, int D,
-                                                   const uint32_t* tag, uint32_t epoch, int check_tags, uint32_t lane, PackedSums& o) {
-  const uint32_t nw = pk.nw;
+// Three steps, so that a caller can place its own loads between them (vmcnt counts in order):
+//   record_slabs_live   which of this wave's slabs this launch spilled (tag loads: multi-chunk programs only)
+//   record_slabs_issue  the sixteen loads of this lane's unit.  row0: the tile's first byte in slab 0; n_units: units of
+//                       the tile that exist (whole records)
+//   block_record_sums   class sums, the meeting in LDS (two barriers: every thread of the block must call)
+struct RecSlabLoads {
+  uint32_t live;  // bit i: slab (wave + 16 i) was spilled by this launch
+  unsigned long long v[16];
+};
+__device__ __forceinline__ void record_slabs_live(int n_slabs, const uint32_t* tag, uint32_t epoch, int check_tags, RecSlabLoads& sl) {
+  const uint32_t lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = (int)(w + 16u * lane);
+  bool ok = lane < 16u && s < n_slabs;
+  if (ok && check_tags) ok = tag[s] == epoch;
+  sl.live = (uint32_t)__ballot(ok);
+}
+__device__ __forceinline__ void record_slabs_issue(const unsigned char* row0, size_t pitch, uint32_t n_units, RecSlabLoads& sl) {
+  const uint32_t lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool mine = lane < n_units;
+  const unsigned char* q = row0 + (size_t)w * pitch + (size_t)lane * 8u;
 #pragma unroll
-  for (int d = 0; d < 16; ++d) o.acc[d] = 0ull;
-  o.pods = 0ull, o.zero_keys = 0u;
-  const unsigned long long cnt_mask = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
-  for (int b0 = (int)lane; b0 < n_slabs; b0 += 256) {
-    bool on[4];
-    unsigned long long w[4][4];
-    uint32_t zk[4];
-    // which of this lane's four slabs this launch wrote (namespace-ordered scans leave most (chunk, workgroup) slabs alone):
-    // the four tags as one batch of loads, then the records of the live slabs only
-#pragma unroll
-    for (int u = 0; u < 4; ++u) on[u] = b0 + 64 * u < n_slabs;
-    if (check_tags) {
-      uint32_t tg[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) tg[u] = tag[min(b0 + 64 * u, n_slabs - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) on[u] = on[u] && tg[u] == epoch;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      w[u][0] = w[u][1] = w[u][2] = w[u][3] = 0ull, zk[u] = 0u;
-      if (on[u]) {
-        const unsigned long long* q = (const unsigned long long*)(base + (size_t)(b0 + 64 * u) * pitch);
-        w[u][0] = q[0], w[u][1] = q[nw > 1u ? 1 : 0], w[u][2] = q[nw > 2u ? 2 : 0], w[u][3] = q[nw > 3u ? 3 : 0];
-        zk[u] = (uint32_t)q[nw];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!on[u] || w[u][0] == 0ull) continue;  // nobody of that workgroup matched this throttle
-      o.pods += w[u][0] & cnt_mask;
-      o.zero_keys |= zk[u];
-#pragma unroll
-      for (int d = 0; d < 16; ++d)
-        if (d < D && pk.width[d]) {
-          const uint32_t k = pk.word[d];
-          const unsigned long long ww = k == 0u ? w[u][0] : k == 1u ? w[u][1] : k == 2u ? w[u][2] : w[u][3];
-          const unsigned long long m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
-          o.acc[d] += (ww >> pk.pos[d]) & m;
-        }
-    }
+  for (int i = 0; i < 16; ++i) {
+    sl.v[i] = 0ull;
+    if (mine && ((sl.live >> i) & 1u)) sl.v[i] = *(const unsigned long long*)(q + (size_t)(16 * i) * pitch);
   }
-  o.pods = wave_sum64(o.pods);
-  if (o.pods == 0ull) return;  // wave-uniform
+}
+__device__ __forceinline__ void block_record_sums(const RecSlabLoads& sl, const PackPlan& pk, RecSumsLds& lds) {
+  const uint32_t x = threadIdx.x, lane = x & 63u, w = __builtin_amdgcn_readfirstlane(x >> 6);
+  const uint32_t units = pk.rec_bytes >> 3, nw = pk.nw;
+  const uint32_t k = lane % units;  // what this unit is: word k of its record, the key-mask unit (k == nw), padding
+  unsigned long long ev = ~0ull;    // the class mask of this lane's word (key-mask unit, padding: everything in class 0)
 #pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) o.zero_keys |= (uint32_t)__shfl_xor((int)o.zero_keys, s);
+  for (int j = 0; j < 4; ++j) ev = (k == (uint32_t)j && (uint32_t)j < nw) ? pk.even[j] : ev;
+  unsigned long long a = 0ull, b = 0ull, o = 0ull;
 #pragma unroll
-  for (int d = 0; d < 16; ++d)
-    if (d < D && pk.width[d]) o.acc[d] = wave_sum64(o.acc[d]);
+  for (int i = 0; i < 16; ++i) a += sl.v[i] & ev, b += sl.v[i] & ~ev, o |= sl.v[i];
+  lds.red[w][lane][0] = k == nw ? o : a;
+  lds.red[w][lane][1] = b;
+  __syncthreads();
+  if (x < 2u * kRecTileUnits) {
+    const uint32_t u = x >> 1, c = x & 1u;
+    const bool is_or = u % units == nw;
+    unsigned long long t = 0ull;
+#pragma unroll
+    for (int ww = 0; ww < kRecWaves; ++ww) {
+      const unsigned long long r = lds.red[ww][u][c];
+      t = is_or ? (t | r) : t + r;
+    }
+    lds.tot[u][c] = t;
+  }
+  __syncthreads();
+}
+// the total of dimension k (in request units) of the record whose first unit is ub, for the lane that asks:
+// desc = pk.desc[k] (0: no field)
+__device__ __forceinline__ unsigned long long packed_field(const RecSumsLds& lds, uint32_t ub, uint32_t desc) {
+  const uint32_t sel = desc & 7u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
+  const unsigned long long s = lds.tot[ub + (sel >> 1)][sel & 1u];
+  const unsigned long long m = wext >= 64u ? ~0ull : (1ull << wext) - 1ull;
+  return wext ? ((s >> pos) & m) << shift : 0ull;
+}
+__device__ __forceinline__ unsigned long long packed_pods(const RecSumsLds& lds, uint32_t ub, const PackPlan& pk) {
+  return lds.tot[ub][0] & ((1ull << (pk.cnt_width + kPackHeadroomBits)) - 1ull);
+}
+__device__ __forceinline__ uint32_t packed_zero_keys(const RecSumsLds& lds, uint32_t ub, const PackPlan& pk) { return (uint32_t)lds.tot[ub + pk.nw][0]; }
+// pk.desc[k] for the lane of dimension k (a select chain over the 16 scalars: no indexed access to kernel arguments)
+__device__ __forceinline__ uint32_t packed_desc_of(const PackPlan& pk, int k, int D) {
+  uint32_t v = 0u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v = (j < D && k == j) ? pk.desc[j] : v;
+  return v;
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char kt_smem[];

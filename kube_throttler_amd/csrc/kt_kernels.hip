@@ -646,24 +646,52 @@ struct ThrLane {
   uint32_t fl, thrl_flag, thrl_has, ovr0, ovr1;
   uint64_t status_fp, spec_fp;
   int64_t calc_v, used_v, spec_v, res_v;  // this lane's dimension; 0 for padding dimensions
-  int64_t used_hi;                        // high word of used_v (tt.used_hi; sign extension when the table is absent)
+  int64_t used_hi_raw;                    // tt.used_hi's word (0 when the table is absent: hi() then extends the sign)
+  bool has_hi;
+  // high word of used_v.  Computed at the point of use: nothing between the loads may wait for one of them
+  __device__ __forceinline__ int64_t hi() const { return has_hi ? used_hi_raw : (used_v < 0 ? (int64_t)-1 : (int64_t)0); }
   uint32_t calc_p, used_p, spec_p, res_p;
   int64_t calc_c, used_c, spec_c, res_c;
   bool calc_hc, used_hc, spec_hc, res_hc;
 };
-__device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, int d, ThrLane& r) {
+// the loads alone: nothing here looks at a loaded value, so a caller can put further independent loads behind them
+// before anything waits (padding dimensions do not load: their values stay 0)
+struct ThrRaw {
+  uint32_t fl, thrl_flag, thrl_has, ovr0, ovr1;
+  uint64_t status_fp, spec_fp;
+  int64_t calc_v, used_v, spec_v, res_v, used_hi;
+  uint32_t calc_p, used_p, spec_p, res_p;
+  int64_t calc_c, used_c, spec_c, res_c;
+  uint8_t calc_hc, used_hc, spec_hc, res_hc;
+  bool has_hi;
+};
+__device__ __forceinline__ void load_thr_raw(const ThrTables& tt, int t, int D, int d, ThrRaw& r) {
   r.fl = tt.flags[t], r.thrl_flag = tt.thrl_flag[t], r.thrl_has = tt.thrl_has[t];
   r.ovr0 = tt.ovr_off[t], r.ovr1 = tt.ovr_off[t + 1];
   r.status_fp = tt.status_msgs_fp[t], r.spec_fp = tt.spec_msgs_fp[t];
   r.calc_p = tt.calc.present[t], r.used_p = tt.used.present[t], r.spec_p = tt.spec.present[t], r.res_p = tt.reserved.present[t];
   r.calc_c = tt.calc.count[t], r.used_c = tt.used.count[t], r.spec_c = tt.spec.count[t], r.res_c = tt.reserved.count[t];
-  r.calc_hc = tt.calc.has_count[t] != 0, r.used_hc = tt.used.has_count[t] != 0, r.spec_hc = tt.spec.has_count[t] != 0,
-  r.res_hc = tt.reserved.has_count[t] != 0;
-  const size_t i = (size_t)t * D + (d < D ? d : 0);
-  const int64_t c = tt.calc.v[i], u = tt.used.v[i], sp = tt.spec.v[i], rs = tt.reserved.v[i];
-  const int64_t uh = tt.used_hi ? tt.used_hi[i] : (u < 0 ? -1 : 0);
-  r.calc_v = d < D ? c : 0, r.used_v = d < D ? u : 0, r.spec_v = d < D ? sp : 0, r.res_v = d < D ? rs : 0;
-  r.used_hi = d < D ? uh : 0;
+  r.calc_hc = tt.calc.has_count[t], r.used_hc = tt.used.has_count[t], r.spec_hc = tt.spec.has_count[t], r.res_hc = tt.reserved.has_count[t];
+  r.calc_v = r.used_v = r.spec_v = r.res_v = r.used_hi = 0;
+  r.has_hi = tt.used_hi != nullptr;
+  if (d < D) {
+    const size_t i = (size_t)t * D + d;
+    r.calc_v = tt.calc.v[i], r.used_v = tt.used.v[i], r.spec_v = tt.spec.v[i], r.res_v = tt.reserved.v[i];
+    if (tt.used_hi) r.used_hi = tt.used_hi[i];
+  }
+}
+__device__ __forceinline__ void thr_from_raw(const ThrRaw& w, ThrLane& r) {
+  r.fl = w.fl, r.thrl_flag = w.thrl_flag, r.thrl_has = w.thrl_has, r.ovr0 = w.ovr0, r.ovr1 = w.ovr1;
+  r.status_fp = w.status_fp, r.spec_fp = w.spec_fp;
+  r.calc_v = w.calc_v, r.used_v = w.used_v, r.spec_v = w.spec_v, r.res_v = w.res_v, r.used_hi_raw = w.used_hi, r.has_hi = w.has_hi;
+  r.calc_p = w.calc_p, r.used_p = w.used_p, r.spec_p = w.spec_p, r.res_p = w.res_p;
+  r.calc_c = w.calc_c, r.used_c = w.used_c, r.spec_c = w.spec_c, r.res_c = w.res_c;
+  r.calc_hc = w.calc_hc != 0, r.used_hc = w.used_hc != 0, r.spec_hc = w.spec_hc != 0, r.res_hc = w.res_hc != 0;
+}
+__device__ __forceinline__ void load_thr(const ThrTables& tt, int t, int D, int d, ThrLane& r) {
+  ThrRaw w;
+  load_thr_raw(tt, t, D, d, w);
+  thr_from_raw(w, r);
 }
 
 // the CheckRec of throttle t from the status as held in the lane registers (stored status unchanged)
@@ -673,7 +701,7 @@ __device__ __forceinline__ void build_check_rec_regs(int t, int T, int D, int d,
   // threshold := status.calculatedThreshold if calculatedAt != zero else spec.threshold (throttle_types.go:129-132)
   const bool calc = (r.fl & kThrCalcAtNonzero) != 0;
   build_check_rec<DT>(t, T, D, d, valid, r.fl, calc ? r.calc_v : r.spec_v, calc ? r.calc_p : r.spec_p, calc ? r.calc_hc : r.spec_hc,
-                      calc ? r.calc_c : r.spec_c, wide_value(r.used_v, r.used_hi, true), r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag,
+                      calc ? r.calc_c : r.spec_c, wide_value(r.used_v, r.hi(), true), r.used_p, r.used_hc, r.used_c, r.res_v, r.res_p, r.res_hc, r.res_c, r.thrl_flag,
                       r.thrl_has, eq, vmax, recs);
 }
 
@@ -698,7 +726,7 @@ __device__ __forceinline__ void finalize_throttle(const ThrTables& tt, int t, in
   if (!live || error) {  // the stored status is returned unchanged
     if (in_d) {
       out.used.v[vi] = r.used_v;
-      if (out.used_hi) out.used_hi[vi] = r.used_hi;
+      if (out.used_hi) out.used_hi[vi] = r.hi();
       out.calc.v[vi] = r.calc_v;
     }
     if (lead) {
@@ -895,15 +923,18 @@ void launch_finalize(const ThrTables& tt, const SelProgram& sp, int D, unsigned 
 }
 
 // kt_reduce_finalize_packed — the slab reduction of a packed scan (kt_aggregate_bitmap PK) and kt_finalize as ONE
-// launch, one WAVE per slab record: the wave sums its record over the workgroups' slabs (packed_record_sums: lane =
-// slab) and — the record being the throttle's only group — goes straight on to finalize that throttle from the sums in
-// its registers, lanes 0..DT-1 as the throttle's dimension group (finalize_throttle above; the other lanes shadow the
-// group and store nothing).  Two dependent launches (a reduction that funnels 10 MB into 140 KB through atomics, then a
-// latency chain over the tables) become one, and the sums never travel through the partial buffer.
-//   * a throttle with several groups (namespace cells): every wave adds its sums to the throttle's partial row and takes
+// launch.  A block of 16 waves takes a tile of whole records (64 / units of them) of one chunk's slab row:
+//   * the threads that will finalize — thread = (record of the tile, dimension), 64 / DT throttles per wave exactly as
+//     in kt_finalize — first request their record's throttle and its stored state (two dependent batches of loads);
+//   * all 16 waves sum the tile over the workgroups' slabs (block_record_sums, kt_index_device.h: coalesced, one batch
+//     of loads in flight beside the ones above) into LDS;
+//   * the finalizing threads cut their totals out of the LDS sums and — the record being the throttle's only group — go
+//     straight on to finalize_throttle.  Two dependent launches (a reduction that funnels 10 MB into 140 KB through
+//     atomics, then a latency chain over the tables) become one, and the sums never travel through the partial buffer.
+//   * a throttle with several groups (namespace cells): every group adds its sums to the throttle's partial row and takes
 //     a ticket; the last to arrive finalizes from the row (and leaves row and ticket zeroed);
 //   * what the scan kernel itself added to the partial buffer (slow-list throttles, overflow pods, selector errors) is
-//     read from the row and added; throttles without any group get a wave of their own (blockIdx.y = chunks).
+//     read from the row and added; throttles without any group get blocks of their own (blockIdx.y = chunks).
 // kt_reconcile_launch only: with several ranks the partial rows cross the all-reduce between reduction and kt_finalize
 // (kt_aggregate_launch -> exchange -> kt_finalize_launch keep the separate kernels).
 struct FusedReduceArgs {
@@ -921,77 +952,101 @@ struct FusedReduceArgs {
   BmChunk ch0;             // n_chunks == 1: the chunk's descriptor by value (one dependent load less)
 };
 template <int DT>
-__global__ __launch_bounds__(256) void kt_reduce_finalize_packed(const FusedReduceArgs f, ThrTables tt, int T, int D, unsigned long long* partial,
-                                                                 int consume, int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
-                                                                 CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wv = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int d = (int)(lane & (DT - 1));
-  const bool valid = lane < (uint32_t)DT;  // the throttle's dimension group
+__global__ __launch_bounds__(kRecBlock) void kt_reduce_finalize_packed(const FusedReduceArgs f, ThrTables tt, int T, int D, unsigned long long* partial,
+                                                                      int consume, int64_t now_s, int32_t now_ns, int apply, ReconcileOut out,
+                                                                      CheckRec<DT>* recs, int rec_eq, const ReqBound vmax, const uint8_t* row_mask) {
+  __shared__ RecSumsLds lds;
+  const uint32_t x = threadIdx.x;
+  const int d = (int)(x & (DT - 1));
+  const uint32_t g = x / DT;  // this thread's throttle of the block
   const int stride = partial_stride(D);
   unsigned long long pv = 0, pc = 0, pods = 0, errs = 0;
   uint32_t t;
+  bool valid;                              // stores something (lanes past the end shadow the last throttle: ballots)
   bool from_row = f.scan_adds_rows != 0;  // (part of) the sums are in the throttle's partial row ...
-  bool met = false;                       // ... put there by other waves of this launch (several groups)
+  bool met = false;                       // ... put there by other groups of this launch
   ThrLane r;
   if (blockIdx.y < f.n_chunks) {
-    const BmChunk ch = f.n_chunks == 1u ? f.ch0 : f.chunks[blockIdx.y];
-    if (wv >= ch.n_thr) return;  // wave-uniform
-    t = f.rank_t[ch.rank0 + wv];
-    // the throttle's stored state is requested BEFORE the slab records: both batches of loads are in flight together
-    load_thr(tt, (int)t, D, d, r);
-    const uint32_t ngrp = f.thr_ngrp[t];
+    BmChunk ch = f.ch0;
+    if (f.n_chunks != 1u) {  // the descriptor as scalars, here and now (nothing later may wait for it behind other loads)
+      const BmChunk* cp = f.chunks + blockIdx.y;
+      ch.n_thr = __builtin_amdgcn_readfirstlane(cp->n_thr), ch.rank0 = __builtin_amdgcn_readfirstlane(cp->rank0);
+      ch.slab_off = __builtin_amdgcn_readfirstlane(cp->slab_off);
+    }
+    const uint32_t units = f.pk.rec_bytes >> 3, rb = (uint32_t)kRecTileUnits / units;
+    const uint32_t rec0 = blockIdx.x * rb;
+    if (rec0 >= ch.n_thr) return;  // block-uniform
+    const uint32_t nrec = min(rb, ch.n_thr - rec0);
+    const bool fin = (x & ~63u) < rb * DT;  // wave-uniform: this wave finalizes
+    valid = g < nrec;
+    const uint32_t gl = valid ? g : nrec - 1u;
+    // The order of the loads is the design (vmcnt counts in order: waiting for a load waits for every load before it):
+    // the slab tags (multi-chunk programs only), the record's throttle, the sixteen slab words — then, the throttle
+    // known, its stored state; the slab words are summed and exchanged through LDS while that last batch is in flight.
     const size_t pitch = ((size_t)ch.n_thr * f.pk.rec_bytes + 15u) & ~(size_t)15u;
-    PackedSums sm;
-    packed_record_sums(f.slab + (size_t)ch.slab_off * 16 + (size_t)wv * f.pk.rec_bytes, pitch, f.n_slabs, f.pk, D,
-                       f.slab_tag + blockIdx.y * kSlabTagStride, f.epoch, f.check_tags, lane, sm);
-    if (ngrp > 1u) {
-      // several groups: meet in the partial row, the last wave to arrive goes on
-      unsigned long long* prow = partial + (size_t)t * stride;
-      uint32_t arrived = 0;
-      if (lane == 0) {
-        // RETURNING atomics: their results feed the ticket's operand, so the ticket is issued after every add has been
-        // performed at the device's coherence point — ordering by data dependence instead of a release fence (an
-        // agent-scope fence writes back and invalidates the XCD's whole L2: 20 000 waves doing that serialised the
-        // configs[4] launch into 0.9 ms)
-        unsigned long long seen = 0;
-        if (sm.pods) {
-          seen |= atomicAdd(prow + 2 * D, sm.pods);
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (k < D) {
-              if (f.pk.width[k] && sm.acc[k]) seen |= atomicAdd(prow + k, sm.acc[k] << f.pk.shift[k]);
-              if ((sm.zero_keys >> k) & 1u) seen |= atomicAdd(prow + D + k, 1ull);
-            }
-        }
-        // (the previous values are sums far below 2^64: the comparison is false, but only the hardware knows)
-        const uint32_t one = 1u + (uint32_t)(seen == ~0ull);
-        arrived = __hip_atomic_fetch_add(f.arrive + t, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RecSlabLoads sl;
+    record_slabs_live(f.n_slabs, f.slab_tag + blockIdx.y * kSlabTagStride, f.epoch, f.check_tags, sl);
+    const unsigned char* row0 = f.slab + (size_t)ch.slab_off * 16 + (size_t)rec0 * f.pk.rec_bytes;
+    if (!fin) {  // (its own copy of the code: the waits of the finalizing waves must not be planned for both kinds)
+      record_slabs_issue(row0, pitch, nrec * units, sl);
+      block_record_sums(sl, f.pk, lds);
+      return;
+    }
+    t = f.rank_t[ch.rank0 + rec0 + gl];
+    record_slabs_issue(row0, pitch, nrec * units, sl);
+    ThrRaw raw;
+    load_thr_raw(tt, (int)t, D, d, raw);
+    uint32_t ngrp = f.thr_ngrp[t];
+    block_record_sums(sl, f.pk, lds);
+    // (the stored state is first looked at HERE: the compiler must not pull the byte -> bool conversions up into the loads)
+    asm volatile("" : "+v"(raw.fl), "+v"(ngrp));
+    thr_from_raw(raw, r);
+    const uint32_t ub = gl * units;
+    const unsigned long long rec_pods = packed_pods(lds, ub, f.pk);
+    const uint32_t zero_keys = packed_zero_keys(lds, ub, f.pk);
+    const unsigned long long mine = rec_pods ? packed_field(lds, ub, packed_desc_of(f.pk, d, D)) : 0ull;
+    // ---- a throttle with several groups: they meet in the partial row, the last group to arrive goes on.  The lane of
+    // dimension d adds that dimension (and its key mark), lane 0 the pod count too — RETURNING atomics: their results feed
+    // the ticket's operand (through a ballot over the group), so the ticket is issued after every add has been performed at
+    // the device's coherence point — ordering by data dependence instead of a release fence (an agent-scope fence writes
+    // back and invalidates the XCD's whole L2: 20 000 waves doing that serialised the configs[4] launch into 0.9 ms)
+    const bool multi = valid && ngrp > 1u;
+    unsigned long long* prow = partial + (size_t)t * stride;
+    unsigned long long seen = 0;
+    if (multi && rec_pods) {
+      if (d == 0) seen |= atomicAdd(prow + 2 * D, rec_pods);
+      if (d < D) {
+        if (mine) seen |= atomicAdd(prow + d, mine);
+        if ((zero_keys >> d) & 1u) seen |= atomicAdd(prow + D + d, 1ull);
       }
-      arrived = __builtin_amdgcn_readfirstlane(arrived);
-      if (arrived + 1u != ngrp) return;
-      if (lane == 0) __hip_atomic_store(f.arrive + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      from_row = met = true;
-    } else if (sm.pods) {
-      pods = sm.pods;
-      // every lane holds all the totals: the lane of dimension d picks its own
-      unsigned long long mine = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k < D && f.pk.width[k]) mine = d == k ? sm.acc[k] << f.pk.shift[k] : mine;
+    }
+    // (the previous values are sums far below 2^64: the comparison is false, but only the hardware knows)
+    const uint32_t one = 1u + (group_bits<DT>(seen == ~0ull) != 0u ? 1u : 0u);
+    uint32_t arrived = 0;
+    if (multi && d == 0) arrived = __hip_atomic_fetch_add(f.arrive + t, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = (uint32_t)__shfl((int)arrived, (int)((x & 63u) & ~(uint32_t)(DT - 1)));  // the group's lane 0
+    const bool last = multi && arrived + 1u == ngrp;
+    if (last && d == 0) __hip_atomic_store(f.arrive + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (multi) {
+      valid = last;  // the other groups are done: their lanes shadow on
+      from_row = from_row || last, met = last;
+    } else if (rec_pods) {
+      pods = rec_pods;
       pv = d < D ? mine : 0ull;
-      pc = d < D ? (sm.zero_keys >> d) & 1u : 0u;  // a non-zero sum marks the key by itself
+      pc = d < D ? (zero_keys >> d) & 1u : 0u;  // a non-zero sum marks the key by itself
     }
   } else {
-    if (wv >= f.n_nogroup) return;
-    t = f.nogroup[wv];
+    const uint32_t i = blockIdx.x * (uint32_t)(kRecBlock / DT) + g;
+    if ((i & ~(uint32_t)(64 / DT - 1)) >= f.n_nogroup) return;  // wave-uniform: no throttle left for this wave
+    valid = i < f.n_nogroup;
+    t = f.nogroup[valid ? i : f.n_nogroup - 1u];
     load_thr(tt, (int)t, D, d, r);
   }
   // ---- what the scan kernel added to the row by itself (slow list, overflow pods, errors) and, for a throttle of
   //      several groups, the sums of all its records
   if (from_row) {
     unsigned long long* prow = partial + (size_t)t * stride;
-    // rows other waves of THIS launch added to are read past the caches; rows only the scan kernel wrote are plain data
+    // rows other groups of THIS launch added to are read past the caches; rows only the scan kernel wrote are plain data
     auto ld = [&](int j) { return met ? __hip_atomic_load(prow + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : prow[j]; };
     const int dd = d < D ? d : 0;
     const unsigned long long a = ld(dd), b = ld(D + dd), pp = ld(2 * D), ee = ld(2 * D + 1);
@@ -1014,9 +1069,10 @@ void launch_reduce_finalize_packed(const ThrTables& tt, const SelProgram& sp, in
   f.n_slabs = n_slabs, f.check_tags = ix.n_chunks > 1 ? 1 : 0, f.pk = pk;
   f.scan_adds_rows = scan_adds_rows ? 1 : 0;
   if (ix.n_chunks == 1 && !ix.h_chunks.empty()) f.ch0 = ix.h_chunks[0];
-  const uint32_t gx = (std::max(ix.bm_max_thr, ix.n_nogroup) + 3u) / 4u;
-  const dim3 g(gx ? gx : 1u, ix.n_chunks + 1u), b(256);
   const int DT = recs ? rec_DT : (D <= 4 ? 4 : D <= 8 ? 8 : 16);
+  const uint32_t rb = (uint32_t)kRecTileUnits / (pk.rec_bytes >> 3), per_ng = (uint32_t)(kRecBlock / DT);
+  const uint32_t gx = std::max((ix.bm_max_thr + rb - 1u) / rb, (ix.n_nogroup + per_ng - 1u) / per_ng);
+  const dim3 g(gx ? gx : 1u, ix.n_chunks + (ix.n_nogroup ? 1u : 0u)), b(kRecBlock);  // the extra row: throttles without a group
   const int eq = rec_eq ? 1 : 0;
   if (DT == 4) hipLaunchKernelGGL(kt_reduce_finalize_packed<4>, g, b, 0, s, f, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<4>*)recs, eq, vmax, row_mask);
   else if (DT == 8) hipLaunchKernelGGL(kt_reduce_finalize_packed<8>, g, b, 0, s, f, tt, sp.T, D, partial, consume ? 1 : 0, now_s, now_ns, apply ? 1 : 0, out, (CheckRec<8>*)recs, eq, vmax, row_mask);

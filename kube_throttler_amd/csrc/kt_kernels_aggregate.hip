@@ -312,36 +312,39 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
   }
 }
 
-// kt_reduce_packed_slabs — the same for slabs of PACKED records (PackPlan).  One WAVE per record, lane = slab: every lane
-// takes the record of its workgroups' slabs apart into its fields (the pod count, one per dimension) in 64-bit
-// accumulators, the wave adds them up across its lanes, and lane 0 adds the sums to the partial buffer — a dozen atomics
-// per record (several groups of one throttle meet there), no cross-block reduction, every CU streaming.
-// check_tags = 0: every workgroup spilled every chunk (single-chunk programs) — no tag reads.
-constexpr int kPackedWaves = 4;  // records per block
-__global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(const unsigned char* slab, const BmChunk* chunks, const uint32_t* rank_t,
-                                                                           int n_slabs, int D, const PackPlan pk, const uint32_t* slab_tag, uint32_t epoch,
-                                                                           int check_tags, unsigned long long* partial) {
+// kt_reduce_packed_slabs — the same for slabs of PACKED records (PackPlan).  One block of 16 waves per tile of whole
+// records of a chunk's slab row: block_record_sums (kt_index_device.h) sums the tile over the workgroups' slabs — coalesced,
+// whole words, class by class — into LDS; then thread = (record, dimension) cuts its total out of the sums and adds it to
+// the partial buffer (several groups of one throttle meet there): a dozen atomics per record, issued by a dozen lanes at
+// once.  check_tags = 0: every workgroup spilled every chunk (single-chunk programs) — no tag reads.
+__global__ __launch_bounds__(kRecBlock) void kt_reduce_packed_slabs(const unsigned char* slab, const BmChunk* chunks, const uint32_t* rank_t,
+                                                                   int n_slabs, int D, const PackPlan pk, const uint32_t* slab_tag, uint32_t epoch,
+                                                                   int check_tags, unsigned long long* partial) {
+  __shared__ RecSumsLds lds;
   const BmChunk ch = chunks[blockIdx.y];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t r = blockIdx.x * kPackedWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (r >= ch.n_thr) return;  // wave-uniform
-  const uint32_t rec = pk.rec_bytes;
-  const size_t pitch = ((size_t)ch.n_thr * rec + 15u) & ~(size_t)15u;
-  const unsigned char* base = slab + (size_t)ch.slab_off * 16 + (size_t)r * rec;
-  PackedSums sm;
-  packed_record_sums(base, pitch, n_slabs, pk, D, slab_tag + blockIdx.y * kSlabTagStride, epoch, check_tags, lane, sm);
-  if (sm.pods == 0ull) return;  // wave-uniform
-  const int stride = partial_stride(D);
-  unsigned long long* prow = partial + (size_t)rank_t[ch.rank0 + r] * stride;
-  if (lane == 0) {
-    atomicAdd(prow + 2 * D, sm.pods);
-#pragma unroll
-    for (int d = 0; d < 16; ++d)
-      if (d < D) {
-        if (pk.width[d] && sm.acc[d]) atomicAdd(prow + d, sm.acc[d] << pk.shift[d]);
-        // key seen: a non-zero sum says so by itself (kt_finalize); a key only ever carried with the value 0 is marked here
-        if ((sm.zero_keys >> d) & 1u) atomicAdd(prow + D + d, 1ull);
-      }
+  const uint32_t units = pk.rec_bytes >> 3, rb = (uint32_t)kRecTileUnits / units;
+  const uint32_t rec0 = blockIdx.x * rb;
+  if (rec0 >= ch.n_thr) return;  // block-uniform
+  const uint32_t nrec = min(rb, ch.n_thr - rec0);
+  const uint32_t x = threadIdx.x, g = x >> 4, d = x & 15u;  // thread = (record g of the tile, dimension d)
+  const size_t pitch = ((size_t)ch.n_thr * pk.rec_bytes + 15u) & ~(size_t)15u;
+  RecSlabLoads sl;
+  record_slabs_live(n_slabs, slab_tag + blockIdx.y * kSlabTagStride, epoch, check_tags, sl);
+  uint32_t t = 0;
+  if (g < nrec) t = rank_t[ch.rank0 + rec0 + g];
+  record_slabs_issue(slab + (size_t)ch.slab_off * 16 + (size_t)rec0 * pk.rec_bytes, pitch, nrec * units, sl);
+  block_record_sums(sl, pk, lds);
+  if (g >= nrec) return;
+  const uint32_t ub = g * units;
+  const unsigned long long pods = packed_pods(lds, ub, pk);
+  if (pods == 0ull) return;  // nobody matched this throttle
+  unsigned long long* prow = partial + (size_t)t * partial_stride(D);
+  if (d == 0u) atomicAdd(prow + 2 * D, pods);
+  if (d < (uint32_t)D) {
+    const unsigned long long mine = packed_field(lds, ub, packed_desc_of(pk, (int)d, D));
+    if (mine) atomicAdd(prow + d, mine);
+    // key seen: a non-zero sum says so by itself (kt_finalize); a key only ever carried with the value 0 is marked here
+    if ((packed_zero_keys(lds, ub, pk) >> d) & 1u) atomicAdd(prow + D + d, 1ull);
   }
 }
 
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(64 * kPackedWaves) void kt_reduce_packed_slabs(cons
     }                                                                                                         \
   }
 
+static_assert(kCUs <= kMaxSlabsPerRecord, "packed_record_sums takes four slabs per lane");
 int aggregate_blocks(int64_t n_rows) {
   int64_t b = (n_rows + kBlockIx - 1) / kBlockIx;
   return (int)(b < 1 ? 1 : b > kCUs ? kCUs : b);
@@ -405,8 +409,9 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   if (packed && sc.defer_reduce) {
     // the caller goes on with kt_reduce_finalize_packed
   } else if (packed) {
+    const uint32_t rb_ = (uint32_t)kRecTileUnits / (bm_args.pk.rec_bytes >> 3);  // records per block
     if (ix.bm_max_thr > 0)
-      hipLaunchKernelGGL(kt_reduce_packed_slabs, dim3((ix.bm_max_thr + kPackedWaves - 1) / kPackedWaves, ix.n_chunks), dim3(64 * kPackedWaves), 0, s, slab,
+      hipLaunchKernelGGL(kt_reduce_packed_slabs, dim3((ix.bm_max_thr + rb_ - 1u) / rb_, ix.n_chunks), dim3(kRecBlock), 0, s, slab,
                          ix.bm_chunks, ix.bm_rank_t, nb, pods.D, bm_args.pk, sc.slab_tag, sc.epoch, ix.n_chunks > 1 ? 1 : 0, partial);
   } else {
     const uint32_t max_pieces = ix.bm_max_thr * (agg_rec_bytes(pods.D, sc.counts) / 16u);

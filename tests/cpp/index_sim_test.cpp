@@ -483,9 +483,10 @@ static int run_file(const char* path, uint32_t chk_budget) {
 }
 
 // ---- packed request words (PackPlan, kt_index.h): the host mirror of write_view_record (kt_kernels.hip), the fold of
-// the aggregate kernel (whole-word adds per matching pod) and packed_record_sums (kt_index_device.h).  For random
-// request populations: fields must not overlap or cross a word, a slab of n_slab pods carrying the maxima must not carry
-// out of its field, and the unpacked sums must be the plain sums.
+// the aggregate kernel (whole-word adds per matching pod) and packed_record_sums / packed_field (kt_index_device.h:
+// whole words summed over up to 256 slabs class by class, the fields cut out of the sums afterwards).  For random request
+// populations: fields must not overlap or cross a word, a slab of n_slab pods carrying the maxima must not carry out of
+// its field, 256 such slabs must not carry out of the field's headroom, and the unpacked sums must be the plain sums.
 static void pack_plan_cases() {
   std::mt19937_64 rng(4242);
   int packed = 0, refused = 0;
@@ -493,6 +494,7 @@ static void pack_plan_cases() {
     const int D = 1 + (int)(rng() % 16);
     const uint64_t n_slab = 1 + rng() % (it % 3 == 0 ? 5000 : 70000);
     const int n = (int)std::min<uint64_t>(n_slab, 1 + rng() % 200);
+    const int n_slabs = 1 + (int)(rng() % 256);
     std::vector<std::vector<uint64_t>> v(n, std::vector<uint64_t>(D, 0));
     unsigned __int128 max_abs[16] = {0};
     uint64_t or_abs[16] = {0};
@@ -500,7 +502,7 @@ static void pack_plan_cases() {
       const int kind = (int)(rng() % 6);
       if (kind == 0) continue;  // nobody requests this resource
       const int unit = kind == 1 ? 0 : (int)(rng() % 30);  // common trailing zeros (memory in MiB, ...)
-      const int bits = 1 + (int)(rng() % (kind == 5 ? 50 : 14));
+      const int bits = 1 + (int)(rng() % (kind == 5 ? 44 : 14));
       for (int i = 0; i < n; ++i) {
         if (rng() % 4 == 0) continue;
         const uint64_t x = (rng() & ((1ull << bits) - 1ull)) << unit;
@@ -512,58 +514,73 @@ static void pack_plan_cases() {
     const PackPlan pk = make_pack_plan(D, max_abs, or_abs, false, n_slab, pad);
     if (pk.nw == 0) {
       ++refused;
-      // a refusal must have a reason: the fields do not fit 4 words (first fit) or a single field needs more than 64 bits
       continue;
     }
     ++packed;
     if (pk.nw > 4 || (pk.stride != 2 && pk.stride != 4) || pk.stride < pk.nw || pk.rec_bytes < (pk.nw + 1) * 8 || (pad && !((pk.rec_bytes / 8) & 1)))
       ++g_fail, fprintf(stderr, "FAIL: pack plan shape nw=%u stride=%u rec=%u\n", pk.nw, pk.stride, pk.rec_bytes);
     // no overlap, nothing crosses a word, the count owns the low bits of word 0
-    uint64_t occ[4] = {pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull, 0, 0, 0};
-    if ((n_slab >> pk.cnt_width) != 0) ++g_fail, fprintf(stderr, "FAIL: the pod count field is too narrow\n");
+    uint64_t occ[4] = {(1ull << pk.cnt_width) - 1ull, 0, 0, 0};
+    if (pk.cnt_width < 64 && (n_slab >> pk.cnt_width) != 0) ++g_fail, fprintf(stderr, "FAIL: the pod count field is too narrow\n");
     for (int d = 0; d < D; ++d) {
       if (!pk.width[d]) {
         if (max_abs[d] != 0) ++g_fail, fprintf(stderr, "FAIL: a used dimension has no field\n");
+        if (pk.desc[d] != 0) ++g_fail, fprintf(stderr, "FAIL: a descriptor without a field\n");
         continue;
       }
-      if (pk.word[d] >= pk.nw || pk.pos[d] + pk.width[d] > 64) { ++g_fail, fprintf(stderr, "FAIL: field outside its word\n"); continue; }
-      const uint64_t m = (pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull) << pk.pos[d];
+      if (pk.word[d] >= pk.nw || pk.pos[d] + pk.width[d] + kPackHeadroomBits > 64) { ++g_fail, fprintf(stderr, "FAIL: field outside its word\n"); continue; }
+      const uint64_t m = ((1ull << pk.width[d]) - 1ull) << pk.pos[d];
       if (occ[pk.word[d]] & m) ++g_fail, fprintf(stderr, "FAIL: fields overlap\n");
       occ[pk.word[d]] |= m;
       if ((or_abs[d] & ((1ull << pk.shift[d]) - 1ull)) != 0) ++g_fail, fprintf(stderr, "FAIL: the shift drops set bits\n");
       // a full slab of the maximum stays inside the field
       const unsigned __int128 worst = (max_abs[d] >> pk.shift[d]) * (unsigned __int128)n_slab;
-      if (pk.width[d] < 64 && (worst >> pk.width[d]) != 0) ++g_fail, fprintf(stderr, "FAIL: a full slab carries out of field %d\n", d);
+      if ((worst >> pk.width[d]) != 0) ++g_fail, fprintf(stderr, "FAIL: a full slab carries out of field %d\n", d);
     }
-    // pack every pod, fold by whole-word adds, unpack
-    uint64_t acc[4] = {0, 0, 0, 0};
+    // every slab: pack its pods and fold by whole-word adds (the aggregate kernel); slab 0 carries the random pods, the
+    // others a full slab of the per-dimension maxima (the worst case the headroom has to hold)
     std::vector<unsigned __int128> want(D, 0);
-    for (int i = 0; i < n; ++i) {
-      uint64_t w[4] = {1ull, 0, 0, 0};
-      for (int d = 0; d < D; ++d) {
-        want[d] += v[i][d];
-        if (pk.width[d]) w[pk.word[d]] += (v[i][d] >> pk.shift[d]) << pk.pos[d];
+    unsigned __int128 want_pods = 0;
+    uint64_t cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < n_slabs; ++sl) {
+      uint64_t acc[4] = {0, 0, 0, 0};
+      if (sl == 0) {
+        for (int i = 0; i < n; ++i) {
+          uint64_t w[4] = {1ull, 0, 0, 0};
+          for (int d = 0; d < D; ++d) {
+            want[d] += v[i][d];
+            if (pk.width[d]) w[pk.word[d]] += (v[i][d] >> pk.shift[d]) << pk.pos[d];
+          }
+          for (int k = 0; k < 4; ++k) acc[k] += w[k];
+        }
+        want_pods += (unsigned)n;
+      } else {
+        acc[0] = n_slab;
+        for (int d = 0; d < D; ++d)
+          if (pk.width[d]) {
+            acc[pk.word[d]] += (uint64_t)((unsigned __int128)((uint64_t)max_abs[d] >> pk.shift[d]) * n_slab) << pk.pos[d];
+            want[d] += max_abs[d] * (unsigned __int128)n_slab;
+          }
+        want_pods += n_slab;
       }
-      for (int k = 0; k < 4; ++k) acc[k] += w[k];
+      for (uint32_t k = 0; k < pk.nw; ++k) cls[2 * k] += acc[k] & pk.even[k], cls[2 * k + 1] += acc[k] & ~pk.even[k];
     }
-    const uint64_t cm = pk.cnt_width >= 64 ? ~0ull : (1ull << pk.cnt_width) - 1ull;
-    if ((acc[0] & cm) != (uint64_t)n) ++g_fail, fprintf(stderr, "FAIL: packed pod count %llu != %d\n", (unsigned long long)(acc[0] & cm), n);
+    const uint64_t got_pods = cls[0] & ((1ull << (pk.cnt_width + kPackHeadroomBits)) - 1ull);
+    if ((unsigned __int128)got_pods != want_pods) ++g_fail, fprintf(stderr, "FAIL: packed pod count %llu (case %d)\n", (unsigned long long)got_pods, it);
     for (int d = 0; d < D; ++d) {
+      const uint32_t desc = pk.desc[d], sel = desc & 7u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
       unsigned __int128 got = 0;
-      if (pk.width[d]) {
-        const uint64_t m = pk.width[d] >= 64 ? ~0ull : (1ull << pk.width[d]) - 1ull;
-        got = (unsigned __int128)((acc[pk.word[d]] >> pk.pos[d]) & m) << pk.shift[d];
-      }
-      if (got != want[d]) { ++g_fail, fprintf(stderr, "FAIL: packed sum of dimension %d differs (case %d)\n", d, it); break; }
+      if (wext) got = (unsigned __int128)((cls[sel] >> pos) & (wext >= 64 ? ~0ull : (1ull << wext) - 1ull)) << shift;
+      if (got != want[d]) { ++g_fail, fprintf(stderr, "FAIL: packed sum of dimension %d differs (case %d, %d slabs)\n", d, it, n_slabs); break; }
     }
   }
-  // negative requests never pack
+  // negative requests never pack, nor does a field that leaves no headroom
   {
     unsigned __int128 mx[16] = {5};
     uint64_t oa[16] = {5};
     if (make_pack_plan(1, mx, oa, true, 100, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: negative requests packed\n");
-    mx[0] = (unsigned __int128)1 << 62, oa[0] = 1ull << 62 | 1ull;
-    if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field wider than 64 bits packed\n");
+    mx[0] = (unsigned __int128)1 << 50, oa[0] = 1ull << 50 | 1ull;
+    if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field without headroom packed\n");
   }
   if (packed < 1000 || refused < 10) ++g_fail, fprintf(stderr, "FAIL: pack plan cases too one-sided (%d packed, %d refused)\n", packed, refused);
   printf("pack plan: %d packed, %d refused\n", packed, refused);
