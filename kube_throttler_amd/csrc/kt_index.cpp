@@ -752,27 +752,41 @@ PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t*
   PackPlan pk;
   if (neg_seen || D < 1 || D > 16 || n_slab_pods == 0) return pk;
   auto bitlen = [](unsigned __int128 x) { int b = 0; while (x) ++b, x >>= 1; return b; };
-  constexpr uint32_t H = (uint32_t)kPackHeadroomBits, kTop = 64u - H;  // every word keeps H free bits above its last field
-  uint32_t fill[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0};
-  pk.cnt_width = (uint8_t)std::max(bitlen(n_slab_pods), (int)H);
-  if (pk.cnt_width > kTop) return PackPlan();
-  fill[0] = pk.cnt_width, count[0] = 1;
-  pk.even[0] = (1ull << pk.cnt_width) - 1ull;  // the pod count is the first field of word 0
+  constexpr int H = kPackHeadroomBits;
+  // fields in placement order per word: dimension (-1: the pod count), position, width
+  struct F { int d; uint32_t pos, w; };
+  std::vector<F> fields[4];
+  uint32_t fill[4] = {0, 0, 0, 0};
+  // every field at least H bits (it is its lower neighbour's headroom) and at most 64 - H (its own sum over the slabs)
+  pk.cnt_width = (uint8_t)std::max(bitlen(n_slab_pods), H);
+  if (pk.cnt_width > 64 - H) return PackPlan();
+  fields[0].push_back({-1, 0u, pk.cnt_width});
+  fill[0] = pk.cnt_width;
   uint32_t nw = 1;
   for (int d = 0; d < D; ++d) {
     if (max_abs[d] == 0) continue;  // no pod carries a non-zero value here: no field
     const int sh = or_abs[d] ? __builtin_ctzll(or_abs[d]) : 0;
-    const int w = std::max(bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods), (int)H);
-    if ((uint32_t)w > kTop) return PackPlan();
+    const int w = std::max(bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods), H);
+    if (w > 64 - H) return PackPlan();
     int k = 0;
-    while (k < 4 && fill[k] + (uint32_t)w > kTop) ++k;
+    while (k < 4 && fill[k] + (uint32_t)w > 64u) ++k;
     if (k == 4) return PackPlan();
-    const uint32_t cls = count[k] & 1u;
     pk.word[d] = (uint8_t)k, pk.pos[d] = (uint8_t)fill[k], pk.width[d] = (uint8_t)w, pk.shift[d] = (uint8_t)sh;
-    pk.desc[d] = pack_desc((uint32_t)k, cls, fill[k], (uint32_t)w + H, (uint32_t)sh);
-    if (!cls) pk.even[k] |= ((1ull << w) - 1ull) << fill[k];
-    fill[k] += (uint32_t)w, ++count[k];
+    fields[k].push_back({d, fill[k], (uint32_t)w});
+    fill[k] += (uint32_t)w;
     nw = std::max(nw, (uint32_t)k + 1u);
+  }
+  for (uint32_t k = 0; k < nw; ++k) {
+    const size_t n = fields[k].size();  // >= 1: a word only exists because a field went there
+    pk.top_pos[k] = (uint8_t)fields[k][n - 1].pos;
+    for (size_t i = 0; i < n; ++i) {
+      const F& f = fields[k][i];
+      const bool top = i + 1 == n;
+      const uint32_t cls = top ? 2u : (uint32_t)(i & 1u);
+      if (cls == 0u) pk.even[k] |= ((1ull << f.w) - 1ull) << f.pos;
+      const uint32_t desc = pack_desc(k, cls, top ? 0u : f.pos, f.w + (uint32_t)H, f.d >= 0 ? pk.shift[f.d] : 0u);
+      if (f.d >= 0) pk.desc[f.d] = desc; else pk.cnt_desc = desc;
+    }
   }
   pk.nw = nw;
   pk.stride = nw <= 2 ? 2u : 4u;

@@ -152,17 +152,22 @@ struct PackPlan {
   uint8_t word[16] = {0}, pos[16] = {0}, width[16] = {0}, shift[16] = {0};
   uint8_t cnt_width = 0;   // the pod count sits in word 0 from bit 0
   // Summing whole words over the slabs (kPackHeadroomBits: up to 256 of them) without taking the fields apart first:
-  // the fields of a word alternate between two classes (even[k] = mask of the 1st, 3rd, ... field of word k), every
-  // field is at least kPackHeadroomBits wide and the last one ends kPackHeadroomBits below the top — so inside
-  // `word & even[k]` (and `word & ~even[k]`) every field has that many zero bits above it, and the sum of 256 such words
-  // carries nowhere.  desc[d]: where the lane of dimension d finds its total afterwards (PackDesc*).
+  // the TOP field of a word (from bit top_pos[k] up) is shifted out and summed by itself; the fields below it alternate
+  // between two classes (even[k] = mask of the 1st, 3rd, ... field of word k), and every field is at least
+  // kPackHeadroomBits wide — so inside `word & even[k]` (and `word & low[k] & ~even[k]`, low[k] = bits below the top
+  // field) every field has that many zero bits above it, and the sum of 256 such words carries nowhere.  desc[d] /
+  // cnt_desc: where the lane of dimension d / the pod count is found afterwards (pack_desc).
   uint64_t even[4] = {0, 0, 0, 0};
+  uint8_t top_pos[4] = {0, 0, 0, 0};
   uint32_t desc[16] = {0};
+  uint32_t cnt_desc = 0;
 };
 constexpr int kPackHeadroomBits = 8;
-// desc: bits 0-2 = 2 * word + class (0: even mask), 8-13 = pos, 16-22 = width + headroom (0: no field), 24-29 = shift
+constexpr int kPackClasses = 3;  // even fields, odd fields, the top field
+// desc: bits 0-3 = 4 * word + class (0: even mask, 1: odd, 2: top field — already shifted down), 8-13 = pos,
+// 16-22 = bits to keep (field + headroom; 0: no field), 24-29 = shift
 __host__ __device__ inline uint32_t pack_desc(uint32_t word, uint32_t cls, uint32_t pos, uint32_t wext, uint32_t shift) {
-  return (word * 2u + cls) | pos << 8 | wext << 16 | shift << 24;
+  return (word * 4u + cls) | pos << 8 | wext << 16 | shift << 24;
 }
 // or_abs[d]: OR of every |request| fed for dimension d (its trailing zeros are common to all of them);
 // pad_odd: pad the record to an odd number of 8-byte words (LDS bank spread) instead of the smallest size

@@ -84,50 +84,15 @@ __device__ inline uint32_t walk_slow_mem(const SelProgram& sp, int t, const uint
   return res;
 }
 
-// Wave-wide sums by DPP (no LDS round trips: ds_bpermute costs ~100 cycles a step, these kernels are latency chains):
-// an inclusive scan inside every row of 16 lanes (row_shr 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3
-// (row_bcast:15), lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the total, read back as a scalar.  Lanes without
-// a source take 0 (old = 0).  Must be called with every lane of the wave active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_add64(unsigned long long v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
-  return v + ((unsigned long long)lo | (unsigned long long)hi << 32);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_or32(uint32_t v) {
-  return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
-  v = dpp_add64<kDppRowShr1, 0xF>(v);
-  v = dpp_add64<kDppRowShr2, 0xF>(v);
-  v = dpp_add64<kDppRowShr4, 0xF>(v);
-  v = dpp_add64<kDppRowShr8, 0xF>(v);
-  v = dpp_add64<kDppRowBcast15, 0xA>(v);
-  v = dpp_add64<kDppRowBcast31, 0xC>(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
-  return (unsigned long long)lo | (unsigned long long)hi << 32;
-}
-__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
-  v = dpp_or32<kDppRowShr1, 0xF>(v);
-  v = dpp_or32<kDppRowShr2, 0xF>(v);
-  v = dpp_or32<kDppRowShr4, 0xF>(v);
-  v = dpp_or32<kDppRowShr8, 0xF>(v);
-  v = dpp_or32<kDppRowBcast15, 0xA>(v);
-  v = dpp_or32<kDppRowBcast31, 0xC>(v);
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // The packed slabs (PackPlan) of one chunk summed over the workgroups' slabs, one BLOCK of 16 waves per tile of
 // kRecTileUnits 8-byte units of the chunk's row of records (whole records: 64 / units of them).
 //   * lane = unit, wave = slab class: wave w reads the tile out of slabs w, w + 16, ... (at most 256 slabs: sixteen loads
 //     per lane, issued as one batch) — every load instruction of a wave covers 512 contiguous bytes, the slab area is read
 //     exactly once and fully coalesced (one wave per record with lane = slab, the first version of this reduction, moved
 //     a cache line per 8-byte word: ~80 MB through L2 for 10 MB of slabs);
-//   * the words are never taken apart per slab: every word is split into its two field classes (PackPlan::even — every
-//     field then has kPackHeadroomBits of zeros above it) and summed whole; the unit behind the words is the OR of the
-//     key masks of pods that carry a key with the value 0;
+//   * the words are never taken apart per slab: every word is split into its top field (shifted down) and the two
+//     classes of the fields below it (PackPlan::even — every field then has kPackHeadroomBits of zeros above it) and
+//     summed whole; the unit behind the words is the OR of the key masks of pods that carry a key with the value 0;
 //   * the sixteen waves meet in LDS: tot[unit][class].
 // Slabs a namespace-ordered scan left alone (multi-chunk programs: most of them) are skipped by their tags, wave-uniformly.
 // packed_field() then lets the lane of (record, dimension) cut its total out of tot — no loop over dimensions anywhere.
@@ -135,8 +100,8 @@ constexpr int kRecBlock = 1024, kRecWaves = kRecBlock / 64, kRecTileUnits = 64;
 constexpr int kMaxSlabsPerRecord = 1 << kPackHeadroomBits;
 static_assert(kMaxSlabsPerRecord == 16 * kRecWaves, "sixteen slabs per wave");
 struct RecSumsLds {
-  unsigned long long red[kRecWaves][kRecTileUnits][2];
-  unsigned long long tot[kRecTileUnits][2];
+  unsigned long long red[kRecWaves][kRecTileUnits][kPackClasses];
+  unsigned long long tot[kRecTileUnits][kPackClasses];
 };
 // Three steps, so that a caller can place its own loads between them (vmcnt counts in order):
 //   record_slabs_live   which of this wave's slabs this launch spilled (tag loads: multi-chunk programs only)
@@ -168,38 +133,48 @@ __device__ __forceinline__ void block_record_sums(const RecSlabLoads& sl, const 
   const uint32_t x = threadIdx.x, lane = x & 63u, w = __builtin_amdgcn_readfirstlane(x >> 6);
   const uint32_t units = pk.rec_bytes >> 3, nw = pk.nw;
   const uint32_t k = lane % units;  // what this unit is: word k of its record, the key-mask unit (k == nw), padding
-  unsigned long long ev = ~0ull;    // the class mask of this lane's word (key-mask unit, padding: everything in class 0)
+  // this lane's word: mask of its even fields, of everything below its top field, position of the top field
+  // (key-mask unit, padding: everything in class 0)
+  unsigned long long ev = ~0ull, low = ~0ull;
+  uint32_t tp = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) ev = (k == (uint32_t)j && (uint32_t)j < nw) ? pk.even[j] : ev;
-  unsigned long long a = 0ull, b = 0ull, o = 0ull;
+  for (int j = 0; j < 4; ++j) {
+    const bool me = k == (uint32_t)j && (uint32_t)j < nw;
+    ev = me ? pk.even[j] : ev;
+    low = me ? (1ull << pk.top_pos[j]) - 1ull : low;
+    tp = me ? pk.top_pos[j] : tp;
+  }
+  const bool word = k < nw;
+  unsigned long long a = 0ull, b = 0ull, c = 0ull, o = 0ull;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) a += sl.v[i] & ev, b += sl.v[i] & ~ev, o |= sl.v[i];
+  for (int i = 0; i < 16; ++i) a += sl.v[i] & ev & low, b += sl.v[i] & ~ev & low, c += sl.v[i] >> tp, o |= sl.v[i];
   lds.red[w][lane][0] = k == nw ? o : a;
   lds.red[w][lane][1] = b;
+  lds.red[w][lane][2] = word ? c : 0ull;
   __syncthreads();
-  if (x < 2u * kRecTileUnits) {
-    const uint32_t u = x >> 1, c = x & 1u;
+  if (x < (uint32_t)(kPackClasses * kRecTileUnits)) {
+    const uint32_t u = x / kPackClasses, cl = x % kPackClasses;
     const bool is_or = u % units == nw;
     unsigned long long t = 0ull;
 #pragma unroll
     for (int ww = 0; ww < kRecWaves; ++ww) {
-      const unsigned long long r = lds.red[ww][u][c];
+      const unsigned long long r = lds.red[ww][u][cl];
       t = is_or ? (t | r) : t + r;
     }
-    lds.tot[u][c] = t;
+    lds.tot[u][cl] = t;
   }
   __syncthreads();
 }
-// the total of dimension k (in request units) of the record whose first unit is ub, for the lane that asks:
-// desc = pk.desc[k] (0: no field)
+// a total (in request units) of the record whose first unit is ub, for the lane that asks: desc = pk.desc[k] of
+// dimension k (0: no field) or pk.cnt_desc (the pod count)
 __device__ __forceinline__ unsigned long long packed_field(const RecSumsLds& lds, uint32_t ub, uint32_t desc) {
-  const uint32_t sel = desc & 7u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
-  const unsigned long long s = lds.tot[ub + (sel >> 1)][sel & 1u];
+  const uint32_t sel = desc & 15u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
+  const unsigned long long s = lds.tot[ub + (sel >> 2)][sel & 3u];
   const unsigned long long m = wext >= 64u ? ~0ull : (1ull << wext) - 1ull;
   return wext ? ((s >> pos) & m) << shift : 0ull;
 }
 __device__ __forceinline__ unsigned long long packed_pods(const RecSumsLds& lds, uint32_t ub, const PackPlan& pk) {
-  return lds.tot[ub][0] & ((1ull << (pk.cnt_width + kPackHeadroomBits)) - 1ull);
+  return packed_field(lds, ub, pk.cnt_desc);
 }
 __device__ __forceinline__ uint32_t packed_zero_keys(const RecSumsLds& lds, uint32_t ub, const PackPlan& pk) { return (uint32_t)lds.tot[ub + pk.nw][0]; }
 // pk.desc[k] for the lane of dimension k (a select chain over the 16 scalars: no indexed access to kernel arguments)

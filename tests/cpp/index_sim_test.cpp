@@ -528,7 +528,7 @@ static void pack_plan_cases() {
         if (pk.desc[d] != 0) ++g_fail, fprintf(stderr, "FAIL: a descriptor without a field\n");
         continue;
       }
-      if (pk.word[d] >= pk.nw || pk.pos[d] + pk.width[d] + kPackHeadroomBits > 64) { ++g_fail, fprintf(stderr, "FAIL: field outside its word\n"); continue; }
+      if (pk.word[d] >= pk.nw || pk.pos[d] + pk.width[d] > 64 || pk.width[d] < kPackHeadroomBits || pk.width[d] > 64 - kPackHeadroomBits) { ++g_fail, fprintf(stderr, "FAIL: field outside its word\n"); continue; }
       const uint64_t m = ((1ull << pk.width[d]) - 1ull) << pk.pos[d];
       if (occ[pk.word[d]] & m) ++g_fail, fprintf(stderr, "FAIL: fields overlap\n");
       occ[pk.word[d]] |= m;
@@ -541,7 +541,7 @@ static void pack_plan_cases() {
     // others a full slab of the per-dimension maxima (the worst case the headroom has to hold)
     std::vector<unsigned __int128> want(D, 0);
     unsigned __int128 want_pods = 0;
-    uint64_t cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t cls[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int sl = 0; sl < n_slabs; ++sl) {
       uint64_t acc[4] = {0, 0, 0, 0};
       if (sl == 0) {
@@ -563,16 +563,20 @@ static void pack_plan_cases() {
           }
         want_pods += n_slab;
       }
-      for (uint32_t k = 0; k < pk.nw; ++k) cls[2 * k] += acc[k] & pk.even[k], cls[2 * k + 1] += acc[k] & ~pk.even[k];
+      // block_record_sums (kt_index_device.h): the top field shifted down, the fields below it in two classes
+      for (uint32_t k = 0; k < pk.nw; ++k) {
+        const uint64_t low = (1ull << pk.top_pos[k]) - 1ull;
+        cls[k][0] += acc[k] & pk.even[k] & low, cls[k][1] += acc[k] & ~pk.even[k] & low, cls[k][2] += acc[k] >> pk.top_pos[k];
+      }
     }
-    const uint64_t got_pods = cls[0] & ((1ull << (pk.cnt_width + kPackHeadroomBits)) - 1ull);
-    if ((unsigned __int128)got_pods != want_pods) ++g_fail, fprintf(stderr, "FAIL: packed pod count %llu (case %d)\n", (unsigned long long)got_pods, it);
-    for (int d = 0; d < D; ++d) {
-      const uint32_t desc = pk.desc[d], sel = desc & 7u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
-      unsigned __int128 got = 0;
-      if (wext) got = (unsigned __int128)((cls[sel] >> pos) & (wext >= 64 ? ~0ull : (1ull << wext) - 1ull)) << shift;
-      if (got != want[d]) { ++g_fail, fprintf(stderr, "FAIL: packed sum of dimension %d differs (case %d, %d slabs)\n", d, it, n_slabs); break; }
-    }
+    auto field = [&](uint32_t desc) -> unsigned __int128 {  // packed_field
+      const uint32_t sel = desc & 15u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
+      if (!wext) return 0;
+      return (unsigned __int128)((cls[sel >> 2][sel & 3u] >> pos) & (wext >= 64 ? ~0ull : (1ull << wext) - 1ull)) << shift;
+    };
+    if (field(pk.cnt_desc) != want_pods) ++g_fail, fprintf(stderr, "FAIL: packed pod count (case %d)\n", it);
+    for (int d = 0; d < D; ++d)
+      if (field(pk.desc[d]) != want[d]) { ++g_fail, fprintf(stderr, "FAIL: packed sum of dimension %d differs (case %d, %d slabs)\n", d, it, n_slabs); break; }
   }
   // negative requests never pack, nor does a field that leaves no headroom
   {
@@ -580,7 +584,7 @@ static void pack_plan_cases() {
     uint64_t oa[16] = {5};
     if (make_pack_plan(1, mx, oa, true, 100, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: negative requests packed\n");
     mx[0] = (unsigned __int128)1 << 50, oa[0] = 1ull << 50 | 1ull;
-    if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field without headroom packed\n");
+    if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field whose sum over the slabs leaves 64 bits packed\n");
   }
   if (packed < 1000 || refused < 10) ++g_fail, fprintf(stderr, "FAIL: pack plan cases too one-sided (%d packed, %d refused)\n", packed, refused);
   printf("pack plan: %d packed, %d refused\n", packed, refused);
