@@ -269,6 +269,9 @@ int32_t kt_synchronize(kt_engine* e, void* stream);
 const char* kt_kernel_name(kt_engine* e, int32_t kernel);
 /* event counters (-1: unknown counter) */
 #define KT_COUNTER_FEW_CHECKS 0 /* kt_check calls served by the few-pod path (shared lock, no copy, no stream sync) */
+#define KT_COUNTER_COMPILES 1   /* selector program compiles + index builds so far (a Throttle event that leaves every
+                                   selector, namespace and flag of its rows as stored — a threshold edit, a status update —
+                                   only re-uploads the throttle tables and does not count) */
 int64_t kt_counter(kt_engine* e, int32_t which);
 
 #ifdef __cplusplus

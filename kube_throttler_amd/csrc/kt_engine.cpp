@@ -64,6 +64,21 @@ struct HostThrottle {
   uint64_t adm_gen = 0;
   uint32_t adm_ns = 0;
 };
+// what the selector program and the index are compiled from
+static bool same_reqs(const std::vector<Req>& a, const std::vector<Req>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); ++i)
+    if (a[i].op != b[i].op || a[i].key != b[i].key || a[i].vals != b[i].vals) return false;
+  return true;
+}
+static bool same_selector(const HostThrottle& a, const HostThrottle& b) {
+  const uint32_t sel = KT_THR_VALID | KT_THR_RESPONSIBLE | KT_THR_CLUSTER;
+  if ((a.flags & sel) != (b.flags & sel) || a.ns != b.ns || a.terms.size() != b.terms.size()) return false;
+  for (size_t k = 0; k < a.terms.size(); ++k)
+    if (a.terms[k].flags != b.terms[k].flags || !same_reqs(a.terms[k].preq, b.terms[k].preq) || !same_reqs(a.terms[k].nreq, b.terms[k].nreq))
+      return false;
+  return true;
+}
 struct HostNamespace {
   bool valid = false;
   std::vector<std::pair<uint32_t, uint32_t>> labels;  // (key id, pair id)
@@ -211,7 +226,9 @@ struct kt_engine {
   size_t ns_compiled = 0;  // namespace rows the compiled program / index cover (compile_program)
   std::vector<HostThrottle> thr;
   int32_t thr_rows_hi = 0;
-  bool program_dirty = true;   // selector / spec / overrides / namespaces changed -> recompile + upload
+  bool program_dirty = true;   // selectors / namespaces / the set of throttle rows changed -> recompile + index + upload
+  bool spec_dirty = false;     // only spec.threshold / overrides / message fingerprints of existing rows changed (the usual
+                               // Throttle event: a threshold edit, the controller's own status update) -> their tables only
   bool status_host_dirty = true;  // host status/reserved rows newer than device
   bool reserved_dev_newer = false;  // device reserved rows newer than the host mirrors (admit with commit)
   bool incremental = false;         // KT_VARIANT_INCREMENTAL: `used` partials maintained by pod deltas
@@ -289,6 +306,7 @@ struct kt_engine {
   uint64_t few_seq = 0;
   std::atomic<bool> few_ready{false};
   std::atomic<int64_t> few_served{0};
+  std::atomic<int64_t> n_compiles{0};
   DevBuf<uint64_t> d_summary;
   DevBuf<uint8_t> d_status;
   DevBuf<int64_t> d_rows;
@@ -524,6 +542,54 @@ int32_t upload_status(kt_engine* e, hipStream_t s) {
 }
 
 // Compile throttles + namespaces into the device selector program, spec tables and index.
+// spec.threshold, the temporary threshold overrides and the fingerprint of the spec's messages of every throttle row:
+// what kt_finalize reads beside the status.  Part of a compile; on its own after Throttle events that left every
+// selector as it was (spec_dirty).
+int32_t upload_spec_tables(kt_engine* e, hipStream_t s) {
+  const int D = e->D;
+  const size_t T = (size_t)e->thr_rows_hi;
+  std::vector<uint32_t> ovr_off(T + 1, 0);
+  std::vector<int64_t> ob_s, oe_s;
+  std::vector<int32_t> ob_ns, oe_ns;
+  std::vector<uint8_t> o_flags;
+  std::vector<uint64_t> spec_fp(T);
+  AmountHostFlat spec, ovr_thr;
+  spec.resize(T, D);
+  size_t n_ovr = 0;
+  for (size_t t = 0; t < T; ++t) n_ovr += e->thr[t].ovr.size();
+  ovr_thr.resize(n_ovr, D);
+  size_t o = 0;
+  for (size_t t = 0; t < T; ++t) {
+    const HostThrottle& h = e->thr[t];
+    spec.set(t, D, h.spec);
+    spec_fp[t] = h.spec_fp;
+    for (const Override& ov : h.ovr) {
+      ob_s.push_back(ov.begin_s);
+      ob_ns.push_back(ov.begin_ns);
+      oe_s.push_back(ov.end_s);
+      oe_ns.push_back(ov.end_ns);
+      o_flags.push_back(ov.flags);
+      ovr_thr.set(o++, D, ov.thr);
+    }
+    ovr_off[t + 1] = (uint32_t)o;
+  }
+  int32_t rc;
+#define UP(dev, host) if ((rc = upload(e, e->dev, host, s)) != KT_OK) return rc
+  UP(d_ovr_off, ovr_off);
+  UP(d_ovr_begin_s, ob_s);
+  UP(d_ovr_begin_ns, ob_ns);
+  UP(d_ovr_end_s, oe_s);
+  UP(d_ovr_end_ns, oe_ns);
+  UP(d_ovr_flags, o_flags);
+  UP(d_spec_fp, spec_fp);
+#undef UP
+  if ((rc = upload_amounts(e, e->d_spec, spec, T, D, s)) != KT_OK) return rc;
+  if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
+  KT_HIP(e, hipStreamSynchronize(s));  // host vectors go out of scope
+  e->spec_dirty = false;
+  return KT_OK;
+}
+
 int32_t compile_program(kt_engine* e, hipStream_t s) {
   static const bool dbg_time = getenv("KT_DEBUG_COMPILE") != nullptr;  // phase times of a recompile on stderr
   auto t_last = std::chrono::steady_clock::now();
@@ -545,31 +611,9 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   e->ns_compiled = NS;
   std::vector<uint32_t> thr_term_off(T + 1, 0), term_thr, term_req_off{0}, req_key, req_val_off{0}, req_val;
   std::vector<uint8_t> term_flags, req_op;
-  std::vector<uint32_t> ovr_off(T + 1, 0);
-  std::vector<int64_t> ob_s, oe_s;
-  std::vector<int32_t> ob_ns, oe_ns;
-  std::vector<uint8_t> o_flags;
-  std::vector<uint64_t> spec_fp(T);
-  AmountHostFlat spec, ovr_thr;
-  spec.resize(T, D);
-  size_t n_ovr = 0;
-  for (size_t t = 0; t < T; ++t) n_ovr += e->thr[t].ovr.size();
-  ovr_thr.resize(n_ovr, D);
   e->uses_keys = false;
-  size_t o = 0;
   for (size_t t = 0; t < T; ++t) {
     const HostThrottle& h = e->thr[t];
-    spec.set(t, D, h.spec);
-    spec_fp[t] = h.spec_fp;
-    for (const Override& ov : h.ovr) {
-      ob_s.push_back(ov.begin_s);
-      ob_ns.push_back(ov.begin_ns);
-      oe_s.push_back(ov.end_s);
-      oe_ns.push_back(ov.end_ns);
-      o_flags.push_back(ov.flags);
-      ovr_thr.set(o++, D, ov.thr);
-    }
-    ovr_off[t + 1] = (uint32_t)o;
     if (h.flags & KT_THR_VALID)
       for (const Term& tm : h.terms) {
         term_thr.push_back((uint32_t)t);
@@ -642,16 +686,8 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   UP(d_req_val, req_val);
   UP(d_ns_term_ok, ns_term_ok);
   UP(d_ns_valid, ns_valid);
-  UP(d_ovr_off, ovr_off);
-  UP(d_ovr_begin_s, ob_s);
-  UP(d_ovr_begin_ns, ob_ns);
-  UP(d_ovr_end_s, oe_s);
-  UP(d_ovr_end_ns, oe_ns);
-  UP(d_ovr_flags, o_flags);
-  UP(d_spec_fp, spec_fp);
 #undef UP
-  if ((rc = upload_amounts(e, e->d_spec, spec, T, D, s)) != KT_OK) return rc;
-  if ((rc = upload_amounts(e, e->d_ovr_thr, ovr_thr, n_ovr, D, s)) != KT_OK) return rc;
+  if ((rc = upload_spec_tables(e, s)) != KT_OK) return rc;
   // result / scratch buffers sized by T
   KT_HIP(e, e->d_partial.reserve(2 * T * kt::partial_stride(D) + 1));  // room for the two limb-sum blocks of a wide reconcile
   e->clean_partial = nullptr;
@@ -738,19 +774,22 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   lap("translate pods + sync");
   e->program_dirty = false;
   ++e->program_gen;
+  e->n_compiles.fetch_add(1, std::memory_order_relaxed);
   return KT_OK;
 }
 
 int32_t ensure_ready(kt_engine* e, hipStream_t s) {
   int32_t rc;
-  if (e->program_dirty || e->status_host_dirty) {
+  if (e->program_dirty || e->spec_dirty || e->status_host_dirty) {
     // uploads reallocate/overwrite device tables that an in-flight kernel of the last stream may read
     if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
   }
   if (e->program_dirty) {
     if ((rc = sync_status_to_host(e)) != KT_OK) return rc;
-    if ((rc = compile_program(e, e->own_stream)) != KT_OK) return rc;
+    if ((rc = compile_program(e, e->own_stream)) != KT_OK) return rc;  // (takes the spec tables along)
     e->status_host_dirty = true;
+  } else if (e->spec_dirty) {
+    if ((rc = upload_spec_tables(e, e->own_stream)) != KT_OK) return rc;
   }
   if (e->status_host_dirty) {
     if ((rc = upload_status(e, e->own_stream)) != KT_OK) return rc;
@@ -1341,10 +1380,17 @@ static int32_t upsert_throttles_locked(kt_engine* e, const kt_snapshot* b, const
       h.terms.push_back(std::move(tm));
     }
     const int32_t row = rows ? rows[i] : i;
-    e->thr[(size_t)row] = std::move(h);
+    HostThrottle& old = e->thr[(size_t)row];
+    if (row < e->thr_rows_hi && same_selector(old, h)) {
+      // the compiled program and the index stand; the namespace side of the terms stays cached
+      h.adm = std::move(old.adm), h.adm_gen = old.adm_gen, h.adm_ns = old.adm_ns;
+      e->spec_dirty = true;
+    } else {
+      e->program_dirty = true;
+    }
+    old = std::move(h);
     e->thr_rows_hi = std::max(e->thr_rows_hi, row + 1);
   }
-  e->program_dirty = true;
   e->status_host_dirty = true;
   // results of earlier launches describe the old throttle set (and its row count): not fetchable any more
   e->reconcile_ready = e->check_ready = false;
@@ -2398,6 +2444,7 @@ int64_t kt_counter(kt_engine* e, int32_t which) {
   if (!e) return -1;
   switch (which) {
     case KT_COUNTER_FEW_CHECKS: return e->few_served.load(std::memory_order_relaxed);
+    case KT_COUNTER_COMPILES: return e->n_compiles.load(std::memory_order_relaxed);
     default: return -1;
   }
 }

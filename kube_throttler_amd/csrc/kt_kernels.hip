@@ -1044,15 +1044,33 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_finalize_packed(const Fus
   }
   // ---- what the scan kernel added to the row by itself (slow list, overflow pods, errors) and, for a throttle of
   //      several groups, the sums of all its records
-  if (from_row) {
+  {
     unsigned long long* prow = partial + (size_t)t * stride;
-    // rows other groups of THIS launch added to are read past the caches; rows only the scan kernel wrote are plain data
-    auto ld = [&](int j) { return met ? __hip_atomic_load(prow + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : prow[j]; };
-    const int dd = d < D ? d : 0;
-    const unsigned long long a = ld(dd), b = ld(D + dd), pp = ld(2 * D), ee = ld(2 * D + 1);
-    pv += d < D ? a : 0ull, pc += d < D ? b : 0ull, pods += pp, errs += ee;
-    if (consume && valid)
-      for (int j = d; j < stride; j += DT) prow[j] = 0ull;
+    // A row other groups of THIS launch added to is read by read-modify-writes — exchange with 0 (consume) or add 0 — at
+    // the very point where those adds were performed: no cache level can answer with an older value, and the row is left
+    // zeroed in the same operation.  The lane of dimension d takes words d and D + d, the group's first lane the pod
+    // and error counts, handed to the other lanes below.
+    unsigned long long p0 = 0, e0 = 0;
+    if (from_row && met) {
+      auto take = [&](int j) {
+        return consume ? __hip_atomic_exchange(prow + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : __hip_atomic_fetch_add(prow + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      if (d < D) pv += take(d), pc += take(D + d);
+      if (d == 0) p0 = take(2 * D), e0 = take(2 * D + 1);
+    }
+    const int leader = (int)((x & 63u) & ~(uint32_t)(DT - 1));
+    p0 = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)p0, leader) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(p0 >> 32), leader) << 32;
+    e0 = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)e0, leader) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(e0 >> 32), leader) << 32;
+    pods += p0, errs += e0;
+    // rows only the scan kernel wrote (slow list, overflow pods, errors) are plain data of the previous launch
+    if (from_row && !met) {
+      const int dd = d < D ? d : 0;
+      const unsigned long long a = prow[dd], b = prow[D + dd], pp = prow[2 * D], ee = prow[2 * D + 1];
+      pv += d < D ? a : 0ull, pc += d < D ? b : 0ull, pods += pp, errs += ee;
+      if (consume && valid)
+        for (int j = d; j < stride; j += DT) prow[j] = 0ull;
+    }
   }
   finalize_throttle<DT>(tt, (int)t, T, D, d, valid, r, pv, pc, pods, errs, now_s, now_ns, apply, out, recs, rec_eq, vmax,
                         row_mask == nullptr || row_mask[t] != 0);

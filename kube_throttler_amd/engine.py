@@ -287,6 +287,10 @@ class Engine:
         """kt_check calls that took the few-pod path (kt_kernels_few.hip) so far."""
         return int(lib().kt_counter(self._h, 0))
 
+    def compiles(self) -> int:
+        """Selector program compiles + index builds so far (Throttle events that leave the selectors alone do not count)."""
+        return int(lib().kt_counter(self._h, 1))
+
     def set_exchange_world(self, world: int):
         """Ranks whose partials the CALLER sums with its own collective (kt_comm_init declares it by itself)."""
         self._ck(lib().kt_set_exchange_world(self._h, world))

@@ -397,7 +397,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
   std::vector<size_t> pod_order(pod_ns.size());
   for (size_t i = 0; i < pod_order.size(); ++i) pod_order[i] = i;
   if (getenv("KT_SIM_SORT")) std::stable_sort(pod_order.begin(), pod_order.end(), [&](size_t a, size_t b) { return pod_ns[a] < pod_ns[b]; });
-  long chunk_visits = 0;
+  long chunk_visits = 0, atoms_sum = 0, atoms_tile_max = 0, atoms_tiles = 0;
   for (size_t oi = 0; oi < pod_order.size(); ++oi) {
     const size_t i = pod_order[oi];
     PodLabels pod;
@@ -428,6 +428,11 @@ static int run_file(const char* path, uint32_t chk_budget) {
           bool ov;
           ids[l] = translate(ix, tile[l], &ov);
           k[l] = nsl_off[tile[l].ns], k1[l] = nsl_off[tile[l].ns + 1];
+        }
+        if (&ch == &ix.bm_chunks[0]) {  // atoms the pods of a tile carry (labels no selector refers to have none)
+          size_t mx = 0;
+          for (int l = 0; l < 64; ++l) atoms_sum += (long)ids[l].size(), mx = std::max(mx, ids[l].size());
+          atoms_tile_max += (long)mx, ++atoms_tiles;
         }
         {
           bool any_words = false;
@@ -478,6 +483,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
     printf("  per 64-pod tile (all chunks): %.1f advance rounds, %.1f peel steps at %.1f %% busy lanes\n", (double)adv_rounds / tiles,
            (double)peel_steps / tiles, peel_steps ? 100.0 * (double)peel_busy / (64.0 * (double)peel_steps) : 0.0);
   if (tiles) printf("  chunks with any word for a tile: %.1f of %zu\n", (double)chunk_visits / tiles, ix.bm_chunks.size());
+  if (atoms_tiles) printf("  atoms per pod: %.2f (largest of a tile: %.2f)\n", (double)atoms_sum / (64.0 * atoms_tiles), (double)atoms_tile_max / atoms_tiles);
   if (g_fail) fprintf(stderr, "%d expectation(s) failed\n", g_fail);
   return g_fail ? 1 : 0;
 }

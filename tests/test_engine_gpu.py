@@ -286,8 +286,13 @@ def test_incremental_event_path(budget, oracle_mod, monkeypatch):
         state[back] = [5, 6]
         eng.upsert_pods(_permute_pods(base, state[back]), rows=back)
         check_state(expect_scan=False)
-        # a throttle change voids the partials: one rescan, then incremental again
+        # Throttle events that leave the selectors alone (status updates, threshold edits) keep the partials ...
         eng.upsert_throttles(base)
+        check_state(expect_scan=False)
+        # ... a selector-level change voids them: one rescan, then incremental again
+        r0 = int(responsible_rows(base)[0])
+        base.thr_flags[r0] &= 0xFFFFFFFF ^ S.THR_RESPONSIBLE
+        eng.upsert_throttles(base.throttle_batch([r0]), rows=np.array([r0], dtype=np.int32))
         check_state(expect_scan=True)
         state[7] = 2399
         eng.upsert_pods(_permute_pods(base, state[7:8]), rows=np.array([7]))
@@ -374,7 +379,11 @@ def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
         state[8] = 11
         eng.upsert_pods(_permute_pods(base, state[[8]]), rows=np.array([8]))
         sweep()
-        eng.upsert_throttles(base)                             # program recompile: atoms re-translated, views rebuilt
+        eng.upsert_throttles(base)                             # selectors unchanged: the throttle tables go up again, nothing else
+        sweep()
+        r0 = int(responsible_rows(base)[0])
+        base.thr_flags[r0] &= 0xFFFFFFFF ^ S.THR_RESPONSIBLE              # program recompile: atoms re-translated, views rebuilt
+        eng.upsert_throttles(base.throttle_batch([r0]), rows=np.array([r0], dtype=np.int32))
         sweep()
     finally:
         eng.close()
@@ -770,6 +779,72 @@ def test_few_pod_checks(budget, shape, oracle_mod, monkeypatch):
         eng.close()
 
 
+def test_throttle_events_that_leave_the_selectors_alone(oracle_mod):
+    """A Throttle event whose selector terms, namespace and VALID / RESPONSIBLE / CLUSTER flags equal the stored row — a
+    threshold edit, an override whose window moves, the controller's own status update coming back through the informer —
+    only re-uploads the throttle tables: the compiled selector program, the index and the pods' atom rows stand
+    (KT_COUNTER_COMPILES does not move).  Anything else recompiles.  Either way the next reconcile + check equal the
+    oracle."""
+    snap = W.generate(W.small(seed=91, n_pods=3000, n_thr=80, n_cluster=30, overrides=1))
+    eng = E.Engine.for_snapshot(snap)
+    try:
+        def sweep():
+            o = oracle_mod.Oracle(snap)
+            rows = responsible_rows(snap)
+            want = o.reconcile(NOW, rows=rows)
+            got_all = eng.reconcile(NOW, apply=True)
+            got = E.ReconcileResult(len(rows), snap.D)
+            for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+                getattr(got, name)[:len(rows)] = getattr(got_all, name)[rows]
+            for tab in ("used", "calc"):
+                for f in ("v", "present", "count", "has_count"):
+                    getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
+            assert_reconcile_equal(got, want, len(rows))
+            snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows)
+            for on_equal in (False, True):
+                st_w, sm_w = o.check(on_equal=on_equal, nthreads=8)
+                st_g, sm_g = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=True)
+                np.testing.assert_array_equal(st_g, st_w)
+                np.testing.assert_array_equal(sm_g, sm_w)
+
+        sweep()
+        c0 = eng.compiles()
+        assert c0 >= 1
+        # threshold edits of four throttles, one of them with a different count threshold too
+        rows = np.array([3, 17, 40, 61])
+        snap.thr_spec.v[rows] = snap.thr_spec.v[rows] // 2 + 1
+        snap.thr_spec.count[rows[:1]] = 2
+        snap.thr_spec.has_count[rows[:1]] = 1
+        eng.upsert_throttles(snap.throttle_batch(rows), rows=rows.astype(np.int32))
+        sweep()
+        assert eng.compiles() == c0, "a threshold edit recompiled the selector program"
+        # an override window that starts later / ends earlier, a changed override threshold
+        if snap.n_ovr:
+            snap.ovr_begin_s[: snap.n_ovr : 2] += 7200
+            snap.ovr_thr.v[: snap.n_ovr] = snap.ovr_thr.v[: snap.n_ovr] // 3 + 1
+        eng.upsert_throttles(snap)           # every row again, status as the last sweep stored it
+        sweep()
+        assert eng.compiles() == c0, "re-feeding the throttles with unchanged selectors recompiled"
+        # a single-pod PreFilter right after such an event takes the few-pod path again once the tables are up
+        eng.check_atomic(rows=np.array([5], dtype=np.int64), want_status=False)
+        # now events that DO change what a selector selects: a throttle stops being this scheduler's, a namespaced
+        # Throttle moves to another namespace
+        resp = responsible_rows(snap)
+        r0 = int(resp[0])
+        snap.thr_flags[r0] &= 0xFFFFFFFF ^ S.THR_RESPONSIBLE
+        eng.upsert_throttles(snap.throttle_batch([r0]), rows=np.array([r0], dtype=np.int32))
+        sweep()
+        assert eng.compiles() == c0 + 1
+        namespaced = [int(t) for t in resp[1:] if not (snap.thr_flags[t] & S.THR_CLUSTER)]
+        r1 = namespaced[0]
+        snap.thr_ns[r1] = (int(snap.thr_ns[r1]) + 1) % snap.n_ns
+        eng.upsert_throttles(snap.throttle_batch([r1]), rows=np.array([r1], dtype=np.int32))
+        sweep()
+        assert eng.compiles() == c0 + 2
+    finally:
+        eng.close()
+
+
 def test_partials_must_match_the_throttle_set(oracle_mod):
     """Between kt_aggregate_launch and the calls that consume its partials (the exchange, kt_finalize_launch) the throttle
     set must not change: a grown row count would read past what the scan filled and the ranks of an all-reduce would
@@ -825,6 +900,16 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None):
         want = o.reconcile(now, rows=rows, nthreads=nthreads)
         got = eng.reconcile(now, apply=True)
         assert not got.error[:T].any()
+        if (got.used.v[rows] != want.used.v[:len(rows)]).any():  # say what differs before the assertion below fires
+            g, w = got.used.v[rows], want.used.v[:len(rows)]
+            bad = np.argwhere(g != w)
+            print("used.v differs in", len(bad), "entries; per dimension", np.bincount(bad[:, 1], minlength=snap.D),
+                  "; pod counts differ in", int((got.used.count[rows] != want.used.count[:len(rows)]).sum()), "throttles")
+            for (i, d) in bad[:24]:
+                print("   throttle", int(rows[i]), "cluster" if snap.thr_flags[rows[i]] & S.THR_CLUSTER else "namespaced", "dim", int(d), "got", int(g[i, d]),
+                      "want", int(w[i, d]), "diff", int(g[i, d] - w[i, d]), "pods got / want", int(got.used.count[rows[i]]), int(want.used.count[i]))
+            again = eng.reconcile(now, apply=False)
+            print("   the same engine again:", int((again.used.v[rows] != w).sum()), "entries differ")
         for f in ("v", "present", "count", "has_count"):
             np.testing.assert_array_equal(getattr(got.used, f)[rows], getattr(want.used, f)[:len(rows)], err_msg=f"used.{f}")
             np.testing.assert_array_equal(getattr(got.calc, f)[rows], getattr(want.calc, f)[:len(rows)], err_msg=f"calc.{f}")

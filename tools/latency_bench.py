@@ -7,8 +7,10 @@ the C-ABI, engine already holding the snapshot).
   upsert_pod1   kt_upsert_pods(1): a pod informer event (stage + kt_ingest_pods + kt_translate_pods)
   sweep         a full reconcile + PreFilter sweep in the steady state, and the first one after ONE pod event (which rebuilds
                 the scan lists, the scan-ordered record copies and the request-sum proof of the overflow guard)
-  recompile     the first kt_check after ONE kt_upsert_throttles: selector program recompile + index rebuild + upload +
-                re-translation of every pod's labels (what ANY throttle / namespace event costs)
+  throttle_event  the first kt_check after ONE kt_upsert_throttles that leaves the row's selector as stored (threshold edit,
+                status update): the throttle tables go up again, nothing is compiled
+  recompile     the first kt_check after ONE kt_upsert_throttles that changes a selector: selector program recompile +
+                index rebuild + upload + re-translation of every pod's labels (also what any namespace event costs)
 (bench.py's cpu_baseline leg adds the CPU restatement's PreFilter of one pod on one core as the yardstick.)
 
     python tools/latency_bench.py --config 2        (prints one JSON object)
@@ -92,7 +94,9 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
         eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
         after.append(full_sweep())
     out["sweep"] = {"steady_ms": round(float(np.median(steady)) * 1e3, 3), "after_pod_event_ms": round(float(np.median(after)) * 1e3, 3), "n": 20}
-    # ---- one throttle event: the next call recompiles the program, rebuilds the index and re-translates the pods
+    # ---- one Throttle event that leaves every selector as it is (a threshold edit, the controller's own status update
+    #      coming back): the throttle tables are uploaded again, program and index stand
+    c0 = eng.compiles()
     ts = []
     for k in range(5):
         t = int(rng.integers(0, snap.n_thr))
@@ -101,8 +105,23 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
         t0 = time.perf_counter()
         eng.check_atomic(rows=rows[:1], want_status=False)
         ts.append(time.perf_counter() - t0)
+    out["throttle_event"] = {"mean_ms": round(float(np.mean(ts)) * 1e3, 3), "min_ms": round(float(np.min(ts)) * 1e3, 3), "n": len(ts),
+                             "compiles": eng.compiles() - c0}
+    # ---- one Throttle event that changes what a selector selects (here: the throttle stops / starts being this
+    #      scheduler's): the next call recompiles the program, rebuilds the index and re-translates the pods — what a
+    #      selector edit or ANY namespace event costs
+    c0 = eng.compiles()
+    ts = []
+    t = int(rng.integers(0, snap.n_thr))
+    for k in range(6):  # an even number of flips: the snapshot ends as it began
+        snap.thr_flags[t] ^= S.THR_RESPONSIBLE
+        one = snap.throttle_batch(np.array([t], dtype=np.int32))
+        eng.upsert_throttles(one, rows=np.array([t], dtype=np.int32))
+        t0 = time.perf_counter()
+        eng.check_atomic(rows=rows[:1], want_status=False)
+        ts.append(time.perf_counter() - t0)
     out["recompile"] = {"mean_ms": round(float(np.mean(ts)) * 1e3, 2), "min_ms": round(float(np.min(ts)) * 1e3, 2), "n": len(ts),
-                        "throttles": int(snap.n_thr), "pods": int(P)}
+                        "throttles": int(snap.n_thr), "pods": int(P), "compiles": eng.compiles() - c0}
     return out
 
 
