@@ -22,7 +22,7 @@ try:
     r = d["roofline"]
     print("%s: %.3e %s %.4f ms/step | check %.3f aggregate %.3f reconcile %.3f step %.3f after-event %s | %s" % (sys.argv[1].split("/")[-1], d["value"], d["unit"], d["ms_per_step"],
           r["check"]["frac"], r["aggregate"]["frac"], r["reconcile"]["frac"], r["step"]["frac"], (r.get("step_after_event") or {}).get("ratio"), r["per_kernel_ms"]))
-    if d.get("latency"): print("   latency:", {k: d["latency"][k] for k in ("check1", "check1_busy", "sweep", "recompile") if k in d["latency"]})
+    if d.get("latency"): print("   latency:", {k: d["latency"][k] for k in ("check1", "check1_busy", "sweep", "throttle_event", "recompile") if k in d["latency"]})
 except Exception as ex:
     print(sys.argv[1], "no bench line:", ex)
 PY
