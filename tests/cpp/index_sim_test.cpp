@@ -8,6 +8,7 @@
 // per chunk", for the simple {any} and the rich {any, veto} image form.  Structural invariants of the chunking are
 // checked on the way.  No device call is made.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -386,8 +387,20 @@ static int run_file(const char* path, uint32_t chk_budget) {
   HostIndex ix;
   const uint32_t thr_bytes = 8 * D + 8;
   const uint32_t agg_budget = 160u * 1024u - aggregate_fixed_lds();
-  build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
-              [&](uint32_t t) { return p.thr[t]; }, NS, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L);
+  // the per-term admission sets as the engine hands them over (it caches them per throttle): [term][namespace words]
+  const uint32_t nsw = (NS + 31) / 32;
+  const size_t G = p.term_thr.size();
+  std::vector<uint32_t> adm_all(G * nsw, 0u);
+  for (uint32_t n = 0; n < NS; ++n)
+    for (size_t g = 0; g < G; ++g)
+      if ((p.ns_term_ok[(size_t)n * p.gw + (g >> 5)] >> (g & 31)) & 1u) adm_all[g * nsw + (n >> 5)] |= 1u << (n & 31);
+  const int reps = getenv("KT_SIM_BUILD_REPS") ? atoi(getenv("KT_SIM_BUILD_REPS")) : 1;
+  for (int rep = 0; rep < reps; ++rep) {
+    const auto t0 = std::chrono::steady_clock::now();
+    build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+                [&](uint32_t t) { return p.thr[t]; }, NS, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L, &adm_all);
+    if (reps > 1) fprintf(stderr, "build_index: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   check_structure(p, ix, agg_budget, chk_budget, thr_bytes);
   long matches = 0, pods = 0;
   // wave-level step counts of scan_tile on full 64-pod tiles: advance rounds and peel steps (max over lanes per round)

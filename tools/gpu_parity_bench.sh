@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, call 6: parity after the class-sum slab reduction (DPP wave sums), bench lines + kernel stats of configs 2 / 4
+# One GPU call while iterating on a kernel: the quick GPU parity suite + one configs[4] shard, bench lines of configs 2 / 4 / 3 / 1 and 2 with 4M pods, rocprofv3 kernel stats of configs 2 / 4.   gpurun --timeout 1500 -- "bash tools/gpu_parity_bench.sh <tag>"
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO
 TAG=${1:-r03f}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, call 7: parity incl. the selector-unchanged Throttle event path, latency legs of configs 2 and 4 (one shard)
+# One GPU call while iterating on the host side: the quick GPU parity suite + the latency legs of configs 2 and 4 (one shard).   gpurun --timeout 1200 -- "bash tools/gpu_parity_latency.sh <tag>"
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO
 TAG=${1:-r03k}
