@@ -3,7 +3,9 @@
 the C-ABI, engine already holding the snapshot).
 
   check1        kt_check(n=1): PreFilter of ONE pod (plugin.go:148-215) — H2D of the row, kernels, D2H of the summary
-  check1_busy   the same while another thread runs kt_reconcile_launch + kt_reconcile_fetch in a loop (one engine lock)
+  check1_busy   the same while another thread runs kt_reconcile_launch + kt_reconcile_fetch in a loop
+  native        check1 / check1_busy once more from native threads (tools/native/busy_latency.c): the Python loops above
+                share the interpreter lock between the timing thread and the reconciling thread
   upsert_pod1   kt_upsert_pods(1): a pod informer event (stage + kt_ingest_pods + kt_translate_pods)
   sweep         a full reconcile + PreFilter sweep in the steady state, and the first one after ONE pod event (which rebuilds
                 the scan lists, the scan-ordered record copies and the request-sum proof of the overflow guard)
@@ -31,6 +33,38 @@ def _pct(xs):
     a = np.sort(np.asarray(xs)) * 1e6
     return {"p50_us": round(float(a[len(a) // 2]), 1), "p99_us": round(float(a[min(len(a) - 1, int(len(a) * 0.99))]), 1),
             "mean_us": round(float(a.mean()), 1), "n": int(len(a))}
+
+
+def _native_calls(eng, rows, now):
+    """The same two measurements from native threads (tools/native/busy_latency.c): no interpreter lock between the
+    timing thread and the reconciling thread — what a cgo caller sees.  None when the shim cannot be built."""
+    import ctypes as C
+    import subprocess
+    here = os.path.join(ROOT, "tools", "native")
+    so = os.path.join(here, "_busy_latency.so")
+    src = os.path.join(here, "busy_latency.c")
+    csrc = os.path.join(ROOT, "kube_throttler_amd", "csrc")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), src, "-L" + csrc, "-lkt_engine", "-lpthread",
+                                   "-Wl,-rpath," + csrc, "-o", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+    except Exception:
+        return None
+    fn = lib.kt_native_check_latency
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    fn.restype = C.c_int64
+    out = {}
+    for key, busy, n in (("check1", 0, len(rows)), ("check1_busy", 1, max(1000, len(rows) // 2))):
+        r = np.ascontiguousarray(rows[:n], dtype=np.int64)
+        us = np.zeros(n, dtype=np.float64)
+        rc = int(fn(eng._h, int(now[0]), n, r.ctypes.data_as(C.c_void_p), us.ctypes.data_as(C.c_void_p), busy))
+        if rc < 0:
+            return {"error": rc}
+        out[key] = _pct(us * 1e-6)
+        if busy:
+            out[key]["reconciles_meanwhile"] = rc
+    return out
 
 
 def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
@@ -69,6 +103,9 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
         stop.set()
         th.join()
     out["check1_busy"] = dict(_pct(busy), reconciles_meanwhile=n_rec[0])
+    nat = _native_calls(eng, rows, now)
+    if nat is not None:
+        out["native"] = nat
     out["few_path_checks"] = eng.few_checks_served()  # kt_check calls served without copy / stream sync (kt_check_few)
     # ---- one pod event
     ts = []
