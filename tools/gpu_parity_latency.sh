@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO
 TAG=${1:-r03k}
 ( time timeout 600 python -m pytest tests -m gpu -x -q -k "not config4 and not rccl" --durations=3 ) > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest: exit $?"; tail -8 $OUT/${TAG}_pytest_gpu.log
 for cfg in 2 4; do
-  KT_DEBUG_COMPILE=${KT_DEBUG_COMPILE_ON:-} timeout 300 python tools/latency_bench.py --config $cfg > $OUT/${TAG}_latency_cfg$cfg.json 2> $OUT/${TAG}_latency_cfg$cfg.err
+  env ${KT_DEBUG_COMPILE_ON:+KT_DEBUG_COMPILE=1} timeout 300 python tools/latency_bench.py --config $cfg > $OUT/${TAG}_latency_cfg$cfg.json 2> $OUT/${TAG}_latency_cfg$cfg.err
   echo "latency cfg$cfg: exit $?"; python - $OUT/${TAG}_latency_cfg$cfg.json <<'PY'
 import json, sys
 try:
