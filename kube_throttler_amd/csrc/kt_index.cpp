@@ -32,6 +32,12 @@ struct BT {  // one indexed term
 };
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// lexicographic order of two runs of n words (what std::vector<uint32_t>::operator< gives)
+inline int memcmp_words(const uint32_t* x, const uint32_t* y, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i)
+    if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+  return 0;
+}
 
 }  // namespace
 
@@ -287,11 +293,22 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   //      ClusterThrottle select different namespaces, and a pod only visits the words of classes that admit its
   //      namespace (config 4: 73 instead of 320 word steps per pod).
   struct TC { uint32_t bt, grp; };
-  struct Grp { uint32_t t; std::vector<uint32_t> adm; };
   std::vector<TC> tcs;
-  std::vector<Grp> grps;
-  std::vector<uint64_t> pat(n_ns, 0ull), cell_pat;
-  std::vector<uint32_t> uni;
+  // groups: their admission sets in one flat array (n_grps x nsw words: a vector per group was 40 000 small allocations
+  // at 10k throttles), the index of their first copy in tcs (the copies of a group are contiguous there)
+  std::vector<uint32_t> grp_adm, grp_first;
+  auto n_grps = [&]() { return grp_first.size(); };
+  auto new_group = [&](const uint32_t* adm) {
+    grp_first.push_back((uint32_t)tcs.size());
+    const size_t o = grp_adm.size();
+    grp_adm.resize(o + nsw, 0u);
+    if (adm) memcpy(grp_adm.data() + o, adm, (size_t)nsw * 4);
+  };
+  tcs.reserve(bts.size() + bts.size() / 2);
+  grp_first.reserve(bts.size());
+  grp_adm.reserve((bts.size() + 16) * nsw);
+  std::vector<uint64_t> cell_pat, cell_pat_sorted, cell_ord;
+  std::vector<uint32_t> cell_adm;
   for (size_t i = 0; i < bts.size();) {
     size_t j = i;
     while (j < bts.size() && first_of[j] == first_of[i]) ++j;
@@ -300,60 +317,86 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     for (size_t q = i + 1; q < j && same; ++q) same = bts[q].adm == bts[i].adm;
     if (same || nt > 64) {
       // one group; with more than 64 terms the copies keep their own admission sets (class = that of the first)
-      grps.push_back(Grp{bts[i].t, bts[i].adm});
-      for (size_t q = i; q < j; ++q) tcs.push_back(TC{(uint32_t)q, (uint32_t)grps.size() - 1});
+      new_group(bts[i].adm.data());
+      for (size_t q = i; q < j; ++q) tcs.push_back(TC{(uint32_t)q, (uint32_t)n_grps() - 1});
     } else {
-      // (a throttle has a handful of cells at most: linear search over its patterns; `pat` is one buffer for all throttles,
-      //  only the entries a throttle touched are cleared again)
-      uni.assign(nsw, 0u);
+      // cells by refinement: start from the union of the terms' admission sets and split every cell by every term in
+      // turn (inside / outside its set) — a throttle has a handful of cells at most, so this is a few dozen word
+      // operations where walking the namespaces bit by bit was a few hundred steps per throttle
+      cell_adm.assign(nsw, 0u);
       for (size_t q = i; q < j; ++q)
-        for (uint32_t wi = 0; wi < nsw; ++wi) {
-          uni[wi] |= bts[q].adm[wi];
-          for (uint32_t m = bts[q].adm[wi]; m; m &= m - 1) {
-            const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
-            if (n < n_ns) pat[n] |= 1ull << (q - i);
+        for (uint32_t wi = 0; wi < nsw; ++wi) cell_adm[wi] |= bts[q].adm[wi];
+      if (n_ns & 31u) cell_adm[nsw - 1] &= (1u << (n_ns & 31u)) - 1u;  // (bits past the last namespace never count)
+      cell_pat.assign(1, 0ull);
+      for (size_t q = i; q < j; ++q) {
+        const size_t nc = cell_pat.size();
+        for (size_t c = 0; c < nc; ++c) {
+          bool in_any = false, out_any = false;
+          for (uint32_t wi = 0; wi < nsw; ++wi) {
+            const uint32_t cw = cell_adm[c * nsw + wi], aw = bts[q].adm[wi];
+            in_any |= (cw & aw) != 0u, out_any |= (cw & ~aw) != 0u;
+          }
+          if (in_any && out_any) {  // split: the part outside the term's set becomes a new cell
+            cell_adm.resize(cell_adm.size() + nsw);
+            for (uint32_t wi = 0; wi < nsw; ++wi) {
+              const uint32_t cw = cell_adm[c * nsw + wi], aw = bts[q].adm[wi];
+              cell_adm[(cell_pat.size()) * nsw + wi] = cw & ~aw, cell_adm[c * nsw + wi] = cw & aw;
+            }
+            cell_pat.push_back(cell_pat[c]);
+            cell_pat[c] |= 1ull << (q - i);
+          } else if (in_any) {
+            cell_pat[c] |= 1ull << (q - i);
           }
         }
-      const size_t g0 = grps.size();
-      cell_pat.clear();
-      for (uint32_t wi = 0; wi < nsw; ++wi)  // cells are created in namespace order
-        for (uint32_t m = uni[wi]; m; m &= m - 1) {
-          const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
-          if (n >= n_ns) continue;
-          size_t c = 0;
-          while (c < cell_pat.size() && cell_pat[c] != pat[n]) ++c;
-          if (c == cell_pat.size()) {
-            cell_pat.push_back(pat[n]);
-            grps.push_back(Grp{bts[i].t, std::vector<uint32_t>(nsw, 0u)});
-          }
-          grps[g0 + c].adm[n >> 5] |= 1u << (n & 31);
-          pat[n] = 0ull;
+      }
+      // cells in the order of their lowest namespace (the order the bit-by-bit walk created them in)
+      cell_ord.resize(cell_pat.size());
+      for (size_t c = 0; c < cell_pat.size(); ++c) {
+        uint32_t low = ~0u;
+        for (uint32_t wi = 0; wi < nsw && low == ~0u; ++wi)
+          if (cell_adm[c * nsw + wi]) low = wi * 32u + (uint32_t)__builtin_ctz(cell_adm[c * nsw + wi]);
+        cell_ord[c] = (uint64_t)low << 32 | (uint64_t)c;
+      }
+      std::sort(cell_ord.begin(), cell_ord.end());
+      const size_t g0 = n_grps();
+      {
+        std::vector<uint64_t>& sorted_pat = cell_pat_sorted;
+        sorted_pat.clear();
+        for (uint64_t oc : cell_ord) {
+          const size_t c = (size_t)(oc & 0xFFFFFFFFull);
+          if (cell_pat[c] == 0ull) continue;  // (an empty union: no namespace in range admits any term)
+          new_group(cell_adm.data() + c * nsw);  // (its first copy is set below: the copies follow once all cells are known)
+          sorted_pat.push_back(cell_pat[c]);
         }
+        cell_pat.swap(sorted_pat);
+      }
       // copies in group order, term order inside a group
-      for (size_t g = g0; g < grps.size(); ++g)
+      for (size_t g = g0; g < n_grps(); ++g) {
+        grp_first[g] = (uint32_t)tcs.size();
         for (size_t q = i; q < j; ++q)
           if ((cell_pat[g - g0] >> (q - i)) & 1ull) tcs.push_back(TC{(uint32_t)q, (uint32_t)g});
+      }
     }
     i = j;
   }
   lap("groups (cells)");
-  std::vector<uint8_t> grp_own_adm(grps.size(), 0);  // group of a >64-term throttle: copies use the term's own set
-  {
-    std::vector<uint32_t> cnt(grps.size(), 0u);
-    for (const TC& c : tcs) ++cnt[c.grp];
-    for (const TC& c : tcs)
-      if (cnt[c.grp] > 64) grp_own_adm[c.grp] = 1;
-  }
-  // order: groups by admission set, copies of a group contiguous
-  std::vector<uint32_t> order(tcs.size());
-  for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    if (tcs[a].grp == tcs[b].grp) return false;
-    const auto& x = grps[tcs[a].grp].adm;
-    const auto& y = grps[tcs[b].grp].adm;
-    if (x != y) return x < y;
-    return tcs[a].grp < tcs[b].grp;
+  const size_t NG = n_grps();
+  grp_first.push_back((uint32_t)tcs.size());  // sentinel: group g's copies are tcs[grp_first[g] .. grp_first[g + 1])
+  auto adm_of = [&](uint32_t g) { return grp_adm.data() + (size_t)g * nsw; };
+  std::vector<uint8_t> grp_own_adm(NG, 0);  // group of a >64-term throttle: copies use the term's own set
+  for (size_t g = 0; g < NG; ++g) grp_own_adm[g] = grp_first[g + 1] - grp_first[g] > 64u;
+  // order: groups by admission set (then by their index), the copies of a group contiguous and in term order — the
+  // GROUPS are sorted, the copies follow them
+  std::vector<uint32_t> gorder(NG);
+  for (uint32_t g = 0; g < NG; ++g) gorder[g] = g;
+  std::sort(gorder.begin(), gorder.end(), [&](uint32_t a, uint32_t b) {
+    const int c = nsw ? memcmp_words(adm_of(a), adm_of(b), nsw) : 0;
+    return c != 0 ? c < 0 : a < b;
   });
+  std::vector<uint32_t> order;
+  order.reserve(tcs.size());
+  for (uint32_t g : gorder)
+    for (uint32_t q = grp_first[g]; q < grp_first[g + 1]; ++q) order.push_back(q);
   lap("sort by admission set");
   // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
   // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
@@ -362,7 +405,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   uint32_t pos = 0, n_cls = 0;
   for (size_t i = 0; i < order.size();) {
     size_t j = i;
-    while (j < order.size() && grps[tcs[order[j]].grp].adm == grps[tcs[order[i]].grp].adm) ++j;
+    while (j < order.size() && (tcs[order[j]].grp == tcs[order[i]].grp || memcmp_words(adm_of(tcs[order[j]].grp), adm_of(tcs[order[i]].grp), nsw) == 0)) ++j;
     for (size_t q = i; q < j; ++q) cls[order[q]] = n_cls;
     ++n_cls;
     const uint32_t sz = (uint32_t)(j - i);
@@ -472,11 +515,11 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       uint32_t run_cls = ~0u;
       uint64_t run_bits = 0;
       size_t run_w = 0;
-      const std::vector<uint32_t>* run_adm = nullptr;
+      const uint32_t* run_adm = nullptr;
       auto flush = [&]() {
         if (run_bits && run_adm)
           for (uint32_t wi = 0; wi < nsw; ++wi)
-            for (uint32_t m = (*run_adm)[wi]; m; m &= m - 1) {
+            for (uint32_t m = run_adm[wi]; m; m &= m - 1) {
               const uint32_t n = wi * 32u + (uint32_t)__builtin_ctz(m);
               if (n < n_ns) nsrows[(size_t)n * W + run_w] |= run_bits;
             }
@@ -506,11 +549,11 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         if (b.slow) hdr[w].slow |= bit;
         if (grp_own_adm[tc.grp]) {  // a copy of a >64-term throttle: its own admission set
           flush();
-          run_adm = &b.adm, run_w = w, run_bits = bit;
+          run_adm = b.adm.data(), run_w = w, run_bits = bit;
           flush();
         } else {
           if (cls[qi] != run_cls) flush();
-          run_cls = cls[qi], run_adm = &grps[tc.grp].adm, run_w = w, run_bits |= bit;
+          run_cls = cls[qi], run_adm = adm_of(tc.grp), run_w = w, run_bits |= bit;
         }
       }
       flush();
@@ -523,11 +566,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     struct Trash {
       std::vector<BT> bts;
       std::vector<std::vector<BT>> bts_part;
-      std::vector<Grp> grps;
       std::vector<std::vector<uint32_t>> pos_rows, neg_rows;
       std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key, rows_of_key;
     };
-    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(grps), std::move(pos_rows), std::move(neg_rows), std::move(pairs_of_key),
+    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(pos_rows), std::move(neg_rows), std::move(pairs_of_key),
                              std::move(rows_of_key)};
     std::thread([trash] { delete trash; }).detach();
   }

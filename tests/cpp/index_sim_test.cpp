@@ -301,6 +301,23 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   EXPECT(ix.rich == (ix.has_veto || ix.has_slow || ix.max_need > 2 || ix.la != 8) && (ix.la == 8 || ix.la == 16 || ix.la == 32), "rich flag / atom slots");
 }
 
+// fingerprint of everything the device gets of an index: two builders that claim the same output must agree bit for bit
+// (how a faster index build is accepted: same fingerprints on the dumped programs and on every random case below)
+static uint64_t index_fingerprint(const HostIndex& ix, uint64_t h) {
+  auto mix = [&](const void* d, size_t n) {
+    const unsigned char* b = (const unsigned char*)d;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  mix(ix.bm_images.data(), ix.bm_images.size());
+  mix(ix.bm_chunks.data(), ix.bm_chunks.size() * sizeof(BmChunk));
+  mix(ix.bm_rank_t.data(), ix.bm_rank_t.size() * 4);
+  mix(ix.bm_chunk_ns.data(), ix.bm_chunk_ns.size() * 4);
+  mix(ix.atom_table.data(), ix.atom_table.size() * 8);
+  mix(ix.slow_thr.data(), ix.slow_thr.size() * 4);
+  return h;
+}
+static uint64_t g_fingerprint = 1469598103934665603ull;  // over all random cases of a run
+
 static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint32_t V, int max_terms, int max_reqs, double p_bad,
                      uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int n_pods, int positive_only = 0) {
   std::mt19937 rng(seed);
@@ -316,6 +333,7 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
   build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
               [&](uint32_t t) { return p.thr[t]; }, n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)K);
   check_structure(p, ix, agg_budget, chk_budget, thr_bytes);
+  g_fingerprint = index_fingerprint(ix, g_fingerprint);
   long matches = 0;
   for (int i = 0; i < n_pods; ++i) {
     PodLabels pod;
@@ -402,6 +420,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
     if (reps > 1) fprintf(stderr, "build_index: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   check_structure(p, ix, agg_budget, chk_budget, thr_bytes);
+  printf("  index fingerprint %016llx\n", (unsigned long long)index_fingerprint(ix, 1469598103934665603ull));
   long matches = 0, pods = 0;
   // wave-level step counts of scan_tile on full 64-pod tiles: advance rounds and peel steps (max over lanes per round)
   long adv_rounds = 0, peel_steps = 0, peel_busy = 0;
@@ -645,7 +664,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%d expectation(s) failed\n", g_fail);
     return 1;
   }
-  printf("index_sim_test: all expectations held (max %ld chunks, %ld matches, %ld simple-form programs, %ld slow confirmations)\n", chunks_seen,
-         matches, simple_seen, g_slow_confirms);
+  printf("index_sim_test: all expectations held (max %ld chunks, %ld matches, %ld simple-form programs, %ld slow confirmations); fingerprint of all indexes %016llx\n",
+         chunks_seen, matches, simple_seen, g_slow_confirms, (unsigned long long)g_fingerprint);
   return 0;
 }
