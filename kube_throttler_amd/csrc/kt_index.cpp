@@ -16,19 +16,21 @@ namespace kt {
 
 namespace {
 
-struct BT {  // one indexed term
+struct BT {  // one indexed term (plain data: tens of thousands of them are built, moved and dropped per index build)
   uint32_t g, t;
   bool adj;                                 // owner has several terms
   bool slow;                                // needs the generic walk to confirm a candidate
   uint32_t need;                            // positive requirements (exact terms); 1 for slow terms with an anchor
-  // positive requirements that enter `any`, one per key: an explicit set of pair atoms (pos_key < 0), or — Exists, not
-  // narrowed by an In on the same key — EVERY atom a pod carrying that key can show up with (pos_key = the key; pos[i]
-  // stays empty: the atoms are those of whole_key(key), expanded only where rows are set)
-  std::vector<std::vector<uint32_t>> pos;
-  std::vector<int64_t> pos_key;
-  std::vector<uint32_t> neg;                // pair atoms of the NotIn requirements
-  std::vector<uint32_t> neg_keys;           // keys of the DoesNotExist requirements (all atoms of the key)
-  std::vector<uint32_t> adm;                // namespace admission set as words
+  // positive requirements that enter `any`, one per key (at most 3 are kept; a slow term keeps its anchor): an explicit
+  // set of pair atoms (pos_key < 0), or — Exists, not narrowed by an In on the same key — EVERY atom a pod carrying that
+  // key can show up with (pos_key = the key: the atoms are those of whole_key(key), expanded only where rows are set).
+  // The pair atoms of all kept positives sit side by side in the atom pool.
+  uint32_t n_pos;
+  int64_t pos_key[3];
+  uint32_t pos_off, pos_cnt;                // atom pool: pair atoms of the positive requirements
+  uint32_t neg_off, neg_cnt;                // atom pool: pair atoms of the NotIn requirements
+  uint32_t nk_off, nk_cnt;                  // key pool: keys of the DoesNotExist requirements (all atoms of the key)
+  const uint32_t* adm;                      // namespace admission set as nsw words (points into the caller's / build_index's array)
 };
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -177,15 +179,32 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   }
   const std::vector<uint32_t>& adm_all = adm_own.empty() && adm_in ? *adm_in : adm_own;  // the caller may hold the per-term sets already
   lap("atoms + admission transpose");
-  // ---- terms (throttles are independent: built by ranges on several host threads, joined in throttle order)
+  // ---- terms (throttles are independent: built by ranges on several host threads, joined in throttle order).  The terms
+  //      are plain records; their atoms and keys go to pools (one pair per part, joined below), the scratch containers
+  //      of the construction are reused from term to term: no allocation per term.
   std::vector<BT> bts;
   std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
+  std::vector<uint32_t> atom_pool, key_pool;
   const size_t term_parts = parallel_parts(T, 512);
   std::vector<std::vector<BT>> bts_part(term_parts);
-  std::vector<std::vector<uint32_t>> first_part(term_parts);
+  std::vector<std::vector<uint32_t>> first_part(term_parts), atoms_part(term_parts), keys_part(term_parts);
   parallel_for(T, 512, [&](size_t t_begin, size_t t_end, size_t part) {
   std::vector<BT>& bts = bts_part[part];
   std::vector<uint32_t>& first_of = first_part[part];
+  std::vector<uint32_t>& atom_pool = atoms_part[part];
+  std::vector<uint32_t>& key_pool = keys_part[part];
+  size_t n_terms = 0;
+  for (size_t t = t_begin; t < t_end; ++t) n_terms += thr_term_off[t + 1] - thr_term_off[t];
+  bts.reserve(n_terms), first_of.reserve(n_terms), atom_pool.reserve(n_terms * 4), key_pool.reserve(n_terms);
+  // positive requirements are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S): a pod carries
+  // one atom per key, so the number of rows in which the term's bit is met is the number of satisfied positive keys
+  struct PosReq {
+    uint32_t key;
+    std::vector<uint32_t> atoms;  // sorted pair atoms
+    bool whole;                   // every atom of the key (Exists)
+  };
+  std::vector<PosReq> pos_by_key;  // slots, reused: n_pos of them are in use
+  std::vector<uint32_t> atoms, both, neg, neg_keys;
   for (size_t t = t_begin; t < t_end; ++t) {
     const ThrInfo ti = thr_info((uint32_t)t);
     if (!ti.live || is_slow_thr[t]) continue;
@@ -196,22 +215,16 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       BT b;
       b.g = g, b.t = (uint32_t)t, b.slow = false, b.need = 0;
       b.adj = thr_term_off[t + 1] - thr_term_off[t] > 1;
-      b.adm.assign(adm_all.begin() + (size_t)g * nsw, adm_all.begin() + (size_t)(g + 1) * nsw);
+      b.adm = adm_all.data() + (size_t)g * nsw;
       bool any_ns = false;
-      for (uint32_t wv : b.adm) any_ns |= wv != 0u;
+      for (uint32_t wi = 0; wi < nsw; ++wi) any_ns |= b.adm[wi] != 0u;
       if (!any_ns) continue;  // admitted nowhere: can never match
       bool never = false;
-      // positive requirements are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S): a pod carries
-      // one atom per key, so the number of rows in which the term's bit is met is the number of satisfied positive keys
-      struct PosReq {
-        uint32_t key;
-        std::vector<uint32_t> atoms;  // sorted pair atoms
-        bool whole;                   // every atom of the key (Exists)
-      };
-      std::vector<PosReq> pos_by_key;
+      size_t n_pos = 0;
+      neg.clear(), neg_keys.clear();
       for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
         const bool pair_op = req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN;
-        std::vector<uint32_t> atoms;
+        atoms.clear();
         if (pair_op) {
           atoms.assign(req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
           std::sort(atoms.begin(), atoms.end());
@@ -219,62 +232,78 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         }
         if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_EXISTS) {
           size_t q = 0;
-          while (q < pos_by_key.size() && pos_by_key[q].key != req_key[r]) ++q;
-          if (q == pos_by_key.size()) {
-            pos_by_key.push_back(PosReq{req_key[r], std::move(atoms), !pair_op});
+          while (q < n_pos && pos_by_key[q].key != req_key[r]) ++q;
+          if (q == n_pos) {
+            if (pos_by_key.size() == n_pos) pos_by_key.emplace_back();
+            pos_by_key[q].key = req_key[r], pos_by_key[q].atoms.assign(atoms.begin(), atoms.end()), pos_by_key[q].whole = !pair_op;
+            ++n_pos;
           } else if (pos_by_key[q].whole) {
             // Exists and In S = In S ; Exists and Exists = Exists
-            pos_by_key[q].atoms = std::move(atoms), pos_by_key[q].whole = !pair_op;
+            pos_by_key[q].atoms.assign(atoms.begin(), atoms.end()), pos_by_key[q].whole = !pair_op;
           } else if (pair_op) {
-            std::vector<uint32_t> both;
+            both.clear();
             std::set_intersection(pos_by_key[q].atoms.begin(), pos_by_key[q].atoms.end(), atoms.begin(), atoms.end(), std::back_inserter(both));
-            pos_by_key[q].atoms = std::move(both);
+            pos_by_key[q].atoms.swap(both);
           }  // In S and Exists = In S: nothing to do
         } else if (pair_op) {
-          for (uint32_t a : atoms) b.neg.push_back(a);  // NotIn with no values: always satisfied
+          for (uint32_t a : atoms) neg.push_back(a);  // NotIn with no values: always satisfied
         } else {
-          b.neg_keys.push_back(req_key[r]);
+          neg_keys.push_back(req_key[r]);
         }
       }
-      for (auto& pk : pos_by_key) {
-        if (!pk.whole && pk.atoms.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
-        b.pos.push_back(std::move(pk.atoms));
-        b.pos_key.push_back(pk.whole ? (int64_t)pk.key : -1);
-      }
+      for (size_t q = 0; q < n_pos; ++q)
+        if (!pos_by_key[q].whole && pos_by_key[q].atoms.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
       if (never) continue;
       // exact shape: <= 3 positive keys (their atom sets are disjoint by construction)
-      const bool exact = b.pos.size() <= 3;
-      if (exact) {
-        b.need = (uint32_t)b.pos.size();
+      size_t keep0 = 0, keep1 = n_pos;  // the positives that are kept: [keep0, keep1)
+      if (n_pos <= 3) {
+        b.need = (uint32_t)n_pos;
       } else {
         // candidates through the requirement with the fewest atoms (a bare key atom last), confirmed by the generic walk
         size_t best = 0, best_cost = ~(size_t)0;
-        for (size_t i = 0; i < b.pos.size(); ++i) {
-          size_t cost = b.pos[i].size();
-          if (b.pos_key[i] >= 0) {
-            auto it = pairs_of_key.find((uint32_t)b.pos_key[i]);
+        for (size_t i = 0; i < n_pos; ++i) {
+          size_t cost = pos_by_key[i].whole ? 0 : pos_by_key[i].atoms.size();
+          if (pos_by_key[i].whole) {
+            auto it = pairs_of_key.find(pos_by_key[i].key);
             const size_t n_atoms = (it == pairs_of_key.end() ? 0 : it->second.size()) + 1;  // its pairs + the key atom
             cost = n_atoms == 1 ? ((size_t)1 << 20) : n_atoms;
           }
           if (cost < best_cost) best_cost = cost, best = i;
         }
-        std::vector<uint32_t> anchor = b.pos[best];
-        const int64_t anchor_key = b.pos_key[best];
-        b.pos.clear(), b.pos_key.clear();
-        b.pos.push_back(std::move(anchor));
-        b.pos_key.push_back(anchor_key);
+        keep0 = best, keep1 = best + 1;
         b.need = 1;
         b.slow = true;
       }
+      b.n_pos = (uint32_t)(keep1 - keep0);
+      b.pos_off = (uint32_t)atom_pool.size();
+      for (size_t q = keep0; q < keep1; ++q) {
+        b.pos_key[q - keep0] = pos_by_key[q].whole ? (int64_t)pos_by_key[q].key : -1;
+        if (!pos_by_key[q].whole) atom_pool.insert(atom_pool.end(), pos_by_key[q].atoms.begin(), pos_by_key[q].atoms.end());
+      }
+      b.pos_cnt = (uint32_t)atom_pool.size() - b.pos_off;
+      b.neg_off = (uint32_t)atom_pool.size(), b.neg_cnt = (uint32_t)neg.size();
+      atom_pool.insert(atom_pool.end(), neg.begin(), neg.end());
+      b.nk_off = (uint32_t)key_pool.size(), b.nk_cnt = (uint32_t)neg_keys.size();
+      key_pool.insert(key_pool.end(), neg_keys.begin(), neg_keys.end());
       first_of.push_back((uint32_t)first);
-      bts.push_back(std::move(b));
+      bts.push_back(b);
     }
   }
   }, nullptr);
+  {
+    size_t n_bt = 0, n_at = 0, n_ky = 0;
+    for (size_t k = 0; k < term_parts; ++k) n_bt += bts_part[k].size(), n_at += atoms_part[k].size(), n_ky += keys_part[k].size();
+    bts.reserve(n_bt), first_of.reserve(n_bt), atom_pool.reserve(n_at), key_pool.reserve(n_ky);
+  }
   for (size_t k = 0; k < term_parts; ++k) {
-    const uint32_t off = (uint32_t)bts.size();
+    const uint32_t off = (uint32_t)bts.size(), a_off = (uint32_t)atom_pool.size(), k_off = (uint32_t)key_pool.size();
     for (uint32_t f : first_part[k]) first_of.push_back(f + off);
-    for (BT& b : bts_part[k]) bts.push_back(std::move(b));
+    for (BT b : bts_part[k]) {
+      b.pos_off += a_off, b.neg_off += a_off, b.nk_off += k_off;
+      bts.push_back(b);
+    }
+    atom_pool.insert(atom_pool.end(), atoms_part[k].begin(), atoms_part[k].end());
+    key_pool.insert(key_pool.end(), keys_part[k].begin(), keys_part[k].end());
   }
   lap("terms");
   out.n_pair_keys = (uint32_t)pair_keys.size();
@@ -314,10 +343,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     while (j < bts.size() && first_of[j] == first_of[i]) ++j;
     const size_t nt = j - i;
     bool same = true;
-    for (size_t q = i + 1; q < j && same; ++q) same = bts[q].adm == bts[i].adm;
+    for (size_t q = i + 1; q < j && same; ++q) same = memcmp_words(bts[q].adm, bts[i].adm, nsw) == 0;
     if (same || nt > 64) {
       // one group; with more than 64 terms the copies keep their own admission sets (class = that of the first)
-      new_group(bts[i].adm.data());
+      new_group(bts[i].adm);
       for (size_t q = i; q < j; ++q) tcs.push_back(TC{(uint32_t)q, (uint32_t)n_grps() - 1});
     } else {
       // cells by refinement: start from the union of the terms' admission sets and split every cell by every term in
@@ -426,21 +455,22 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   out.bm_words = W;
   // ---- atoms -> ids (= bitmap rows; row 0 = no atom)
   {
-    std::vector<uint32_t> atoms;
-    std::unordered_set<uint32_t> whole_keys;  // keys some kept term names at key level
+    // the distinct atoms of the kept terms: the atom pool holds exactly their pair atoms (with many repeats: a program
+    // names a few hundred distinct pairs tens of thousands of times — a hash set instead of sorting the whole pool)
+    std::unordered_set<uint32_t> distinct, whole_keys;  // whole_keys: keys some kept term names at key level
+    distinct.reserve(4096);
+    for (uint32_t a : atom_pool) distinct.insert(a);
+    for (uint32_t k : key_pool) whole_keys.insert(k);
     for (auto& b : bts) {
-      for (size_t i = 0; i < b.pos.size(); ++i) {
+      for (uint32_t i = 0; i < b.n_pos; ++i)
         if (b.pos_key[i] >= 0) whole_keys.insert((uint32_t)b.pos_key[i]);
-        for (uint32_t a : b.pos[i]) atoms.push_back(a);
-      }
-      for (uint32_t a : b.neg) atoms.push_back(a);
-      for (uint32_t k : b.neg_keys) whole_keys.insert(k);
-      out.has_veto |= !b.neg.empty() || !b.neg_keys.empty();
+      out.has_veto |= b.neg_cnt != 0u || b.nk_cnt != 0u;
       out.has_slow |= b.slow;
       if (!b.slow) out.max_need = std::max(out.max_need, b.need);
     }
     for (uint32_t k : whole_keys)
-      for (uint32_t a : whole_key(k)) atoms.push_back(a);
+      for (uint32_t a : whole_key(k)) distinct.insert(a);
+    std::vector<uint32_t> atoms(distinct.begin(), distinct.end());
     out.la = atom_slots(out.n_keys, max_labels);
     // the simple instantiation <8 atoms, no veto family, need <= 2> covers matchLabels-style programs; everything else
     // takes the rich one, whose images carry {any, veto} pairs
@@ -481,20 +511,15 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   out.bm_rank_t.clear();
   // bitmap rows: of every key named at key level (all its atoms), and of every term's pair atoms
   std::unordered_map<uint32_t, std::vector<uint32_t>> rows_of_key;
-  for (auto& b : bts) {
-    for (int64_t k : b.pos_key)
-      if (k >= 0) rows_of_key.emplace((uint32_t)k, std::vector<uint32_t>());
-    for (uint32_t k : b.neg_keys) rows_of_key.emplace(k, std::vector<uint32_t>());
-  }
+  for (auto& b : bts)
+    for (uint32_t i = 0; i < b.n_pos; ++i)
+      if (b.pos_key[i] >= 0) rows_of_key.emplace((uint32_t)b.pos_key[i], std::vector<uint32_t>());
+  for (uint32_t k : key_pool) rows_of_key.emplace(k, std::vector<uint32_t>());
   for (auto& kv : rows_of_key)
     for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
-  std::vector<std::vector<uint32_t>> pos_rows(bts.size()), neg_rows(bts.size());  // pair atoms only
-  parallel_for(bts.size(), 2048, [&](size_t q0, size_t q1, size_t) {
-    for (size_t q = q0; q < q1; ++q) {
-      for (auto& ps : bts[q].pos)
-        for (uint32_t a : ps) pos_rows[q].push_back(row_of.find(a)->second);
-      for (uint32_t a : bts[q].neg) neg_rows[q].push_back(row_of.find(a)->second);
-    }
+  std::vector<uint32_t> pool_row(atom_pool.size());  // bitmap row of every pooled pair atom
+  parallel_for(atom_pool.size(), 8192, [&](size_t q0, size_t q1, size_t) {
+    for (size_t q = q0; q < q1; ++q) pool_row[q] = row_of.find(atom_pool[q])->second;
   }, nullptr);
   {
     std::vector<uint32_t> by_num(G2, ~0u);
@@ -536,20 +561,20 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         const size_t w = c >> 6;
         term_t[c] = b.t | kTermReal | (b.adj ? kTermAdj : 0u);
         term_g[c] = b.g;
-        if (b.pos.empty()) hdr[w].univ |= bit;
-        for (uint32_t r : pos_rows[tc.bt]) any[(size_t)r * W + w] |= bit;
-        for (uint32_t r : neg_rows[tc.bt]) vet[(size_t)r * W + w] |= bit;
-        for (int64_t k : b.pos_key)
-          if (k >= 0)
-            for (uint32_t r : rows_of_key.find((uint32_t)k)->second) any[(size_t)r * W + w] |= bit;
-        for (uint32_t k : b.neg_keys)
-          for (uint32_t r : rows_of_key.find(k)->second) vet[(size_t)r * W + w] |= bit;
+        if (b.n_pos == 0u) hdr[w].univ |= bit;
+        for (uint32_t q = b.pos_off; q < b.pos_off + b.pos_cnt; ++q) any[(size_t)pool_row[q] * W + w] |= bit;
+        for (uint32_t q = b.neg_off; q < b.neg_off + b.neg_cnt; ++q) vet[(size_t)pool_row[q] * W + w] |= bit;
+        for (uint32_t i = 0; i < b.n_pos; ++i)
+          if (b.pos_key[i] >= 0)
+            for (uint32_t r : rows_of_key.find((uint32_t)b.pos_key[i])->second) any[(size_t)r * W + w] |= bit;
+        for (uint32_t q = b.nk_off; q < b.nk_off + b.nk_cnt; ++q)
+          for (uint32_t r : rows_of_key.find(key_pool[q])->second) vet[(size_t)r * W + w] |= bit;
         if (b.need >= 2) hdr[w].m2 |= bit;
         if (b.need >= 3) hdr[w].m3 |= bit;
         if (b.slow) hdr[w].slow |= bit;
         if (grp_own_adm[tc.grp]) {  // a copy of a >64-term throttle: its own admission set
           flush();
-          run_adm = b.adm.data(), run_w = w, run_bits = bit;
+          run_adm = b.adm, run_w = w, run_bits = bit;
           flush();
         } else {
           if (cls[qi] != run_cls) flush();
@@ -561,16 +586,17 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   }
   lap("full bitmaps");
   {
-    // the construction's own containers (tens of thousands of small vectors) are handed to a helper thread to be freed: a
-    // recompile is on the scheduler's critical path, their destructors alone were a third of it
+    // the construction's larger containers are handed to a helper thread to be freed: a recompile is on the scheduler's
+    // critical path (when the terms still were tens of thousands of small vectors their destructors were a third of it)
     struct Trash {
       std::vector<BT> bts;
       std::vector<std::vector<BT>> bts_part;
-      std::vector<std::vector<uint32_t>> pos_rows, neg_rows;
+      std::vector<std::vector<uint32_t>> atoms_part, keys_part;
+      std::vector<uint32_t> atom_pool, pool_row;
       std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key, rows_of_key;
     };
-    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(pos_rows), std::move(neg_rows), std::move(pairs_of_key),
-                             std::move(rows_of_key)};
+    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(atoms_part), std::move(keys_part), std::move(atom_pool), std::move(pool_row),
+                             std::move(pairs_of_key), std::move(rows_of_key)};
     std::thread([trash] { delete trash; }).detach();
   }
   lap("hand-off of the scratch containers");
