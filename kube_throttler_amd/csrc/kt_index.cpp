@@ -136,23 +136,35 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   const uint32_t nsw = (n_ns + 31) / 32;
   std::unordered_set<uint32_t> pair_keys, key_atoms;
   std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key;
-  for (size_t t = 0; t < T; ++t) {
-    const ThrInfo ti = thr_info((uint32_t)t);
-    if (!ti.live || is_slow_thr[t]) continue;
-    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
-      for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
-        if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
-          if (req_val_off[r + 1] > req_val_off[r]) pair_keys.insert(req_key[r]);
-          auto& v = pairs_of_key[req_key[r]];
-          v.insert(v.end(), req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
-        } else {
-          key_atoms.insert(req_key[r]);
+  {
+    // a program names a few hundred distinct pairs tens of thousands of times: every key's list is kept sorted and
+    // duplicate-free as it grows (a binary search per value), the map lookups go through a small direct-mapped cache
+    constexpr uint32_t kSlots = 256;
+    uint32_t pk_key[kSlots], ka_key[kSlots];
+    std::vector<uint32_t>* pk_list[kSlots];
+    for (uint32_t i = 0; i < kSlots; ++i) pk_key[i] = ka_key[i] = 0u, pk_list[i] = nullptr;
+    bool ka_zero_done = false;
+    for (size_t t = 0; t < T; ++t) {
+      const ThrInfo ti = thr_info((uint32_t)t);
+      if (!ti.live || is_slow_thr[t]) continue;
+      for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g)
+        for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
+          const uint32_t key = req_key[r], slot = key & (kSlots - 1);
+          if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_NOT_IN) {
+            if (pk_list[slot] == nullptr || pk_key[slot] != key) pk_list[slot] = &pairs_of_key[key], pk_key[slot] = key;  // (node-based map: the address stays)
+            std::vector<uint32_t>& v = *pk_list[slot];
+            for (uint32_t q = req_val_off[r]; q < req_val_off[r + 1]; ++q) {
+              const auto it = std::lower_bound(v.begin(), v.end(), req_val[q]);
+              if (it == v.end() || *it != req_val[q]) v.insert(it, req_val[q]);
+            }
+          } else if (key == 0u ? !ka_zero_done : ka_key[slot] != key) {
+            key_atoms.insert(key);
+            if (key == 0u) ka_zero_done = true; else ka_key[slot] = key;
+          }
         }
-      }
-  }
-  for (auto& kv : pairs_of_key) {
-    std::sort(kv.second.begin(), kv.second.end());
-    kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+    }
+    for (auto& kv : pairs_of_key)
+      if (!kv.second.empty()) pair_keys.insert(kv.first);
   }
   auto whole_key = [&](uint32_t key) {  // every atom a pod carrying `key` can show up with, sorted
     std::vector<uint32_t> a;
@@ -519,7 +531,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
   std::vector<uint32_t> pool_row(atom_pool.size());  // bitmap row of every pooled pair atom
   parallel_for(atom_pool.size(), 8192, [&](size_t q0, size_t q1, size_t) {
-    for (size_t q = q0; q < q1; ++q) pool_row[q] = row_of.find(atom_pool[q])->second;
+    const uint32_t mask = (uint32_t)out.atom_table.size() - 1u;
+    for (size_t q = q0; q < q1; ++q) {  // the device's translation table (open addressing) is the faster map here too
+      uint32_t sl = atom_slot(atom_pool[q], mask);
+      while ((uint32_t)out.atom_table[sl] != atom_pool[q]) sl = (sl + 1) & mask;
+      pool_row[q] = (uint32_t)(out.atom_table[sl] >> 32);
+    }
   }, nullptr);
   {
     std::vector<uint32_t> by_num(G2, ~0u);
