@@ -101,7 +101,16 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
                  int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full) {
-  out = HostIndex();
+  {
+    // a fresh index in the OLD index's storage: the full bitmaps and the chunk images are a few megabytes that would
+    // otherwise be unmapped and faulted in again page by page on every build
+    HostIndex fresh;
+    auto keep = [](auto& dst, auto& src) { src.clear(), dst = std::move(src); };
+    keep(fresh.full_any, out.full_any), keep(fresh.full_veto, out.full_veto), keep(fresh.full_nsrows, out.full_nsrows);
+    keep(fresh.full_hdr, out.full_hdr), keep(fresh.full_term_t, out.full_term_t), keep(fresh.full_term_g, out.full_term_g);
+    keep(fresh.full_term_rank, out.full_term_rank), keep(fresh.full_real, out.full_real), keep(fresh.bm_images, out.bm_images);
+    out = std::move(fresh);
+  }
   (void)term_thr;
   static const bool dbg_time = getenv("KT_DEBUG_COMPILE") != nullptr;  // phase times on stderr
   auto t_last = std::chrono::steady_clock::now();
@@ -429,11 +438,21 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // order: groups by admission set (then by their index), the copies of a group contiguous and in term order — the
   // GROUPS are sorted, the copies follow them
   std::vector<uint32_t> gorder(NG);
-  for (uint32_t g = 0; g < NG; ++g) gorder[g] = g;
-  std::sort(gorder.begin(), gorder.end(), [&](uint32_t a, uint32_t b) {
-    const int c = nsw ? memcmp_words(adm_of(a), adm_of(b), nsw) : 0;
-    return c != 0 ? c < 0 : a < b;
-  });
+  if (nsw <= 2) {  // up to 64 namespaces: the whole admission set is one 64-bit sort key
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(NG);
+    for (uint32_t g = 0; g < NG; ++g) {
+      const uint32_t* a = adm_of(g);
+      keyed[g] = {nsw == 2 ? (uint64_t)a[0] << 32 | a[1] : nsw == 1 ? (uint64_t)a[0] : 0ull, g};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (uint32_t g = 0; g < NG; ++g) gorder[g] = keyed[g].second;
+  } else {
+    for (uint32_t g = 0; g < NG; ++g) gorder[g] = g;
+    std::sort(gorder.begin(), gorder.end(), [&](uint32_t a, uint32_t b) {
+      const int c = memcmp_words(adm_of(a), adm_of(b), nsw);
+      return c != 0 ? c < 0 : a < b;
+    });
+  }
   std::vector<uint32_t> order;
   order.reserve(tcs.size());
   for (uint32_t g : gorder)
@@ -521,6 +540,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   real.assign((size_t)W * 64, 0);
   out.n_ns = n_ns;
   out.bm_rank_t.clear();
+  lap("  (bitmaps: zero fill)");
   // bitmap rows: of every key named at key level (all its atoms), and of every term's pair atoms
   std::unordered_map<uint32_t, std::vector<uint32_t>> rows_of_key;
   for (auto& b : bts)
@@ -529,6 +549,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   for (uint32_t k : key_pool) rows_of_key.emplace(k, std::vector<uint32_t>());
   for (auto& kv : rows_of_key)
     for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
+  lap("  (bitmaps: rows of keys)");
   std::vector<uint32_t> pool_row(atom_pool.size());  // bitmap row of every pooled pair atom
   parallel_for(atom_pool.size(), 8192, [&](size_t q0, size_t q1, size_t) {
     const uint32_t mask = (uint32_t)out.atom_table.size() - 1u;
@@ -550,6 +571,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       if (tc.grp != last_g) out.bm_rank_t.push_back(bts[tc.bt].t), last_g = tc.grp;
       term_rank[c] = (uint32_t)out.bm_rank_t.size() - 1;
     }
+    lap("  (bitmaps: pool rows + ranks)");
     // the bits: every 64-bit word column of the bitmaps belongs to one range of term numbers — ranges on several threads
     parallel_for(W, 32, [&](size_t w_begin, size_t w_end, size_t) {
       // the namespace rows are set once per RUN of copies of one class inside a word (they share the admission set)
@@ -656,6 +678,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   uint64_t slab_run = 0;
   out.bm_chunks.clear();
   out.bm_images.clear();
+  out.bm_images.reserve(((size_t)R * W * 8 * (veto ? 2 : 1) + (size_t)W * (sizeof(WordHdr) + 64 * 10 + 64)) * 5 / 4 + ((size_t)n_ns + 8) * 4 * 64);  // (one allocation instead of a regrowth per chunk)
   out.bm_chunk_ns.clear();
   const uint32_t nsw = (n_ns + 31) / 32;
   out.ns_words = nsw ? nsw : 1u;
