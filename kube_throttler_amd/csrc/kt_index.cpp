@@ -67,7 +67,7 @@ size_t parallel_parts(size_t n, size_t min_per_part) {
 void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t nsw, uint32_t n_ns, uint32_t gw, std::vector<uint32_t>& out) {
   out.assign((size_t)n_ns * gw, 0u);
   const size_t gb = (G + 31) / 32;
-  parallel_for(gb, 64, [&](size_t b0, size_t b1, size_t) {
+  parallel_for(gb, 256, [&](size_t b0, size_t b1, size_t) {
     for (size_t bg = b0; bg < b1; ++bg)
       for (uint32_t bn = 0; bn < nsw; ++bn) {
         uint32_t a[32];
@@ -206,10 +206,11 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   std::vector<BT> bts;
   std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
   std::vector<uint32_t> atom_pool, key_pool;
-  const size_t term_parts = parallel_parts(T, 512);
+  // (a part is at least 2500 throttles: the terms are cheap now, a thread has to earn its start-up)
+  const size_t term_parts = parallel_parts(T, 2500);
   std::vector<std::vector<BT>> bts_part(term_parts);
   std::vector<std::vector<uint32_t>> first_part(term_parts), atoms_part(term_parts), keys_part(term_parts);
-  parallel_for(T, 512, [&](size_t t_begin, size_t t_end, size_t part) {
+  parallel_for(T, 2500, [&](size_t t_begin, size_t t_end, size_t part) {
   std::vector<BT>& bts = bts_part[part];
   std::vector<uint32_t>& first_of = first_part[part];
   std::vector<uint32_t>& atom_pool = atoms_part[part];
@@ -248,8 +249,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         atoms.clear();
         if (pair_op) {
           atoms.assign(req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
-          std::sort(atoms.begin(), atoms.end());
-          atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
+          if (atoms.size() > 1) {
+            std::sort(atoms.begin(), atoms.end());
+            atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
+          }
         }
         if (req_op[r] == KT_OP_IN || req_op[r] == KT_OP_EXISTS) {
           size_t q = 0;
@@ -438,25 +441,29 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // order: groups by admission set (then by their index), the copies of a group contiguous and in term order — the
   // GROUPS are sorted, the copies follow them
   std::vector<uint32_t> gorder(NG);
-  if (nsw <= 2) {  // up to 64 namespaces: the whole admission set is one 64-bit sort key
+  {
+    // the first 64 namespaces of the set as one 64-bit key decide most comparisons; the rest of the words only on a tie
     std::vector<std::pair<uint64_t, uint32_t>> keyed(NG);
     for (uint32_t g = 0; g < NG; ++g) {
       const uint32_t* a = adm_of(g);
-      keyed[g] = {nsw == 2 ? (uint64_t)a[0] << 32 | a[1] : nsw == 1 ? (uint64_t)a[0] : 0ull, g};
+      keyed[g] = {nsw >= 2 ? (uint64_t)a[0] << 32 | a[1] : nsw == 1 ? (uint64_t)a[0] : 0ull, g};
     }
-    std::sort(keyed.begin(), keyed.end());
+    if (nsw <= 2) {
+      std::sort(keyed.begin(), keyed.end());
+    } else {
+      std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+        if (x.first != y.first) return x.first < y.first;
+        const int c = memcmp_words(adm_of(x.second) + 2, adm_of(y.second) + 2, nsw - 2);
+        return c != 0 ? c < 0 : x.second < y.second;
+      });
+    }
     for (uint32_t g = 0; g < NG; ++g) gorder[g] = keyed[g].second;
-  } else {
-    for (uint32_t g = 0; g < NG; ++g) gorder[g] = g;
-    std::sort(gorder.begin(), gorder.end(), [&](uint32_t a, uint32_t b) {
-      const int c = memcmp_words(adm_of(a), adm_of(b), nsw);
-      return c != 0 ? c < 0 : a < b;
-    });
   }
   std::vector<uint32_t> order;
   order.reserve(tcs.size());
   for (uint32_t g : gorder)
     for (uint32_t q = grp_first[g]; q < grp_first[g + 1]; ++q) order.push_back(q);
+  if (dbg_time) fprintf(stderr, "  build_index: (%zu groups, %zu copies, %zu terms)\n", NG, tcs.size(), bts.size());
   lap("sort by admission set");
   // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
   // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
@@ -551,7 +558,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
   lap("  (bitmaps: rows of keys)");
   std::vector<uint32_t> pool_row(atom_pool.size());  // bitmap row of every pooled pair atom
-  parallel_for(atom_pool.size(), 8192, [&](size_t q0, size_t q1, size_t) {
+  parallel_for(atom_pool.size(), 32768, [&](size_t q0, size_t q1, size_t) {
     const uint32_t mask = (uint32_t)out.atom_table.size() - 1u;
     for (size_t q = q0; q < q1; ++q) {  // the device's translation table (open addressing) is the faster map here too
       uint32_t sl = atom_slot(atom_pool[q], mask);
@@ -573,7 +580,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     lap("  (bitmaps: pool rows + ranks)");
     // the bits: every 64-bit word column of the bitmaps belongs to one range of term numbers — ranges on several threads
-    parallel_for(W, 32, [&](size_t w_begin, size_t w_end, size_t) {
+    parallel_for(W, 160, [&](size_t w_begin, size_t w_end, size_t) {
       // the namespace rows are set once per RUN of copies of one class inside a word (they share the admission set)
       // instead of once per copy
       uint32_t run_cls = ~0u;
