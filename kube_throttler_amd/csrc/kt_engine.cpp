@@ -611,6 +611,17 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   e->ns_compiled = NS;
   std::vector<uint32_t> thr_term_off(T + 1, 0), term_thr, term_req_off{0}, req_key, req_val_off{0}, req_val;
   std::vector<uint8_t> term_flags, req_op;
+  {
+    size_t n_terms = 0, n_reqs = 0, n_vals = 0;
+    for (size_t t = 0; t < T; ++t)
+      if (e->thr[t].flags & KT_THR_VALID)
+        for (const Term& tm : e->thr[t].terms) {
+          ++n_terms, n_reqs += tm.preq.size();
+          for (const Req& r : tm.preq) n_vals += r.vals.size();
+        }
+    term_thr.reserve(n_terms), term_flags.reserve(n_terms), term_req_off.reserve(n_terms + 1);
+    req_op.reserve(n_reqs), req_key.reserve(n_reqs), req_val_off.reserve(n_reqs + 1), req_val.reserve(n_vals);
+  }
   e->uses_keys = false;
   for (size_t t = 0; t < T; ++t) {
     const HostThrottle& h = e->thr[t];
