@@ -157,6 +157,11 @@ def test_index_builder_against_cpu_scan_replay(tool):
     out = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "all expectations held" in out.stdout
+    # The fingerprint of everything the device gets of all these indexes.  A faster index BUILD must leave it alone (that
+    # is how the round-3 rewrite of the builder's phases was accepted, together with the fingerprints of the dumped
+    # BASELINE programs); a change of the index LAYOUT moves it on purpose — then re-pin it here after the GPU parity
+    # tests have passed on the new layout.
+    assert "fingerprint of all indexes 0bbc04af4b86bec0" in out.stdout, out.stdout[-400:]
 
 
 def test_label_key_value_validation(tool):
