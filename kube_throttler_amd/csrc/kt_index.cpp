@@ -33,6 +33,15 @@ struct BT {  // one indexed term (plain data: tens of thousands of them are buil
   const uint32_t* adm;                      // namespace admission set as nsw words (points into the caller's / build_index's array)
 };
 
+struct TC { uint32_t bt, grp; };  // a term copy: the term and the group (namespace cell of its throttle) it belongs to
+// The construction's larger containers, one set per host thread, kept from build to build: a recompile is on the
+// scheduler's critical path, and a few megabytes of fresh vectors are a few thousand page faults per build.
+struct BuildScratch {
+  std::vector<BT> bts;
+  std::vector<TC> tcs;
+  std::vector<uint32_t> first_of, atom_pool, key_pool, grp_adm, grp_first, gorder, order, num, cls, pool_row, by_num;
+};
+
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // lexicographic order of two runs of n words (what std::vector<uint32_t>::operator< gives)
 inline int memcmp_words(const uint32_t* x, const uint32_t* y, uint32_t n) {
@@ -203,18 +212,23 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // ---- terms (throttles are independent: built by ranges on several host threads, joined in throttle order).  The terms
   //      are plain records; their atoms and keys go to pools (one pair per part, joined below), the scratch containers
   //      of the construction are reused from term to term: no allocation per term.
-  std::vector<BT> bts;
-  std::vector<uint32_t> first_of;  // index into bts of the first term of the same throttle
-  std::vector<uint32_t> atom_pool, key_pool;
-  // (a part is at least 2500 throttles: the terms are cheap now, a thread has to earn its start-up)
-  const size_t term_parts = parallel_parts(T, 2500);
-  std::vector<std::vector<BT>> bts_part(term_parts);
-  std::vector<std::vector<uint32_t>> first_part(term_parts), atoms_part(term_parts), keys_part(term_parts);
-  parallel_for(T, 2500, [&](size_t t_begin, size_t t_end, size_t part) {
-  std::vector<BT>& bts = bts_part[part];
-  std::vector<uint32_t>& first_of = first_part[part];
-  std::vector<uint32_t>& atom_pool = atoms_part[part];
-  std::vector<uint32_t>& key_pool = keys_part[part];
+  static thread_local BuildScratch scratch;
+  std::vector<BT>& bts = scratch.bts;
+  std::vector<uint32_t>& first_of = scratch.first_of;  // index into bts of the first term of the same throttle
+  std::vector<uint32_t>&atom_pool = scratch.atom_pool, &key_pool = scratch.key_pool;
+  bts.clear(), first_of.clear(), atom_pool.clear(), key_pool.clear();
+  // (a part is at least 8000 throttles: the terms are cheap now, a thread has to earn its start-up and the joining of
+  //  the parts; a single part writes straight into the final containers)
+  const size_t term_parts = parallel_parts(T, 8000);
+  std::vector<std::vector<BT>> bts_part(term_parts > 1 ? term_parts : 0);
+  std::vector<std::vector<uint32_t>> first_part(bts_part.size()), atoms_part(bts_part.size()), keys_part(bts_part.size());
+  std::vector<BT>& bts_all = bts;
+  std::vector<uint32_t>&first_all = first_of, &atoms_all = atom_pool, &keys_all = key_pool;
+  parallel_for(T, 8000, [&](size_t t_begin, size_t t_end, size_t part) {
+  std::vector<BT>& bts = term_parts > 1 ? bts_part[part] : bts_all;
+  std::vector<uint32_t>& first_of = term_parts > 1 ? first_part[part] : first_all;
+  std::vector<uint32_t>& atom_pool = term_parts > 1 ? atoms_part[part] : atoms_all;
+  std::vector<uint32_t>& key_pool = term_parts > 1 ? keys_part[part] : keys_all;
   size_t n_terms = 0;
   for (size_t t = t_begin; t < t_end; ++t) n_terms += thr_term_off[t + 1] - thr_term_off[t];
   bts.reserve(n_terms), first_of.reserve(n_terms), atom_pool.reserve(n_terms * 4), key_pool.reserve(n_terms);
@@ -314,12 +328,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
   }
   }, nullptr);
-  {
+  if (term_parts > 1) {
     size_t n_bt = 0, n_at = 0, n_ky = 0;
     for (size_t k = 0; k < term_parts; ++k) n_bt += bts_part[k].size(), n_at += atoms_part[k].size(), n_ky += keys_part[k].size();
     bts.reserve(n_bt), first_of.reserve(n_bt), atom_pool.reserve(n_at), key_pool.reserve(n_ky);
   }
-  for (size_t k = 0; k < term_parts; ++k) {
+  for (size_t k = 0; k < bts_part.size(); ++k) {
     const uint32_t off = (uint32_t)bts.size(), a_off = (uint32_t)atom_pool.size(), k_off = (uint32_t)key_pool.size();
     for (uint32_t f : first_part[k]) first_of.push_back(f + off);
     for (BT b : bts_part[k]) {
@@ -345,11 +359,12 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   //      groups sort by their admission set: the words of the bitmaps become class-pure even when the terms of a
   //      ClusterThrottle select different namespaces, and a pod only visits the words of classes that admit its
   //      namespace (config 4: 73 instead of 320 word steps per pod).
-  struct TC { uint32_t bt, grp; };
-  std::vector<TC> tcs;
+  std::vector<TC>& tcs = scratch.tcs;
+  tcs.clear();
   // groups: their admission sets in one flat array (n_grps x nsw words: a vector per group was 40 000 small allocations
   // at 10k throttles), the index of their first copy in tcs (the copies of a group are contiguous there)
-  std::vector<uint32_t> grp_adm, grp_first;
+  std::vector<uint32_t>&grp_adm = scratch.grp_adm, &grp_first = scratch.grp_first;
+  grp_adm.clear(), grp_first.clear();
   auto n_grps = [&]() { return grp_first.size(); };
   auto new_group = [&](const uint32_t* adm) {
     grp_first.push_back((uint32_t)tcs.size());
@@ -440,7 +455,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   for (size_t g = 0; g < NG; ++g) grp_own_adm[g] = grp_first[g + 1] - grp_first[g] > 64u;
   // order: groups by admission set (then by their index), the copies of a group contiguous and in term order — the
   // GROUPS are sorted, the copies follow them
-  std::vector<uint32_t> gorder(NG);
+  std::vector<uint32_t>& gorder = scratch.gorder;
+  gorder.assign(NG, 0u);
   {
     // the first 64 namespaces of the set as one 64-bit key decide most comparisons; the rest of the words only on a tie
     std::vector<std::pair<uint64_t, uint32_t>> keyed(NG);
@@ -459,7 +475,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     for (uint32_t g = 0; g < NG; ++g) gorder[g] = keyed[g].second;
   }
-  std::vector<uint32_t> order;
+  std::vector<uint32_t>& order = scratch.order;
+  order.clear();
   order.reserve(tcs.size());
   for (uint32_t g : gorder)
     for (uint32_t q = grp_first[g]; q < grp_first[g + 1]; ++q) order.push_back(q);
@@ -468,7 +485,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // term numbers: a class (run of groups with the same admission set) never straddles a 64-bit word of the bitmaps
   // unless it is larger than one (128 for big programs: fewer, fuller words per namespace)
   const uint32_t gran = tcs.size() <= 4096 ? 64u : 128u;
-  std::vector<uint32_t> num(tcs.size()), cls(tcs.size());  // term number and class (= admission set) of every copy
+  std::vector<uint32_t>&num = scratch.num, &cls = scratch.cls;  // term number and class (= admission set) of every copy
+  num.assign(tcs.size(), 0u), cls.assign(tcs.size(), 0u);
   uint32_t pos = 0, n_cls = 0;
   for (size_t i = 0; i < order.size();) {
     size_t j = i;
@@ -557,7 +575,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   for (auto& kv : rows_of_key)
     for (uint32_t a : whole_key(kv.first)) kv.second.push_back(row_of[a]);
   lap("  (bitmaps: rows of keys)");
-  std::vector<uint32_t> pool_row(atom_pool.size());  // bitmap row of every pooled pair atom
+  std::vector<uint32_t>& pool_row = scratch.pool_row;  // bitmap row of every pooled pair atom
+  pool_row.assign(atom_pool.size(), 0u);
   parallel_for(atom_pool.size(), 32768, [&](size_t q0, size_t q1, size_t) {
     const uint32_t mask = (uint32_t)out.atom_table.size() - 1u;
     for (size_t q = q0; q < q1; ++q) {  // the device's translation table (open addressing) is the faster map here too
@@ -567,7 +586,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
   }, nullptr);
   {
-    std::vector<uint32_t> by_num(G2, ~0u);
+    std::vector<uint32_t>& by_num = scratch.by_num;
+    by_num.assign(G2, ~0u);
     for (size_t q = 0; q < tcs.size(); ++q) by_num[num[q]] = (uint32_t)q;
     // dense ranks: one per GROUP in number order (a throttle with several cells has several; the slab reduction adds
     // them all into the throttle's row) — the one sequential pass
@@ -632,17 +652,13 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   }
   lap("full bitmaps");
   {
-    // the construction's larger containers are handed to a helper thread to be freed: a recompile is on the scheduler's
-    // critical path (when the terms still were tens of thousands of small vectors their destructors were a third of it)
+    // what is not kept for the next build (BuildScratch) and is large goes to a helper thread to be freed
     struct Trash {
-      std::vector<BT> bts;
       std::vector<std::vector<BT>> bts_part;
       std::vector<std::vector<uint32_t>> atoms_part, keys_part;
-      std::vector<uint32_t> atom_pool, pool_row;
       std::unordered_map<uint32_t, std::vector<uint32_t>> pairs_of_key, rows_of_key;
     };
-    Trash* trash = new Trash{std::move(bts), std::move(bts_part), std::move(atoms_part), std::move(keys_part), std::move(atom_pool), std::move(pool_row),
-                             std::move(pairs_of_key), std::move(rows_of_key)};
+    Trash* trash = new Trash{std::move(bts_part), std::move(atoms_part), std::move(keys_part), std::move(pairs_of_key), std::move(rows_of_key)};
     std::thread([trash] { delete trash; }).detach();
   }
   lap("hand-off of the scratch containers");
