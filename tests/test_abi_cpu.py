@@ -89,3 +89,17 @@ def test_headers_are_plain_c(tmp_path):
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{root}/include", str(src), "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_native_latency_shim_builds_against_the_header(tmp_path, built_lib):
+    """tools/native/busy_latency.c (the single-pod calls timed from native threads, what tools/latency_bench.py loads on
+    the GPU box) is plain C over include/kt_engine.h: it must compile without a warning and link against the library."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "kube_throttler_amd", "csrc")
+    so = tmp_path / "busy.so"
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", f"-I{root}/include",
+                           os.path.join(root, "tools", "native", "busy_latency.c"), f"-L{csrc}", "-lkt_engine", "-lpthread",
+                           f"-Wl,-rpath,{csrc}", "-o", str(so)])
+    import ctypes
+    lib = ctypes.CDLL(str(so))
+    assert hasattr(lib, "kt_native_check_latency")
