@@ -3,11 +3,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace kt {
 
 constexpr int kWave = 64;
 constexpr int64_t kInf = INT64_MAX;
+
+// KT_DEBUG_POISON=1: every device allocation of the engine is filled with 0xA5 before anything is written to it, so
+// that a kernel that reads memory no launch wrote (round 3: the slab of an aggregate workgroup without tiles) gives
+// wrong results on EVERY box instead of on the ones whose allocator hands back dirty pages.  The -m gpu suite is run
+// under it once per round (tools/gpu_poison_suite.sh).
+inline hipError_t kt_alloc_device(void** p, size_t bytes) {
+  static const bool poison = [] { const char* v = getenv("KT_DEBUG_POISON"); return v && *v && *v != '0'; }();
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && poison && bytes) {
+    e = hipMemset(*p, 0xA5, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  return e;
+}
 
 // pod_flags word in HBM: bits 0-3 = KT_POD_* state, bits 16-31 = request-key presence mask.
 constexpr uint32_t kPodValid = 0x1u, kPodSchedMatch = 0x2u, kPodScheduled = 0x4u, kPodFinished = 0x8u;

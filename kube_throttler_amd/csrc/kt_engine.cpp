@@ -94,7 +94,7 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
     size_t want = std::max<size_t>(n, 16);
-    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    hipError_t e = kt::kt_alloc_device((void**)&p, want * sizeof(T));
     if (e == hipSuccess) cap = want;
     return e;
   }
@@ -983,12 +983,12 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   e->pods.L = e->L;
   e->pods.DS = kt::req_stride(e->D);
   e->pods.LS = kt::label_stride(e->L);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.ns, cap * 4);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.flags, cap * 4);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.req, cap * 8 * e->pods.DS);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lpair, cap * 4 * e->pods.LS);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.lkey, cap * 4 * e->pods.LS);
-  if (r == hipSuccess) r = hipMalloc((void**)&e->pods.meta, cap * 8);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.ns, cap * 4);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.flags, cap * 4);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.req, cap * 8 * e->pods.DS);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.lpair, cap * 4 * e->pods.LS);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.lkey, cap * 4 * e->pods.LS);
+  if (r == hipSuccess) r = kt::kt_alloc_device((void**)&e->pods.meta, cap * 8);
   e->pods.LA = 8;
   if (r == hipSuccess) r = hipMemsetAsync(e->pods.flags, 0, cap * 4, e->own_stream);
   if (r == hipSuccess) r = hipMemsetAsync(e->pods.meta, 0, cap * 8, e->own_stream);

@@ -815,7 +815,7 @@ static hipError_t up(T*& dev, size_t& cap, const std::vector<T>& h, hipStream_t 
     if (dev) (void)hipFree(dev);
     dev = nullptr;
     cap = 0;
-    hipError_t e = hipMalloc((void**)&dev, need * sizeof(T));
+    hipError_t e = kt_alloc_device((void**)&dev, need * sizeof(T));
     if (e != hipSuccess) return e;
     cap = need;
   }

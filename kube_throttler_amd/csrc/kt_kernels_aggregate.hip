@@ -96,9 +96,14 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   if (by_ns) {
     const int64_t tpb = (n_wtiles + gridDim.x - 1) / gridDim.x;
     t_lo = min((int64_t)blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
-    if (t_lo >= t_hi) return;
-    ns_lo = (uint32_t)(a.v_meta[t_lo * kWave] & kMetaNsMask);
-    ns_hi = (uint32_t)(a.v_meta[min(t_hi * kWave, n_rows) - 1] & kMetaNsMask);
+    // A workgroup without tiles must NOT return: the reductions of single-chunk programs read every launched
+    // workgroup's slab without looking at tags, so it spills its zeroed table like everybody else (round 3 returned
+    // here and left the slab as the allocator or an earlier, larger scan had it).  launch_aggregate_indexed sizes the
+    // grid so that no workgroup is empty; this is the second line of defence.
+    if (t_lo < t_hi) {
+      ns_lo = (uint32_t)(a.v_meta[t_lo * kWave] & kMetaNsMask);
+      ns_hi = (uint32_t)(a.v_meta[min(t_hi * kWave, n_rows) - 1] & kMetaNsMask);
+    }
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
   }
   for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
@@ -389,7 +394,13 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   const bool packed = bm_args.v_pk != nullptr && bm_args.ix.by_ns && !sc.counts && sc.sign == 1 && sc.nonneg &&
                       bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false);
   if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
-  const int nb = aggregate_blocks(n_rows);
+  int nb = aggregate_blocks(n_rows);
+  if (bm_args.ix.by_ns) {
+    // contiguous tile ranges of ceil(tiles / nb) tiles: launch exactly the workgroups that own at least one tile (with
+    // 10 163 tiles and 256 workgroups the last one would own none).  ceil(tiles / nb) is the same for the smaller grid.
+    const int64_t tiles = (n_rows + kWave - 1) / kWave, tpb = (tiles + nb - 1) / nb;
+    nb = (int)((tiles + tpb - 1) / tpb);
+  }
   dim3 g_(nb), b_(kBlockIx);
   const size_t lds_bm = bm_total;
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;

@@ -15,6 +15,9 @@ from . import snapshot as S
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "libkt_engine.so")
+# A/B runs only (a fix shown red on the previous library, green on this one): another build of the SAME C-ABI
+if os.environ.get("KT_ENGINE_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["KT_ENGINE_LIB"])
 _LIB = None
 
 KT_OK = 0
