@@ -184,6 +184,14 @@ int32_t kt_comm_allreduce_partial(kt_engine* e, void* stream);
  * the number of ranks here, so that the engine's exact-range guard covers the sum over all of them (2^60 per rank up to 4
  * ranks, 2^62 / world beyond); kt_comm_init does it by itself. */
 int32_t kt_set_exchange_world(kt_engine* e, int32_t world);
+/* Wide sums (two blocks of limb sums, see kt_reconcile_fetch_used_hi) change the LAYOUT of the exchanged buffer, and
+ * whether a rank's requests leave int64 is a local fact: with more than one rank an engine never goes wide by itself
+ * (the aggregate answers KT_ERR_OVERFLOW_RISK instead, as rounds 1-2 did) — the host switches EVERY rank with
+ * mode = 1 (always two blocks; exact either way), mode = 0 returns to the per-engine decision.  Not for incremental engines. */
+int32_t kt_set_wide_sums(kt_engine* e, int32_t mode);
+/* Words (int64) of the aggregate that is pending, and whether they are the two-block form: what a caller's own
+ * collective has to sum.  KT_ERR_NOT_READY without a pending kt_aggregate_launch. */
+int32_t kt_partial_words(kt_engine* e, int64_t* n_int64, int32_t* wide);
 int32_t kt_comm_destroy(kt_engine* e);
 
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */

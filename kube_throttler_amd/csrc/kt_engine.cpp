@@ -161,6 +161,7 @@ struct kt_engine {
   // RW-safe caches while the reconcile workers run)
   std::shared_mutex mu;
   std::mutex small_mu;  // serialises the few-pod callers among themselves (one scratch / pinned slot)
+  std::mutex ingest_mu; // settle_ingest
   // Every call except the few-pod check takes op_mu first: among themselves those calls are serialised exactly as under
   // the single mutex of rounds 1-2 (every interleaving equals some serial order).  What they take of `mu` depends on what
   // they do to the state a few-pod check reads (pod tables, selector program + index, namespace table, CheckRecs):
@@ -187,6 +188,22 @@ struct kt_engine {
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
   unsigned long long n_overflow = 0;
+  // Pod events without a stream synchronisation (round 4): a small batch is packed into one of kEvSlots pinned slots the
+  // kernels read directly, an event is recorded behind its kernels and the call returns; upserts / deletes pipeline on the
+  // engine's stream, EVERY other entry point first waits for the last event (settle_ingest) — it is then as if the feed
+  // calls had blocked themselves, which is what they did up to round 3.
+  static constexpr int kEvSlots = 8;
+  static constexpr size_t kEvSlotBytes = 64 * 1024;
+  struct EvSlot {
+    uint8_t* h = nullptr;
+    hipEvent_t ev = nullptr;
+    bool used = false;
+  } ev_slots[kEvSlots];
+  int ev_next = 0;
+  std::atomic<bool> ingest_pending{false};
+  hipEvent_t ingest_ev = nullptr;            // the event behind the newest asynchronous feed call
+  unsigned long long* h_overflow = nullptr;  // pinned: n_overflow as the newest asynchronous translate left it
+  bool overflow_in_flight = false;
   DevBuf<int64_t> d_countable;                   // rows of the pods a reconcile scans (kt_compact_countable)
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
@@ -296,6 +313,7 @@ struct kt_engine {
   int recs_cur = 0;
   hipEvent_t recs_ev[2] = {nullptr, nullptr};
   bool recs_ev_pending[2] = {false, false};
+  int32_t wide_mode = 0;  // kt_set_wide_sums: 0 = decided per engine (single rank only), 1 = always two blocks
   bool recs_prev_valid = false;  // the other buffer holds complete records of the same (program, on_equal, DT)
   uint8_t* recs_ptr() { return d_recs2[recs_cur].p; }
   // ---- few-pod check path (kt_kernels_few.hip)
@@ -355,11 +373,27 @@ struct kt_engine {
 
 namespace {
 
+static bool getenv_flag(const char* name) {
+  const char* v = getenv(name);
+  return v && *v && *v != '0';
+}
+// what asynchronous pod feed calls left in flight: wait for it (any thread; idempotent)
+inline void settle_ingest(kt_engine* e) {
+  if (!e->ingest_pending.load(std::memory_order_acquire)) return;
+  std::lock_guard<std::mutex> g(e->ingest_mu);
+  if (!e->ingest_pending.load(std::memory_order_acquire)) return;
+  (void)hipSetDevice(e->device);
+  (void)hipEventSynchronize(e->ingest_ev);
+  if (e->overflow_in_flight) e->n_overflow = *e->h_overflow, e->overflow_in_flight = false;
+  e->ingest_pending.store(false, std::memory_order_release);
+}
 // state feed: nobody else inside
 struct StateLock {
   std::unique_lock<std::mutex> op;
   std::unique_lock<std::shared_mutex> ex;
-  explicit StateLock(kt_engine* e) : op(e->op_mu), ex(e->mu) {}
+  explicit StateLock(kt_engine* e, bool settle = true) : op(e->op_mu), ex(e->mu) {
+    if (settle) settle_ingest(e);
+  }
 };
 // launches / fetches: serialised among themselves (op_mu), beside few-pod checks (shared) — unless this call will have to
 // recompile or re-upload state those checks read (the dirty flags are only written under op_mu + exclusive mu, so reading
@@ -371,6 +405,7 @@ struct LaunchLock {
   explicit LaunchLock(kt_engine* e, bool force_exclusive = false) : op(e->op_mu) {
     if (force_exclusive || e->program_dirty || e->status_host_dirty) ex = std::unique_lock<std::shared_mutex>(e->mu);
     else sh = std::shared_lock<std::shared_mutex>(e->mu);
+    settle_ingest(e);
   }
 };
 // CheckRecs about to be rewritten IN PLACE: no few-pod check may start on them (recs_valid = false under recs_mu) and
@@ -1039,6 +1074,11 @@ int32_t kt_engine_destroy(kt_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   if (e->small_stream) (void)hipStreamDestroy(e->small_stream);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
+  for (auto& sl : e->ev_slots) {
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+    if (sl.h) (void)hipHostFree(sl.h);
+  }
+  if (e->h_overflow) (void)hipHostFree(e->h_overflow);
   DevBuf<uint32_t>* u32s[] = {&e->d_thr_term_off, &e->d_term_thr, &e->d_term_req_off, &e->d_req_key, &e->d_req_val_off,
                               &e->d_req_val, &e->d_ns_term_ok, &e->d_thr_flags, &e->d_thrl_flag, &e->d_thrl_has,
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
@@ -1241,15 +1281,33 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
                  o_lk = sect((size_t)(le - lb) * 4), o_lp = sect((size_t)(le - lb) * 4), o_co = sect((cn + 1) * 4),
                  o_ci = sect(ke - kb), o_cp = sect((size_t)(ke - kb) * 4), o_cr = sect((size_t)(ke - kb) * 8 * D),
                  o_op = sect(cn * 4), o_ov = sect((size_t)cn * 8 * D);
-    KT_HIP(e, e->d_stage.reserve(off + 16));
-    uint8_t* st = e->d_stage.p;
-    // a small batch (an informer event) is packed in pinned host memory and crosses in ONE copy; a bulk load copies
-    // its sections straight from the caller's arrays
-    const bool packed = off <= kPinnedStageBytes;
+    // an informer event or a coalesced handful of them (the whole batch fits one pinned slot): no device staging copy —
+    // the kernels read the slot where it lies — and no stream synchronisation: an event behind the kernels, and
+    // settle_ingest() in every entry point that is not a pod feed call
+    const bool slot_path = n <= chunk && off + 16 <= kt_engine::kEvSlotBytes && !e->incremental && !getenv_flag("KT_SYNC_INGEST");
+    kt_engine::EvSlot* slot = nullptr;
+    if (slot_path) {
+      slot = &e->ev_slots[e->ev_next];
+      e->ev_next = (e->ev_next + 1) % kt_engine::kEvSlots;
+      if (!slot->h) {
+        KT_HIP(e, hipHostMalloc((void**)&slot->h, kt_engine::kEvSlotBytes, hipHostMallocDefault));
+        KT_HIP(e, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+      }
+      if (!e->h_overflow) KT_HIP(e, hipHostMalloc((void**)&e->h_overflow, 64, hipHostMallocDefault));
+      if (slot->used) KT_HIP(e, hipEventSynchronize(slot->ev));  // (eight feed calls ago: long done)
+    } else {
+      settle_ingest(e);  // the staged path below synchronises anyway
+      KT_HIP(e, e->d_stage.reserve(off + 16));
+    }
+    uint8_t* st = slot_path ? slot->h : e->d_stage.p;
+    // a small batch is packed in pinned host memory and crosses in ONE copy; a bulk load copies its sections straight
+    // from the caller's arrays
+    const bool packed = !slot_path && off <= kPinnedStageBytes;
     if (packed && !e->h_stage) KT_HIP(e, hipHostMalloc((void**)&e->h_stage, kPinnedStageBytes, hipHostMallocDefault));
 #define CP(o, src, bytes)                                                                               \
   if ((bytes) > 0) {                                                                                    \
-    if (packed) memcpy(e->h_stage + (o), (src), (bytes));                                               \
+    if (slot_path) memcpy(slot->h + (o), (src), (bytes));                                               \
+    else if (packed) memcpy(e->h_stage + (o), (src), (bytes));                                          \
     else KT_HIP(e, hipMemcpyAsync(st + (o), (src), (bytes), hipMemcpyHostToDevice, s));                 \
   }
     if (rows) CP(o_rows, rows + c0, (size_t)cn * 8);
@@ -1293,34 +1351,72 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     if (!e->program_dirty && e->pods.latom) {  // atom rows of the new content (a dirty program translates every row when compiled)
       kt::launch_translate_pods(e->pods, cn, pb.rows, pb.row0, e->dindex, e->d_overflow.p, s);
       KT_HIP(e, hipGetLastError());
-      KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
+      if (slot_path) {
+        KT_HIP(e, hipMemcpyAsync(e->h_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
+        e->overflow_in_flight = true;
+      } else {
+        KT_HIP(e, hipMemcpyAsync(&e->n_overflow, e->d_overflow.p, 8, hipMemcpyDeviceToHost, s));
+      }
     }
     if ((drc = delta_scan(e, cn, pb.rows, pb.row0, +1, s)) != KT_OK) return drc;
     if (patch && (drc = patch_views(e, cn, pb.rows, pb.row0, s)) != KT_OK) return drc;
-    KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+    if (slot_path) {
+      KT_HIP(e, hipEventRecord(slot->ev, s));
+      slot->used = true;
+      std::lock_guard<std::mutex> g(e->ingest_mu);
+      e->ingest_ev = slot->ev;
+      e->ingest_pending.store(true, std::memory_order_release);
+    } else {
+      KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
+    }
   }
   e->pod_rows_hi = hi;
+  e->last_stream = s;
   return KT_OK;
 }
 
 int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* b, const int64_t* rows) {
   if (!e || !b) return KT_ERR_INVALID_ARGUMENT;
-  StateLock lk(e);
+  StateLock lk(e, /*settle=*/false);  // pod feed calls pipeline on the engine's stream
   KT_HIP(e, hipSetDevice(e->device));
-  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  // kernels of another stream may still read the pod tables; what is in flight on the engine's own stream is ordered
+  // before this call's kernels by the stream itself
+  if (e->last_stream && e->last_stream != e->own_stream) {
+    settle_ingest(e);
+    KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  }
   return upsert_pods_locked(e, b, rows);
 }
 
 int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   if (!e || (n > 0 && !rows)) return KT_ERR_INVALID_ARGUMENT;
-  StateLock lk(e);
+  StateLock lk(e, /*settle=*/false);  // pipelines with the other pod feed calls (see kt_upsert_pods)
   KT_HIP(e, hipSetDevice(e->device));
   for (int64_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)rows[i]);
   if (n <= 0) return KT_OK;
-  if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
-  KT_HIP(e, e->d_rows.reserve((size_t)n));
-  KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
+  const bool slot_path = (size_t)n * 8 <= kt_engine::kEvSlotBytes && !e->incremental && !getenv_flag("KT_SYNC_INGEST");
+  if (!slot_path || (e->last_stream && e->last_stream != e->own_stream)) {
+    settle_ingest(e);
+    if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
+  }
+  kt_engine::EvSlot* slot = nullptr;
+  const int64_t* rows_dev;
+  if (slot_path) {
+    slot = &e->ev_slots[e->ev_next];
+    e->ev_next = (e->ev_next + 1) % kt_engine::kEvSlots;
+    if (!slot->h) {
+      KT_HIP(e, hipHostMalloc((void**)&slot->h, kt_engine::kEvSlotBytes, hipHostMallocDefault));
+      KT_HIP(e, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+    }
+    if (slot->used) KT_HIP(e, hipEventSynchronize(slot->ev));
+    memcpy(slot->h, rows, (size_t)n * 8);
+    rows_dev = (const int64_t*)slot->h;
+  } else {
+    KT_HIP(e, e->d_rows.reserve((size_t)n));
+    KT_HIP(e, hipMemcpyAsync(e->d_rows.p, rows, (size_t)n * 8, hipMemcpyHostToDevice, e->own_stream));
+    rows_dev = e->d_rows.p;
+  }
   const unsigned __int128 no_max[KT_MAX_DIMS] = {0};
   const uint64_t no_or[KT_MAX_DIMS] = {0};
   const bool patch = views_patchable(e, n, no_max, no_or, false);
@@ -1330,15 +1426,24 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   }
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   {
-    int32_t drc = delta_scan(e, n, e->d_rows.p, 0, -1, e->own_stream);
+    int32_t drc = delta_scan(e, n, rows_dev, 0, -1, e->own_stream);
     if (drc != KT_OK) return drc;
   }
-  kt::launch_delete_pods(e->pods, n, e->d_rows.p, e->own_stream);
+  kt::launch_delete_pods(e->pods, n, rows_dev, e->own_stream);
   if (patch) {  // the rows' meta words are 0 now: their records stop counting
-    int32_t prc = patch_views(e, n, e->d_rows.p, 0, e->own_stream);
+    int32_t prc = patch_views(e, n, rows_dev, 0, e->own_stream);
     if (prc != KT_OK) return prc;
   }
-  KT_HIP(e, hipStreamSynchronize(e->own_stream));
+  if (slot_path) {
+    KT_HIP(e, hipEventRecord(slot->ev, e->own_stream));
+    slot->used = true;
+    std::lock_guard<std::mutex> g(e->ingest_mu);
+    e->ingest_ev = slot->ev;
+    e->ingest_pending.store(true, std::memory_order_release);
+  } else {
+    KT_HIP(e, hipStreamSynchronize(e->own_stream));
+  }
+  e->last_stream = e->own_stream;
   return KT_OK;
 }
 
@@ -1558,8 +1663,26 @@ int32_t kt_comm_init(kt_engine* e, int32_t rank, int32_t world, const void* id12
 int32_t kt_set_exchange_world(kt_engine* e, int32_t world) {
   if (!e || world < 1) return KT_ERR_INVALID_ARGUMENT;
   StateLock lk(e);
-  if (world != e->exchange_world && (world > 4 || e->exchange_world > 4)) e->req_sums_valid = false;
+  if (world != e->exchange_world && (world > 4 || e->exchange_world > 4 || e->wide)) e->req_sums_valid = false;  // (a wide engine decides again: kt_set_wide_sums)
   e->exchange_world = world;
+  return KT_OK;
+}
+
+int32_t kt_set_wide_sums(kt_engine* e, int32_t mode) {
+  if (!e || (mode != 0 && mode != 1)) return KT_ERR_INVALID_ARGUMENT;
+  StateLock lk(e);
+  if (mode == 1 && e->incremental) return e->fail(KT_ERR_UNSUPPORTED, "kt_set_wide_sums(1): an incremental engine keeps int64 partials");
+  if (mode != e->wide_mode) e->req_sums_valid = false;  // the next aggregate decides again
+  e->wide_mode = mode;
+  return KT_OK;
+}
+
+int32_t kt_partial_words(kt_engine* e, int64_t* n_int64, int32_t* wide) {
+  if (!e || !n_int64) return KT_ERR_INVALID_ARGUMENT;
+  LaunchLock lk(e);
+  if (!e->agg_pending) return e->fail(KT_ERR_NOT_READY, "kt_partial_words: no partials pending (kt_aggregate_launch first)");
+  *n_int64 = (int64_t)e->agg_words;
+  if (wide) *wide = e->agg_wide ? 1 : 0;
   return KT_OK;
 }
 
@@ -1687,10 +1810,6 @@ int32_t kt_set_status(kt_engine* e, int32_t n, const int32_t* rows, const kt_sta
 // ---------------------------------------------------------------------------------------------------
 // reconcile
 // ---------------------------------------------------------------------------------------------------
-static bool getenv_flag(const char* name) {
-  const char* v = getenv(name);
-  return v && *v && *v != '0';
-}
 
 // every aggregate launch gets an epoch; a workgroup stamps the slabs it spills with it (kt_reduce_bitmap_slabs then
 // leaves alone what a namespace-ordered scan did not write)
@@ -1717,7 +1836,7 @@ static int32_t slab_tags(kt_engine* e, kt::AggScan& sc, hipStream_t s) {
 // when the bound passes 2^60 and resets it.  2^60 per GPU leaves the headroom for up to 8 ranks' partials to meet in an
 // all-reduce.
 static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
-  if (e->req_sums_valid) return KT_OK;
+  if (e->req_sums_valid && !(e->wide_mode == 1 && !e->wide)) return KT_OK;
   KT_HIP(e, e->d_req_sums.reserve(32));
   kt::launch_sum_abs_requests(e->pods, e->pod_rows_hi, e->d_req_sums.p, s);
   KT_HIP(e, hipGetLastError());
@@ -1737,8 +1856,21 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
                        "promote to big decimals); an incremental engine needs a coarser scale for it", d);
       if ((unsigned __int128)e->pod_rows_hi * (unsigned __int128)e->exchange_world > ((unsigned __int128)1 << 30))
         return e->fail(KT_ERR_OVERFLOW_RISK, "dimension %d: wide sums hold for up to 2^30 pods over all ranks", d);
+      // Several ranks: the layout of the exchanged buffer (one block of int64 sums, or two blocks of limb sums) must be
+      // the SAME on every rank, and this total is a local fact — another rank's shard may well stay below the bound.  So
+      // a rank never goes wide by itself: the caller switches every rank with kt_set_wide_sums(e, 1).
+      if (e->exchange_world > 1 && e->wide_mode != 1)
+        return e->fail(KT_ERR_OVERFLOW_RISK,
+                       "dimension %d: the requests of this rank's pods add up beyond the exact range of one int64 block; with %d ranks "
+                       "the two-block form must be agreed: call kt_set_wide_sums(e, 1) on every rank", d, e->exchange_world);
       wide = true;
     }
+  }
+  if (e->wide_mode == 1 && !wide) {
+    if (e->incremental) return e->fail(KT_ERR_UNSUPPORTED, "kt_set_wide_sums(1): an incremental engine keeps int64 partials");
+    if ((unsigned __int128)e->pod_rows_hi * (unsigned __int128)e->exchange_world > ((unsigned __int128)1 << 30))
+      return e->fail(KT_ERR_OVERFLOW_RISK, "wide sums hold for up to 2^30 pods over all ranks");
+    wide = true;
   }
   if (wide != e->wide) e->countable_valid = false;  // packed request words only exist for sums inside int64
   e->wide = wide;
@@ -1890,6 +2022,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   KT_CHECK_PARTIALS_CURRENT(e, "kt_finalize_launch");
   int32_t rc = ensure_ready(e, s);
   if (rc != KT_OK) return rc;
+  if (!e->agg_pending) e->agg_wide = e->wide;  // caller-provided partials, no aggregate of ours pending: the current mode's layout
   e->agg_pending = false;  // consumed (or caller-provided partials: nothing was pending)
   kt::ReconcileOut out{e->d_out_used.tab(), e->d_out_calc.tab(), e->d_out_used_hi.p, e->d_out_calc_updated.p, e->d_out_thrl_flag.p,
                        e->d_out_thrl_has.p, e->d_out_thrl_pod.p, e->d_out_error.p, e->d_out_next_s.p, e->d_out_next_ns.p};
@@ -1907,6 +2040,16 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
     wbuf = keep_prev ? 1 - e->recs_cur : e->recs_cur;
   }
   if (apply && !keep_prev) recs_invalidate_and_drain(e);
+  if (apply && keep_prev) {
+    // wbuf is the PREVIOUS generation's buffer — exactly what a concurrent few-pod check reads while the current buffer's
+    // event is pending.  No new check may pick it (recs_prev_valid = false under recs_mu; such a check then waits on the
+    // current buffer's event) and the one in flight has to finish before the finalize below rewrites it.
+    {
+      std::lock_guard<std::mutex> g(e->recs_mu);
+      e->recs_prev_valid = false;
+    }
+    if (e->few_ready) std::lock_guard<std::mutex> drain(e->small_mu);
+  }
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
     if (e->fused_pending) {
@@ -1954,7 +2097,9 @@ int32_t kt_partial_used_buffer(kt_engine* e, void** device_ptr, int64_t* n_int64
   int32_t rc = ensure_ready(e, e->own_stream);
   if (rc != KT_OK) return rc;
   *device_ptr = e->partial();
-  *n_int64 = (int64_t)e->thr_rows_hi * kt::partial_stride(e->D) * (e->wide ? 2 : 1);
+  // the words of the PENDING aggregate when there is one (a pod batch or kt_set_wide_sums may flip `wide` at the next
+  // kt_aggregate_launch: re-query after each aggregate, or use kt_partial_words)
+  *n_int64 = e->agg_pending ? (int64_t)e->agg_words : (int64_t)e->thr_rows_hi * kt::partial_stride(e->D) * ((e->wide || e->wide_mode == 1) ? 2 : 1);
   return KT_OK;
 }
 
@@ -2339,6 +2484,7 @@ int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_eq
     std::shared_lock<std::shared_mutex> rd(e->mu);
     std::lock_guard<std::mutex> sl(e->small_mu);
     KT_HIP(e, hipSetDevice(e->device));
+    settle_ingest(e);  // a pod event fed just before: PreFilter sees it
     const int32_t rc = check_few_shared(e, n, pod_rows, on_equal, out_summary);
     if (rc != 0) return rc < 0 ? rc : KT_OK;
   }

@@ -39,6 +39,7 @@ EXPORTS = [
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
     "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter", "kt_reconcile_fetch_used_hi",
+    "kt_set_wide_sums", "kt_partial_words",
 ]
 
 
@@ -112,6 +113,8 @@ def lib():
         L.kt_comm_allreduce_partial.argtypes = [C.c_void_p, C.c_void_p]
         L.kt_comm_destroy.argtypes = [C.c_void_p]
         L.kt_set_exchange_world.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_set_wide_sums.argtypes = [C.c_void_p, C.c_int32]
+        L.kt_partial_words.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.kt_counter.argtypes = [C.c_void_p, C.c_int32]
         L.kt_reconcile_fetch_used_hi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_counter.restype = C.c_int64
@@ -300,6 +303,17 @@ class Engine:
 
     def partial_words(self) -> int:
         return self.throttle_rows() * (2 * self.D + 2)
+
+    def set_wide_sums(self, mode: int):
+        """1: always the two-block (limb sums) form of the partial buffer — what every rank of a multi-rank exchange must
+        agree on; 0: decided per engine (single rank)."""
+        self._ck(lib().kt_set_wide_sums(self._h, mode))
+
+    def pending_partial_words(self):
+        """(int64 words, two-block form?) of the aggregate that is pending."""
+        n, w = C.c_int64(), C.c_int32()
+        self._ck(lib().kt_partial_words(self._h, C.byref(n), C.byref(w)))
+        return int(n.value), bool(w.value)
 
     def finalize_launch(self, now, apply=True, stream=None):
         self._ck(lib().kt_finalize_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, stream))

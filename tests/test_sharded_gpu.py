@@ -222,3 +222,74 @@ def test_two_gpus_with_the_native_exchange(oracle_mod):
         np.testing.assert_array_equal(sm, sm_w[begin:begin + len(sm)])
         begin += len(sm)
     assert begin == full.n_pods
+
+
+def test_two_skewed_ranks_agree_on_wide_sums(oracle_mod):
+    """whether a rank's requests leave int64 is a LOCAL fact.  Rank 0 holds 64 pods x 2^59 (its sums leave
+    int64), rank 1 holds 64 small pods (its sums do not).  Left to themselves the ranks would exchange buffers of
+    different layouts; so with exchange_world = 2 the wide rank refuses (KT_ERR_OVERFLOW_RISK, as rounds 1-2 did) until the
+    host switches EVERY rank with kt_set_wide_sums(1) — then both fill two blocks, the blocks add up rank-wise, and the
+    finalize on the sum equals the oracle's 128-bit arithmetic on the unsharded snapshot."""
+    import torch
+    cfg = W.small(seed=46, n_pods=128, n_thr=6, n_cluster=3, D=3)
+
+    def shaped(c, row0):
+        snap = W.generate(c)
+        first = snap.pod_ctr_off[:snap.n_pods]
+        nc = int(snap.pod_ctr_off[snap.n_pods])
+        snap.ctr_req[:nc, 0] = 0
+        big = (np.arange(snap.n_pods) + row0) < 64
+        snap.ctr_req[first[big], 0] = 1 << 59
+        snap.ctr_req[first[~big], 0] = 1000
+        snap.ctr_present[first] |= 1
+        snap.thr_spec.v[:snap.n_thr, 0] = (1 << 62) + 7
+        snap.thr_spec.present[:snap.n_thr] |= 1
+        return snap
+
+    full = shaped(cfg, 0)
+    now = (cfg.now_s, 0)
+    T, D = full.n_thr, full.D
+    rows = _responsible(full)
+    want = oracle_mod.Oracle(full).reconcile(now, rows=rows, nthreads=4, wide=True)
+    assert (want.used_hi[:len(rows)] != (want.used.v[:len(rows)] < 0) * -1).any(), "the case must leave int64"
+    engines = [E.Engine.for_snapshot(shaped(cfg.shard(r, 2), r * 64)) for r in range(2)]
+    try:
+        for e in engines:
+            e.set_exchange_world(2)
+        # left to themselves: rank 0 refuses, rank 1 would have filled ONE block
+        with pytest.raises(E.EngineError) as ei:
+            engines[0].aggregate_launch()
+        assert ei.value.code == -4 and "kt_set_wide_sums" in str(ei.value)
+        engines[1].aggregate_launch()
+        assert engines[1].pending_partial_words() == (T * (2 * D + 2), False)
+        # agreed: two blocks on both ranks
+        parts = []
+        for e in engines:
+            e.set_wide_sums(1)
+            words = 2 * T * (2 * D + 2)
+            part = torch.zeros(words, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            e.use_partial_buffer(part.data_ptr(), words)
+            e.aggregate_launch()
+            assert e.pending_partial_words() == (words, True)
+            assert e.partial_used_buffer()[1] == words
+            e.synchronize()
+            parts.append(part)
+        total = parts[0] + parts[1]
+        torch.cuda.synchronize()
+        for r, e in enumerate(engines):
+            buf = total.clone()
+            torch.cuda.synchronize()
+            e.use_partial_buffer(buf.data_ptr(), buf.numel())
+            e.finalize_launch(now, apply=False)
+            got = e.reconcile_fetch()
+            hi, any_wide = e.reconcile_fetch_used_hi()
+            assert any_wide
+            np.testing.assert_array_equal(got.used.v[rows], want.used.v[:len(rows)], err_msg=f"rank {r} used, low words")
+            np.testing.assert_array_equal(hi[rows], want.used_hi[:len(rows)], err_msg=f"rank {r} used, high words")
+            np.testing.assert_array_equal(got.used.count[rows], want.used.count[:len(rows)])
+            np.testing.assert_array_equal(got.thrl_flag[rows], want.thrl_flag[:len(rows)])
+            e.use_partial_buffer(None, 0)
+    finally:
+        for e in engines:
+            e.close()

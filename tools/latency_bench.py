@@ -6,7 +6,12 @@ the C-ABI, engine already holding the snapshot).
   check1_busy   the same while another thread runs kt_reconcile_launch + kt_reconcile_fetch in a loop
   native        check1 / check1_busy once more from native threads (tools/native/busy_latency.c): the Python loops above
                 share the interpreter lock between the timing thread and the reconciling thread
-  upsert_pod1   kt_upsert_pods(1): a pod informer event (stage + kt_ingest_pods + kt_translate_pods)
+  upsert_pod1   kt_upsert_pods(1): a pod informer event — the call alone (packs the event into a pinned slot, enqueues
+                kt_ingest_pods + kt_translate_pods + kt_patch_scan_views, records an event; no stream synchronisation)
+  upsert_pod64_per_pod  a coalesced batch of 64 events through the same call, per pod
+  upsert1_then_check1   one event + kt_check(n=1) of that pod: the check waits for the ingest (settle_ingest)
+  upsert_pod1_blocking  the form of rounds 1-3 (KT_SYNC_INGEST=1: device staging copy + stream synchronisation)
+  delete_pod1   kt_delete_pods(1)
   sweep         a full reconcile + PreFilter sweep in the steady state, and the first one after ONE pod event (which rebuilds
                 the scan lists, the scan-ordered record copies and the request-sum proof of the overflow guard)
   throttle_event  the first kt_check after ONE kt_upsert_throttles that leaves the row's selector as stored (threshold edit,
@@ -17,6 +22,7 @@ the C-ABI, engine already holding the snapshot).
 
     python tools/latency_bench.py --config 2        (prints one JSON object)
 bench.py embeds the same object as "latency" (N = 1 runs)."""
+import ctypes as C
 import json
 import os
 import sys
@@ -107,14 +113,47 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
     if nat is not None:
         out["native"] = nat
     out["few_path_checks"] = eng.few_checks_served()  # kt_check calls served without copy / stream sync (kt_check_few)
-    # ---- one pod event
+    # ---- pod informer events (throttle_controller.go:400-536: one handler call per event).  Only the foreign call is
+    #      timed (batch, struct and row array are built before); the call returns once its kernels are enqueued, the next
+    #      entry point that is not a pod feed call waits for them (settle_ingest) — upsert1_then_check1 is that sum.
+    from kube_throttler_amd import engine as E
+    lib = E.lib()
+
+    def feed(batch, reps, then_check=False, per_pod=True):
+        ts = []
+        for _ in range(reps):
+            rs = np.unique(rng.integers(0, P, size=batch).astype(np.int64))
+            one = snap.pod_batch(rs)
+            st = one.as_struct()
+            rp = rs.ctypes.data_as(C.c_void_p)
+            row1[0] = rs[0]
+            t0 = time.perf_counter()
+            rc = lib.kt_upsert_pods(eng._h, C.byref(st), rp)
+            if then_check:
+                call1()
+            t1 = time.perf_counter()
+            assert rc == 0
+            ts.append((t1 - t0) / (len(rs) if per_pod else 1))
+        eng.synchronize()
+        return _pct(ts)
+    feed(1, 20)
+    out["upsert_pod1"] = feed(1, n_upsert)                           # one event, the call alone
+    out["upsert_pod64_per_pod"] = feed(64, max(20, n_upsert // 4))   # a coalesced batch of 64 events, per pod
+    out["upsert1_then_check1"] = feed(1, n_upsert, then_check=True)  # event + PreFilter of that pod (waits for the ingest)
+    os.environ["KT_SYNC_INGEST"] = "1"                               # the blocking form of rounds 1-3, for comparison
+    try:
+        out["upsert_pod1_blocking"] = feed(1, max(50, n_upsert // 2))
+    finally:
+        del os.environ["KT_SYNC_INGEST"]
     ts = []
-    for r in rng.integers(0, P, size=n_upsert):
-        one = snap.pod_batch(np.array([int(r)], dtype=np.int64))
+    for r in rng.integers(0, P, size=max(50, n_upsert // 2)):
+        rs = np.array([int(r)], dtype=np.int64)
         t0 = time.perf_counter()
-        eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
+        lib.kt_delete_pods(eng._h, 1, rs.ctypes.data_as(C.c_void_p))
         ts.append(time.perf_counter() - t0)
-    out["upsert_pod1"] = _pct(ts)
+        eng.upsert_pods(snap.pod_batch(rs), rows=rs)                 # the pod comes back: the state stays configs' own
+    out["delete_pod1"] = _pct(ts)
+    eng.synchronize()
     # ---- a full sweep (reconcile + PreFilter of every pod) right after ONE pod event, against the steady sweep: the event
     #      voids the scan lists / scan-ordered record copies / request-sum proof, the next sweep rebuilds them
     def full_sweep():
