@@ -196,6 +196,12 @@ def main():
         tot, n = eng.timing_read(fam)
         k_ms[name] = tot / max(n, 1)
 
+    per_rank_kernel_ms = None
+    if world > 1:  # every rank's kernel times, so that the first multi-GPU run explains itself
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: round(v, 6) for k, v in k_ms.items()} | {"exchange": None if exchange_ms is None else round(exchange_ms, 6)})
+        per_rank_kernel_ms = gathered
+
     decisions_per_step = float(P_total) * float(T)
     ms_per_step = elapsed * 1e3 / args.steps
     value = decisions_per_step * args.steps / elapsed
@@ -219,6 +225,7 @@ def main():
     engine_version = E.version()
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     pmc_kernels = {}
+    pmc_source = None
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as fh:
@@ -229,6 +236,7 @@ def main():
             src = pmc.get("_source", {}).get(key)
             if isinstance(src, dict) and src.get("engine_version") == engine_version:
                 pmc_kernels = pmc.get(key, {})
+                pmc_source = "profiles/%s_* (same kernel sources: %s)" % (src.get("tag"), engine_version.split("src=")[-1])
         except Exception:
             pmc_kernels = {}
     dom_kernel = eng.kernel_name(E.KERNEL_CHECK if dominant == "check" else E.KERNEL_AGGREGATE)
@@ -237,24 +245,64 @@ def main():
     if sym(dom_kernel) in pmc_kernels:
         traffic = pmc_kernels[sym(dom_kernel)].get("hbm_bytes_per_launch")
 
+    SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; MI355X peak engine clock (MI355X_MICROARCH.md)
+
+    def bound_of(kn, ms_events):
+        """What bounds the kernel, from the hash-gated profile of the SAME sources (profiles/pmc_summary.json): actual HBM
+        traffic against the roofline, VALU issue time (a wave-level VALU instruction holds its SIMD for 4 cycles) and LDS
+        bank-conflict cycles per LDS-active cycle.  Durations: the rocprofv3 average when the profile has one."""
+        rec = pmc_kernels.get(sym(kn))
+        if not rec:
+            return None
+        ns = rec.get("rocprof_avg_ns")
+        dur = ns * 1e-9 if ns else ms_events * 1e-3
+        out = {"profile": pmc_source, "rocprof_avg_ms": None if not ns else round(ns * 1e-6, 6)}
+        if rec.get("hbm_bytes_per_launch") and dur > 0:
+            out["hbm_actual_bytes"] = rec["hbm_bytes_per_launch"]
+            out["hbm_actual_frac"] = round(rec["hbm_bytes_per_launch"] / dur / 1e9 / HBM_PEAK_GBS, 4)
+        sq = rec.get("sq") or {}
+        if sq.get("SQ_INSTS_VALU") and dur > 0:
+            out["valu_busy"] = round(sq["SQ_INSTS_VALU"] * 4.0 / (SIMDS * dur * CLOCK_HZ), 4)
+            out["valu_insts_per_launch"] = sq["SQ_INSTS_VALU"]
+        if sq.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_conflict_frac"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"], 4)
+        if sq.get("SQ_WAVE_CYCLES"):
+            out["wave_wait_frac"] = round(sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"], 4)
+        return out
+
     def kernel_roofline(name, fam, nbytes):
         ms = k_ms[name]
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         kn = eng.kernel_name(fam)
-        return {"kernel": kn, "avg_launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": nbytes,
-                "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
-                "traffic": pmc_kernels.get(sym(kn), {}).get("hbm_bytes_per_launch")}
+        d = {"kernel": kn, "avg_launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": nbytes,
+             "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
+             "traffic_profiled": pmc_kernels.get(sym(kn), {}).get("hbm_bytes_per_launch"), "bound_by": bound_of(kn, ms)}
+        ns = pmc_kernels.get(sym(kn), {}).get("rocprof_avg_ns")
+        if ns:  # the un-instrumented duration (same sources): the HIP-event figure above carries the events' own cost
+            d["frac_rocprof"] = round(nbytes / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)
+        return d
 
     # reconcile = the three launches that turn pods into stored status (aggregate scan + slab reduction + finalize; the
     # fused kernel reports all of it under `aggregate`) against the aggregation's algorithmic bytes
     rec_ms = k_ms["aggregate"] + k_ms["reduce"] + k_ms["finalize"]
     slowest = max(("check", "aggregate", "reduce", "finalize"), key=lambda k: k_ms[k])
     fam_of = {"check": E.KERNEL_CHECK, "aggregate": E.KERNEL_AGGREGATE, "reduce": E.KERNEL_REDUCE, "finalize": E.KERNEL_FINALIZE}
+    # HIP events around every launch keep consecutive kernels from overlapping their ramps: the instrumented pass is a few
+    # microseconds longer per step than the timed region, so these per-kernel figures are upper bounds (their sum may
+    # exceed ms_per_step); the rocprofv3 averages of the same sources, when profiled, are quoted beside them
+    prof_ms = {}
+    for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("reduce", E.KERNEL_REDUCE), ("finalize", E.KERNEL_FINALIZE)):
+        ns = pmc_kernels.get(sym(eng.kernel_name(fam)), {}).get("rocprof_avg_ns")
+        if ns and k_ms[name] > 0:
+            prof_ms[name] = round(ns * 1e-6, 6)
     roofline = {
         "bound": "hbm", "kernel": dom_kernel,
         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-        "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(k_ms[dominant], 6),
+        "traffic": traffic, "traffic_source": pmc_source, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(k_ms[dominant], 6),
         "per_kernel_ms": {k: round(v, 6) for k, v in k_ms.items()},
+        "per_kernel_ms_note": "HIP events on the launch stream, instrumented pass (upper bounds: the events keep kernels from overlapping)",
+        "per_kernel_ms_rocprof": prof_ms or None,
+        "launch_gaps_ms": round(ms_per_step - sum(prof_ms.values()), 6) if len(prof_ms) >= 2 else None,
         "dominant_by": "algorithmic bytes per launch",
         "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes),
         "aggregate": kernel_roofline("aggregate", E.KERNEL_AGGREGATE, agg_bytes),
@@ -343,6 +391,7 @@ def main():
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
             "per_rank_ms_per_step": [round(x, 6) for x in rank_ms],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 6),
+            "per_rank_kernel_ms": per_rank_kernel_ms,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "latency": latency,
         }
         print(json.dumps(out))

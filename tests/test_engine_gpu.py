@@ -1077,3 +1077,71 @@ def test_reconcile_stress_fresh_engines(oracle_mod, preset):
             eng.close()
     print("configs[%d]: %d fresh-engine rounds, %d mismatching reconciles" % (preset, rounds, len(failures)))
     assert not failures, "\n".join(failures[:20])
+
+
+@pytest.mark.parametrize("budget", [None, 6000])
+def test_event_bursts_then_prefilter(budget, oracle_mod, monkeypatch):
+    """Pod feed calls return once their kernels are enqueued (round 4: pinned event slots, no stream synchronisation) and
+    pipeline among themselves; every other entry point waits for them first.  Bursts of 1-20 single-pod upserts / deletes
+    (more than the eight slots: slots are reused), each followed AT ONCE by kt_check(n = 1..4) of pods the burst touched
+    — the few-pod path on its own stream — and now and then by a reconcile: every summary word and every `used` equals the
+    oracle on the pods as fed (throttle_controller.go:400-536: the handler's effect is visible to the next PreFilter)."""
+    if budget:
+        monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
+    base = W.generate(W.small(seed=74, n_pods=1800, n_thr=80, n_cluster=40))
+    P = 1500
+    rng = np.random.default_rng(74)
+    state = np.full(P, -1, dtype=np.int64)
+    state[:1000] = np.arange(1000)
+    eng = E.Engine(base.D, max(base.L, 1), P, max(base.n_thr, 1), max(base.n_ns, 1))
+    try:
+        eng.upsert_namespaces(base)
+        eng.upsert_throttles(base)
+        eng.upsert_pods(_permute_pods(base, np.arange(1000)), rows=np.arange(1000))
+        rows_t = responsible_rows(base)
+
+        def reconcile_and_compare():
+            n = int(np.nonzero(state >= 0)[0].max()) + 1
+            snap = _with_pods(base, state[:n])
+            want = oracle_mod.Oracle(snap).reconcile(NOW, rows=rows_t)
+            got = eng.reconcile(NOW, apply=True)
+            ok = want.error[:len(rows_t)] == 0
+            np.testing.assert_array_equal(got.used.v[rows_t][ok], want.used.v[:len(rows_t)][ok])
+            np.testing.assert_array_equal(got.used.count[rows_t][ok], want.used.count[:len(rows_t)][ok])
+            snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows_t)
+            base.thr_used, base.thr_calc = snap.thr_used, snap.thr_calc
+            base.thr_flags, base.thr_thrl_flag, base.thr_thrl_has = snap.thr_flags, snap.thr_thrl_flag, snap.thr_thrl_has
+
+        reconcile_and_compare()
+        checkers = {k: eng.checker(k) for k in (1, 2, 3, 4)}
+        checkers[1][2]()                                                 # CheckRecs of on_equal = False are built
+        served0 = eng.few_checks_served()
+        n_checks = 0
+        for burst in range(40):
+            touched = []
+            for _ in range(int(rng.integers(1, 21))):
+                r = int(rng.integers(0, P))
+                if rng.random() < .2 and state[r] >= 0:
+                    state[r] = -1
+                    eng.delete_pods(np.array([r], dtype=np.int64))
+                else:
+                    state[r] = int(rng.integers(0, 1800))
+                    eng.upsert_pods(_permute_pods(base, state[[r]]), rows=np.array([r]))
+                    touched.append(r)
+            live = [r for r in dict.fromkeys(touched) if state[r] >= 0]
+            if live:
+                pick = np.array(live[-int(rng.integers(1, 5)):], dtype=np.int64)
+                rows_c, sum_c, call_c = checkers[len(pick)]
+                rows_c[:] = pick
+                call_c()                                                 # kt_check right behind the burst: nothing in between
+                sm = sum_c.copy()
+                n_checks += 1
+                n = int(np.nonzero(state >= 0)[0].max()) + 1
+                snap = _with_pods(base, state[:n])
+                _, sm_w = oracle_mod.Oracle(snap).check(rows=pick, want_status=False, nthreads=2)
+                np.testing.assert_array_equal(sm, sm_w, err_msg=f"burst {burst}: rows {pick}")
+            if burst % 8 == 7:
+                reconcile_and_compare()
+        assert eng.few_checks_served() - served0 >= n_checks - 5, "the few-pod path was hardly taken"
+    finally:
+        eng.close()

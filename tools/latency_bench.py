@@ -168,6 +168,7 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
     for r in rng.integers(0, P, size=20):
         one = snap.pod_batch(np.array([int(r)], dtype=np.int64))
         eng.upsert_pods(one, rows=np.array([int(r)], dtype=np.int64))
+        eng.synchronize()  # the feed call no longer waits for its kernels: what is compared is the SWEEP (rebuilt views or not)
         after.append(full_sweep())
     out["sweep"] = {"steady_ms": round(float(np.median(steady)) * 1e3, 3), "after_pod_event_ms": round(float(np.median(after)) * 1e3, 3), "n": 20}
     # ---- one Throttle event that leaves every selector as it is (a threshold edit, the controller's own status update

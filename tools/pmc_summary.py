@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """Summarise a tools/profile.sh output directory into profiles/ (tracked).
 
-    python tools/pmc_summary.py gpurun_out/prof_<tag> <round> <key>
+    python tools/pmc_summary.py gpurun_out/prof_<tag> <round> <key> [gpurun_out/sq_<tag>]
 
 Writes profiles/<round>_<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
 profiles/<round>_<tag>_pmc.csv (per-kernel FETCH_SIZE / WRITE_SIZE averages) and merges
 profiles/pmc_summary.json[<key>] = {kernel: {hbm_bytes_per_launch, fetch_bytes, write_bytes, ...}}.
+
+With the SQ counter directory of tools/pmc_sq.sh as a fourth argument the per-kernel averages of the SQ / LDS counters
+are merged in as well (`sq`), and the rocprofv3 average duration of every kernel (`rocprof_avg_ns`, `rocprof_calls`) —
+bench.py derives `hbm_actual_frac`, `valu_busy` and `lds_conflict_frac` from them when the library that runs reports the
+same source hash.
 
 Units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory-side;
 on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced stream and is
@@ -38,8 +43,39 @@ def counter_avgs(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
 
 
+def kernel_stats(d):
+    """{short kernel name: (average ns, calls)} from rocprofv3 --kernel-trace --stats (several instantiations of one
+    kernel are weighted by their calls)"""
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "kt_" not in row["Name"]:
+                    continue
+                k = short(row["Name"])
+                tot, n = acc.get(k, (0.0, 0))
+                acc[k] = (tot + float(row["TotalDurationNs"]), n + int(row["Calls"]))
+    return {k: (tot / n, n) for k, (tot, n) in acc.items() if n}
+
+
+SQ_KEEP = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES",
+           "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_INSTS_LDS", "SQ_INSTS_LDS_ATOMIC", "SQ_INSTS_SALU")
+
+
+def sq_counters(d):
+    acc = {}
+    for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] not in SQ_KEEP or "kt_" not in row["Kernel_Name"]:
+                    continue
+                acc.setdefault(short(row["Kernel_Name"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
 def main():
     src, rnd, key = sys.argv[1], sys.argv[2], sys.argv[3]
+    sq_dir = sys.argv[4] if len(sys.argv) > 4 else None
     tag = os.path.basename(src.rstrip("/")).replace("prof_", "")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
@@ -62,6 +98,14 @@ def main():
         rows.append([k, fn, round(fb), round(2 * fb), wn, round(wb), round(2 * fb + wb)])
         summ[k] = {"fetch_bytes_raw": round(fb), "fetch_bytes_x2": round(2 * fb), "write_bytes": round(wb),
                    "hbm_bytes_per_launch": round(2 * fb + wb), "launches": fn}
+    for k, (avg, n) in kernel_stats(os.path.join(src, "trace")).items():
+        summ.setdefault(k, {}).update({"rocprof_avg_ns": round(avg, 1), "rocprof_calls": n})
+    if sq_dir:
+        for k, cs in sq_counters(sq_dir).items():
+            summ.setdefault(k, {})["sq"] = {c: round(v, 1) for c, v in sorted(cs.items())}
+        st = os.path.join(sq_dir, "summary.txt")
+        if os.path.exists(st):
+            shutil.copy(st, os.path.join(prof, f"{rnd}_{tag}_sq_counters.txt"))
     with open(os.path.join(prof, f"{rnd}_{tag}_pmc.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "fetch_launches", "FETCH_SIZE_bytes_raw", "FETCH_SIZE_bytes_x2_gfx950", "write_launches",
