@@ -9,9 +9,6 @@ namespace kt {
 // same bytes, so that the reduction streams whole records as 16-byte pieces
 __host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool counts) { return n_thr * agg_rec_bytes(D, counts); }
 
-// per wave: the queue of matches the packed fold drains 64 at a time (kt_aggregate_bitmap, PK)
-constexpr uint32_t kFoldQueue = 128;
-
 struct BmAggArgs {
   const uint64_t* meta;  // pod tables
   const uint16_t* latom;
@@ -25,7 +22,7 @@ struct BmAggArgs {
   const int64_t* rows;  // nullable: the pods to scan are rows[0..n_rows) instead of row0 + [0, n_rows)
   int64_t row0, n_rows;
   BmIndexArgs ix;
-  uint32_t off_rank, off_tab, off_list;
+  uint32_t off_rank, off_tab;
   uint32_t n_slow;
   int32_t D, DS, LS, T;
   int32_t counts;  // table keeps per-key pod counts instead of the presence mask
@@ -38,7 +35,6 @@ struct BmAggArgs {
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
   int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
-  int32_t fold_queue;    // PK: matches are listed per wave and folded 64 at a time (0: the adds are issued per peel step)
   PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
   const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
 };
@@ -54,20 +50,17 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
   const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
   if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
-  static const bool no_queue = getenv("KT_NO_FOLD_QUEUE") != nullptr;
-  a.fold_queue = no_queue ? 0 : 1;
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
   a.off_tab = take(packed ? ix.bm_max_thr * a.pk.rec_bytes : agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
-  a.off_list = take((kBlockIx / kWave) * kFoldQueue * 4u);
   plan_bitmap_index(ix, a.ix, take);
   a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && (sc.v_req || packed)) ? 1u : 0u;
   *total = o;
   return a;
 }
 
-uint32_t aggregate_fixed_lds() { return 64 + (kBlockIx / kWave) * kFoldQueue * 4u; }
+uint32_t aggregate_fixed_lds() { return 64; }
 
 // kt_aggregate_bitmap — `used` partials of this GPU's pod rows: affectedPods + fold Add for all throttles
 // (throttle_controller.go:116-119,221-246; clusterthrottle_controller.go:119-122,224-270).
@@ -202,29 +195,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       }
 
       uint32_t last_r = 0xFFFFFFFFu;
-      // Packed fold through a queue (round 4).  An LDS atomic costs its ~5 ns per wave INSTRUCTION whatever the number of
-      // active lanes, and a peel step has a fifth to a third of its lanes busy: issuing the adds per step spends three to
-      // five instructions' worth of the atomic pipe per instruction's worth of work.  The peel only lists the matches —
-      // (pod lane, record) pairs, compacted by ballot + mbcnt — and the wave folds 64 of them at a time with lane = match:
-      // the pod's packed words come from its lane by ds_bpermute, every atomic instruction has all lanes busy.
-      lds_u32wp fq = (lds_u32wp)(lds + a.off_list) + wave * kFoldQueue;
-      uint32_t q_head = 0, q_n = 0;  // wave-uniform
-      auto fold_queue = [&](uint32_t cnt) {  // lane j takes entry j of the first cnt (<= 64)
-        const bool vv = lane < cnt;
-        const uint32_t e = fq[(q_head + lane) & (kFoldQueue - 1u)];
-        const uint32_t pl = e >> 16, r = e & 0xFFFFu;
-        KT_LDS unsigned char* rp = tab + (vv ? r : 0u) * rec;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if ((uint32_t)k >= a.pk.nw) break;  // wave-uniform
-          const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)pw[k], (int)pl), hi = (uint32_t)__shfl((int)(uint32_t)(pw[k] >> 32), (int)pl);
-          const unsigned long long v = (unsigned long long)lo | (unsigned long long)hi << 32;
-          if (vv && v != 0ull) lds_add64((lds_u64wp)rp + k, v);
-        }
-        const uint32_t zk = (uint32_t)__shfl((int)zero_keys, (int)pl);
-        if (vv && zk) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        q_head = (q_head + cnt) & (kFoldQueue - 1u), q_n -= cnt;
-      };
       scan_tile<LA, VETO, NEED, VETO>(
           bm, scan_counted, ns, ro,
           [&](bool has, uint32_t c) {
@@ -232,28 +202,16 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
             // a throttle with several terms is counted once
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
-            if constexpr (PK) {
-              if (a.fold_queue) {  // list the match; fold when 64 are waiting
-                last_r = ok ? r : last_r;
-                const uint64_t mk = __ballot(ok);
-                if (ok) fq[(q_head + q_n + lane_rank(mk)) & (kFoldQueue - 1u)] = lane << 16 | r;
-                q_n += (uint32_t)__popcll(mk);
-                if (q_n >= (uint32_t)kWave) fold_queue((uint32_t)kWave);
-                return;
-              }
-            }
             if (ok) {
               last_r = r;
               KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
               lds_u64wp tv = (lds_u64wp)rp;
               if constexpr (PK) {
-                if (!a.fold_queue) {  // (A/B runs: KT_NO_FOLD_QUEUE=1 — the adds issued per peel step)
 #pragma unroll
-                  for (int k = 0; k < 4; ++k)
-                    if (pw[k] != 0ull) lds_add64(tv + k, pw[k]);  // words past pk.nw hold 0
-                  if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  return;
-                }
+                for (int k = 0; k < 4; ++k)
+                  if (pw[k] != 0ull) lds_add64(tv + k, pw[k]);  // words past pk.nw hold 0
+                if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
               }
               lds_u32wp tu = (lds_u32wp)(rp + (uint32_t)D * 8);
 #pragma unroll
@@ -273,9 +231,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
           [&](uint32_t c) {
             return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
           });
-      if constexpr (PK) {
-        if (q_n) fold_queue(q_n);  // the rest of this tile's matches (< 64): the packed words in the registers are this tile's
-      }
     }
     __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);

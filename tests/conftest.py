@@ -33,3 +33,19 @@ def oracle_mod():
     from oracle import kt_oracle
     kt_oracle.lib()
     return kt_oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_device_first():
+    """On a GPU box, let torch initialise its HIP context BEFORE the engine's library makes its first HIP call: the tests
+    that hand torch tensors to the engine (test_sharded_gpu, the two-GPU exchange) otherwise initialise torch after dozens
+    of engines have come and gone in the same process, and once (round 4, call r04c) that late initialisation answered
+    "No HIP GPUs are available" although the engine's own kernels had just run.  A no-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield
