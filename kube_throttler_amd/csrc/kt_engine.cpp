@@ -1165,7 +1165,8 @@ static bool views_patchable(const kt_engine* e, int64_t n, const unsigned __int1
   }
   return true;
 }
-static int32_t patch_views(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, hipStream_t s) {
+// the views a pod event batch of n rows has to be applied to (host bookkeeping included: call once per batch)
+static kt::ViewPatch view_patch_of(kt_engine* e, int64_t n) {
   kt::ViewPatch v{};
   if (e->countable_valid) {
     v.vc_meta = e->d_vc_meta.p, v.vc_latom = e->d_vc_latom.p, v.vc_req = e->pack.nw ? nullptr : e->d_vc_req.p, v.vc_pk = e->pack.nw ? e->d_vc_pk.p : nullptr;
@@ -1179,6 +1180,10 @@ static int32_t patch_views(kt_engine* e, int64_t n, const int64_t* rows_dev, int
   }
   v.dirty = e->d_view_dirty.p;
   if ((e->countable_valid && e->countable_by_ns) || e->order_all_valid) e->view_check_dirty = true;
+  return v;
+}
+static int32_t patch_views(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row0, hipStream_t s) {
+  const kt::ViewPatch v = view_patch_of(e, n);
   kt::launch_patch_scan_views(e->pods, n, rows_dev, row0, v, s);
   KT_HIP(e, hipGetLastError());
   return KT_OK;
@@ -1344,6 +1349,21 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     // incremental engines: out with the old content of these rows, in with the new (a row that is not valid yet /
     // any more contributes nothing either way)
     if (e->incremental && e->program_dirty) e->agg_valid = false;  // selectors changed: the next reconcile rescans
+    if (slot_path && cn <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION")) {
+      // ONE launch: ingest + translate + view patch, the overflow counter straight into the pinned word
+      const bool tr = !e->program_dirty && e->pods.latom;
+      kt::ViewPatch v{};
+      if (patch) v = view_patch_of(e, cn);
+      kt::launch_feed_small(e->pods, pb, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, s);
+      KT_HIP(e, hipGetLastError());
+      if (tr) e->overflow_in_flight = true;
+      KT_HIP(e, hipEventRecord(slot->ev, s));
+      slot->used = true;
+      std::lock_guard<std::mutex> g(e->ingest_mu);
+      e->ingest_ev = slot->ev;
+      e->ingest_pending.store(true, std::memory_order_release);
+      continue;
+    }
     int32_t drc = delta_scan(e, cn, pb.rows, pb.row0, -1, s);
     if (drc != KT_OK) return drc;
     kt::launch_ingest_pods(e->pods, pb, s);
@@ -1425,14 +1445,19 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
     e->order_all_valid = false;
   }
   if (e->incremental && e->program_dirty) e->agg_valid = false;
-  {
+  if (slot_path && n <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION")) {
+    kt::ViewPatch v{};
+    if (patch) v = view_patch_of(e, n);
+    kt::launch_unfeed_small(e->pods, n, rows_dev, patch ? &v : nullptr, e->own_stream);
+    KT_HIP(e, hipGetLastError());
+  } else {
     int32_t drc = delta_scan(e, n, rows_dev, 0, -1, e->own_stream);
     if (drc != KT_OK) return drc;
-  }
-  kt::launch_delete_pods(e->pods, n, rows_dev, e->own_stream);
-  if (patch) {  // the rows' meta words are 0 now: their records stop counting
-    int32_t prc = patch_views(e, n, rows_dev, 0, e->own_stream);
-    if (prc != KT_OK) return prc;
+    kt::launch_delete_pods(e->pods, n, rows_dev, e->own_stream);
+    if (patch) {  // the rows' meta words are 0 now: their records stop counting
+      int32_t prc = patch_views(e, n, rows_dev, 0, e->own_stream);
+      if (prc != KT_OK) return prc;
+    }
   }
   if (slot_path) {
     KT_HIP(e, hipEventRecord(slot->ev, e->own_stream));
@@ -1900,6 +1925,9 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
   // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
   const bool by_ns = (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
   if ((rc = settle_view_patches(e, s)) != KT_OK) return rc;
+  // pod events appended records behind the listed ones; a scan that will gather through the row list instead of streaming
+  // the view cannot tell them from the list's zeroed padding: list again
+  if (e->countable_valid && e->view_extra && !(!getenv_flag("KT_NO_SCAN_VIEW") && (by_ns || e->dindex.n_chunks == 1))) e->countable_valid = false;
   if (e->cfg.kernel_variant != 1 && (!e->countable_valid || e->countable_by_ns != by_ns)) {  // pods changed since the last scan: which rows does a reconcile look at
     if (e->last_stream && e->last_stream != s) KT_HIP(e, hipStreamSynchronize(e->last_stream));
     KT_HIP(e, e->d_countable.reserve((size_t)e->cfg.pod_capacity + 1));
@@ -1972,11 +2000,14 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
         e->last_kernel[KT_KERNEL_AGGREGATE] = "kt_aggregate_dense";
       } else {
         kt::AggScan sc;
-        sc.n = (int64_t)e->n_countable + (getenv_flag("KT_NO_SCAN_VIEW") ? 0 : e->view_extra), sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
+        sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
         sc.overflow_pods = e->n_overflow != 0;
         sc.limb = limb;
         // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
         sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
+        // (records appended behind the listed ones by pod events exist in the VIEW only: a scan that gathers through the
+        //  row list — KT_NO_NS_ORDER on a multi-chunk index — must not run over the list's zeroed padding = pod row 0)
+        if (sc.by_ns) sc.n += e->view_extra;
         if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
         if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
         if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;

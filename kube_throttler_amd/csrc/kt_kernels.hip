@@ -25,54 +25,55 @@ static inline int grid_for(int64_t n, int per_block = kBlock, int max_blocks = 2
 //   even for +0, :48-54); c.SetMax(ic); c.Add(overhead) when overhead != nil.
 // One thread per pod; D and the container count are tiny, the kernel is bound by the plane writes.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatchDev b) {
+__device__ __forceinline__ void ingest_one(const PodTable& pods, const PodBatchDev& b, int64_t i) {
   const int D = pods.D, L = pods.L;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = b.rows ? b.rows[i] : b.row0 + i;
-    int64_t c[16], ic[16];
-    uint32_t cp = 0, icp = 0;
+  const int64_t row = b.rows ? b.rows[i] : b.row0 + i;
+  int64_t c[16], ic[16];
+  uint32_t cp = 0, icp = 0;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) c[d] = 0, ic[d] = 0;
-    const uint32_t k0 = b.ctr_off[i] - b.ctr_base, k1 = b.ctr_off[i + 1] - b.ctr_base;
-    for (uint32_t k = k0; k < k1; ++k) {
-      const uint32_t pm = b.ctr_present[k];
-      const bool init = b.ctr_init[k] != 0;
-      for (int d = 0; d < D; ++d) {
-        if (!((pm >> d) & 1u)) continue;
-        const int64_t q = b.ctr_req[(int64_t)k * D + d];
-        if (init) {
-          ic[d] = ((icp >> d) & 1u) ? (ic[d] >= q ? ic[d] : q) : q;
-        } else {
-          c[d] += q;
-        }
+  for (int d = 0; d < 16; ++d) c[d] = 0, ic[d] = 0;
+  const uint32_t k0 = b.ctr_off[i] - b.ctr_base, k1 = b.ctr_off[i + 1] - b.ctr_base;
+  for (uint32_t k = k0; k < k1; ++k) {
+    const uint32_t pm = b.ctr_present[k];
+    const bool init = b.ctr_init[k] != 0;
+    for (int d = 0; d < D; ++d) {
+      if (!((pm >> d) & 1u)) continue;
+      const int64_t q = b.ctr_req[(int64_t)k * D + d];
+      if (init) {
+        ic[d] = ((icp >> d) & 1u) ? (ic[d] >= q ? ic[d] : q) : q;
+      } else {
+        c[d] += q;
       }
-      if (init) icp |= pm; else cp |= pm;
     }
-    for (int d = 0; d < D; ++d)
-      if ((icp >> d) & 1u) c[d] = ((cp >> d) & 1u) ? (c[d] >= ic[d] ? c[d] : ic[d]) : ic[d];
-    cp |= icp;
-    const uint32_t op = b.ovh_present[i];
-    if (op >> 31) {
-      for (int d = 0; d < D; ++d)
-        if ((op >> d) & 1u) c[d] += b.ovh[i * D + d];
-      cp |= op & 0xFFFFu;
-    }
-    cp &= (1u << D) - 1u;
-    uint32_t nz = 0;
-    for (int d = 0; d < D; ++d) nz |= (((cp >> d) & 1u) && c[d] != 0 ? 1u : 0u) << d;
-    for (int d = 0; d < pods.DS; ++d) pods.req[(int64_t)row * pods.DS + d] = (d < D && ((cp >> d) & 1u)) ? c[d] : 0;
-    pods.ns[row] = b.ns[i];
-    pods.flags[row] = (b.flags[i] & 0xFu) | (cp << kPresentShift);
-    // the record the indexed scans stream (kMeta*); the atom row follows from kt_translate_pods
-    pods.meta[row] = (uint64_t)(b.ns[i] & (uint32_t)kMetaNsMask) | (uint64_t)(b.flags[i] & 0xFu) << kMetaStateShift |
-                     (uint64_t)cp << kMetaPresentShift | (uint64_t)nz << kMetaNzShift;
-    const uint32_t l0 = b.label_off[i] - b.label_base, l1 = b.label_off[i + 1] - b.label_base;
-    for (int l = 0; l < pods.LS; ++l) {
-      const bool have = l < L && l0 + l < l1;
-      pods.lpair[(int64_t)row * pods.LS + l] = have ? b.label_pair[l0 + l] : 0u;
-      pods.lkey[(int64_t)row * pods.LS + l] = have ? b.label_key[l0 + l] : 0u;
-    }
+    if (init) icp |= pm; else cp |= pm;
   }
+  for (int d = 0; d < D; ++d)
+    if ((icp >> d) & 1u) c[d] = ((cp >> d) & 1u) ? (c[d] >= ic[d] ? c[d] : ic[d]) : ic[d];
+  cp |= icp;
+  const uint32_t op = b.ovh_present[i];
+  if (op >> 31) {
+    for (int d = 0; d < D; ++d)
+      if ((op >> d) & 1u) c[d] += b.ovh[i * D + d];
+    cp |= op & 0xFFFFu;
+  }
+  cp &= (1u << D) - 1u;
+  uint32_t nz = 0;
+  for (int d = 0; d < D; ++d) nz |= (((cp >> d) & 1u) && c[d] != 0 ? 1u : 0u) << d;
+  for (int d = 0; d < pods.DS; ++d) pods.req[(int64_t)row * pods.DS + d] = (d < D && ((cp >> d) & 1u)) ? c[d] : 0;
+  pods.ns[row] = b.ns[i];
+  pods.flags[row] = (b.flags[i] & 0xFu) | (cp << kPresentShift);
+  // the record the indexed scans stream (kMeta*); the atom row follows from kt_translate_pods
+  pods.meta[row] = (uint64_t)(b.ns[i] & (uint32_t)kMetaNsMask) | (uint64_t)(b.flags[i] & 0xFu) << kMetaStateShift |
+                   (uint64_t)cp << kMetaPresentShift | (uint64_t)nz << kMetaNzShift;
+  const uint32_t l0 = b.label_off[i] - b.label_base, l1 = b.label_off[i + 1] - b.label_base;
+  for (int l = 0; l < pods.LS; ++l) {
+    const bool have = l < L && l0 + l < l1;
+    pods.lpair[(int64_t)row * pods.LS + l] = have ? b.label_pair[l0 + l] : 0u;
+    pods.lkey[(int64_t)row * pods.LS + l] = have ? b.label_key[l0 + l] : 0u;
+  }
+}
+__global__ __launch_bounds__(kBlock) void kt_ingest_pods(PodTable pods, PodBatchDev b) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * kBlock) ingest_one(pods, b, i);
 }
 
 __global__ __launch_bounds__(kBlock) void kt_delete_pods(PodTable pods, int64_t n, const int64_t* rows) {
@@ -98,42 +99,46 @@ __device__ __forceinline__ uint32_t atom_id_of(const uint64_t* table, uint32_t m
   }
 }
 
+// one pod row; out: the thread's LA slots of LDS scratch
+template <int LA>
+__device__ __forceinline__ void translate_one(const PodTable& pods, int64_t row, const uint64_t* table, uint32_t mask, int key_atoms,
+                                              unsigned long long* n_overflow, uint16_t* out) {
+  const int LS = pods.LS;
+  uint32_t cnt = 0;
+  for (int l = 0; l < LS; ++l) {
+    const uint32_t pr = pods.lpair[row * LS + l];
+    if (pr == 0u) continue;  // empty slot
+    // one atom per label: the pair when some selector names it, else the key atom when some selector names the key
+    uint32_t id = atom_id_of(table, mask, pr);
+    if (!id && key_atoms) id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
+    if (id) {
+      if (cnt < (uint32_t)LA) out[cnt] = (uint16_t)id;
+      ++cnt;
+    }
+  }
+  for (uint32_t k = cnt; k < (uint32_t)LA; ++k) out[k] = 0;
+  const bool over = cnt > (uint32_t)LA;
+  const uint64_t m = pods.meta[row];
+  if (over) {
+    if ((m >> kMetaStateShift) & kPodValid) atomicAdd(n_overflow, 1ull);
+    pods.meta[row] = m | kMetaOverflow;
+  } else if (m & kMetaOverflow) {
+    pods.meta[row] = m & ~kMetaOverflow;
+  }
+  const kt_u32x4* src = (const kt_u32x4*)out;
+  kt_u32x4* dst = (kt_u32x4*)(pods.latom + row * LA);
+#pragma unroll
+  for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
+}
+
 template <int LA>
 __global__ __launch_bounds__(kBlock) void kt_translate_pods(PodTable pods, int64_t n, const int64_t* rows, int64_t row0,
                                                            const uint64_t* table, uint32_t mask, int key_atoms,
                                                            unsigned long long* n_overflow) {
   __shared__ __attribute__((aligned(16))) uint16_t out[kBlock][LA];
-  const int LS = pods.LS;
   for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += (int64_t)gridDim.x * kBlock) {
     const int64_t i = i0 + threadIdx.x;
-    if (i < n) {
-      const int64_t row = rows ? rows[i] : row0 + i;
-      uint32_t cnt = 0;
-      for (int l = 0; l < LS; ++l) {
-        const uint32_t pr = pods.lpair[row * LS + l];
-        if (pr == 0u) continue;  // empty slot
-        // one atom per label: the pair when some selector names it, else the key atom when some selector names the key
-        uint32_t id = atom_id_of(table, mask, pr);
-        if (!id && key_atoms) id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
-        if (id) {
-          if (cnt < (uint32_t)LA) out[threadIdx.x][cnt] = (uint16_t)id;
-          ++cnt;
-        }
-      }
-      for (uint32_t k = cnt; k < (uint32_t)LA; ++k) out[threadIdx.x][k] = 0;
-      const bool over = cnt > (uint32_t)LA;
-      const uint64_t m = pods.meta[row];
-      if (over) {
-        if ((m >> kMetaStateShift) & kPodValid) atomicAdd(n_overflow, 1ull);
-        pods.meta[row] = m | kMetaOverflow;
-      } else if (m & kMetaOverflow) {
-        pods.meta[row] = m & ~kMetaOverflow;
-      }
-      const kt_u32x4* src = (const kt_u32x4*)&out[threadIdx.x][0];
-      kt_u32x4* dst = (kt_u32x4*)(pods.latom + row * LA);
-#pragma unroll
-      for (int q = 0; q < LA / 8; ++q) dst[q] = src[q];
-    }
+    if (i < n) translate_one<LA>(pods, rows ? rows[i] : row0 + i, table, mask, key_atoms, n_overflow, &out[threadIdx.x][0]);
   }
 }
 
@@ -360,10 +365,7 @@ __global__ __launch_bounds__(256) void kt_build_scan_view(PodTable pods, int64_t
 //     stays as a record whose meta word says so (the scan's own `countable` test skips it);
 //   * a newly countable pod is appended (row-ordered list) — or, in a namespace-ordered list, raises `dirty`: the
 //     next scan then rebuilds (so does a pod that moved to another namespace).
-__global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch v) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int64_t p = rows ? rows[i] : row0 + i;
+__device__ __forceinline__ void patch_one(const PodTable& pods, int64_t p, const ViewPatch& v) {
   const uint64_t meta = pods.meta[p];
   const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
   const bool countable = (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
@@ -372,15 +374,19 @@ __global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_
     if (pos < 0 && countable) {
       if (v.by_ns) {
         *v.dirty = 1u;  // has to be sorted in
-      } else {
+      } else if (atomicCAS((int*)&v.pos_c[p], -1, -2) == -1) {
+        // (the row is claimed first: a batch that names the same row twice must not append two records — ADVICE r3)
         pos = (int64_t)atomicAdd(v.n_c, 1ull);
         if (pos >= v.cap_c) {
           *v.dirty = 1u;
+          v.pos_c[p] = -1;
           pos = -1;
         } else {
-          v.pos_c[p] = (int32_t)pos;
           v.vc_rows[pos] = p;
+          v.pos_c[p] = (int32_t)pos;
         }
+      } else {
+        pos = -1;  // another entry of this batch appends the row (its record is written from the same table content)
       }
     }
     if (pos >= 0) {
@@ -404,6 +410,56 @@ __global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_
     }
   }
 }
+__global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  patch_one(pods, rows ? rows[i] : row0 + i, v);
+}
+
+// kt_feed_small — ONE launch for a pod informer event or a handful of them (n <= 256, one workgroup): what kt_ingest_pods,
+// kt_translate_pods and kt_patch_scan_views do one after the other, per thread = pod (each phase only reads what the same
+// thread wrote in the phase before), and the overflow counter as the batch left it goes straight to the pinned word the
+// host reads after the event — three dependent launches and a copy less on the path from a pod event to the next PreFilter.
+//   do_translate: the compiled program is current (else every row is translated when it is compiled)
+//   has_patch   : there are scan views to patch
+template <int LA>
+__global__ __launch_bounds__(kBlock) void kt_feed_small(PodTable pods, PodBatchDev b, const uint64_t* table, uint32_t mask, int key_atoms,
+                                                        unsigned long long* n_overflow, int do_translate, int has_patch, const ViewPatch v,
+                                                        unsigned long long* host_overflow) {
+  __shared__ __attribute__((aligned(16))) uint16_t out[kBlock][LA];
+  const int64_t i = threadIdx.x;
+  if (i < b.n) {
+    const int64_t row = b.rows ? b.rows[i] : b.row0 + i;
+    ingest_one(pods, b, i);
+    if (do_translate) translate_one<LA>(pods, row, table, mask, key_atoms, n_overflow, &out[threadIdx.x][0]);
+    if (has_patch) patch_one(pods, row, v);
+  }
+  if (do_translate && host_overflow) {
+    __syncthreads();
+    if (threadIdx.x == 0) *host_overflow = __hip_atomic_load(n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// the same for deletes: kt_delete_pods + kt_patch_scan_views
+__global__ __launch_bounds__(kBlock) void kt_unfeed_small(PodTable pods, int64_t n, const int64_t* rows, int has_patch, const ViewPatch v) {
+  const int64_t i = threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = rows[i];
+  pods.flags[p] = 0;
+  pods.meta[p] = 0;
+  if (has_patch) patch_one(pods, p, v);
+}
+void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
+                       const ViewPatch* v, unsigned long long* host_overflow, hipStream_t s) {
+  const ViewPatch vp = v ? *v : ViewPatch{};
+  const int tr = do_translate ? 1 : 0, hp = v ? 1 : 0;
+  if (pods.LA == 8) hipLaunchKernelGGL(kt_feed_small<8>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
+  else if (pods.LA == 16) hipLaunchKernelGGL(kt_feed_small<16>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
+  else hipLaunchKernelGGL(kt_feed_small<32>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
+}
+void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, hipStream_t s) {
+  hipLaunchKernelGGL(kt_unfeed_small, dim3(1), dim3(kBlock), 0, s, pods, n, rows, v ? 1 : 0, v ? *v : ViewPatch{});
+}
+
 void launch_patch_scan_views(const PodTable& pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch& v, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(kt_patch_scan_views, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pods, n, rows, row0, v);

@@ -45,6 +45,12 @@ void launch_patch_scan_views(const PodTable& pods, int64_t n, const int64_t* row
 // exact per-dimension sums of |request| over the valid rows of [0, n): out[2d] low-half sum, out[2d+1] high-half sum (32 words)
 void launch_sum_abs_requests(const PodTable& pods, int64_t n, unsigned long long* out, hipStream_t s);
 void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev, hipStream_t s);
+// small pod event batches (n <= kFeedSmallMax) as ONE launch: ingest + translate + view patch / delete + view patch
+constexpr int64_t kFeedSmallMax = 256;
+struct IndexDev;
+void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
+                       const ViewPatch* v, unsigned long long* host_overflow, hipStream_t s);
+void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
                                 uint32_t* out_present, hipStream_t s);
 

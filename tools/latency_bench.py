@@ -9,7 +9,9 @@ the C-ABI, engine already holding the snapshot).
   upsert_pod1   kt_upsert_pods(1): a pod informer event — the call alone (packs the event into a pinned slot, enqueues
                 kt_ingest_pods + kt_translate_pods + kt_patch_scan_views, records an event; no stream synchronisation)
   upsert_pod64_per_pod  a coalesced batch of 64 events through the same call, per pod
-  upsert1_then_check1   one event + kt_check(n=1) of that pod: the check waits for the ingest (settle_ingest)
+  upsert1_then_check1   one event + kt_check(n=1) of that pod: the check waits for the ingest (settle_ingest);
+                ..._unfused: with KT_NO_FEED_FUSION=1 (kt_ingest_pods + kt_translate_pods + copy + kt_patch_scan_views
+                instead of the single kt_feed_small launch)
   upsert_pod1_blocking  the form of rounds 1-3 (KT_SYNC_INGEST=1: device staging copy + stream synchronisation)
   delete_pod1   kt_delete_pods(1)
   sweep         a full reconcile + PreFilter sweep in the steady state, and the first one after ONE pod event (which rebuilds
@@ -140,6 +142,11 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
     out["upsert_pod1"] = feed(1, n_upsert)                           # one event, the call alone
     out["upsert_pod64_per_pod"] = feed(64, max(20, n_upsert // 4))   # a coalesced batch of 64 events, per pod
     out["upsert1_then_check1"] = feed(1, n_upsert, then_check=True)  # event + PreFilter of that pod (waits for the ingest)
+    os.environ["KT_NO_FEED_FUSION"] = "1"                            # three launches + a copy instead of kt_feed_small
+    try:
+        out["upsert1_then_check1_unfused"] = feed(1, max(50, n_upsert // 2), then_check=True)
+    finally:
+        del os.environ["KT_NO_FEED_FUSION"]
     os.environ["KT_SYNC_INGEST"] = "1"                               # the blocking form of rounds 1-3, for comparison
     try:
         out["upsert_pod1_blocking"] = feed(1, max(50, n_upsert // 2))
