@@ -202,8 +202,11 @@ struct kt_engine {
   int ev_next = 0;
   std::atomic<bool> ingest_pending{false};
   hipEvent_t ingest_ev = nullptr;            // the event behind the newest asynchronous feed call
-  unsigned long long* h_overflow = nullptr;  // pinned: n_overflow as the newest asynchronous translate left it
+  unsigned long long* h_overflow = nullptr;  // pinned: n_overflow as the newest asynchronous translate left it; word 1: the
+                                             // sequence number of the last event kernel (kt_feed_small / kt_unfeed_small) that finished
   bool overflow_in_flight = false;
+  unsigned long long ingest_seq = 0;         // sequence numbers handed to the event kernels
+  unsigned long long ingest_spin_seq = 0;    // != 0: the newest asynchronous feed call signals h_overflow[1] = this (settle_ingest spins)
   DevBuf<int64_t> d_countable;                   // rows of the pods a reconcile scans (kt_compact_countable)
   DevBuf<unsigned long long> d_n_countable;
   unsigned long long n_countable = 0;
@@ -339,6 +342,7 @@ struct kt_engine {
 
   // ---- staging
   DevBuf<uint8_t> d_stage;
+  DevBuf<uint8_t> d_ev_stage;  // kt_feed_small's device copy of a pinned event slot (kEvSlotBytes, allocated once)
   uint8_t* h_stage = nullptr;  // pinned: small batches cross in one copy
 
   // ---- RCCL communicator (kt_comm_*): opaque ncclComm_t, rank / world
@@ -383,7 +387,19 @@ inline void settle_ingest(kt_engine* e) {
   std::lock_guard<std::mutex> g(e->ingest_mu);
   if (!e->ingest_pending.load(std::memory_order_acquire)) return;
   (void)hipSetDevice(e->device);
-  (void)hipEventSynchronize(e->ingest_ev);
+  bool done = false;
+  if (e->ingest_spin_seq && e->h_overflow) {
+    // the event kernel stores its sequence number into pinned memory behind a system-scope release of everything it
+    // wrote: a few microseconds of polling instead of hipEventSynchronize's 35-40 (the event is the fallback)
+    volatile unsigned long long* sq = e->h_overflow + 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0; !(done = *sq >= e->ingest_spin_seq); ++it) {
+      __builtin_ia32_pause();
+      if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) (void)hipEventSynchronize(e->ingest_ev);
   if (e->overflow_in_flight) e->n_overflow = *e->h_overflow, e->overflow_in_flight = false;
   e->ingest_pending.store(false, std::memory_order_release);
 }
@@ -774,11 +790,11 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const bool full_when_chunked = !hook && !getenv("KT_CHUNK_HALF");
     kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
                     (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L, &adm_all,
-                    full_when_chunked ? lds_all - kt::check_fixed_lds() : 0u);
+                    full_when_chunked ? lds_all - kt::check_fixed_lds() : 0u, kt::check_word_lds(D));
     lap("build_index");
     // a program that fits half the LDS as rows but still came out in several chunks (per-term tables): larger chunks
     if (full_when_chunked && e->hindex.bm_chunks.size() > 1 && e->hindex.cut_chk_budget != lds_all - kt::check_fixed_lds())
-      kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes);
+      kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, kt::check_word_lds(D));
     lap("cut_chunks (full LDS)");
   }
   kt::index_group_counts(e->hindex, (uint32_t)T);
@@ -1084,7 +1100,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
   for (auto* b : u32s) b->release();
   DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
-                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_status, &e->d_stage, &e->d_slab, &e->d_admit};
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_status, &e->d_stage, &e->d_ev_stage, &e->d_slab, &e->d_admit};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_used_hi.release(); e->d_out_used_hi.release();
@@ -1298,13 +1314,21 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
         KT_HIP(e, hipHostMalloc((void**)&slot->h, kt_engine::kEvSlotBytes, hipHostMallocDefault));
         KT_HIP(e, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
       }
-      if (!e->h_overflow) KT_HIP(e, hipHostMalloc((void**)&e->h_overflow, 64, hipHostMallocDefault));
+      if (!e->h_overflow) {
+      KT_HIP(e, hipHostMalloc((void**)&e->h_overflow, 64, hipHostMallocDefault));
+      memset(e->h_overflow, 0, 64);  // (word 1 is the sequence number settle_ingest compares with)
+    }
       if (slot->used) KT_HIP(e, hipEventSynchronize(slot->ev));  // (eight feed calls ago: long done)
     } else {
       settle_ingest(e);  // the staged path below synchronises anyway
       KT_HIP(e, e->d_stage.reserve(off + 16));
     }
-    uint8_t* st = slot_path ? slot->h : e->d_stage.p;
+    // ONE launch (kt_feed_small) for an event batch: the workgroup first pulls the whole slot over the link with all its
+    // threads, the batch pointers name that device copy (KT_FEED_NO_STAGE=1: the kernel walks the slot over the link)
+    const bool fused = slot_path && cn <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION");
+    const bool dev_copy = fused && !getenv_flag("KT_FEED_NO_STAGE");
+    if (dev_copy) KT_HIP(e, e->d_ev_stage.reserve(kt_engine::kEvSlotBytes));
+    uint8_t* st = dev_copy ? e->d_ev_stage.p : slot_path ? slot->h : e->d_stage.p;
     // a small batch is packed in pinned host memory and crosses in ONE copy; a bulk load copies its sections straight
     // from the caller's arrays
     const bool packed = !slot_path && off <= kPinnedStageBytes;
@@ -1349,18 +1373,22 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     // incremental engines: out with the old content of these rows, in with the new (a row that is not valid yet /
     // any more contributes nothing either way)
     if (e->incremental && e->program_dirty) e->agg_valid = false;  // selectors changed: the next reconcile rescans
-    if (slot_path && cn <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION")) {
+    if (fused) {
       // ONE launch: ingest + translate + view patch, the overflow counter straight into the pinned word
       const bool tr = !e->program_dirty && e->pods.latom;
       kt::ViewPatch v{};
       if (patch) v = view_patch_of(e, cn);
-      kt::launch_feed_small(e->pods, pb, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, s);
+      const bool spin = !getenv_flag("KT_INGEST_EVENT_WAIT");  // (A/B: wait on the event as the first form of this path did)
+      const unsigned long long seq = ++e->ingest_seq;
+      kt::launch_feed_small(e->pods, pb, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, dev_copy ? slot->h : nullptr,
+                            dev_copy ? e->d_ev_stage.p : nullptr, dev_copy ? (uint32_t)off : 0u, spin ? e->h_overflow + 1 : nullptr, seq, s);
       KT_HIP(e, hipGetLastError());
       if (tr) e->overflow_in_flight = true;
       KT_HIP(e, hipEventRecord(slot->ev, s));
       slot->used = true;
       std::lock_guard<std::mutex> g(e->ingest_mu);
       e->ingest_ev = slot->ev;
+      e->ingest_spin_seq = spin ? seq : 0ull;
       e->ingest_pending.store(true, std::memory_order_release);
       continue;
     }
@@ -1385,6 +1413,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       slot->used = true;
       std::lock_guard<std::mutex> g(e->ingest_mu);
       e->ingest_ev = slot->ev;
+      e->ingest_spin_seq = 0ull;  // several kernels: the event says when the last one is done
       e->ingest_pending.store(true, std::memory_order_release);
     } else {
       KT_HIP(e, hipStreamSynchronize(s));  // staging buffer is reused by the next chunk
@@ -1445,10 +1474,16 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
     e->order_all_valid = false;
   }
   if (e->incremental && e->program_dirty) e->agg_valid = false;
+  unsigned long long spin_seq = 0ull;
   if (slot_path && n <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION")) {
     kt::ViewPatch v{};
     if (patch) v = view_patch_of(e, n);
-    kt::launch_unfeed_small(e->pods, n, rows_dev, patch ? &v : nullptr, e->own_stream);
+    if (!e->h_overflow) {
+      KT_HIP(e, hipHostMalloc((void**)&e->h_overflow, 64, hipHostMallocDefault));
+      memset(e->h_overflow, 0, 64);  // (word 1 is the sequence number settle_ingest compares with)
+    }
+    if (!getenv_flag("KT_INGEST_EVENT_WAIT")) spin_seq = ++e->ingest_seq;
+    kt::launch_unfeed_small(e->pods, n, rows_dev, patch ? &v : nullptr, spin_seq ? e->h_overflow + 1 : nullptr, spin_seq, e->own_stream);
     KT_HIP(e, hipGetLastError());
   } else {
     int32_t drc = delta_scan(e, n, rows_dev, 0, -1, e->own_stream);
@@ -1464,6 +1499,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
     slot->used = true;
     std::lock_guard<std::mutex> g(e->ingest_mu);
     e->ingest_ev = slot->ev;
+    e->ingest_spin_seq = spin_seq;
     e->ingest_pending.store(true, std::memory_order_release);
   } else {
     KT_HIP(e, hipStreamSynchronize(e->own_stream));

@@ -45,7 +45,7 @@
 namespace kt {
 
 constexpr uint32_t kKeyAtom = 0x80000000u;
-constexpr uint32_t kCheckWordLds = 64u * 8u + 176u;  // = check_word_lds(): TermInfo[64] + WordVerdict<16> per word
+constexpr uint32_t kCheckWordLds = 64u * 8u + 560u;  // = check_word_lds(16): TermInfo[64] + WordVerdict<16> per word (the worst case)
 
 // term_t[] entry of a chunk image: throttle row | flags
 constexpr uint32_t kTermAdj = 0x80000000u;   // multi-term throttle: a match repeating the lane's previous throttle is dropped
@@ -91,6 +91,7 @@ struct BmChunk {
   uint32_t slab_off;  // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
   uint32_t has_slow;  // some term of the chunk needs the generic walk
   uint32_t img_bytes;
+  uint32_t has_adj;   // some throttle of the chunk has several terms (the check's wordwise form then applies its run masks)
 };
 
 struct AtomId {
@@ -219,7 +220,7 @@ struct IndexDev {
 };
 
 // LDS budgets: a chunk must satisfy
-//   check     : lds_bytes + n_words*kCheckWordLds (term info + verdict masks) <= chk_budget
+//   check     : lds_bytes + n_words*chk_word (term info + verdict masks: check_word_lds(D)) <= chk_budget
 //   aggregate : lds_bytes + n_words*64*2 (ranks) + n_thr * thr_bytes      <= agg_budget
 // (both kernels lay LDS out once, for the maxima over all chunks, so the maxima have to fit too).
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
@@ -228,7 +229,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
-                 int max_labels, const std::vector<uint32_t>* adm_in = nullptr, uint32_t chk_budget_full = 0);
+                 int max_labels, const std::vector<uint32_t>* adm_in = nullptr, uint32_t chk_budget_full = 0,
+                 uint32_t chk_word = kCheckWordLds);
 // adm_in (optional): the namespace admission set of every term as bit words [terms][(n_ns + 31) / 32] (= ns_term_ok
 // transposed), when the caller holds it already; chk_budget_full (optional): the check budget to cut for when the
 // program needs several chunks anyway (one cut instead of two)
@@ -236,7 +238,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
 void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t nsw, uint32_t n_ns, uint32_t gw, std::vector<uint32_t>& out);
 void parallel_for(size_t n, size_t min_per_part, const std::function<void(size_t, size_t, size_t)>& f, size_t* parts_out);
 // chunk images of an index build_index numbered, for other LDS budgets (no renumbering)
-void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes);
+// chk_word: the check kernel's LDS bytes per word beside the image (check_word_lds(D); the default is the worst case)
+void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, uint32_t chk_word = kCheckWordLds);
 // groups per throttle row and the rows without any, from bm_rank_t (after the final cut)
 void index_group_counts(HostIndex& h, uint32_t T);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);
@@ -255,7 +258,7 @@ struct SelProgram;
 // LDS the two scan kernels need beside the chunk image and its per-term / per-throttle tables
 uint32_t aggregate_fixed_lds();
 uint32_t check_fixed_lds();
-uint32_t check_word_lds();  // check: bytes per 64-bit word of term numbers beside the image (TermInfo + WordVerdict)
+uint32_t check_word_lds(int D);  // check: bytes per 64-bit word of term numbers beside the image (TermInfo + WordVerdict<DT>)
 // which pods an aggregate scan covers and how they enter the target buffer
 struct AggScan {
   int64_t n = 0;                 // pods

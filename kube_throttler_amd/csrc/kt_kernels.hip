@@ -416,17 +416,34 @@ __global__ __launch_bounds__(256) void kt_patch_scan_views(PodTable pods, int64_
   patch_one(pods, rows ? rows[i] : row0 + i, v);
 }
 
+// The completion signal of the event kernels: everything the workgroup wrote is made visible device-wide (a release fence
+// at system scope writes the XCD's L2 back), then the sequence number goes to the pinned word the host spins on —
+// hipEventSynchronize on the event behind such a kernel took 35-40 us of the 47 us from a pod event to the PreFilter
+// that sees it (`latency.upsert1_then_check1`); the event stays as the fallback and for the slot's reuse.
+__device__ __forceinline__ void signal_host(unsigned long long* host_seq, unsigned long long seq) {
+  if (!host_seq) return;
+  __threadfence_system();
+  __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // kt_feed_small — ONE launch for a pod informer event or a handful of them (n <= 256, one workgroup): what kt_ingest_pods,
 // kt_translate_pods and kt_patch_scan_views do one after the other, per thread = pod (each phase only reads what the same
 // thread wrote in the phase before), and the overflow counter as the batch left it goes straight to the pinned word the
 // host reads after the event — three dependent launches and a copy less on the path from a pod event to the next PreFilter.
 //   do_translate: the compiled program is current (else every row is translated when it is compiled)
 //   has_patch   : there are scan views to patch
+//   stage_src / stage_dst / stage_bytes: the batch lies in a pinned HOST slot; the workgroup first copies it to device
+//                 scratch with all its threads (one trip over the link, 16 bytes per thread and pass) — `b` points into the
+//                 copy — instead of every thread walking offsets -> containers -> requests over the link one dependent
+//                 access after the other
 template <int LA>
 __global__ __launch_bounds__(kBlock) void kt_feed_small(PodTable pods, PodBatchDev b, const uint64_t* table, uint32_t mask, int key_atoms,
                                                         unsigned long long* n_overflow, int do_translate, int has_patch, const ViewPatch v,
-                                                        unsigned long long* host_overflow) {
+                                                        unsigned long long* host_overflow, const u128* stage_src, u128* stage_dst, uint32_t stage_bytes,
+                                                        unsigned long long* host_seq, unsigned long long seq) {
   __shared__ __attribute__((aligned(16))) uint16_t out[kBlock][LA];
+  for (uint32_t o = threadIdx.x; o < (stage_bytes + 15u) / 16u; o += kBlock) stage_dst[o] = stage_src[o];
+  __syncthreads();
   const int64_t i = threadIdx.x;
   if (i < b.n) {
     const int64_t row = b.rows ? b.rows[i] : b.row0 + i;
@@ -434,30 +451,39 @@ __global__ __launch_bounds__(kBlock) void kt_feed_small(PodTable pods, PodBatchD
     if (do_translate) translate_one<LA>(pods, row, table, mask, key_atoms, n_overflow, &out[threadIdx.x][0]);
     if (has_patch) patch_one(pods, row, v);
   }
-  if (do_translate && host_overflow) {
-    __syncthreads();
-    if (threadIdx.x == 0) *host_overflow = __hip_atomic_load(n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (do_translate && host_overflow) *host_overflow = __hip_atomic_load(n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    signal_host(host_seq, seq);
   }
 }
 // the same for deletes: kt_delete_pods + kt_patch_scan_views
-__global__ __launch_bounds__(kBlock) void kt_unfeed_small(PodTable pods, int64_t n, const int64_t* rows, int has_patch, const ViewPatch v) {
+__global__ __launch_bounds__(kBlock) void kt_unfeed_small(PodTable pods, int64_t n, const int64_t* rows, int has_patch, const ViewPatch v,
+                                                          unsigned long long* host_seq, unsigned long long seq) {
   const int64_t i = threadIdx.x;
-  if (i >= n) return;
-  const int64_t p = rows[i];
-  pods.flags[p] = 0;
-  pods.meta[p] = 0;
-  if (has_patch) patch_one(pods, p, v);
+  if (i < n) {
+    const int64_t p = rows[i];
+    pods.flags[p] = 0;
+    pods.meta[p] = 0;
+    if (has_patch) patch_one(pods, p, v);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) signal_host(host_seq, seq);
 }
 void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
-                       const ViewPatch* v, unsigned long long* host_overflow, hipStream_t s) {
+                       const ViewPatch* v, unsigned long long* host_overflow, const void* stage_src, void* stage_dst, uint32_t stage_bytes,
+                       unsigned long long* host_seq, unsigned long long seq, hipStream_t s) {
   const ViewPatch vp = v ? *v : ViewPatch{};
   const int tr = do_translate ? 1 : 0, hp = v ? 1 : 0;
-  if (pods.LA == 8) hipLaunchKernelGGL(kt_feed_small<8>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
-  else if (pods.LA == 16) hipLaunchKernelGGL(kt_feed_small<16>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
-  else hipLaunchKernelGGL(kt_feed_small<32>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow);
+  const u128* ss = (const u128*)stage_src;
+  u128* sd = (u128*)stage_dst;
+  if (pods.LA == 8) hipLaunchKernelGGL(kt_feed_small<8>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
+  else if (pods.LA == 16) hipLaunchKernelGGL(kt_feed_small<16>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
+  else hipLaunchKernelGGL(kt_feed_small<32>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
 }
-void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, hipStream_t s) {
-  hipLaunchKernelGGL(kt_unfeed_small, dim3(1), dim3(kBlock), 0, s, pods, n, rows, v ? 1 : 0, v ? *v : ViewPatch{});
+void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, unsigned long long* host_seq,
+                         unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(kt_unfeed_small, dim3(1), dim3(kBlock), 0, s, pods, n, rows, v ? 1 : 0, v ? *v : ViewPatch{}, host_seq, seq);
 }
 
 void launch_patch_scan_views(const PodTable& pods, int64_t n, const int64_t* rows, int64_t row0, const ViewPatch& v, hipStream_t s) {

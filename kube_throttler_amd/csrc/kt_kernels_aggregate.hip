@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
             if (ok) {
               last_r = r;
-              KT_LDS unsigned char* rp = tab + r * rec;  // the throttle's record
+              KT_LDS unsigned char* rp = tab + __umul24(r, rec);  // the throttle's record (rank < 2^15, record <= 272 bytes)
               lds_u64wp tv = (lds_u64wp)rp;
               if constexpr (PK) {
 #pragma unroll

@@ -32,9 +32,13 @@ struct alignas(16) WordVerdict {
   uint64_t seg_lo, seg_hi;
   uint64_t tight;      // kRecTight: the request row has to be compared with thr[] / head[]
   uint64_t exc;        // kRecExceedsByCount
-  uint64_t act;        // kRecActiveByCount
+  uint64_t act;        // kRecActiveByCount (also folded into act_nib[0][*])
   uint64_t ins;        // kRecInsufficientByCount
-  uint64_t act_d[DT];  // active_mask bit d: a pod that requests dimension d is `active`
+  // "a pod that requests dimension d is `active`" (active_mask bit d), tabulated per NIBBLE of the pod's non-zero mask:
+  // act_nib[q][v] = act | OR of the masks of the dimensions 4q + b with bit b of v set — a lane gets its pod's `active`
+  // terms of the word with DT / 4 eight-byte reads and as many ORs (round 3 read DT masks and selected them one by one:
+  // 4 b128 reads, 24 VALU and 16 registers per visited word at DT = 8)
+  uint64_t act_nib[DT / 4][16];
 };
 // TermInfo word 0: throttle row | kTiAdj
 //          word 1: active_mask (16 bits) | counter shift when the pod requests an active dimension << 16
@@ -93,8 +97,10 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
 }
 
 uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
-static_assert(sizeof(WordVerdict<16>) == 176 && 64u * 8u + sizeof(WordVerdict<16>) == kCheckWordLds, "kCheckWordLds (kt_index.h) follows WordVerdict");
-uint32_t check_word_lds() { return 64u * 8u + (uint32_t)sizeof(WordVerdict<16>); }  // TermInfo + WordVerdict per 64-bit word
+static_assert(sizeof(WordVerdict<16>) == 560 && 64u * 8u + sizeof(WordVerdict<16>) == kCheckWordLds, "kCheckWordLds (kt_index.h) follows WordVerdict");
+static_assert(sizeof(WordVerdict<8>) == 304, "WordVerdict<8>");
+// TermInfo + WordVerdict per 64-bit word, for an engine with D dimensions
+uint32_t check_word_lds(int D) { return 64u * 8u + (uint32_t)(D <= 8 ? sizeof(WordVerdict<8>) : sizeof(WordVerdict<16>)); }
 
 // SMALL: a launch of a few pods (one PreFilter call, an admission queue): grid = (chunks, tiles), every workgroup scans
 //        ONE tile against ONE chunk, so that the chunks of a large program are walked side by side instead of one after
@@ -107,11 +113,20 @@ template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;
   // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
-  // being peeled one by one.  Pays when a pod matches several terms per word (measured: config 4's 130 matches per pod,
-  // check 1.27 -> 0.92 ms); with a match or two per pod the peel is cheaper and the masks' registers do not fit the
-  // 64-VGPR budget of the two-workgroups-per-CU instantiation (config 2: 33.6 -> 38.2 us, 56 B of scratch), which
-  // therefore keeps the peel.
+  // being peeled one by one: three popcounts per visited word, and only the matches of tight throttles go through the
+  // peel.  Round 3 had it in the one-workgroup-per-CU instantiation only (config 4's 130 matches per pod: 1.27 -> 0.92 ms):
+  // with one mask per dimension its registers did not fit the 64-VGPR budget of the two-per-CU one (config 2: 33.6 -> 38.2
+  // us, 56 B of scratch).  With the per-nibble tables (WordVerdict::act_nib) a visit holds 12 mask registers instead of
+  // 28, and the two-per-CU instantiation takes it too: config 2's peel was 10.7 steps per tile at 21 % busy lanes,
+  // half of the kernel's instructions (KT_CHECK_PEEL=1 at build time restores the peel there: A/B).
+#ifdef KT_CHECK_PEEL
   constexpr bool WORDWISE = !FULL && WPE < 8;
+#else
+  constexpr bool WORDWISE = !FULL;
+#endif
+  // the verdict masks of a word are requested together with its atom rows (scan_tile's pre hook) where registers allow;
+  // the 64-VGPR instantiation reads them when the rows have been consumed
+  constexpr bool PREFETCH = WPE < 8;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
@@ -174,13 +189,17 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const uint64_t m_tight = __ballot(real && (rf.x & kRecTight) != 0), m_exc = __ballot(real && xc);
           const uint64_t m_act = __ballot(real && (rf.x & kRecActiveByCount) != 0), m_ins = __ballot(real && (rf.x & kRecInsufficientByCount) != 0);
           KT_LDS WordVerdict<DT>* wvp = (KT_LDS WordVerdict<DT>*)(lds + a.off_wv) + (c >> 6);
-          uint64_t mine = ln == 0u ? m_lo : ln == 1u ? m_hi : ln == 2u ? m_tight : ln == 3u ? m_exc : ln == 4u ? m_act : m_ins;
+          const uint64_t mine = ln == 0u ? m_lo : ln == 1u ? m_hi : ln == 2u ? m_tight : ln == 3u ? m_exc : ln == 4u ? m_act : m_ins;
+          // act_nib[q][v], entry e = 16 q + v: lane e (and lane e - 64 ... : DT = 16 has 64 entries, one per lane)
+          const uint32_t eq = ln >> 4, ev = ln & 15u;
+          uint64_t tab = m_act;
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             const uint64_t m = __ballot(real && ((rf.y >> d) & 1u) != 0);
-            mine = ln == 6u + (uint32_t)d ? m : mine;
+            tab |= ((uint32_t)(d >> 2) == eq && ((ev >> (d & 3)) & 1u)) ? m : 0ull;
           }
-          if (ln < 6u + (uint32_t)DT) ((KT_LDS uint64_t*)wvp)[ln] = mine;
+          if (ln < 6u) ((KT_LDS uint64_t*)wvp)[ln] = mine;
+          if (ln < 4u * (uint32_t)DT) ((KT_LDS uint64_t*)wvp)[6u + ln] = tab;
         }
       }
     }
@@ -305,45 +324,65 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       } else {
       // every match that needs no comparison is settled per WORD with mask algebra (WordVerdict), the matches of tight
       // throttles are peeled into the list as bare term numbers
-      KT_LDS const WordVerdict<DT>* wv = (KT_LDS const WordVerdict<DT>*)(lds + a.off_wv);
-      // the word's verdict masks are requested as soon as the word is known (pre), so that they arrive with the atom rows
+      KT_LDS const unsigned char* wv = lds + a.off_wv;
+      // this pod's entries of the per-nibble `active` tables, as byte offsets into a word's WordVerdict (kept in registers
+      // where there is room; the 64-VGPR instantiation recomputes them from the non-zero mask per visited word)
+      auto nib_offset = [&](int q) { return (uint32_t)offsetof(WordVerdict<DT>, act_nib) + (uint32_t)q * 128u + ((nz >> (4 * q)) & 15u) * 8u; };
+      uint32_t nib_off[DT / 4];
+#pragma unroll
+      for (int q = 0; q < DT / 4; ++q) nib_off[q] = PREFETCH ? nib_offset(q) : 0u;
+      const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
+      // class counters of this tile (v_bcnt accumulates); they start from what the earlier chunks carried over
+      uint32_t n_exc = (uint32_t)(my >> 4) & 0xFFFFFu, n_act = (uint32_t)(my >> 24) & 0xFFFFFu, n_ins = (uint32_t)(my >> 44);
       struct VerdictRegs {
         u64x2 seg, te, ai;
-        u64x2 ad[DT / 2];
+        uint64_t nib[DT / 4];
       };
-      scan_tile<LA, VETO, NEED, (VETO && WPE < 8)>(
-          bm, scan_on, ns, ro,
-          [&](bool has, uint32_t c) { push(has, c); },
-          [&](uint32_t c) {
-            return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
-          },
-          [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
-            // a throttle with several terms is reported once: the lowest match of every run
-            const uint64_t v = x | q.seg.y;
-            x &= (v ^ (v - q.seg.x)) & v;
-            uint64_t act = q.ai.x;
+      auto fetch = [&](uint32_t w) -> VerdictRegs {
+        KT_LDS const unsigned char* q = wv + __umul24(w, (uint32_t)sizeof(WordVerdict<DT>));
+        VerdictRegs r;
+        r.seg = u64x2{0ull, 0ull};
+        if (seg_on) r.seg = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, seg_lo));  // {seg_lo, seg_hi}
+        r.te = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, tight));              // {tight, exc}
+        r.ai = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, act));                // {act, ins}
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-              const uint64_t m = 0ull - (uint64_t)((nz >> d) & 1u);  // all ones when the pod requests dimension d
-              act |= ((d & 1) ? q.ad[d / 2].y : q.ad[d / 2].x) & m;
-            }
-            const uint64_t xf = x & ~q.te.x & ~q.te.y;  // settled here, not exceeded by count
-            const uint64_t n_exc = (uint64_t)__popcll(x & ~q.te.x & q.te.y);
-            const uint64_t n_act = (uint64_t)__popcll(xf & act);
-            const uint64_t n_ins = (uint64_t)__popcll(xf & ~act & q.ai.y);
-            my += n_exc << 4 | n_act << 24 | n_ins << 44;
-            return x & q.te.x;
-          },
-          [&](uint32_t w) -> VerdictRegs {
-            KT_LDS const WordVerdict<DT>* q = wv + w;
-            VerdictRegs r;
-            r.seg = *(KT_LDS const u64x2*)&q->seg_lo;  // {seg_lo, seg_hi}
-            r.te = *(KT_LDS const u64x2*)&q->tight;    // {tight, exc}
-            r.ai = *(KT_LDS const u64x2*)&q->act;      // {act, ins}
+        for (int k = 0; k < DT / 4; ++k) r.nib[k] = *(KT_LDS const unsigned long long*)(q + (PREFETCH ? nib_off[k] : nib_offset(k)));
+        return r;
+      };
+      auto settle = [&](uint64_t x, const VerdictRegs& q) -> uint64_t {
+        if (seg_on) {  // a throttle with several terms is reported once: the lowest match of every run
+          const uint64_t v = x | q.seg.y;
+          x &= (v ^ (v - q.seg.x)) & v;
+        }
+        uint64_t act = q.nib[0];  // (act-by-count is part of every entry of nibble 0's table)
 #pragma unroll
-            for (int d = 0; d < DT / 2; ++d) r.ad[d] = *(KT_LDS const u64x2*)&q->act_d[2 * d];
-            return r;
-          });
+        for (int k = 1; k < DT / 4; ++k) act |= q.nib[k];
+        const uint64_t xe = x & ~q.te.x & q.te.y;   // exceeded by count
+        const uint64_t xf = x & ~q.te.x & ~q.te.y;  // settled here, not exceeded by count
+        const uint64_t xa = xf & act, xi = xf & ~act & q.ai.y;
+        n_exc += (uint32_t)__popc((uint32_t)xe) + (uint32_t)__popc((uint32_t)(xe >> 32));
+        n_act += (uint32_t)__popc((uint32_t)xa) + (uint32_t)__popc((uint32_t)(xa >> 32));
+        n_ins += (uint32_t)__popc((uint32_t)xi) + (uint32_t)__popc((uint32_t)(xi >> 32));
+        return x & q.te.x;
+      };
+      auto confirm_slow = [&](uint32_t c) {
+        return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
+      };
+      auto peel_tight = [&](bool has, uint32_t c) { push(has, c); };
+      if constexpr (PREFETCH) {
+        scan_tile<LA, VETO, NEED, VETO>(
+            bm, scan_on, ns, ro, peel_tight, confirm_slow,
+            [&](uint32_t, uint64_t x, const VerdictRegs& q) -> uint64_t { return settle(x, q); },
+            [&](uint32_t w) -> VerdictRegs { return fetch(w); });
+      } else {
+        scan_tile<LA, VETO, NEED, false>(
+            bm, scan_on, ns, ro, peel_tight, confirm_slow,
+            [&](uint32_t w, uint64_t x, int) -> uint64_t {
+              if (__ballot(x != 0ull) == 0ull) return 0ull;  // nobody of the tile matched a term of this word
+              return settle(x, fetch(w));
+            });
+      }
+      my = (unsigned long long)n_exc << 4 | (unsigned long long)n_act << 24 | (unsigned long long)n_ins << 44;
       }
       if (n_list) drain();
       // ---- lane = pod: the 8-byte summary word
@@ -411,7 +450,8 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
   const size_t lds_bytes = bm_total;
   // two workgroups per CU (8 waves per SIMD) when two LDS footprints fit; KT_CHECK_WGS_PER_CU=1 forces one (A/B runs)
-  static const int force_wgs = getenv("KT_CHECK_WGS_PER_CU") ? atoi(getenv("KT_CHECK_WGS_PER_CU")) : 0;
+  const char* force_env = getenv("KT_CHECK_WGS_PER_CU");  // (read per launch: tests switch it)
+  const int force_wgs = force_env ? atoi(force_env) : 0;
   const bool small = sm != nullptr && n <= kCheckSmallMax;
   if (small) {
     (void)hipMemsetAsync(summary, 0, (size_t)n * 8, s);  // the counters meet by atomics

@@ -49,8 +49,10 @@ void launch_delete_pods(const PodTable& pods, int64_t n, const int64_t* rows_dev
 constexpr int64_t kFeedSmallMax = 256;
 struct IndexDev;
 void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
-                       const ViewPatch* v, unsigned long long* host_overflow, hipStream_t s);
-void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, hipStream_t s);
+                       const ViewPatch* v, unsigned long long* host_overflow, const void* stage_src, void* stage_dst, uint32_t stage_bytes,
+                       unsigned long long* host_seq, unsigned long long seq, hipStream_t s);
+void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, unsigned long long* host_seq,
+                         unsigned long long seq, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,
                                 uint32_t* out_present, hipStream_t s);
 

@@ -105,6 +105,9 @@ def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True),
             st_g, sm_g = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=True)
             np.testing.assert_array_equal(st_g, st_w, err_msg=f"status matrix on_equal={on_equal}")
             np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"summary on_equal={on_equal}")
+            # the PreFilter sweep proper (summary words only: the lean / wordwise instantiations of the check kernel)
+            _, sm_l = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=False)
+            np.testing.assert_array_equal(sm_l, sm_w, err_msg=f"summary of the lean sweep on_equal={on_equal}")
         return st_w, sm_w, want
     finally:
         eng.close()
@@ -117,6 +120,20 @@ def test_random_small_rich(seed, variant, oracle_mod):
     snap = W.generate(W.small(seed=seed))
     st, sm, rec = run_full_parity(snap, oracle_mod, variant)
     assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED, S.ACTIVE}
+
+
+@pytest.mark.parametrize("shape", ["simple-multiterm", "rich-16-dims", "simple-12-dims", "rich-one-per-cu"])
+def test_lean_sweep_shapes(shape, oracle_mod, monkeypatch):
+    """The PreFilter sweep (summary words only) settles matches per 64-bit word with the WordVerdict masks and the
+    per-nibble `active` tables: the simple and the rich instantiation, two workgroups per CU and one, 8 and 16 dimension
+    slots (two / four nibbles), throttles with several terms (run masks) — run_full_parity compares the lean sweep too."""
+    cfg = {"simple-multiterm": W.small(seed=31, n_pods=3000, n_thr=96, n_cluster=48, rich_ops=0, terms=(1, 3), reqs=(1, 2)),
+           "rich-16-dims": W.small(seed=32, n_pods=3000, n_thr=96, n_cluster=48, D=16),
+           "simple-12-dims": W.small(seed=33, n_pods=3000, n_thr=96, n_cluster=48, D=12, rich_ops=0, terms=(1, 2), reqs=(1, 2)),
+           "rich-one-per-cu": W.small(seed=34, n_pods=3000, n_thr=96, n_cluster=48)}[shape]
+    if shape == "rich-one-per-cu":
+        monkeypatch.setenv("KT_CHECK_WGS_PER_CU", "1")
+    run_full_parity(W.generate(cfg), oracle_mod, E.VARIANT_INDEXED)
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=VIDS)

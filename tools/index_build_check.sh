@@ -3,12 +3,12 @@
 # everything the device gets must not move — on the random suite of index_sim_test and on the real selector programs of
 # BASELINE configs[2] and the configs[4] shard — and the phase times tell what the change bought (minimum of 12 builds,
 # single-threaded unless THREADS is set).       usage: tools/index_build_check.sh
-# The pinned values are those of the round-3 layout; a change of the index LAYOUT moves them on purpose (re-pin here and
+# The pinned values are those of the round-4 layout (classes numbered larger-first, BmChunk::has_adj, check words of 1072 B in the simulator); a change of the index LAYOUT moves them on purpose (re-pin here and
 # in tests/test_host_cpu.py after the GPU parity tests have passed on the new layout).
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
-WANT="0bbc04af4b86bec0 ba41aa232eaa3d41 abc588a8bdcd55be"
+WANT="910654f0285ce8d4 853433156406dca8 550ee9c06b34ca3e"
 make -C kube_throttler_amd/csrc 2>&1 | grep -E "error|warning"
 make -C kube_throttler_amd/host index_sim_test 2>&1 | grep -E "error|warning"
 for c in 2 4; do
