@@ -9,6 +9,22 @@ namespace kt {
 // same bytes, so that the reduction streams whole records as 16-byte pieces
 __host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool counts) { return n_thr * agg_rec_bytes(D, counts); }
 
+// what a tile needs of its 64 pods before it can start (kt_aggregate_bitmap's fetch_tile)
+template <int DT, int LA, bool PK>
+struct TileRecAgg {
+  int64_t p;
+  uint64_t meta;
+  u32x4 raw[LA / 8];
+  int64_t v[PK ? 1 : DT];             // plain fold: the request row
+  unsigned long long pw[PK ? 4 : 1];  // packed fold: the packed words
+};
+// (requesting a tile's records ahead of the tile: measured, not kept — see kTilePrefetch in kt_kernels_check.hip)
+#ifdef KT_TILE_PREFETCH
+constexpr bool kAggPrefetch = true;
+#else
+constexpr bool kAggPrefetch = false;
+#endif
+
 struct BmAggArgs {
   const uint64_t* meta;  // pod tables
   const uint16_t* latom;
@@ -113,33 +129,66 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const uint32_t rec = PK ? a.pk.rec_bytes : agg_rec_bytes(D, counts);
     const uint32_t tab_bytes = (n_thr * rec + 15u) & ~15u;
     KT_LDS unsigned char* tab = lds + a.off_tab;
+    // the tile's records — meta word, atom row AND the request words: every lane's, so that the request does not hang off
+    // the meta word by another trip to memory (kAggPrefetch: requested ahead of the tile — measured, not kept)
+    const int64_t wt0 = by_ns ? t_lo + wave : (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
+    const int64_t wt_step = by_ns ? (int64_t)(kBlockIx / kWave) : wstep;
+    auto fetch_tile = [&](int64_t wt) {
+      TileRecAgg<DT, LA, PK> r;
+      const int64_t ic = min(wt * kWave + lane, n_rows - 1);
+      r.p = a.rows ? a.rows[ic] : a.row0 + ic;
+      r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
+      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
+      if constexpr (!PK) {
+        load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : r.p, r.v);
+      } else {
+        const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
+        const u64x2 q0 = q[0];
+        r.pw[0] = q0.x, r.pw[1] = q0.y, r.pw[2] = 0ull, r.pw[3] = 0ull;
+        if (a.pk.stride > 2u) {
+          const u64x2 q1 = q[1];
+          r.pw[2] = q1.x, r.pw[3] = q1.y;
+        }
+      }
+      return r;
+    };
+    TileRecAgg<DT, LA, PK> cur{};
+    if (kAggPrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
     lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
-    int64_t wt = by_ns ? t_lo + wave : (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-    for (; wt < t_hi; wt += by_ns ? (int64_t)(kBlockIx / kWave) : wstep) {
-      // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off)
+    for (int64_t wt = wt0; wt < t_hi; wt += wt_step) {
+      // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
+      //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
+      if (!kAggPrefetch) cur = fetch_tile(wt);
       const int64_t i = wt * kWave + lane;
       const bool in = i < n_rows;
-      const int64_t ic = min(i, n_rows - 1);
-      const int64_t p = a.rows ? a.rows[ic] : a.row0 + ic;
-      const uint64_t meta = by_ns ? a.v_meta[ic] : a.meta[p];
+      const int64_t p = cur.p;
+      const uint64_t meta = cur.meta;
       u32x4 raw[LA / 8];
-      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : p, raw);
+#pragma unroll
+      for (int q = 0; q < LA / 8; ++q) raw[q] = cur.raw[q];
       const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
       // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
       // (isNotFinished, pod_util.go:26-28) and only matter for error detection (slow list)
       const bool countable = in && (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
       const bool counted = countable && !(st & kPodFinished);
-      if (__ballot(countable) == 0ull) continue;
+      TileRecAgg<DT, LA, PK> nxt{};  // (only looked at when there is a next tile)
+      if (__ballot(countable) == 0ull) {
+        if (kAggPrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);
+        cur = nxt;
+        continue;
+      }
       const uint32_t ns = countable ? (uint32_t)(meta & kMetaNsMask) : 0u;
       const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
       // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
       // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
       const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
-      // ResourceAmountOfPod: the request row (or its packed words), for counted pods only (exec-masked 128-bit loads)
+      // ResourceAmountOfPod: the request row (or its packed words) travelled with the record — every lane's, so that
+      // the request does not hang off the meta word by another trip to memory; what a pod that is not counted brought
+      // is dropped here
       int64_t v[DT];             // plain fold (dead in the PK instantiations)
       unsigned long long pw[4];  // packed fold (dead in the others)
 #pragma unroll
@@ -147,21 +196,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
 #pragma unroll
       for (int k = 0; k < 4; ++k) pw[k] = 0ull;
       if constexpr (!PK) {
-        if (counted) load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : p, v);
-        if (a.limb) {
 #pragma unroll
-          for (int d = 0; d < DT; ++d) v[d] = limb_of(v[d], a.limb);
-        }
+        for (int d = 0; d < DT; ++d) v[d] = counted ? limb_of(cur.v[d], a.limb) : 0;
       } else {
-        if (counted) {
-          const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
-          const u64x2 q0 = q[0];
-          pw[0] = q0.x, pw[1] = q0.y;
-          if (a.pk.stride > 2u) {
-            const u64x2 q1 = q[1];
-            pw[2] = q1.x, pw[3] = q1.y;
-          }
-        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = counted ? cur.pw[k] : 0ull;
       }
       const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
       uint32_t ro[LA];
@@ -194,6 +233,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
           for (int t = 0; t < a.T; ++t) walk_one((uint32_t)t, overflow);
       }
 
+      // the next tile's records: in flight during this tile's scan where the registers are there (the packed fold)
+      const bool more = wt + wt_step < t_hi;  // wave-uniform
+      constexpr bool EARLY = PK && LA <= 16;  // (32 atom slots: the second record does not fit the registers)
+      if (kAggPrefetch && EARLY && more) nxt = fetch_tile(wt + wt_step);
       uint32_t last_r = 0xFFFFFFFFu;
       scan_tile<LA, VETO, NEED, VETO>(
           bm, scan_counted, ns, ro,
@@ -231,6 +274,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
           [&](uint32_t c) {
             return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
           });
+      if (kAggPrefetch && !EARLY && more) nxt = fetch_tile(wt + wt_step);
+      cur = nxt;
     }
     __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);

@@ -1,4 +1,6 @@
 // kt_kernels_check.hip — kt_check_bitmap: PreFilter for n pods through the exact term bitmaps of the selector index (gfx950).
+#include <type_traits>
+
 #include "kt_scan.h"
 
 namespace kt {
@@ -46,6 +48,24 @@ struct alignas(16) WordVerdict {
 // counter shifts: 4 = exceeds, 24 = active, 44 = insufficient, 0 = not throttled (nothing to count)
 constexpr uint32_t kTiAdj = 0x00100000u, kTiTight = 0x10000000u;
 constexpr int kTiShActive = 16, kTiShIdle = 22;
+
+// what a tile needs of its 64 pods before it can start (kt_check_bitmap's fetch_tile)
+template <int LA>
+struct TileRec {
+  uint32_t p;                  // pod row
+  uint64_t meta;
+  u32x4 raw[LA / 8];           // atom row
+  unsigned long long carried;  // class counters of the earlier chunks
+};
+// Requesting a tile's records early — the first tile's before the chunk is staged, every later one's behind the scan of
+// the tile before it — was measured and NOT kept (round 4: check 28.0 -> 31.6 us at 1M pods, 79.9 -> 85.3 at 4M; the
+// aggregate 23.4 -> 25.1): the kernels are bound by instruction issue, not by the chain of trips to memory, and the
+// second record costs registers.  -DKT_TILE_PREFETCH builds that form.
+#ifdef KT_TILE_PREFETCH
+constexpr bool kTilePrefetch = true;
+#else
+constexpr bool kTilePrefetch = false;
+#endif
 
 struct BmCheckArgs {
   const uint64_t* meta;  // pod tables
@@ -111,7 +131,15 @@ uint32_t check_word_lds(int D) { return 64u * 8u + (uint32_t)(D <= 8 ? sizeof(Wo
 //       (summary words only, no slow list: the PreFilter sweep) keeps neither code path nor their registers
 template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
-  constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;
+  constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;  // drains in the middle of a scan (the list ran full)
+#ifndef KT_DRAIN_FINAL_8
+#define KT_DRAIN_FINAL_8 2  // (4 = the whole rows at once costs the 64-VGPR instantiation 80 B of scratch inside the scan)
+#endif
+#ifdef KT_DRAIN_SERIAL
+  constexpr int kDrainFinalUnroll = kDrainUnroll;
+#else
+  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : DT / 2;  // the drain behind the scan
+#endif
   // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
   // being peeled one by one: three popcounts per visited word, and only the matches of tight throttles go through the
   // peel.  Round 3 had it in the one-workgroup-per-CU instantiation only (config 4's 130 matches per pod: 1.27 -> 0.92 ms):
@@ -159,6 +187,23 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
     const bool first = ci == 0, last = ci == last_ci;
     const BmChunk ch = a.ix.chunks[ci];
+    // the tile's records, always from valid addresses: lanes past the end re-read the last pod and are switched off by
+    // `on` (kTilePrefetch: requested ahead of the tile — measured, not kept)
+    const uint32_t wt0 = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : by_ns ? t_lo + wave : blockIdx.x * (kBlockIx / kWave) + wave;
+    const uint32_t wt_step = SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
+    auto fetch_tile = [&](uint32_t wt) {
+      TileRec<LA> r;
+      const uint32_t i = wt * kWave + lane;
+      const uint32_t ic = min(i, n - 1u);
+      r.p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
+      r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
+      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
+      const unsigned long long* carry_w = by_ns ? (const unsigned long long*)a.carry + ic : (const unsigned long long*)a.summary + (by_ns ? r.p : i);
+      r.carried = (!SMALL && !first && i < n) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      return r;
+    };
+    TileRec<LA> cur{};
+    if (kTilePrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     __syncthreads();  // nobody reads the previous image any more
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     {  // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
@@ -204,35 +249,42 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
     }
     __syncthreads();
-    for (uint32_t wt = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : by_ns ? t_lo + wave : blockIdx.x * (kBlockIx / kWave) + wave;
-         wt < t_hi; wt += SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep) {
-      // ---- the tile's records: always from valid addresses (lanes past the end re-read the last pod and are
-      //      switched off by `on`)
+    for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
+      // ---- the tile's records (requested before the chunk was staged / behind the previous tile's scan: fetch_tile)
+      if (!kTilePrefetch) cur = fetch_tile(wt);
       const uint32_t i = wt * kWave + lane;
       const bool in = i < n;
       const uint32_t ic = min(i, n - 1u);
-      const uint32_t p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
+      const uint32_t p = cur.p;
       const uint32_t si = by_ns ? p : i;  // the pod's index in the summary words / status matrix
-      const uint64_t meta = by_ns ? a.v_meta[ic] : a.meta[p];
+      const uint64_t meta = cur.meta;
       u32x4 raw[LA / 8];
-      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : p, raw);
+#pragma unroll
+      for (int q = 0; q < LA / 8; ++q) raw[q] = cur.raw[q];
       // class counters so far (bit 1 = error) ride in the summary word (namespace order: the carry word) between chunks
       unsigned long long* carry_w = by_ns ? (unsigned long long*)a.carry + ic : (unsigned long long*)a.summary + si;
-      const unsigned long long carried =
-          (!SMALL && !first && in) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      const unsigned long long carried = cur.carried;
       cnt[lane] = 0ull;
       unsigned long long my = carried & ~3ull;  // this lane's class counters
       const bool on = in && ((meta >> kMetaStateShift) & kPodValid) != 0;
       const uint32_t ns = on ? (uint32_t)(meta & kMetaNsMask) : 0u;
       const uint32_t nz = (uint32_t)(meta >> kMetaNzShift);
       // affectedClusterThrottles: the pod's Namespace object must exist (clusterthrottle_controller.go:273-276)
-      bool pod_err = (carried & 2ull) != 0 || (on & (a.ns_valid[ns] == 0));
+      // (the byte is requested here and looked at behind the scan: a tile is a chain of dependent trips to memory — two
+      //  tiles per wave at 1M pods — and this one hangs off the record's namespace)
+      const uint32_t ns_ok_raw = a.ns_valid[ns];
+      bool pod_err = (carried & 2ull) != 0;
       uint32_t ro[LA];
       atom_row_offsets<LA>(raw, bm.row_bytes, ro);
       uint32_t n_list = 0;  // wave-uniform
       uint32_t last_t = 0xFFFFFFFFu;
 
-      auto drain = [&]() {
+      // UNROLL (a std::integral_constant): pieces of the request row / thr[] / head[] requested per batch.  The drain behind
+      // the scan (nothing of the scan is live any more) asks for the whole rows at once in every instantiation: with two
+      // tiles per wave the kernel is a latency chain, and the 64-VGPR instantiation's one-piece-at-a-time loop was four
+      // dependent trips to memory per tile
+      auto drain = [&](auto unroll_tag) {
+        constexpr int UNROLL = decltype(unroll_tag)::value;
         // ---- lane = listed (pod lane, throttle): the full comparison; pod row / non-zero mask come from the pod's
         //      lane by ds_bpermute
         for (uint32_t base = 0; base < n_list; base += kWave) {
@@ -241,23 +293,46 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           const uint32_t e = list[vv ? j : 0u];
           // the list holds throttle rows — or, WORDWISE, term numbers (their row is one LDS read away, taken here with
           // every lane busy instead of in the peel)
-          const uint32_t pl = e >> 20, t = !WORDWISE ? e & kTermRowMask : tinfo[e & kTermRowMask].x & kTermRowMask;
+          const uint32_t pl = e >> 20;
+          // WORDWISE: the term's TermInfo (LDS) has the throttle row AND the pod-independent verdict bits — no trip to the
+          // flags in global memory before the rows can be requested
+          u32x2 ti = {0u, 0u};
+          if (WORDWISE) ti = tinfo[e & kTermRowMask];
+          const uint32_t t = WORDWISE ? ti.x & kTermRowMask : e & kTermRowMask;
           const uint32_t prow = (uint32_t)__shfl((int)p, (int)pl);
           const uint32_t psi = FULL ? (uint32_t)__shfl((int)si, (int)pl) : 0u;
           const uint32_t pnz = (uint32_t)__shfl((int)nz, (int)pl);
           const CheckRec<DT>* rc = recs + t;
-          const u32x2 fa = g_rflags[t];
           const kt_i64x2* xr = (const kt_i64x2*)(a.req + (uint64_t)prow * (uint32_t)DS);
-          bool exc = (fa.x & kRecExceedsByCount) != 0, ins = (fa.x & kRecInsufficientByCount) != 0;
-#pragma unroll kDrainUnroll
-          for (int q = 0; q < DT / 2; ++q) {
-            const kt_i64x2 x = xr[2 * q < DS ? q : 0];  // pieces past the row re-read piece 0 and are masked by pnz
-            const kt_i64x2 th = *(const kt_i64x2*)(rc->thr + 2 * q);
-            const kt_i64x2 hd = *(const kt_i64x2*)(rc->head + 2 * q);
-            const bool nz0 = (pnz >> (2 * q)) & 1u, nz1 = (pnz >> (2 * q + 1)) & 1u;
-            exc |= (nz0 && x.x > th.x) || (nz1 && x.y > th.y);
-            ins |= (nz0 && x.x > hd.x) || (nz1 && x.y > hd.y);
+          u32x2 fa;  // {flags, active_mask}
+          if (WORDWISE) {
+            const uint32_t sh_act = (ti.y >> kTiShActive) & 63u, sh_idle = (ti.y >> kTiShIdle) & 63u;
+            fa.x = (sh_act == 4u ? kRecExceedsByCount : 0u) | (sh_idle == 24u ? kRecActiveByCount : 0u) | (sh_idle == 44u ? kRecInsufficientByCount : 0u);
+            fa.y = ti.y & 0xFFFFu;
+          } else {
+            fa = g_rflags[t];
           }
+          bool exc = false, ins = false;
+#pragma unroll 1
+          for (int q0 = 0; q0 < DT / 2; q0 += UNROLL) {
+            // one batch: UNROLL pieces of the three rows in flight together, nothing looks at a value before all are requested
+            kt_i64x2 x[UNROLL], th[UNROLL], hd[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+              const int q = q0 + u;
+              x[u] = xr[2 * q < DS ? q : 0];  // pieces past the row re-read piece 0 and are masked by pnz
+              th[u] = *(const kt_i64x2*)(rc->thr + 2 * q);
+              hd[u] = *(const kt_i64x2*)(rc->head + 2 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+              const int q = q0 + u;
+              const bool nz0 = (pnz >> (2 * q)) & 1u, nz1 = (pnz >> (2 * q + 1)) & 1u;
+              exc |= (nz0 && x[u].x > th[u].x) || (nz1 && x[u].y > th[u].y);
+              ins |= (nz0 && x[u].x > hd[u].x) || (nz1 && x[u].y > hd[u].y);
+            }
+          }
+          exc |= (fa.x & kRecExceedsByCount) != 0, ins |= (fa.x & kRecInsufficientByCount) != 0;
           const bool act = (fa.x & kRecActiveByCount) || (pnz & fa.y);
           const uint32_t st = exc ? 4u : act ? 2u : ins ? 3u : 1u;
           if (vv) {
@@ -272,7 +347,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         if (mk == 0ull) return;
         if (want) list[n_list + lane_rank(mk)] = lane << 20 | t;
         n_list += (uint32_t)__popcll(mk);
-        if (n_list > kListCap - kWave) drain();
+        if (n_list > kListCap - kWave) drain(std::integral_constant<int, kDrainUnroll>());
       };
 
       // a pod whose relevant atoms did not fit its atom row is not scanned through the bitmaps: its lane walks EVERY
@@ -384,7 +459,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
       my = (unsigned long long)n_exc << 4 | (unsigned long long)n_act << 24 | (unsigned long long)n_ins << 44;
       }
-      if (n_list) drain();
+      TileRec<LA> nxt{};  // (only looked at when there is a next tile)
+      if (kTilePrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);  // (wave-uniform)
+      if (n_list) drain(std::integral_constant<int, kDrainFinalUnroll>());
+      pod_err |= on & (ns_ok_raw == 0u);
       // ---- lane = pod: the 8-byte summary word
       if (SMALL) {
         // this workgroup's share of the tile's counters; the last workgroup to arrive gives the words their final form
@@ -419,6 +497,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           *carry_w = c | (pod_err ? 2ull : 0ull);
         }
       }
+      cur = nxt;
     }
   }
 }
