@@ -12,7 +12,7 @@ __host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool co
 // what a tile needs of its 64 pods before it can start (kt_aggregate_bitmap's fetch_tile)
 template <int DT, int LA, bool PK>
 struct TileRecAgg {
-  int64_t p;
+  uint32_t p;
   uint64_t meta;
   u32x4 raw[LA / 8];
   int64_t v[PK ? 1 : DT];             // plain fold: the request row
@@ -78,6 +78,37 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
 
 uint32_t aggregate_fixed_lds() { return 64; }
 
+// The throttles without a rank (unconvertible selectors: the slow list) and — for a pod whose relevant atoms did not fit
+// its atom row (kMetaOverflow) — EVERY throttle: walked term by term over the raw labels, straight to the partial rows
+// with atomics.  Out of line on purpose: inlined, the compiler hoisted the walk's address arithmetic (label rows, term
+// tables) into every tile's prologue and kept its pointers in scalar registers the hot loop then had to spill.
+__device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram* sp_, const uint32_t* slow_thr, uint32_t n_slow, int T,
+                                                                const uint32_t* lpair, const uint32_t* lkey, int LS, const int64_t* req,
+                                                                int D, int DS, unsigned long long* partial, int sign, int limb, uint32_t p,
+                                                                uint32_t ns, bool countable, bool counted, bool overflow, uint32_t present) {
+  const SelProgram& sp = *sp_;
+  const int pstride = partial_stride(D);
+  const uint32_t* lp = lpair + (uint64_t)p * (uint32_t)LS;
+  const uint32_t* lk = lkey + (uint64_t)p * (uint32_t)LS;
+  auto walk_one = [&](uint32_t t, bool lane_on) {
+    const uint32_t res = walk_slow_mem(sp, (int)t, sp.ns_term_ok + (size_t)ns * sp.gw, lane_on, lp, lk, LS);
+    unsigned long long* pr = partial + (size_t)t * pstride;
+    if (res & kSlowError) atomicAdd(pr + 2 * D + 1, (unsigned long long)(long long)sign);
+    if ((res & kSlowMatched) && counted) {
+      for (int d = 0; d < D; ++d)
+        if ((present >> d) & 1u) {
+          const int64_t vd = limb_of(req[(uint64_t)p * (uint32_t)DS + d], limb);
+          if (vd != 0) atomicAdd(pr + d, (unsigned long long)(sign * vd));
+          atomicAdd(pr + D + d, (unsigned long long)(long long)sign);
+        }
+      atomicAdd(pr + 2 * D, (unsigned long long)(long long)sign);
+    }
+  };
+  for (uint32_t ks = 0; ks < n_slow; ++ks) walk_one(slow_thr[ks], countable && !overflow);
+  if (__ballot(overflow) != 0ull)
+    for (int t = 0; t < T; ++t) walk_one((uint32_t)t, overflow);
+}
+
 // kt_aggregate_bitmap — `used` partials of this GPU's pod rows: affectedPods + fold Add for all throttles
 // (throttle_controller.go:116-119,221-246; clusterthrottle_controller.go:119-122,224-270).
 // The workgroup walks the chunks of the index: chunk image in, table of the chunk's throttles zeroed, every tile of
@@ -96,29 +127,29 @@ template <int DT, int LA, bool VETO, int NEED, bool PK>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
-  const int pstride = partial_stride(D);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
-  const int64_t n_rows = a.n_rows;
-  const int64_t n_wtiles = (n_rows + kWave - 1) / kWave;
-  const int64_t wstep = (int64_t)gridDim.x * (kBlockIx / kWave);
+  // pod rows and list positions fit 32 bits (pod_capacity <= 2^31): no 64-bit index arithmetic in the tile loop
+  const uint32_t n_rows = (uint32_t)a.n_rows;
+  const uint32_t n_wtiles = (uint32_t)(((uint64_t)n_rows + kWave - 1) / kWave);
+  const uint32_t wstep = gridDim.x * (uint32_t)(kBlockIx / kWave);
   KT_LDS const uint16_t* trank = (KT_LDS const uint16_t*)(lds + a.off_rank);
   const bool counts = a.counts != 0;
   // namespace order (a.ix.by_ns): this workgroup owns the tiles [t_lo, t_hi) and only walks — and only spills the
   // tables of — the chunks that hold words of their namespaces
   const bool by_ns = a.ix.by_ns != 0u;
-  int64_t t_lo = 0, t_hi = n_wtiles;
+  uint32_t t_lo = 0, t_hi = n_wtiles;
   uint32_t ns_lo = 0, ns_hi = 0;
   if (by_ns) {
-    const int64_t tpb = (n_wtiles + gridDim.x - 1) / gridDim.x;
-    t_lo = min((int64_t)blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
+    const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
+    t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
     // A workgroup without tiles must NOT return: the reductions of single-chunk programs read every launched
     // workgroup's slab without looking at tags, so it spills its zeroed table like everybody else (round 3 returned
     // here and left the slab as the allocator or an earlier, larger scan had it).  launch_aggregate_indexed sizes the
     // grid so that no workgroup is empty; this is the second line of defence.
     if (t_lo < t_hi) {
-      ns_lo = (uint32_t)(a.v_meta[t_lo * kWave] & kMetaNsMask);
-      ns_hi = (uint32_t)(a.v_meta[min(t_hi * kWave, n_rows) - 1] & kMetaNsMask);
+      ns_lo = (uint32_t)(a.v_meta[(uint64_t)t_lo * kWave] & kMetaNsMask);
+      ns_hi = (uint32_t)(a.v_meta[min((uint64_t)t_hi * kWave, (uint64_t)n_rows) - 1u] & kMetaNsMask);
     }
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
   }
@@ -131,12 +162,12 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     KT_LDS unsigned char* tab = lds + a.off_tab;
     // the tile's records — meta word, atom row AND the request words: every lane's, so that the request does not hang off
     // the meta word by another trip to memory (kAggPrefetch: requested ahead of the tile — measured, not kept)
-    const int64_t wt0 = by_ns ? t_lo + wave : (int64_t)blockIdx.x * (kBlockIx / kWave) + wave;
-    const int64_t wt_step = by_ns ? (int64_t)(kBlockIx / kWave) : wstep;
-    auto fetch_tile = [&](int64_t wt) {
+    const uint32_t wt0 = by_ns ? t_lo + wave : blockIdx.x * (uint32_t)(kBlockIx / kWave) + wave;
+    const uint32_t wt_step = by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
+    auto fetch_tile = [&](uint32_t wt) {
       TileRecAgg<DT, LA, PK> r;
-      const int64_t ic = min(wt * kWave + lane, n_rows - 1);
-      r.p = a.rows ? a.rows[ic] : a.row0 + ic;
+      const uint32_t ic = min(wt * kWave + lane, n_rows - 1u);
+      r.p = a.rows ? (uint32_t)a.rows[ic] : (uint32_t)a.row0 + ic;
       r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
       load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
       if constexpr (!PK) {
@@ -159,13 +190,13 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
-    for (int64_t wt = wt0; wt < t_hi; wt += wt_step) {
+    for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
       // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
       //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
       if (!kAggPrefetch) cur = fetch_tile(wt);
-      const int64_t i = wt * kWave + lane;
+      const uint32_t i = wt * kWave + lane;
       const bool in = i < n_rows;
-      const int64_t p = cur.p;
+      const uint32_t p = cur.p;
       const uint64_t meta = cur.meta;
       u32x4 raw[LA / 8];
 #pragma unroll
@@ -210,34 +241,16 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).
       const bool overflow = a.has_overflow && countable && (meta & kMetaOverflow) != 0;
       const bool scan_counted = counted && !overflow;
-      if (ci == 0 && (a.n_slow || a.has_overflow)) {
-        const SelProgram& sp = *a.sp;
-        const uint32_t* lp = a.lpair + (uint64_t)p * (uint32_t)a.LS;
-        const uint32_t* lk = a.lkey + (uint64_t)p * (uint32_t)a.LS;
-        auto walk_one = [&](uint32_t t, bool lane_on) {
-          const uint32_t res = walk_slow_mem(sp, (int)t, sp.ns_term_ok + (size_t)ns * sp.gw, lane_on, lp, lk, a.LS);
-          unsigned long long* pr = a.partial + (size_t)t * pstride;
-          if (res & kSlowError) atomicAdd(pr + 2 * D + 1, (unsigned long long)(long long)a.sign);
-          if ((res & kSlowMatched) && counted) {
-            for (int d = 0; d < D; ++d)
-              if ((present >> d) & 1u) {
-                const int64_t vd = limb_of(a.req[(uint64_t)p * (uint32_t)DS + d], a.limb);
-                if (vd != 0) atomicAdd(pr + d, (unsigned long long)(a.sign * vd));
-                atomicAdd(pr + D + d, (unsigned long long)(long long)a.sign);
-              }
-            atomicAdd(pr + 2 * D, (unsigned long long)(long long)a.sign);
-          }
-        };
-        for (uint32_t ks = 0; ks < a.n_slow; ++ks) walk_one(a.slow_thr[ks], countable && !overflow);
-        if (__ballot(overflow) != 0ull)
-          for (int t = 0; t < a.T; ++t) walk_one((uint32_t)t, overflow);
-      }
+      if (ci == 0 && (a.n_slow || a.has_overflow))
+        agg_walk_without_rank(a.sp, a.slow_thr, a.n_slow, a.T, a.lpair, a.lkey, a.LS, a.req, D, DS, a.partial, a.sign, a.limb, p, ns, countable,
+                              counted, overflow, present);
 
       // the next tile's records: in flight during this tile's scan where the registers are there (the packed fold)
       const bool more = wt + wt_step < t_hi;  // wave-uniform
       constexpr bool EARLY = PK && LA <= 16;  // (32 atom slots: the second record does not fit the registers)
       if (kAggPrefetch && EARLY && more) nxt = fetch_tile(wt + wt_step);
       uint32_t last_r = 0xFFFFFFFFu;
+      const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
       scan_tile<LA, VETO, NEED, VETO>(
           bm, scan_counted, ns, ro,
           [&](bool has, uint32_t c) {
@@ -250,9 +263,13 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
               KT_LDS unsigned char* rp = tab + __umul24(r, rec);  // the throttle's record (rank < 2^15, record <= 272 bytes)
               lds_u64wp tv = (lds_u64wp)rp;
               if constexpr (PK) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  if (pw[k] != 0ull) lds_add64(tv + k, pw[k]);  // words past pk.nw hold 0
+                // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
+                // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
+                // testing the words lane by lane only bought exec-mask juggling
+                lds_add64(tv, pw[0]);
+                if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+                if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+                if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
                 if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return;
               }
