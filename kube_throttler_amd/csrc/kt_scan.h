@@ -108,6 +108,32 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+
+// Three-input boolean functions on both halves of a 64-bit word: gfx950's v_bitop3_b32 takes any truth table; only the
+// symmetric ones are used here (xor3 0x96, majority 0xE8, or3 0xFE), so the operand order does not matter.
+template <int TT>
+__device__ __forceinline__ uint64_t bitop3_64(uint64_t a, uint64_t b, uint64_t c) {
+  const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, TT);
+  const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), TT);
+  return (uint64_t)lo | (uint64_t)hi << 32;
+}
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0x96>(a, b, c); }
+__device__ __forceinline__ uint64_t maj3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0xE8>(a, b, c); }
+__device__ __forceinline__ uint64_t or3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0xFE>(a, b, c); }
+
+// How many of eight bitmap rows hold each bit, as a 2-bit number (ones, twos) — EXACT as long as no bit is met more than
+// three times, which the index guarantees for the rows of one pod (a pod carries one atom per key, an exactly indexed
+// term has at most three positive keys, a `slow` term keeps one): two full adders and a half adder over the rows, a
+// full adder over their sums; at most one of the four carries can be set.  13 three-input operations per half where the
+// running 2-bit counter (c1 ^= c0 & r; c0 ^= r) took 24.
+__device__ __forceinline__ void count8(const uint64_t (&r)[8], uint64_t& ones, uint64_t& twos) {
+  const uint64_t s1 = xor3_64(r[0], r[1], r[2]), c1 = maj3_64(r[0], r[1], r[2]);
+  const uint64_t s2 = xor3_64(r[3], r[4], r[5]), c2 = maj3_64(r[3], r[4], r[5]);
+  const uint64_t s3 = r[6] ^ r[7], c3 = r[6] & r[7];
+  ones = xor3_64(s1, s2, s3);
+  twos = or3_64(c1, c2, c3) | maj3_64(s1, s2, s3);
+}
+
 // A pod's atom row (PodTable::latom, LA u16 ids) as byte offsets of its bitmap rows: LA/8 128-bit loads, issued from
 // an always-valid address.
 template <int LA>
@@ -184,22 +210,33 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
       KT_LDS const unsigned char* col = b.rows + w * (VETO ? 16u : 8u);
       uint64_t xx, vet = 0;
       if (NEED >= 3) {
-        // hits per term as a 2-bit counter (c1 c0): a pod carries at most one atom of any requirement and an exactly
-        // indexed term has at most three positive keys, so the count never passes 3 — three 64-bit operations per atom
-        // where the any / two / three accumulators took five
+        // hits per term as a 2-bit number (c1 c0): a pod carries at most one atom of any requirement and an exactly
+        // indexed term has at most three positive keys, so the count never passes 3.  Eight rows at a time through a
+        // small adder tree of three-input operations (count8); the groups of eight are added as 2-bit numbers.
+        static_assert(LA % 8 == 0, "atom slots come in eights");
         uint64_t c0 = 0, c1 = 0;
 #pragma unroll
-        for (int l = 0; l < LA; ++l) {
-          uint64_t r;
-          if (VETO) {
-            const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
-            r = rv.x;
-            vet |= rv.y;
-          } else {
-            r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+        for (int g8 = 0; g8 < LA / 8; ++g8) {
+          uint64_t r[8], v8[8];
+#pragma unroll
+          for (int l = 0; l < 8; ++l) {
+            if (VETO) {
+              const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[8 * g8 + l]);
+              r[l] = rv.x, v8[l] = rv.y;
+            } else {
+              r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
+              v8[l] = 0;
+            }
           }
-          c1 ^= c0 & r;
-          c0 ^= r;
+          if (VETO) vet |= or3_64(or3_64(v8[0], v8[1], v8[2]), or3_64(v8[3], v8[4], v8[5]), v8[6] | v8[7]);
+          uint64_t ones, twos;
+          count8(r, ones, twos);
+          if (g8 == 0) {
+            c0 = ones, c1 = twos;
+          } else {  // (the total still does not pass 3: at most one carry)
+            c1 |= twos | (c0 & ones);
+            c0 ^= ones;
+          }
         }
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
         const uint64_t any = h0.x | c0 | c1, two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
@@ -216,20 +253,27 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           }
         }
       } else {
-        uint64_t any = h0.x, two = 0;
+        // any = the terms met in some row; an exactly indexed term of this form has at most two positive keys, each met by
+        // at most one of the pod's atoms, so "both met" is "met, and in an even number of rows": the OR and the XOR of the
+        // rows — order-free, three rows per instruction — replace the running any / two pair (two |= any & r; any |= r)
+        uint64_t any = h0.x, par = 0;
 #pragma unroll
-        for (int l = 0; l < LA; ++l) {
-          uint64_t r;
-          if (VETO) {
-            const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[l]);
-            r = rv.x;
-            vet |= rv.y;
-          } else {
-            r = *(KT_LDS const unsigned long long*)(col + ro[l]);
+        for (int g8 = 0; g8 < LA / 8; ++g8) {
+          uint64_t r[8];
+#pragma unroll
+          for (int l = 0; l < 8; ++l) {
+            if (VETO) {
+              const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[8 * g8 + l]);
+              r[l] = rv.x;
+              vet |= rv.y;
+            } else {
+              r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
+            }
           }
-          if (NEED >= 2) two |= any & r;
-          any |= r;
+          any = or3_64(or3_64(r[0], r[1], r[2]), or3_64(r[3], r[4], r[5]), or3_64(r[6], r[7], any));
+          if (NEED >= 2) par = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], par));
         }
+        const uint64_t two = any & ~par;  // (only looked at under m2: the terms with two positive keys)
         xx = any;
         if (NEED >= 2) xx = (any & ~h0.y) | (two & h0.y);
         uint64_t slow = 0;
