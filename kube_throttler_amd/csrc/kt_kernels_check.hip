@@ -129,7 +129,10 @@ uint32_t check_word_lds(int D) { return 64u * 8u + (uint32_t)(D <= 8 ? sizeof(Wo
 // WPE:  waves per SIMD the register allocation has to leave room for (4: one workgroup per CU, 8: two)
 // FULL: the launch also wants the status matrix and / or has throttles on the slow list — the lean instantiation
 //       (summary words only, no slow list: the PreFilter sweep) keeps neither code path nor their registers
-template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL>
+// ONE:  the index is ONE chunk and the sweep runs in row order (the two-per-CU sweep of programs that fit half the LDS:
+//       BASELINE configs 1-3) — no chunk loop, no carry words, no namespace-ordered views: none of their registers either
+//       (the 64-VGPR instantiation spilled a handful of them, and a reload in the chunk prologue is a trip to memory)
+template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL, bool ONE = false>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;  // drains in the middle of a scan (the list ran full)
 #ifndef KT_DRAIN_FINAL_8
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   KT_LDS u32x2* tinfo = (KT_LDS u32x2*)(lds + a.off_tinfo);
   const uint32_t n_wtiles = (n + kWave - 1) / kWave;
   const uint32_t wstep = gridDim.x * (kBlockIx / kWave);
-  const uint32_t n_chunks = a.ix.n_chunks;
+  const uint32_t n_chunks = ONE ? 1u : a.ix.n_chunks;
   const uint32_t c_lo = SMALL ? blockIdx.x : 0u, c_hi = SMALL ? blockIdx.x + 1u : n_chunks;
   // namespace order (a.ix.by_ns; rows[] sorted by namespace, results indexed by pod row): this workgroup owns the
   // tiles [t_lo, t_hi) and only walks the chunks that hold words of their namespaces
-  const bool by_ns = !SMALL && a.ix.by_ns != 0u;
+  const bool by_ns = !SMALL && !ONE && a.ix.by_ns != 0u;
   uint32_t t_lo = 0, t_hi = n_wtiles, ns_lo = 0, ns_hi = 0, last_ci = n_chunks - 1u;
   if (by_ns) {
     const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   }
   for (uint32_t ci = c_lo; ci < c_hi; ++ci) {
     if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
-    const bool first = ci == 0, last = ci == last_ci;
+    const bool first = ONE || ci == 0, last = ONE || ci == last_ci;
     const BmChunk ch = a.ix.chunks[ci];
     // the tile's records, always from valid addresses: lanes past the end re-read the last pod and are switched off by
     // `on` (kTilePrefetch: requested ahead of the tile — measured, not kept)
@@ -427,17 +430,17 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       auto settle = [&](uint64_t x, const VerdictRegs& q) -> uint64_t {
         if (seg_on) {  // a throttle with several terms is reported once: the lowest match of every run
           const uint64_t v = x | q.seg.y;
-          x &= (v ^ (v - q.seg.x)) & v;
+          x = andn_64(x, v - q.seg.x);  // (= x & (v ^ (v - seg_lo)) & v, x being part of v)
         }
         uint64_t act = q.nib[0];  // (act-by-count is part of every entry of nibble 0's table)
 #pragma unroll
         for (int k = 1; k < DT / 4; ++k) act |= q.nib[k];
-        const uint64_t xe = x & ~q.te.x & q.te.y;   // exceeded by count
-        const uint64_t xf = x & ~q.te.x & ~q.te.y;  // settled here, not exceeded by count
-        const uint64_t xa = xf & act, xi = xf & ~act & q.ai.y;
-        n_exc += (uint32_t)__popc((uint32_t)xe) + (uint32_t)__popc((uint32_t)(xe >> 32));
-        n_act += (uint32_t)__popc((uint32_t)xa) + (uint32_t)__popc((uint32_t)(xa >> 32));
-        n_ins += (uint32_t)__popc((uint32_t)xi) + (uint32_t)__popc((uint32_t)(xi >> 32));
+        const uint64_t xe = and_not_and_64(x, q.te.x, q.te.y);  // not tight, exceeded by count
+        const uint64_t xf = and_not_not_64(x, q.te.x, q.te.y);  // settled here, not exceeded by count
+        const uint64_t xa = xf & act, xi = and_not_and_64(xf, act, q.ai.y);
+        n_exc = (uint32_t)__popc((uint32_t)xe) + ((uint32_t)__popc((uint32_t)(xe >> 32)) + n_exc);
+        n_act = (uint32_t)__popc((uint32_t)xa) + ((uint32_t)__popc((uint32_t)(xa >> 32)) + n_act);
+        n_ins = (uint32_t)__popc((uint32_t)xi) + ((uint32_t)__popc((uint32_t)(xi >> 32)) + n_ins);
         return x & q.te.x;
       };
       auto confirm_slow = [&](uint32_t c) {
@@ -502,18 +505,19 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   }
 }
 
-#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_)                                               \
+#define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_, ONE_)                                         \
   {                                                                                                             \
-    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_>;                                    \
+    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_, ONE_>;                              \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
     hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                     \
   }
 #define KT_BM_CASE(DT_, LA_, VETO_, NEED_)                                                   \
   {                                                                                          \
-    if (small) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, true)                           \
-    else if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, false)                      \
-    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false)               \
-    else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false, false)                               \
+    if (small) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, true, false)                    \
+    else if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, false, false)               \
+    else if (two_per_cu && one) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false, true)  \
+    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false, false)        \
+    else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false, false, false)                        \
   }
 
 // returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
@@ -553,6 +557,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds) fprintf(stderr, "kt_check_bitmap: lds=%u (%d per CU) chunks=%u LA=%d veto=%u need=%u\n", bm_total, two_per_cu ? 2 : 1, ix.n_chunks, LA, ix.has_veto, ix.max_need);
   const bool rich = ix.rich;
+  const bool one = ix.n_chunks == 1 && bm_args.ix.by_ns == 0u && !getenv("KT_CHECK_NO_ONE");  // (A/B: the generic two-per-CU form)
 #ifdef KT_FAST_BUILD
   KT_BM_CASE(8, 8, false, 2)
 #else

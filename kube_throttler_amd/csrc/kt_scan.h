@@ -117,7 +117,16 @@ __device__ __forceinline__ uint64_t bitop3_64(uint64_t a, uint64_t b, uint64_t c
   const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), TT);
   return (uint64_t)lo | (uint64_t)hi << 32;
 }
+// (measured, profiles/r04_valu_rates.txt: v_bitop3_b32 issues in 2.7 cycles per wave and SIMD like the two-operand
+//  v_or_b32 / v_xor_b32, where the three-operand forms the compiler picks by itself — v_or3_b32, v_bfi_b32, v_and_or_b32 —
+//  take 4.4: every three-input boolean step of the scans is spelled as a bitop3 with its truth table.  Table index =
+//  a << 2 | b << 1 | c, operand 0 the most significant bit: profiles/r04_bitop3_probe.txt.)
 __device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0x96>(a, b, c); }
+__device__ __forceinline__ uint64_t andn_64(uint64_t a, uint64_t b) { return bitop3_64<0x30>(a, b, b); }                   // a & ~b
+__device__ __forceinline__ uint64_t and_not_and_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0x20>(a, b, c); }  // a & ~b & c
+__device__ __forceinline__ uint64_t and_not_not_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0x10>(a, b, c); }  // a & ~b & ~c
+__device__ __forceinline__ uint64_t and_nand_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0x70>(a, b, c); }     // a & ~(b & c)
+__device__ __forceinline__ uint64_t mux_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0xD8>(a, b, c); }          // c ? b : a
 __device__ __forceinline__ uint64_t maj3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0xE8>(a, b, c); }
 __device__ __forceinline__ uint64_t or3_64(uint64_t a, uint64_t b, uint64_t c) { return bitop3_64<0xFE>(a, b, c); }
 
@@ -239,10 +248,10 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           }
         }
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
-        const uint64_t any = h0.x | c0 | c1, two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
-        xx = (any & ~h0.y) | (two & h0.y);
-        xx = (xx & ~h1.x) | (three & h1.x);
-        xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
+        const uint64_t any = or3_64(h0.x, c0, c1), two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
+        xx = mux_64(any, two, h0.y);    // (any & ~m2) | (two & m2)
+        xx = mux_64(xx, three, h1.x);   // (xx & ~m3) | (three & m3)
+        xx = and_not_and_64(xx, vet, (uint64_t)e.z | (uint64_t)e.w << 32);
         xx = adv ? xx : 0ull;
         if (b.has_slow) {
           uint64_t sl = xx & h1.y;
@@ -273,15 +282,15 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           any = or3_64(or3_64(r[0], r[1], r[2]), or3_64(r[3], r[4], r[5]), or3_64(r[6], r[7], any));
           if (NEED >= 2) par = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], par));
         }
-        const uint64_t two = any & ~par;  // (only looked at under m2: the terms with two positive keys)
         xx = any;
-        if (NEED >= 2) xx = (any & ~h0.y) | (two & h0.y);
+        if (NEED >= 2) xx = and_nand_64(any, par, h0.y);  // under m2 (two positive keys): met, and in an even number of rows
         uint64_t slow = 0;
         if (VETO) {  // the rich instantiation also serves programs with `slow` shapes
           const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
           slow = h1.y;
         }
-        xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
+        if (VETO) xx = and_not_and_64(xx, vet, (uint64_t)e.z | (uint64_t)e.w << 32);
+        else xx &= (uint64_t)e.z | (uint64_t)e.w << 32;
         xx = adv ? xx : 0ull;
         if (VETO && b.has_slow) {
           uint64_t sl = xx & slow;

@@ -19,7 +19,21 @@ __global__ __launch_bounds__(1024) void rate(unsigned* out, unsigned seed, int i
     if (OP == 6) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r) : "v"(b));                             \
     if (OP == 7) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(r) : "v"(b));                         \
     if (OP == 8) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r) : "v"(b));                              \
-    if (OP == 9) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(b));
+    if (OP == 9) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(b));                                 \
+    if (OP == 10) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "v"(b));                                \
+    if (OP == 11) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(b));                                \
+    if (OP == 12) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r));                                      \
+    if (OP == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(b));                       \
+    if (OP == 14) asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(b));                                    \
+    if (OP == 15) asm volatile("v_ffbl_b32 %0, %0" : "+v"(r));                                            \
+    if (OP == 16) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r) : "v"(b));                                \
+    if (OP == 17) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(r));                                       \
+    if (OP == 18) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));                   \
+    if (OP == 19) asm volatile("v_cmp_ne_u32 vcc, %0, %1" : : "v"(r), "v"(b) : "vcc");                    \
+    if (OP == 20) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(r) : "v"(b));              \
+    if (OP == 21) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));                \
+    if (OP == 22) asm volatile("v_readlane_b32 s12, %0, 3" : : "v"(r) : "s12");                           \
+    if (OP == 23) asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "+v"(r) : "v"(b));
     REP8(STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7))
   }
   out[blockIdx.x * 1024 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -53,5 +67,19 @@ int main() {
   run<7>("v_lshl_add_u32", d);
   run<8>("v_mul_lo_u32", d);
   run<9>("v_xor_b32", d);
+  run<10>("v_and_b32", d);
+  run<11>("v_add_u32", d);
+  run<12>("v_lshlrev_b32", d);
+  run<13>("v_cndmask (vcc)", d);
+  run<14>("v_mov_b32", d);
+  run<15>("v_ffbl_b32", d);
+  run<16>("v_min_u32", d);
+  run<17>("v_bfe_u32", d);
+  run<18>("v_add3_u32", d);
+  run<19>("v_cmp_ne_u32", d);
+  run<20>("v_cndmask (sgpr)", d);
+  run<21>("v_mad_u32_u24", d);
+  run<22>("v_readlane_b32", d);
+  run<23>("v_mul_u24 sdwa", d);
   return 0;
 }
