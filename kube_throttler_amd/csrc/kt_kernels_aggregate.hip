@@ -137,7 +137,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const bool counts = a.counts != 0;
   // namespace order (a.ix.by_ns): this workgroup owns the tiles [t_lo, t_hi) and only walks — and only spills the
   // tables of — the chunks that hold words of their namespaces
-  const bool by_ns = a.ix.by_ns != 0u;
+  // (the packed fold only runs over the namespace-ordered scan view: known when the kernel is compiled — every record is
+  //  then read at its list position, nothing hangs off the row list any more)
+  const bool by_ns = PK || a.ix.by_ns != 0u;
   uint32_t t_lo = 0, t_hi = n_wtiles;
   uint32_t ns_lo = 0, ns_hi = 0;
   if (by_ns) {
@@ -218,8 +220,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
       const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
       // ResourceAmountOfPod: the request row (or its packed words) travelled with the record — every lane's, so that
-      // the request does not hang off the meta word by another trip to memory; what a pod that is not counted brought
-      // is dropped here
+      // the request does not hang off the meta word by another trip to memory.  What a pod that is not counted brought
+      // is never looked at: its lane takes no part in the scan (scan_counted), so no match is ever handed to it.
       int64_t v[DT];             // plain fold (dead in the PK instantiations)
       unsigned long long pw[4];  // packed fold (dead in the others)
 #pragma unroll
@@ -228,10 +230,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       for (int k = 0; k < 4; ++k) pw[k] = 0ull;
       if constexpr (!PK) {
 #pragma unroll
-        for (int d = 0; d < DT; ++d) v[d] = counted ? limb_of(cur.v[d], a.limb) : 0;
+        for (int d = 0; d < DT; ++d) v[d] = limb_of(cur.v[d], a.limb);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pw[k] = counted ? cur.pw[k] : 0ull;
+        for (int k = 0; k < 4; ++k) pw[k] = cur.pw[k];
       }
       const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
       uint32_t ro[LA];
