@@ -1326,9 +1326,12 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     // ONE launch (kt_feed_small) for an event batch: the workgroup first pulls the whole slot over the link with all its
     // threads, the batch pointers name that device copy (KT_FEED_NO_STAGE=1: the kernel walks the slot over the link)
     const bool fused = slot_path && cn <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION");
-    const bool dev_copy = fused && !getenv_flag("KT_FEED_NO_STAGE");
+    // an informer event proper — a pod or a few: one wave per pod, the slot pulled into LDS (kt_feed_few); the batch
+    // pointers are then byte offsets into the slot (KT_NO_FEED_FEW=1: kt_feed_small's thread per pod, A/B)
+    const bool few = fused && cn <= kt::kFeedFewMax && off <= kt::kFeedFewSlotMax && !getenv_flag("KT_NO_FEED_FEW");
+    const bool dev_copy = fused && !few && !getenv_flag("KT_FEED_NO_STAGE");
     if (dev_copy) KT_HIP(e, e->d_ev_stage.reserve(kt_engine::kEvSlotBytes));
-    uint8_t* st = dev_copy ? e->d_ev_stage.p : slot_path ? slot->h : e->d_stage.p;
+    uint8_t* st = few ? (uint8_t*)nullptr : dev_copy ? e->d_ev_stage.p : slot_path ? slot->h : e->d_stage.p;
     // a small batch is packed in pinned host memory and crosses in ONE copy; a bulk load copies its sections straight
     // from the caller's arrays
     const bool packed = !slot_path && off <= kPinnedStageBytes;
@@ -1380,8 +1383,12 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       if (patch) v = view_patch_of(e, cn);
       const bool spin = !getenv_flag("KT_INGEST_EVENT_WAIT");  // (A/B: wait on the event as the first form of this path did)
       const unsigned long long seq = ++e->ingest_seq;
-      kt::launch_feed_small(e->pods, pb, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, dev_copy ? slot->h : nullptr,
-                            dev_copy ? e->d_ev_stage.p : nullptr, dev_copy ? (uint32_t)off : 0u, spin ? e->h_overflow + 1 : nullptr, seq, s);
+      if (few)
+        kt::launch_feed_few(e->pods, pb, rows != nullptr, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, slot->h, (uint32_t)off,
+                            spin ? e->h_overflow + 1 : nullptr, seq, s);
+      else
+        kt::launch_feed_small(e->pods, pb, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, dev_copy ? slot->h : nullptr,
+                              dev_copy ? e->d_ev_stage.p : nullptr, dev_copy ? (uint32_t)off : 0u, spin ? e->h_overflow + 1 : nullptr, seq, s);
       KT_HIP(e, hipGetLastError());
       if (tr) e->overflow_in_flight = true;
       KT_HIP(e, hipEventRecord(slot->ev, s));

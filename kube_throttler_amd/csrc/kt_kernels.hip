@@ -457,6 +457,112 @@ __global__ __launch_bounds__(kBlock) void kt_feed_small(PodTable pods, PodBatchD
     signal_host(host_seq, seq);
   }
 }
+// kt_feed_few — an informer event proper (n <= kFeedFewMax pods): ONE WAVE PER POD.  kt_feed_small runs a pod's ingest,
+// translation and view patch in one THREAD — some forty dependent trips to memory for a single pod, 20 of the 28 us from
+// the event to the kernel's completion signal.  Here the workgroup pulls the pinned slot into LDS (one trip over the
+// link), then a pod's wave works lane-parallel: lane d sums dimension d over the containers (PodRequestResourceList),
+// lane l copies and translates label l (one probe of the atom table per lane, all in flight together), the masks are
+// ballots, the atom row is compacted by mbcnt; only the view patch stays one lane's work.
+//   b: the batch as BYTE OFFSETS into the slot (the pointer fields hold offsets); has_rows: b.rows is a list
+template <int LA>
+__global__ __launch_bounds__(kBlock) void kt_feed_few(PodTable pods, PodBatchDev b, int has_rows, const uint64_t* table, uint32_t mask, int key_atoms,
+                                                      unsigned long long* n_overflow, int do_translate, int has_patch, const ViewPatch v,
+                                                      unsigned long long* host_overflow, const u128* slot, uint32_t slot_bytes,
+                                                      unsigned long long* host_seq, unsigned long long seq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];  // the slot, then one atom row per wave
+  const uint32_t n16 = (slot_bytes + 15u) / 16u;
+  for (uint32_t o = threadIdx.x; o < n16; o += kBlock) ((u128*)few_lds)[o] = slot[o];
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if ((int64_t)wave < b.n) {
+    auto at = [&](const void* off) -> const unsigned char* { return few_lds + (size_t)off; };
+    const uint32_t i = wave;
+    const int D = pods.D, DS = pods.DS, L = pods.L, LS = pods.LS;
+    const int64_t row = has_rows ? ((const int64_t*)at(b.rows))[i] : b.row0 + i;
+    const uint32_t* ctr_off = (const uint32_t*)at(b.ctr_off);
+    const uint8_t* ctr_init = (const uint8_t*)at(b.ctr_init);
+    const uint32_t* ctr_present = (const uint32_t*)at(b.ctr_present);
+    const int64_t* ctr_req = (const int64_t*)at(b.ctr_req);
+    // ---- PodRequestResourceList (resourcelist.go:27-46), lane = dimension: sum of the containers, max with every init
+    //      container, plus the overhead — exactly ingest_one's arithmetic, one dimension per lane
+    const int d = (int)lane;
+    int64_t c = 0, ic = 0;
+    bool cp = false, icp = false;
+    const uint32_t k0 = ctr_off[i] - b.ctr_base, k1 = ctr_off[i + 1] - b.ctr_base;
+    for (uint32_t k = k0; k < k1; ++k) {  // (wave-uniform)
+      const uint32_t pm = ctr_present[k];
+      const bool init = ctr_init[k] != 0;
+      if (d < D && ((pm >> d) & 1u)) {
+        const int64_t q = ctr_req[(int64_t)k * D + d];
+        if (init) {
+          ic = icp ? (ic >= q ? ic : q) : q;
+          icp = true;
+        } else {
+          c += q;
+          cp = true;
+        }
+      }
+    }
+    if (icp) c = cp ? (c >= ic ? c : ic) : ic;
+    cp = cp || icp;
+    const uint32_t op = ((const uint32_t*)at(b.ovh_present))[i];
+    if ((op >> 31) && d < D && ((op >> d) & 1u)) {
+      c += ((const int64_t*)at(b.ovh))[(int64_t)i * D + d];
+      cp = true;
+    }
+    const uint32_t dmask = (1u << D) - 1u;
+    const uint32_t cpm = (uint32_t)__ballot(d < D && cp) & dmask;
+    const uint32_t nz = (uint32_t)__ballot(d < D && cp && c != 0) & dmask;
+    if (d < DS) pods.req[row * DS + d] = (d < D && cp) ? c : 0;
+    const uint32_t ns = ((const uint32_t*)at(b.ns))[i], fl = ((const uint32_t*)at(b.flags))[i];
+    if (lane == 0) {
+      pods.ns[row] = ns;
+      pods.flags[row] = (fl & 0xFu) | (cpm << kPresentShift);
+    }
+    uint64_t meta = (uint64_t)(ns & (uint32_t)kMetaNsMask) | (uint64_t)(fl & 0xFu) << kMetaStateShift | (uint64_t)cpm << kMetaPresentShift |
+                    (uint64_t)nz << kMetaNzShift;
+    // ---- labels, lane = label slot
+    const uint32_t* label_off = (const uint32_t*)at(b.label_off);
+    const uint32_t l0 = label_off[i] - b.label_base, l1 = label_off[i + 1] - b.label_base;
+    const bool have = (int)lane < L && l0 + lane < l1;
+    const uint32_t pair = have ? ((const uint32_t*)at(b.label_pair))[l0 + lane] : 0u;
+    const uint32_t key = have ? ((const uint32_t*)at(b.label_key))[l0 + lane] : 0u;
+    if ((int)lane < LS) {
+      pods.lpair[row * LS + lane] = pair;
+      pods.lkey[row * LS + lane] = key;
+    }
+    if (do_translate) {
+      // one atom per label: the pair when some selector names it, else the key atom when some selector names the key;
+      // the atoms keep the labels' order (rank among the lanes that found one)
+      uint32_t id = 0;
+      if ((int)lane < LS && pair != 0u) {
+        id = atom_id_of(table, mask, pair);
+        if (!id && key_atoms) id = atom_id_of(table, mask, kKeyAtom | key);
+      }
+      const uint64_t mk = __ballot(id != 0u);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+      const uint32_t cnt = (uint32_t)__popcll(mk);
+      uint16_t* out = (uint16_t*)(few_lds + ((size_t)n16 * 16u) + (size_t)wave * LA * 2u);
+      if (lane < (uint32_t)LA) out[lane] = 0;
+      if (id != 0u && rank < (uint32_t)LA) out[rank] = (uint16_t)id;
+      if (lane < (uint32_t)(LA / 8)) ((kt_u32x4*)(pods.latom + row * LA))[lane] = ((const kt_u32x4*)out)[lane];
+      if (cnt > (uint32_t)LA) {
+        if (lane == 0 && ((meta >> kMetaStateShift) & kPodValid)) atomicAdd(n_overflow, 1ull);
+        meta |= kMetaOverflow;
+      }
+    }
+    if (lane == 0) pods.meta[row] = meta;
+    if (has_patch) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the wave's stores before the patch reads the rows back
+      if (lane == 0) patch_one(pods, row, v);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (do_translate && host_overflow) *host_overflow = __hip_atomic_load(n_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    signal_host(host_seq, seq);
+  }
+}
 // the same for deletes: kt_delete_pods + kt_patch_scan_views
 __global__ __launch_bounds__(kBlock) void kt_unfeed_small(PodTable pods, int64_t n, const int64_t* rows, int has_patch, const ViewPatch v,
                                                           unsigned long long* host_seq, unsigned long long seq) {
@@ -480,6 +586,17 @@ void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDe
   if (pods.LA == 8) hipLaunchKernelGGL(kt_feed_small<8>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
   else if (pods.LA == 16) hipLaunchKernelGGL(kt_feed_small<16>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
   else hipLaunchKernelGGL(kt_feed_small<32>, dim3(1), dim3(kBlock), 0, s, pods, b, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, ss, sd, stage_bytes, host_seq, seq);
+}
+void launch_feed_few(const PodTable& pods, const PodBatchDev& b_off, bool has_rows, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
+                     const ViewPatch* v, unsigned long long* host_overflow, const void* slot, uint32_t slot_bytes, unsigned long long* host_seq,
+                     unsigned long long seq, hipStream_t s) {
+  const ViewPatch vp = v ? *v : ViewPatch{};
+  const int tr = do_translate ? 1 : 0, hp = v ? 1 : 0, hr = has_rows ? 1 : 0;
+  const u128* sl = (const u128*)slot;
+  const size_t lds = (((size_t)slot_bytes + 15u) & ~(size_t)15u) + (size_t)kFeedFewMax * (size_t)pods.LA * 2u;
+  if (pods.LA == 8) hipLaunchKernelGGL(kt_feed_few<8>, dim3(1), dim3(kBlock), lds, s, pods, b_off, hr, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, sl, slot_bytes, host_seq, seq);
+  else if (pods.LA == 16) hipLaunchKernelGGL(kt_feed_few<16>, dim3(1), dim3(kBlock), lds, s, pods, b_off, hr, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, sl, slot_bytes, host_seq, seq);
+  else hipLaunchKernelGGL(kt_feed_few<32>, dim3(1), dim3(kBlock), lds, s, pods, b_off, hr, ix.atom_table, ix.atom_mask, (int)ix.has_key_atoms, n_overflow, tr, hp, vp, host_overflow, sl, slot_bytes, host_seq, seq);
 }
 void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, unsigned long long* host_seq,
                          unsigned long long seq, hipStream_t s) {

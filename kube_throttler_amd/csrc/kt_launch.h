@@ -51,6 +51,12 @@ struct IndexDev;
 void launch_feed_small(const PodTable& pods, const PodBatchDev& b, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
                        const ViewPatch* v, unsigned long long* host_overflow, const void* stage_src, void* stage_dst, uint32_t stage_bytes,
                        unsigned long long* host_seq, unsigned long long seq, hipStream_t s);
+// n <= kFeedFewMax pods, whose batch fits kFeedFewSlotMax bytes: one wave per pod (kt_feed_few); b_off holds BYTE OFFSETS into the slot
+constexpr int64_t kFeedFewMax = 4;
+constexpr uint32_t kFeedFewSlotMax = 32 * 1024;
+void launch_feed_few(const PodTable& pods, const PodBatchDev& b_off, bool has_rows, const IndexDev& ix, unsigned long long* n_overflow, bool do_translate,
+                     const ViewPatch* v, unsigned long long* host_overflow, const void* slot, uint32_t slot_bytes, unsigned long long* host_seq,
+                     unsigned long long seq, hipStream_t s);
 void launch_unfeed_small(const PodTable& pods, int64_t n, const int64_t* rows, const ViewPatch* v, unsigned long long* host_seq,
                          unsigned long long seq, hipStream_t s);
 void launch_gather_pod_requests(const PodTable& pods, int64_t n, const int64_t* rows_dev, int64_t* out_v,

@@ -236,6 +236,55 @@ def test_incremental_feed_matches_bulk(oracle_mod):
         eng.close()
 
 
+@pytest.mark.parametrize("shape", ["default", "wide", "sixteen-dims"])
+def test_event_sized_batches_match_bulk(shape, oracle_mod, monkeypatch):
+    """Pods fed as informer events — batches of one to four, in scrambled row order, every row twice (garbage first) — end
+    in the state a bulk load gives: kt_feed_few (one wave per pod: lane = dimension / label slot, the batch read from LDS)
+    against kt_ingest_pods + kt_translate_pods.  The generator gives init containers, overhead, explicit zeros and absent
+    keys; `wide` carries more relevant labels than atom slots (overflow pods), `sixteen-dims` 16 dimension slots."""
+    cfg = {"default": W.small(seed=41, n_pods=400, n_thr=48, n_cluster=24),
+           "wide": W.small(seed=42, n_pods=300, n_thr=160, n_cluster=96, D=4, n_ns=4, K=48, V=2, L=40, terms=(1, 3), reqs=(1, 4)),
+           "sixteen-dims": W.small(seed=43, n_pods=300, n_thr=48, n_cluster=24, D=16)}[shape]
+    final = W.generate(cfg)
+    cfg2 = W.small(seed=cfg.seed + 100, n_pods=cfg.n_pods_total, n_thr=cfg.n_thr, n_cluster=cfg.n_cluster, D=cfg.D, n_ns=cfg.n_ns, K=cfg.K, V=cfg.V,
+                   L=cfg.L)
+    other = W.generate(cfg2)
+    bulk = E.Engine.for_snapshot(final, E.VARIANT_INDEXED)
+    eng = E.Engine(final.D, final.L, final.n_pods + 8, final.n_thr + 4, final.n_ns + 4)
+    try:
+        eng.upsert_namespaces(final)
+        eng.upsert_throttles(final)
+        eng.reconcile(NOW, apply=False)   # compiles the program: the events below are translated as they arrive
+        rng = np.random.default_rng(7)
+        for snap in (other, final):
+            order = rng.permutation(final.n_pods)
+            k = 0
+            while k < len(order):
+                nb = int(rng.integers(1, 5))
+                rows = np.sort(order[k:k + nb]).astype(np.int64)
+                eng.upsert_pods(_permute_pods(snap, rows), rows=rows)
+                k += nb
+        gv, gp = eng.fetch_pod_requests(n=final.n_pods)
+        bv, bp = bulk.fetch_pod_requests(n=final.n_pods)
+        np.testing.assert_array_equal(gp, bp, err_msg="pod request presence")
+        np.testing.assert_array_equal(gv, bv, err_msg="pod request values")
+        o = oracle_mod.Oracle(final)
+        rows_t = responsible_rows(final)
+        want = o.reconcile(NOW, rows=rows_t)
+        got = eng.reconcile(NOW, apply=True)
+        np.testing.assert_array_equal(got.used.v[rows_t], want.used.v[:len(rows_t)])
+        np.testing.assert_array_equal(got.used.present[rows_t], want.used.present[:len(rows_t)])
+        np.testing.assert_array_equal(got.used.count[rows_t], want.used.count[:len(rows_t)])
+        final.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows_t)
+        st_w, sm_w = o.check()
+        st_g, sm_g = eng.check(n=final.n_pods, want_status=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+    finally:
+        eng.close()
+        bulk.close()
+
+
 def _with_pods(base, src_rows):
     """A copy of `base` (same namespaces / throttles) whose pod row r holds base's pod src_rows[r] (-1: row deleted)."""
     import copy
