@@ -249,7 +249,8 @@ def main():
 
     def bound_of(kn, ms_events):
         """What bounds the kernel, from the hash-gated profile of the SAME sources (profiles/pmc_summary.json): actual HBM
-        traffic against the roofline, VALU issue time (a wave-level VALU instruction holds its SIMD for 4 cycles) and LDS
+        traffic against the roofline, VALU issue time (4 cycles per wave-level instruction assumed — an upper bound: the logic /
+        add / bitop3 instructions issue in 2.4-2.7, the three-operand and multiplier ones in 4.1-4.5, profiles/r04_valu_rates.txt) and LDS
         bank-conflict cycles per LDS-active cycle.  Durations: the rocprofv3 average when the profile has one."""
         rec = pmc_kernels.get(sym(kn))
         if not rec:
