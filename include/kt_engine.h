@@ -93,7 +93,11 @@ const char* kt_last_error(kt_engine* e);
 int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* batch, const int32_t* ns_rows);
 /* Pods: the effective request of each pod is computed ON DEVICE from the batch's containers —
  * resourcelist.PodRequestResourceList (pkg/resourcelist/resourcelist.go:27-46) + ResourceAmountOfPod
- * (resource_amount.go:71-76).  */
+ * (resource_amount.go:71-76).
+ * The arrays are copied during the call.  A batch that fits a 64 KB pinned slot (an informer event, or a few dozen
+ * coalesced ones) does NOT wait for the device: the call enqueues one kernel and returns; every other entry point — a
+ * kt_check issued right behind it included — first waits for the newest such call, so the order "feed the event, then
+ * the next PreFilter sees it" holds (kt_delete_pods and kt_upsert_pod likewise).  Larger batches block as before. */
 int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* batch, const int64_t* pod_rows);
 /* Throttles: spec (threshold, overrides, selector), stored status and reserved amounts of each row. */
 int32_t kt_upsert_throttles(kt_engine* e, const kt_snapshot* batch, const int32_t* thr_rows);
