@@ -16,6 +16,7 @@
 #include <set>
 #include <vector>
 
+#include "../../kube_throttler_amd/host/kt_anchor.h"
 #include "kt_index.h"
 #include "../../include/kt_snapshot.h"
 
@@ -372,6 +373,98 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
   return (long)chunks_first * 1000000L + matches % 1000000L + (ix.rich ? 0 : 500000000L);
 }
 
+// ---- anchored mode (groundwork of the inverted scan, kube_throttler_amd/host/kt_anchor.h): the program split by anchor
+//      atom, one index per anchor built by the SAME kt::build_index, a pod walked through the sub-indexes of anchor 0 and of
+//      the pairs it carries — the union must be exactly the brute-force result of the ORIGINAL program, every throttle
+//      reported once.  Returns word visits over all pods (g_word_steps delta).
+struct AnchoredIndexes {
+  std::vector<AnchorSubProgram> subs;
+  std::vector<Program> progs;  // the sub-programs as Programs (scan() confirms slow shapes / walks slow throttles through them)
+  std::vector<HostIndex> ix;
+  std::map<uint32_t, size_t> by_anchor;
+  AnchorSplitStats stats;
+  size_t words = 0, chunks = 0;
+};
+static void build_anchored(const Program& p, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int max_labels, AnchoredIndexes& A) {
+  const size_t T = p.thr.size();
+  std::vector<uint8_t> anchorable(T, 0);
+  for (size_t t = 0; t < T; ++t) {
+    bool ok = p.thr[t].live && p.thr_term_off[t + 1] - p.thr_term_off[t] <= 64u;
+    for (uint32_t g = p.thr_term_off[t]; g < p.thr_term_off[t + 1] && ok; ++g) ok = !(p.term_flags[g] & KT_TERM_POD_SEL_INVALID);
+    anchorable[t] = ok;
+  }
+  A.subs = anchor_split(p.thr_term_off, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val, anchorable, &A.stats);
+  A.progs.resize(A.subs.size()), A.ix.resize(A.subs.size());
+  for (size_t k = 0; k < A.subs.size(); ++k) {
+    const AnchorSubProgram& sp = A.subs[k];
+    Program& q = A.progs[k];
+    q.thr_term_off = sp.thr_term_off, q.term_flags = sp.term_flags, q.term_req_off = sp.term_req_off, q.req_op = sp.req_op;
+    q.req_key = sp.req_key, q.req_val_off = sp.req_val_off, q.req_val = sp.req_val;
+    q.n_ns = p.n_ns, q.K = p.K, q.V = p.V;
+    for (uint32_t t : sp.thr_orig) q.thr.push_back(p.thr[t]);
+    const uint32_t G = (uint32_t)sp.term_orig.size();
+    for (size_t v = 0; v + 1 < sp.thr_term_off.size(); ++v)
+      for (uint32_t g = sp.thr_term_off[v]; g < sp.thr_term_off[v + 1]; ++g) q.term_thr.push_back((uint32_t)v);
+    q.gw = (G + 31) / 32 + 1;
+    q.ns_term_ok.assign((size_t)p.n_ns * q.gw, 0u);
+    for (uint32_t n = 0; n < p.n_ns; ++n)
+      for (uint32_t g = 0; g < G; ++g)
+        if (ns_ok(p, sp.term_orig[g], n)) q.ns_term_ok[(size_t)n * q.gw + (g >> 5)] |= 1u << (g & 31);
+    build_index(A.ix[k], q.thr_term_off, q.term_thr, q.term_flags, q.term_req_off, q.req_op, q.req_key, q.req_val_off, q.req_val,
+                [&](uint32_t t) { return q.thr[t]; }, p.n_ns, q.ns_term_ok, q.gw, agg_budget, chk_budget, thr_bytes, max_labels);
+    check_structure(q, A.ix[k], agg_budget, chk_budget, thr_bytes);
+    A.by_anchor[sp.anchor] = k;
+    A.words += A.ix[k].bm_words, A.chunks += A.ix[k].bm_chunks.size();
+  }
+}
+// the walk of ONE pod: anchor 0 + the anchors it carries; out: original throttle -> 1 (match) / 2 (error)
+static std::map<uint32_t, int> scan_anchored(const AnchoredIndexes& A, const PodLabels& pod) {
+  std::map<uint32_t, int> out;
+  auto walk = [&](uint32_t anchor) {
+    const auto it = A.by_anchor.find(anchor);
+    if (it == A.by_anchor.end()) return;
+    const size_t k = it->second;
+    for (const auto& kv : scan(A.progs[k], A.ix[k], pod)) {
+      const uint32_t t = A.subs[k].thr_orig[kv.first];
+      EXPECT(!out.count(t), "throttle %u reported by two anchors (second: %u)", t, anchor);
+      out[t] = kv.second;
+    }
+  };
+  walk(0u);
+  for (uint32_t pr : pod.pairs) walk(pr);
+  return out;
+}
+static long anchored_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint32_t V, int max_terms, int max_reqs, double p_bad,
+                          uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int n_pods, long* visits_classic, long* visits_anchored) {
+  std::mt19937 rng(seed);
+  Program p = random_program(rng, T, n_ns, K, V, max_terms, max_reqs, p_bad);
+  HostIndex classic;
+  build_index(classic, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+              [&](uint32_t t) { return p.thr[t]; }, n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)K);
+  AnchoredIndexes A;
+  build_anchored(p, agg_budget, chk_budget, thr_bytes, (int)K, A);
+  long matches = 0;
+  for (int i = 0; i < n_pods; ++i) {
+    PodLabels pod;
+    pod.ns = rng() % n_ns;
+    for (uint32_t k = 1; k <= K; ++k)
+      if (rng() % 100 < 55) pod.keys.push_back(k), pod.pairs.push_back(p.pair(k, rng() % V));
+    long w0 = g_word_steps;
+    (void)scan(p, classic, pod);
+    *visits_classic += g_word_steps - w0, w0 = g_word_steps;
+    const std::map<uint32_t, int> got = scan_anchored(A, pod);
+    *visits_anchored += g_word_steps - w0;
+    for (uint32_t t = 0; t < T; ++t) {
+      const int want = brute(p, t, pod);
+      const auto it = got.find(t);
+      const int have = it == got.end() ? 0 : it->second;
+      EXPECT(have == want, "anchored: seed %u pod %d throttle %u: sub-indexes say %d, program says %d", seed, i, t, have, want);
+      matches += want == 1;
+    }
+  }
+  return matches;
+}
+
 // ---- file mode: the REAL selector program of a BASELINE config + a pod sample (tools/dump_program.py)
 static std::vector<uint32_t> read_array(FILE* fh) {
   uint32_t n = 0;
@@ -628,7 +721,9 @@ static void pack_plan_cases() {
   printf("pack plan: %d packed, %d refused\n", packed, refused);
 }
 
+static int run_anchored(int argc, char** argv);
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--anchored")) return run_anchored(argc, argv);
   if (argc > 1) return run_file(argv[1], argc > 2 ? (uint32_t)atoi(argv[2]) : 80u * 1024u - check_fixed_lds());
   pack_plan_cases();
   long chunks_seen = 0, matches = 0, simple_seen = 0;
@@ -666,5 +761,94 @@ int main(int argc, char** argv) {
   }
   printf("index_sim_test: all expectations held (max %ld chunks, %ld matches, %ld simple-form programs, %ld slow confirmations); fingerprint of all indexes %016llx\n",
          chunks_seen, matches, simple_seen, g_slow_confirms, (unsigned long long)g_fingerprint);
+  return 0;
+}
+
+// the dumped program of a BASELINE config (tools/dump_program.py) as a Program + its pod sample
+static bool load_dump(const char* path, Program& p, std::vector<PodLabels>& pods, uint32_t* D, uint32_t* L) {
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return false;
+  const std::vector<uint32_t> hdr = read_array(fh);
+  p.thr_term_off = read_array(fh);
+  p.term_thr = read_array(fh);
+  for (uint32_t f : read_array(fh)) p.term_flags.push_back((uint8_t)f);
+  p.term_req_off = read_array(fh);
+  for (uint32_t o : read_array(fh)) p.req_op.push_back((uint8_t)o);
+  p.req_key = read_array(fh);
+  p.req_val_off = read_array(fh);
+  p.req_val = read_array(fh);
+  const std::vector<uint32_t> live = read_array(fh), cluster = read_array(fh), thr_ns = read_array(fh);
+  p.ns_term_ok = read_array(fh);
+  const std::vector<uint32_t> pod_ns = read_array(fh), loff = read_array(fh), lkey = read_array(fh), lpair = read_array(fh);
+  fclose(fh);
+  p.n_ns = hdr[2], p.gw = hdr[3], *D = hdr[5];
+  for (uint32_t t = 0; t < hdr[0]; ++t) p.thr.push_back(ThrInfo{live[t] != 0, cluster[t] != 0, thr_ns[t]});
+  *L = 1;
+  for (size_t i = 0; i + 1 < loff.size(); ++i) {
+    *L = std::max(*L, loff[i + 1] - loff[i]);
+    PodLabels pod;
+    pod.ns = pod_ns[i];
+    for (uint32_t j = loff[i]; j < loff[i + 1]; ++j) pod.keys.push_back(lkey[j]), pod.pairs.push_back(lpair[j]);
+    pods.push_back(pod);
+  }
+  return true;
+}
+
+static int run_anchored(int argc, char** argv) {
+  if (argc > 2) {  // a dumped program: visits per pod of the classic index and of the per-anchor indexes, exactness on a sample
+    Program p;
+    std::vector<PodLabels> pods;
+    uint32_t D = 8, L = 8;
+    if (!load_dump(argv[2], p, pods, &D, &L)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+    const uint32_t thr_bytes = 8 * D + 8, agg_budget = 160u * 1024u - aggregate_fixed_lds(), chk_budget = 160u * 1024u - check_fixed_lds();
+    HostIndex classic;
+    build_index(classic, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+                [&](uint32_t t) { return p.thr[t]; }, p.n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L);
+    const auto t0 = std::chrono::steady_clock::now();
+    AnchoredIndexes A;
+    build_anchored(p, agg_budget, chk_budget, thr_bytes, (int)L, A);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    long vc = 0, va = 0, matches = 0, v_max = 0;
+    const size_t T = p.thr.size();
+    for (size_t i = 0; i < pods.size(); ++i) {
+      long w0 = g_word_steps;
+      const auto one = scan(p, classic, pods[i]);
+      vc += g_word_steps - w0, w0 = g_word_steps;
+      const auto got = scan_anchored(A, pods[i]);
+      va += g_word_steps - w0, v_max = std::max(v_max, g_word_steps - w0);
+      EXPECT(got == one, "pod %zu: the per-anchor indexes and the classic index disagree (%zu vs %zu throttles)", i, got.size(), one.size());
+      if (i % 16 == 0)
+        for (uint32_t t = 0; t < T; ++t) {
+          const int want = brute(p, t, pods[i]);
+          const auto b = got.find(t);
+          EXPECT((b == got.end() ? 0 : b->second) == want, "anchored: pod %zu throttle %u", i, t);
+        }
+      matches += (long)got.size();
+    }
+    size_t max_words = 0, max_chunks = 0;
+    for (const HostIndex& ix : A.ix) max_words = std::max<size_t>(max_words, ix.bm_words), max_chunks = std::max(max_chunks, ix.bm_chunks.size());
+    printf("%s: %zu throttles, %zu terms -> %zu anchors (anchor 0: %zu throttles kept whole), %zu virtual throttles, %zu term copies (%.2fx)\n", argv[2], T,
+           A.stats.n_terms_in, A.stats.n_anchors, A.stats.n_unanchored_throttles, A.stats.n_virtual_throttles, A.stats.n_terms_out,
+           (double)A.stats.n_terms_out / (double)std::max<size_t>(1, A.stats.n_terms_in));
+    printf("  per-anchor indexes: %zu words in all (classic: %u), largest %zu words / %zu chunk(s); split + %zu index builds %.1f ms (one thread)\n", A.words,
+           classic.bm_words, max_words, max_chunks, A.ix.size(), ms);
+    printf("  %zu pods: %.2f matches per pod; word visits per pod: classic %.2f, per-anchor %.2f (max %ld)\n", pods.size(),
+           (double)matches / (double)pods.size(), (double)vc / (double)pods.size(), (double)va / (double)pods.size(), v_max);
+    if (g_fail) { fprintf(stderr, "%d expectation(s) failed\n", g_fail); return 1; }
+    printf("index_sim_test --anchored: all expectations held\n");
+    return 0;
+  }
+  long vc = 0, va = 0, matches = 0;
+  for (uint32_t seed = 1; seed <= 30; ++seed) {
+    matches += anchored_case(seed, 40 + seed % 60, 1 + seed % 9, 6, 4, 3, 3, seed % 5 == 0 ? 0.05 : 0.0, 160 << 10, 160 << 10, 160, 200, &vc, &va);
+    matches += anchored_case(1000 + seed, 200 + seed * 7, 2 + seed % 17, 8, 5, 4, 4, seed % 4 == 0 ? 0.02 : 0.0, 12000 + 700 * (seed % 7),
+                             9000 + 500 * (seed % 5), 16 + 8 * (seed % 20), 100, &vc, &va);
+  }
+  matches += anchored_case(77, 3000, 32, 16, 16, 4, 3, 0.0, 160 << 10, 140 << 10, 72, 64, &vc, &va);  // configs[4]-like shapes
+  matches += anchored_case(79, 300, 5, 12, 3, 3, 6, 0.0, 160 << 10, 160 << 10, 72, 300, &vc, &va);    // slow shapes (> 3 positive keys)
+  matches += anchored_case(80, 24, 6, 8, 3, 150, 2, 0.0, 160 << 10, 160 << 10, 72, 100, &vc, &va);    // > 64 terms: kept whole
+  if (matches < 1000) ++g_fail, fprintf(stderr, "FAIL: only %ld matches\n", matches);
+  if (g_fail) { fprintf(stderr, "%d expectation(s) failed\n", g_fail); return 1; }
+  printf("index_sim_test --anchored: all expectations held (%ld matches; word visits: classic %ld, per-anchor %ld)\n", matches, vc, va);
   return 0;
 }

@@ -2,6 +2,7 @@
 (kube_throttler_amd/quantity.py) — two implementations of the same restated apimachinery grammar."""
 import os
 import subprocess
+import sys
 from fractions import Fraction
 
 import pytest
@@ -167,6 +168,28 @@ def test_index_builder_against_cpu_scan_replay(tool):
     out3 = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_INDEX_THREADS="3"))
     assert out3.returncode == 0, out3.stderr[-2000:]
     assert "fingerprint of all indexes 910654f0285ce8d4" in out3.stdout, out3.stdout[-400:]
+
+
+def test_anchor_split_against_brute_force(tool, tmp_path):
+    """The selector program split by anchor atom (kube_throttler_amd/host/kt_anchor.h — groundwork of the inverted scan,
+    not wired into the engine): per throttle one copy per anchor value of its terms' `In` requirements, each copy vetoing
+    the earlier anchors; one index per anchor from the SAME kt::build_index.  A pod walked through the sub-indexes of
+    anchor 0 and of the pairs it carries must give exactly the brute-force result of the ORIGINAL program, every throttle
+    reported once — random programs (all operators, slow shapes, > 64 terms, unconvertible terms), and the real program of
+    a BASELINE configs[4] shard, where it also has to pay: < 25 word visits per pod where the classic index needs 75."""
+    subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test"), "--anchored"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "--anchored: all expectations held" in out.stdout
+    dump = str(tmp_path / "cfg4.bin")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "4", "--pods", "1024", dump],
+                          stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test"), "--anchored", dump], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-1000:]
+    assert "--anchored: all expectations held" in out.stdout
+    import re
+    m = re.search(r"word visits per pod: classic ([0-9.]+), per-anchor ([0-9.]+)", out.stdout)
+    assert m and float(m.group(1)) > 60 and float(m.group(2)) < 25, out.stdout[-600:]
 
 
 def test_label_key_value_validation(tool):
