@@ -109,7 +109,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
-                 int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full, uint32_t chk_word) {
+                 int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full, uint32_t chk_word, const HostIndex* atoms_from) {
   {
     // a fresh index in the OLD index's storage: the full bitmaps and the chunk images are a few megabytes that would
     // otherwise be unmapped and faulted in again page by page on every build
@@ -183,6 +183,21 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     }
     for (auto& kv : pairs_of_key)
       if (!kv.second.empty()) pair_keys.insert(kv.first);
+  }
+  if (atoms_from) {
+    // an imposed numbering: which atoms a pod carrying a key can show up with is a fact of THAT table (a pair another
+    // part of the full program names is a pair atom for every pod, whether this program names it or not)
+    pairs_of_key.clear(), pair_keys.clear(), key_atoms.clear();
+    for (size_t i = 0; i < atoms_from->atoms.size(); ++i) {
+      const uint32_t atom = atoms_from->atoms[i].atom, key = atoms_from->atom_key[i];
+      if (atom & kKeyAtom) {
+        key_atoms.insert(key);
+      } else {
+        std::vector<uint32_t>& v = pairs_of_key[key];
+        v.insert(std::lower_bound(v.begin(), v.end(), atom), atom);
+        pair_keys.insert(key);
+      }
+    }
   }
   auto whole_key = [&](uint32_t key) {  // every atom a pod carrying `key` can show up with, sorted
     std::vector<uint32_t> a;
@@ -539,7 +554,18 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     out.rich = out.has_veto || out.has_slow || out.max_need > 2 || out.la != 8;
     std::sort(atoms.begin(), atoms.end());
     atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
-    for (uint32_t i = 0; i < atoms.size(); ++i) out.atoms.push_back(AtomId{atoms[i], i + 1});
+    if (atoms_from) {
+      out.atoms = atoms_from->atoms, out.atom_key = atoms_from->atom_key;
+      out.la = atoms_from->la, out.rich = true;
+    } else {
+      std::unordered_map<uint32_t, uint32_t> key_of_pair;
+      for (auto& kv : pairs_of_key)
+        for (uint32_t a : kv.second) key_of_pair.emplace(a, kv.first);
+      for (uint32_t i = 0; i < atoms.size(); ++i) {
+        out.atoms.push_back(AtomId{atoms[i], i + 1});
+        out.atom_key.push_back((atoms[i] & kKeyAtom) ? (atoms[i] & ~kKeyAtom) : key_of_pair[atoms[i]]);
+      }
+    }
   }
   const uint32_t A = (uint32_t)out.atoms.size();
   const uint32_t R = A + 1;
@@ -587,7 +613,9 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     const uint32_t mask = (uint32_t)out.atom_table.size() - 1u;
     for (size_t q = q0; q < q1; ++q) {  // the device's translation table (open addressing) is the faster map here too
       uint32_t sl = atom_slot(atom_pool[q], mask);
-      while ((uint32_t)out.atom_table[sl] != atom_pool[q]) sl = (sl + 1) & mask;
+      while (out.atom_table[sl] != 0ull && (uint32_t)out.atom_table[sl] != atom_pool[q]) sl = (sl + 1) & mask;
+      // (an imposed numbering may lack a pair this program names — an anchor veto on a value no term that can match names:
+      //  no pod carries it as an atom, row 0 = "no row")
       pool_row[q] = (uint32_t)(out.atom_table[sl] >> 32);
     }
   }, nullptr);
@@ -634,8 +662,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         term_t[c] = b.t | kTermReal | (b.adj ? kTermAdj : 0u);
         term_g[c] = b.g;
         if (b.n_pos == 0u) hdr[w].univ |= bit;
-        for (uint32_t q = b.pos_off; q < b.pos_off + b.pos_cnt; ++q) any[(size_t)pool_row[q] * W + w] |= bit;
-        for (uint32_t q = b.neg_off; q < b.neg_off + b.neg_cnt; ++q) vet[(size_t)pool_row[q] * W + w] |= bit;
+        for (uint32_t q = b.pos_off; q < b.pos_off + b.pos_cnt; ++q)
+          if (pool_row[q]) any[(size_t)pool_row[q] * W + w] |= bit;
+        for (uint32_t q = b.neg_off; q < b.neg_off + b.neg_cnt; ++q)
+          if (pool_row[q]) vet[(size_t)pool_row[q] * W + w] |= bit;
         for (uint32_t i = 0; i < b.n_pos; ++i)
           if (b.pos_key[i] >= 0)
             for (uint32_t r : rows_of_key.find((uint32_t)b.pos_key[i])->second) any[(size_t)r * W + w] |= bit;
@@ -742,6 +772,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
     // ---- image of words [w0, w1)
     BmChunk ch{};
     ch.w0 = w0, ch.n_words = w1 - w0;
+    ch.ns_base = 0u, ch.ns_cnt = 0xFFFFFFFFu;
     ch.stride = ch.n_words | 1u;
     r_lo = ~0u, r_hi = 0;
     for (size_t c = (size_t)w0 * 64; c < (size_t)w1 * 64; ++c)

@@ -92,6 +92,11 @@ struct BmChunk {
   uint32_t has_slow;  // some term of the chunk needs the generic walk
   uint32_t img_bytes;
   uint32_t has_adj;   // some throttle of the chunk has several terms (the check's wordwise form then applies its run masks)
+  // the namespace rows the chunk's word lists serve: [ns_base, ns_base + ns_cnt).  A classic index serves all of them
+  // (0, 0xFFFFFFFF); the chunks of an anchored index (host/kt_anchor.h: one sub-index per anchor atom, concatenated) each
+  // serve the block of VIRTUAL namespaces of their anchor — nsl_off is then indexed by (namespace - ns_base).  Not read by
+  // the kernels yet (NEXT.md #1b).
+  uint32_t ns_base, ns_cnt;
 };
 
 struct AtomId {
@@ -110,6 +115,7 @@ struct HostIndex {
   uint32_t la = 8;        // atom slots per pod the scan kernels are instantiated for (8 / 16 / 32)
   bool rich = false;      // image in the {any, veto} form, kernels in the <VETO, NEED 3> instantiation
   std::vector<AtomId> atoms;               // referenced atom -> id (1..A)
+  std::vector<uint32_t> atom_key;          // key id of every entry of `atoms` (a pair's key; a key atom's own key)
   std::vector<uint64_t> atom_table;        // open-addressing table for the device: atom | id << 32, 0 = empty
   std::vector<BmChunk> bm_chunks;
   std::vector<unsigned char> bm_images;    // chunk images back to back
@@ -230,7 +236,10 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
                  int max_labels, const std::vector<uint32_t>* adm_in = nullptr, uint32_t chk_budget_full = 0,
-                 uint32_t chk_word = kCheckWordLds);
+                 uint32_t chk_word = kCheckWordLds, const HostIndex* atoms_from = nullptr);
+// atoms_from (optional): the atom numbering is IMPOSED — that of another index (its atoms / atom_key / atom_table / la) —
+// instead of derived from this program: the sub-indexes of an anchored index (host/kt_anchor.h) share the numbering of the
+// full program, against which the pods' atom rows are translated once; the image form is then always the rich one
 // adm_in (optional): the namespace admission set of every term as bit words [terms][(n_ns + 31) / 32] (= ns_term_ok
 // transposed), when the caller holds it already; chk_budget_full (optional): the check budget to cut for when the
 // program needs several chunks anyway (one cut instead of two)

@@ -57,7 +57,7 @@ std::vector<AnchorSubProgram> anchor_split(const std::vector<uint32_t>& thr_term
                                            const std::vector<uint32_t>& term_req_off, const std::vector<uint8_t>& req_op,
                                            const std::vector<uint32_t>& req_key, const std::vector<uint32_t>& req_val_off,
                                            const std::vector<uint32_t>& req_val, const std::vector<uint8_t>& thr_anchorable,
-                                           AnchorSplitStats* stats) {
+                                           AnchorSplitStats* stats, const std::vector<uint8_t>* term_kept) {
   const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
   std::map<uint32_t, AnchorSubProgram> subs;
   AnchorSplitStats st;
@@ -71,6 +71,10 @@ std::vector<AnchorSubProgram> anchor_split(const std::vector<uint32_t>& thr_term
     bool anchorable = t < thr_anchorable.size() && thr_anchorable[t] != 0 && g1 > g0;
     for (uint32_t g = g0; g < g1 && anchorable; ++g) {
       TermAnchor& a = ta[g - g0];
+      if (term_kept && !(*term_kept)[g]) {
+        a.dead = true;  // matches nowhere: no copy, no anchors
+        continue;
+      }
       for (uint32_t r = term_req_off[g]; r < term_req_off[g + 1]; ++r) {
         if (req_op[r] != KT_OP_IN) continue;
         std::vector<uint32_t> v(req_val.begin() + req_val_off[r], req_val.begin() + req_val_off[r + 1]);
@@ -136,6 +140,102 @@ std::vector<AnchorSubProgram> anchor_split(const std::vector<uint32_t>& thr_term
   st.n_anchors = out.size();
   if (stats) *stats = st;
   return out;
+}
+
+
+void build_anchored_index(AnchoredIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint8_t>& term_flags,
+                          const std::vector<uint32_t>& term_req_off, const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
+                          const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
+                          const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns, const std::vector<uint32_t>& ns_term_ok, uint32_t gw,
+                          uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int max_labels, uint32_t chk_word, const HostIndex& classic) {
+  const size_t T = thr_term_off.empty() ? 0 : thr_term_off.size() - 1;
+  // what may be split: live throttles without an unconvertible podSelector term and with at most 64 terms (the others keep
+  // their place on the slow list of block 0)
+  std::vector<uint8_t> anchorable(T, 0);
+  for (size_t t = 0; t < T; ++t) {
+    bool ok = thr_info((uint32_t)t).live && thr_term_off[t + 1] - thr_term_off[t] <= 64u;
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1] && ok; ++g) ok = !(term_flags[g] & KT_TERM_POD_SEL_INVALID);
+    anchorable[t] = ok;
+  }
+  // the terms that can match at all (build_index's own rules: a live throttle, a namespace side that admits something)
+  const size_t G_all = term_req_off.empty() ? 0 : term_req_off.size() - 1;
+  std::vector<uint8_t> kept(G_all, 0);
+  for (size_t t = 0; t < T; ++t) {
+    const ThrInfo ti = thr_info((uint32_t)t);
+    if (!ti.live) continue;
+    for (uint32_t g = thr_term_off[t]; g < thr_term_off[t + 1]; ++g) {
+      if (ti.cluster && (term_flags[g] & KT_TERM_NS_SEL_INVALID)) continue;
+      if (!ti.cluster && ti.ns >= n_ns) continue;
+      bool any = false;
+      for (uint32_t n = 0; n < n_ns && !any; ++n) any = (ns_term_ok[(size_t)n * gw + (g >> 5)] >> (g & 31)) & 1u;
+      kept[g] = any;
+    }
+  }
+  out = AnchoredIndex();
+  const std::vector<AnchorSubProgram> subs = anchor_split(thr_term_off, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, anchorable, &out.stats, &kept);
+  out.n_ns = n_ns;
+  HostIndex& ox = out.ix;
+  ox.atoms = classic.atoms, ox.atom_key = classic.atom_key, ox.atom_table = classic.atom_table;
+  ox.bm_rows = classic.bm_rows, ox.la = classic.la, ox.rich = true;
+  ox.n_pair_keys = classic.n_pair_keys, ox.n_key_atoms = classic.n_key_atoms, ox.n_keys = classic.n_keys, ox.n_ns = n_ns;
+  const uint32_t n_blocks = (uint32_t)subs.size();
+  ox.ns_words = ((size_t)n_blocks * n_ns + 31) / 32;
+  if (!ox.ns_words) ox.ns_words = 1;
+  uint64_t slab_run = 0;
+  std::vector<uint32_t> term_thr_unused;
+  for (uint32_t c = 0; c < n_blocks; ++c) {
+    const AnchorSubProgram& sp = subs[c];
+    out.block_anchor.push_back(sp.anchor);
+    out.blk_chunk0.push_back((uint32_t)ox.bm_chunks.size());
+    // the namespace side of the copied terms: the original term's
+    const uint32_t G = (uint32_t)sp.term_orig.size(), gws = (G + 31) / 32 + 1;
+    std::vector<uint32_t> ok((size_t)n_ns * gws, 0u);
+    for (uint32_t g = 0; g < G; ++g) {
+      const uint32_t og = sp.term_orig[g];
+      for (uint32_t n = 0; n < n_ns; ++n)
+        if ((ns_term_ok[(size_t)n * gw + (og >> 5)] >> (og & 31)) & 1u) ok[(size_t)n * gws + (g >> 5)] |= 1u << (g & 31);
+    }
+    HostIndex sx;
+    build_index(sx, sp.thr_term_off, term_thr_unused, sp.term_flags, sp.term_req_off, sp.req_op, sp.req_key, sp.req_val_off, sp.req_val,
+                [&](uint32_t v) { return thr_info(sp.thr_orig[v]); }, n_ns, ok, gws, agg_budget, chk_budget, thr_bytes, max_labels, nullptr, 0u,
+                chk_word, &classic);
+    const uint32_t rank_base = (uint32_t)ox.bm_rank_t.size();
+    for (uint32_t r : sx.bm_rank_t) ox.bm_rank_t.push_back(sp.thr_orig[r]);
+    for (uint32_t v : sx.slow_thr) ox.slow_thr.push_back(sp.thr_orig[v]);
+    for (size_t k = 0; k < sx.bm_chunks.size(); ++k) {
+      BmChunk ch = sx.bm_chunks[k];
+      const size_t img0 = ox.bm_images.size();
+      ox.bm_images.insert(ox.bm_images.end(), sx.bm_images.begin() + ch.img_off, sx.bm_images.begin() + ch.img_off + ch.img_bytes);
+      // throttle rows and term ids of the original program
+      uint32_t* tt = (uint32_t*)(ox.bm_images.data() + img0 + ch.off_term_t);
+      uint32_t* tg = (uint32_t*)(ox.bm_images.data() + img0 + ch.off_term_g);
+      for (uint32_t i = 0; i < ch.n_words * 64u; ++i) {
+        if (!(tt[i] & kTermReal)) continue;
+        tt[i] = (tt[i] & ~kTermRowMask) | sp.thr_orig[tt[i] & kTermRowMask];
+        tg[i] = sp.term_orig[tg[i]];
+      }
+      ch.img_off = (uint32_t)img0;
+      ch.rank0 += rank_base;
+      ch.ns_base = c * n_ns, ch.ns_cnt = n_ns;
+      ch.slab_off = (uint32_t)(slab_run / 16);
+      slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull) + 8192ull;
+      // which virtual namespaces have words here
+      const size_t b0 = ox.bm_chunk_ns.size();
+      ox.bm_chunk_ns.resize(b0 + ox.ns_words, 0u);
+      for (uint32_t n = 0; n < n_ns; ++n)
+        if ((sx.bm_chunk_ns[k * sx.ns_words + (n >> 5)] >> (n & 31)) & 1u) {
+          const uint32_t vns = c * n_ns + n;
+          ox.bm_chunk_ns[b0 + (vns >> 5)] |= 1u << (vns & 31);
+        }
+      ox.bm_max_lds = std::max(ox.bm_max_lds, ch.lds_bytes), ox.bm_max_thr = std::max(ox.bm_max_thr, ch.n_thr);
+      ox.bm_max_words = std::max(ox.bm_max_words, ch.n_words);
+      ox.bm_chunks.push_back(ch);
+    }
+    ox.bm_words += sx.bm_words;
+    ox.has_veto |= sx.has_veto, ox.has_slow |= sx.has_slow, ox.max_need = std::max(ox.max_need, sx.max_need);
+  }
+  out.blk_chunk0.push_back((uint32_t)ox.bm_chunks.size());
+  ox.bm_slab_bytes = slab_run;
 }
 
 }  // namespace kt

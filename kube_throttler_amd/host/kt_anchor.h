@@ -20,7 +20,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
+
+#include "../csrc/kt_index.h"
 
 namespace kt {
 
@@ -41,11 +44,32 @@ struct AnchorSplitStats {
 };
 
 // thr_anchorable[t]: the throttle may be split (live, no unconvertible podSelector term, <= 64 terms); everything else goes
-// to anchor 0 untouched.  key_of_pair(pair id) -> key id (the requirement that names the pair carries it).
+// to anchor 0 untouched.  term_kept[g] (optional): the term can match at all (its throttle is live, some namespace admits
+// it) — the others are left out: they contribute neither copies nor anchors, so that every anchor is a pair some KEPT term
+// names, i.e. an atom of the classic index.
 std::vector<AnchorSubProgram> anchor_split(const std::vector<uint32_t>& thr_term_off, const std::vector<uint8_t>& term_flags,
                                            const std::vector<uint32_t>& term_req_off, const std::vector<uint8_t>& req_op,
                                            const std::vector<uint32_t>& req_key, const std::vector<uint32_t>& req_val_off,
                                            const std::vector<uint32_t>& req_val, const std::vector<uint8_t>& thr_anchorable,
-                                           AnchorSplitStats* stats = nullptr);
+                                           AnchorSplitStats* stats = nullptr, const std::vector<uint8_t>* term_kept = nullptr);
+
+
+// The per-anchor indexes CONCATENATED into one chunked index the scan kernels can walk as it is (NEXT.md #1): block c = the
+// c-th anchor (block 0: anchor 0) serves the VIRTUAL namespaces [c * n_ns, (c + 1) * n_ns) — an item (pod, anchor it
+// carries) is a virtual pod of namespace c * n_ns + pod.ns — through BmChunk::ns_base / ns_cnt; every sub-index is built
+// by kt::build_index with the atom numbering of `classic` imposed (the pods' atom rows are translated once), its ranks,
+// throttle rows and term ids rewritten to the original program's.
+struct AnchoredIndex {
+  HostIndex ix;                        // chunks of all blocks back to back; atoms / atom_table = classic's
+  std::vector<uint32_t> block_anchor;  // block -> anchor pair id (block 0: 0)
+  std::vector<uint32_t> blk_chunk0;    // [blocks + 1] first chunk of every block
+  uint32_t n_ns = 0;                   // real namespaces per block
+  AnchorSplitStats stats;
+};
+void build_anchored_index(AnchoredIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint8_t>& term_flags,
+                          const std::vector<uint32_t>& term_req_off, const std::vector<uint8_t>& req_op, const std::vector<uint32_t>& req_key,
+                          const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
+                          const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns, const std::vector<uint32_t>& ns_term_ok, uint32_t gw,
+                          uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int max_labels, uint32_t chk_word, const HostIndex& classic);
 
 }  // namespace kt

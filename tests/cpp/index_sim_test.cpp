@@ -167,12 +167,19 @@ static std::vector<uint32_t> translate(const HostIndex& ix, const PodLabels& pod
 
 // replays scan_tile (kt_scan.h) for one pod -> per-throttle result (1 match / 2 error), checks "reported once"
 static long g_matches_exact = 0, g_slow_confirms = 0, g_word_steps = 0, g_admitted = 0;
-static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const PodLabels& pod) {
+static long g_word_useful = 0, g_word_hit = 0;  // visited words in which some atom of the pod (or a term without positive requirement) has an admitted bit / that hold a match
+// c0 / c1: the chunks walked (an anchored index: those of the item's block); walk_slow: the slow list too
+static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const PodLabels& pod, size_t c0 = 0, size_t c1 = ~(size_t)0,
+                                    bool walk_slow = true) {
   std::map<uint32_t, int> out;
   bool overflow = false;
   const std::vector<uint32_t> ids = translate(ix, pod, &overflow);
   const size_t fam = ix.rich ? 2 : 1;
-  for (const BmChunk& ch : ix.bm_chunks) {
+  for (size_t ci = c0; ci < std::min(c1, ix.bm_chunks.size()); ++ci) {
+    const BmChunk& ch = ix.bm_chunks[ci];
+    // the namespace rows the chunk's word lists serve (kt_index.h: BmChunk::ns_base / ns_cnt)
+    if (pod.ns < ch.ns_base || pod.ns - ch.ns_base >= ch.ns_cnt) continue;
+    const uint32_t ns_rel = pod.ns - ch.ns_base;
     const unsigned char* img = ix.bm_images.data() + ch.img_off;
     const uint64_t* rows = (const uint64_t*)img;
     const WordHdr* hdr = (const WordHdr*)(img + ch.off_hdr);
@@ -183,7 +190,7 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
     const uint32_t* term_g = (const uint32_t*)(img + ch.off_term_g);
     EXPECT(ch.off_term_t == ch.lds_bytes, "LDS part must end where term_t starts");
     uint32_t last_t = ~0u, last_r = ~0u, prev_w = ~0u;
-    for (uint32_t k = nsl_off[pod.ns]; k < nsl_off[pod.ns + 1]; ++k) {
+    for (uint32_t k = nsl_off[ns_rel]; k < nsl_off[ns_rel + 1]; ++k) {
       const uint32_t w = nsl[k].w;
       EXPECT(w < ch.n_words, "word %u of %u", w, ch.n_words);
       EXPECT(prev_w == ~0u || w > prev_w, "word list of ns %u not ascending", pod.ns);
@@ -199,8 +206,10 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
         two |= any & r;
         any |= r;
       }
+      if (any & nsl[k].mask) ++g_word_useful;
       uint64_t x = (any & ~hdr[w].m2) | (two & hdr[w].m2);
       x = (x & ~hdr[w].m3) | (three & hdr[w].m3);
+      if (x & ~vet & nsl[k].mask) ++g_word_hit;
       if (!ix.rich) EXPECT(hdr[w].m3 == 0 && hdr[w].slow == 0, "simple image with need-3 / slow terms");
       x &= ~vet & nsl[k].mask;
       uint64_t sl = x & hdr[w].slow;
@@ -233,9 +242,9 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       }
     }
     // the namespace's word list is exactly the words its admission can touch
-    for (uint32_t k = nsl_off[pod.ns]; k < nsl_off[pod.ns + 1]; ++k) EXPECT(nsl[k].mask != 0, "empty mask in the word list of ns %u", pod.ns);
+    for (uint32_t k = nsl_off[ns_rel]; k < nsl_off[ns_rel + 1]; ++k) EXPECT(nsl[k].mask != 0, "empty mask in the word list of ns %u", pod.ns);
   }
-  for (uint32_t t : ix.slow_thr) {
+  for (uint32_t t : walk_slow ? ix.slow_thr : std::vector<uint32_t>()) {
     const int r = brute(p, t, pod);  // walk_slow_mem IS the in-order walk
     EXPECT(!out.count(t), "slow throttle %u also indexed", t);
     if (r) out[t] = r;
@@ -434,6 +443,32 @@ static std::map<uint32_t, int> scan_anchored(const AnchoredIndexes& A, const Pod
   for (uint32_t pr : pod.pairs) walk(pr);
   return out;
 }
+// the same walk through the CONCATENATED anchored index (kt_anchor.h: build_anchored_index — the structure the device will
+// get): an item (pod, block) is a virtual pod of namespace block * n_ns + pod.ns walking the block's chunks
+static std::map<uint32_t, int> scan_concat(const Program& p, const AnchoredIndex& AX, const std::map<uint32_t, uint32_t>& block_of, const PodLabels& pod) {
+  std::map<uint32_t, int> out;
+  auto walk = [&](uint32_t c) {
+    PodLabels item = pod;
+    item.ns = c * AX.n_ns + pod.ns;
+    PodLabels real = pod;  // (slow confirmations / the slow list evaluate the ORIGINAL program: the pod's real namespace)
+    (void)real;
+    for (const auto& kv : scan(p, AX.ix, item, AX.blk_chunk0[c], AX.blk_chunk0[c + 1], /*walk_slow=*/false)) {
+      EXPECT(!out.count(kv.first), "throttle %u reported by two blocks (second: %u)", kv.first, c);
+      out[kv.first] = kv.second;
+    }
+  };
+  walk(0u);
+  for (uint32_t pr : pod.pairs) {
+    const auto it = block_of.find(pr);
+    if (it != block_of.end()) walk(it->second);
+  }
+  for (uint32_t t : AX.ix.slow_thr) {  // walked with block 0's item, in the pod's real namespace
+    const int r = brute(p, t, pod);
+    EXPECT(!out.count(t), "slow throttle %u also indexed", t);
+    if (r) out[t] = r;
+  }
+  return out;
+}
 static long anchored_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint32_t V, int max_terms, int max_reqs, double p_bad,
                           uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, int n_pods, long* visits_classic, long* visits_anchored) {
   std::mt19937 rng(seed);
@@ -443,6 +478,11 @@ static long anchored_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, 
               [&](uint32_t t) { return p.thr[t]; }, n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)K);
   AnchoredIndexes A;
   build_anchored(p, agg_budget, chk_budget, thr_bytes, (int)K, A);
+  AnchoredIndex AX;
+  build_anchored_index(AX, p.thr_term_off, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+                       [&](uint32_t t) { return p.thr[t]; }, n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)K, kCheckWordLds, classic);
+  std::map<uint32_t, uint32_t> block_of;
+  for (uint32_t c = 1; c < AX.block_anchor.size(); ++c) block_of[AX.block_anchor[c]] = c;
   long matches = 0;
   for (int i = 0; i < n_pods; ++i) {
     PodLabels pod;
@@ -454,6 +494,8 @@ static long anchored_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, 
     *visits_classic += g_word_steps - w0, w0 = g_word_steps;
     const std::map<uint32_t, int> got = scan_anchored(A, pod);
     *visits_anchored += g_word_steps - w0;
+    const std::map<uint32_t, int> got2 = scan_concat(p, AX, block_of, pod);
+    EXPECT(got2 == got, "anchored: seed %u pod %d: the concatenated index and the per-anchor indexes disagree (%zu vs %zu)", seed, i, got2.size(), got.size());
     for (uint32_t t = 0; t < T; ++t) {
       const int want = brute(p, t, pod);
       const auto it = got.find(t);
@@ -808,14 +850,27 @@ static int run_anchored(int argc, char** argv) {
     AnchoredIndexes A;
     build_anchored(p, agg_budget, chk_budget, thr_bytes, (int)L, A);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    long vc = 0, va = 0, matches = 0, v_max = 0;
+    const auto t1 = std::chrono::steady_clock::now();
+    AnchoredIndex AX;
+    build_anchored_index(AX, p.thr_term_off, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
+                         [&](uint32_t t) { return p.thr[t]; }, p.n_ns, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L, check_word_lds((int)D), classic);
+    const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    std::map<uint32_t, uint32_t> block_of;
+    for (uint32_t c = 1; c < AX.block_anchor.size(); ++c) block_of[AX.block_anchor[c]] = c;
+    long vc = 0, va = 0, vx = 0, matches = 0, v_max = 0;
+    std::vector<long> useful(pods.size()), hit(pods.size()), visited(pods.size());
     const size_t T = p.thr.size();
     for (size_t i = 0; i < pods.size(); ++i) {
       long w0 = g_word_steps;
+      const long u0 = g_word_useful, h0 = g_word_hit;
       const auto one = scan(p, classic, pods[i]);
+      useful[i] = g_word_useful - u0, hit[i] = g_word_hit - h0, visited[i] = g_word_steps - w0;
       vc += g_word_steps - w0, w0 = g_word_steps;
       const auto got = scan_anchored(A, pods[i]);
-      va += g_word_steps - w0, v_max = std::max(v_max, g_word_steps - w0);
+      va += g_word_steps - w0, v_max = std::max(v_max, g_word_steps - w0), w0 = g_word_steps;
+      const auto got2 = scan_concat(p, AX, block_of, pods[i]);
+      vx += g_word_steps - w0;
+      EXPECT(got2 == one, "pod %zu: the concatenated anchored index and the classic index disagree (%zu vs %zu throttles)", i, got2.size(), one.size());
       EXPECT(got == one, "pod %zu: the per-anchor indexes and the classic index disagree (%zu vs %zu throttles)", i, got.size(), one.size());
       if (i % 16 == 0)
         for (uint32_t t = 0; t < T; ++t) {
@@ -834,6 +889,26 @@ static int run_anchored(int argc, char** argv) {
            classic.bm_words, max_words, max_chunks, A.ix.size(), ms);
     printf("  %zu pods: %.2f matches per pod; word visits per pod: classic %.2f, per-anchor %.2f (max %ld)\n", pods.size(),
            (double)matches / (double)pods.size(), (double)vc / (double)pods.size(), (double)va / (double)pods.size(), v_max);
+    {
+      // what a lane-private word skip would walk (NEXT.md): per pod the words with an admitted bit of one of its atoms; a
+      // tile of 64 pods in namespace order steps max-over-lanes times
+      std::vector<size_t> ord(pods.size());
+      for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return pods[a].ns < pods[b].ns; });
+      double su = 0, sh = 0, tmax_u = 0, tmax_v = 0, tmax_h = 0;
+      size_t tiles = 0;
+      for (size_t i0 = 0; i0 < ord.size(); i0 += 64, ++tiles) {
+        long mu = 0, mv = 0, mh = 0;
+        for (size_t i = i0; i < std::min(ord.size(), i0 + 64); ++i) mu = std::max(mu, useful[ord[i]]), mv = std::max(mv, visited[ord[i]]), mh = std::max(mh, hit[ord[i]]);
+        tmax_u += mu, tmax_v += mv, tmax_h += mh;
+      }
+      for (size_t i = 0; i < pods.size(); ++i) su += useful[i], sh += hit[i];
+      printf("  classic index, words with an admitted atom bit per pod: %.2f (with a match: %.2f); per tile of 64 pods in namespace order, max over lanes: visited %.1f, useful %.1f, with a match %.1f\n",
+             su / pods.size(), sh / pods.size(), tmax_v / tiles, tmax_u / tiles, tmax_h / tiles);
+    }
+    printf("  concatenated (shared atom numbering, one chunked index over %zu virtual namespaces): %zu chunks, %u words, images %.1f MB, largest LDS part %u B / %u throttles / %u words per chunk, slab scratch %.0f MB; %.2f word visits per pod; built in %.1f ms\n",
+           (size_t)AX.block_anchor.size() * AX.n_ns, AX.ix.bm_chunks.size(), AX.ix.bm_words, AX.ix.bm_images.size() / 1048576.0, AX.ix.bm_max_lds, AX.ix.bm_max_thr,
+           AX.ix.bm_max_words, AX.ix.bm_slab_bytes / 1048576.0, (double)vx / (double)pods.size(), ms2);
     if (g_fail) { fprintf(stderr, "%d expectation(s) failed\n", g_fail); return 1; }
     printf("index_sim_test --anchored: all expectations held\n");
     return 0;

@@ -162,12 +162,12 @@ def test_index_builder_against_cpu_scan_replay(tool):
     # is how the round-3 rewrite of the builder's phases was accepted, together with the fingerprints of the dumped
     # BASELINE programs); a change of the index LAYOUT moves it on purpose — then re-pin it here after the GPU parity
     # tests have passed on the new layout.
-    assert "fingerprint of all indexes 910654f0285ce8d4" in out.stdout, out.stdout[-400:]
+    assert "fingerprint of all indexes 0f45a244af442de0" in out.stdout, out.stdout[-400:]
     # the builder's phases on several host threads (only programs beyond 16k throttles split by themselves): parts built
     # side by side and joined must give the same indexes
     out3 = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_INDEX_THREADS="3"))
     assert out3.returncode == 0, out3.stderr[-2000:]
-    assert "fingerprint of all indexes 910654f0285ce8d4" in out3.stdout, out3.stdout[-400:]
+    assert "fingerprint of all indexes 0f45a244af442de0" in out3.stdout, out3.stdout[-400:]
 
 
 def test_anchor_split_against_brute_force(tool, tmp_path):
@@ -176,7 +176,8 @@ def test_anchor_split_against_brute_force(tool, tmp_path):
     the earlier anchors; one index per anchor from the SAME kt::build_index.  A pod walked through the sub-indexes of
     anchor 0 and of the pairs it carries must give exactly the brute-force result of the ORIGINAL program, every throttle
     reported once — random programs (all operators, slow shapes, > 64 terms, unconvertible terms), and the real program of
-    a BASELINE configs[4] shard, where it also has to pay: < 25 word visits per pod where the classic index needs 75."""
+    a BASELINE configs[4] shard, where it also has to pay: < 25 word visits per pod where the classic index needs 75.
+    Both as separate per-anchor indexes and as ONE concatenated chunked index over virtual namespaces."""
     subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(HOST, "index_sim_test"), "--anchored"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -190,6 +191,11 @@ def test_anchor_split_against_brute_force(tool, tmp_path):
     import re
     m = re.search(r"word visits per pod: classic ([0-9.]+), per-anchor ([0-9.]+)", out.stdout)
     assert m and float(m.group(1)) > 60 and float(m.group(2)) < 25, out.stdout[-600:]
+    # the CONCATENATED form (build_anchored_index: every sub-index built on the classic index's atom numbering, chunk c
+    # serving the virtual namespaces [c * n_ns, (c + 1) * n_ns) through BmChunk::ns_base / ns_cnt — what the device would
+    # get): walked item by item it reports exactly what the classic index reports, in as few word visits
+    m2 = re.search(r"concatenated .*? ([0-9.]+) word visits per pod", out.stdout)
+    assert m2 and abs(float(m2.group(1)) - float(m.group(2))) < 1e-9, out.stdout[-800:]
 
 
 def test_label_key_value_validation(tool):
