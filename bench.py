@@ -66,6 +66,13 @@ def main():
     ap.add_argument("--native-comm", action="store_true",
                     help="exchange the partials with the engine's own RCCL communicator (kt_comm_*); the default when N > 1")
     ap.add_argument("--torch-comm", action="store_true", help="N > 1: run the exchange through torch.distributed instead")
+    ap.add_argument("--overlap", action="store_true",
+                    help="one GPU: the check of step i on a second stream beside the reconcile of step i + 1 (the PreFilter "
+                         "and the controller run concurrently in the reference too); every check still reads the status its own "
+                         "step's reconcile stored")
+    ap.add_argument("--sweep", action="store_true",
+                    help="one GPU: the step as ONE kt_sweep_launch — PreFilter sweep (against the stored status) and the reconcile scan "
+                         "fused into one pass over the pod tables — instead of kt_reconcile_launch + kt_check_launch")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: fixed rows per GPU (default); strong: the config's total pod count divided over the GPUs")
     args = ap.parse_args()
@@ -153,6 +160,9 @@ def main():
                     e1.record(ts)
                     xchg_events.append((e0, e1))
                 eng.finalize_launch(now, True, stream)
+            elif args.sweep:
+                eng.sweep_launch(now, True, False, stream)  # check (stored status) + reconcile: one pass over the pod tables
+                return
             else:
                 eng.reconcile_launch(now, True, stream)  # one GPU: nothing to exchange between scan and finalize
             eng.check_launch(per_gpu, None, False, False, stream)
@@ -162,6 +172,39 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # --overlap: two streams.  A carries the reconciles, B the checks; check(i) waits for finalize(i) (it reads the CheckRecs
+    # that finalize left behind) and runs beside aggregate(i + 1), which reads nothing a check writes.  The engine keeps two
+    # generations of CheckRecs once single-pod checks are in use (kt_engine.cpp finalize_locked: keep_prev), so finalize(i + 1)
+    # writes the buffer check(i) is NOT reading; finalize(i + 2) rewrites the one check(i) read and therefore waits for it.
+    overlap = args.overlap and world == 1 and not args.native_comm
+    overlap_identical = None
+    serial_step = step  # the instrumented pass below times the kernels one after the other in either mode
+    if overlap:
+        ts2 = torch.cuda.Stream()
+        stream2 = ts2.cuda_stream
+        ev_fin = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_chk = [torch.cuda.Event(), torch.cuda.Event()]
+        step()  # the serial form once: its results are what the overlapped loop has to reproduce bit for bit
+        fence()
+        _, ref_summary = eng.check_fetch(per_gpu, False)
+        ref_rec = eng.reconcile_fetch()
+        eng.check_atomic(rows=np.zeros(1, np.int64), want_status=False)  # a PreFilter call: switches the double buffer on
+        fence()
+        n_over = [0]
+
+        def step(timed_exchange=False):  # noqa: F811 — replaces the serial step from here on
+            i = n_over[0]
+            n_over[0] += 1
+            if i >= 2:
+                ts.wait_event(ev_chk[i % 2])  # check(i - 2) has released the CheckRec buffer finalize(i) rewrites
+            with torch.cuda.stream(ts):
+                eng.reconcile_launch(now, True, stream)
+            ev_fin[i % 2].record(ts)
+            ts2.wait_event(ev_fin[i % 2])
+            with torch.cuda.stream(ts2):
+                eng.check_launch(per_gpu, None, False, False, stream2)
+            ev_chk[i % 2].record(ts2)
 
     for _ in range(args.warmup):
         step()
@@ -181,11 +224,17 @@ def main():
         dist.all_gather(all_t, te)
         rank_ms = [float(t.item()) * 1e3 / args.steps for t in all_t]
         elapsed = max(float(t.item()) for t in all_t)  # MAX over ranks
+    if overlap:
+        _, got_summary = eng.check_fetch(per_gpu, False)
+        got_rec = eng.reconcile_fetch()
+        overlap_identical = bool(np.array_equal(got_summary, ref_summary) and all(
+            np.array_equal(np.asarray(getattr(got_rec, f)), np.asarray(getattr(ref_rec, f)))
+            for f in ("thrl_flag", "thrl_has", "thrl_pod", "error")) and np.array_equal(got_rec.used.v, ref_rec.used.v))
     # per-kernel durations: HIP events on the launch stream, same steps again
     eng.timing_enable(True)
     eng.timing_reset()
     for _ in range(min(args.steps, 20)):
-        step(timed_exchange=True)
+        serial_step(timed_exchange=True)
     fence()
     eng.timing_enable(False)
     exchange_ms = (sum(a.elapsed_time(b) for a, b in xchg_events) / len(xchg_events)) if xchg_events else None
@@ -218,6 +267,9 @@ def main():
     # reported in full below, and `step` prices the whole step against the roofline.
     dominant = "check" if chk_bytes >= agg_bytes else "aggregate"
     dom_bytes = chk_bytes if dominant == "check" else agg_bytes
+    fused_sweep = eng.kernel_name(E.KERNEL_CHECK) == "kt_sweep_bitmap"
+    if fused_sweep:  # ONE launch is both scans: it processes the check's AND the aggregation's units (SURVEY.md 8d figures of both)
+        dominant, dom_bytes = "check", chk_bytes + agg_bytes
     achieved = dom_bytes / (k_ms[dominant] * 1e-3) / 1e9 if k_ms[dominant] > 0 else 0.0
     # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/profile.sh + tools/pmc_summary.py) is only quoted when it
     # was measured on the SAME kernel sources as the library that just ran (kt_version() carries their hash)
@@ -305,7 +357,8 @@ def main():
         "per_kernel_ms_rocprof": prof_ms or None,
         "launch_gaps_ms": round(ms_per_step - sum(prof_ms.values()), 6) if len(prof_ms) >= 2 else None,
         "dominant_by": "algorithmic bytes per launch",
-        "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes),
+        "fused_sweep": fused_sweep,
+        "check": kernel_roofline("check", E.KERNEL_CHECK, chk_bytes + agg_bytes if fused_sweep else chk_bytes),
         "aggregate": kernel_roofline("aggregate", E.KERNEL_AGGREGATE, agg_bytes),
         "reconcile": {"kernels": [eng.kernel_name(E.KERNEL_AGGREGATE), eng.kernel_name(E.KERNEL_REDUCE), eng.kernel_name(E.KERNEL_FINALIZE)],
                       "ms": round(rec_ms, 6), "algorithmic_bytes": agg_bytes,
@@ -386,7 +439,10 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.config], "pods_total": P_total, "pods_per_gpu": per_gpu,
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
-                       "step": "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
+                       "step": "sweep(check all pods against the stored status + aggregate, one pass)+finalize(apply)" if args.sweep
+                               else "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
+                       "streams": "check(i) on a second stream beside reconcile(i+1); check(i) after finalize(i)" if overlap else "one",
+                       "overlap_identical_to_serial": overlap_identical,
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
                        "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},

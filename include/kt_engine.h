@@ -223,6 +223,14 @@ int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_
 #define KT_CHECK_STATUS_MATRIX 0x1u /* also produce the n x throttle_rows status matrix (parity / reason strings) */
 int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
                         void* stream);
+/* The PreFilter sweep of EVERY pod row against the stored status and the reconcile of every throttle as ONE pass over the
+ * pod tables: what a host that re-evaluates the whole cluster calls instead of kt_check_launch(all rows) followed by
+ * kt_reconcile_launch.  Results (kt_check_fetch for rows [0, pod rows in use), kt_reconcile_fetch) are bit for bit those
+ * of that pair: the verdicts are PreFilter's against the status stored BEFORE this reconcile (plugin.go:148-215 reads the
+ * informer cache the controllers write later), the new status is reconcile's (throttle_controller.go:84-133).  One
+ * selector scan per pod instead of two where the program allows it (one index chunk, no slow list, requests that pack);
+ * otherwise the two launches run one after the other inside the call.  flags: KT_RECONCILE_APPLY. */
+int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t on_equal, void* stream);
 /* out_summary [n] ; out_status [n][n_throttle_rows] (nullable; needs KT_CHECK_STATUS_MATRIX), where
  * n_throttle_rows = 1 + highest throttle row ever upserted (kt_throttle_rows). Synchronises. */
 int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* out_status);

@@ -304,6 +304,7 @@ struct kt_engine {
   bool fused_pending = false;
   int fused_nb = 0;
   uint32_t fused_epoch = 0;
+  kt::PackPlan fused_pack;  // the plan the pending slabs were written with (the aggregate's view plan, or kt_sweep_launch's own)
   size_t agg_words = 0;
   uint64_t program_gen = 0, agg_gen = 0;
   int32_t exchange_world = 1;  // ranks whose partials meet in the reconcile's all-reduce (kt_comm_init / kt_set_exchange_world)
@@ -2059,7 +2060,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
                                                      pass == 0 ? std::function<void()>(after_scan) : std::function<void()>());
         if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
         e->last_kernel[KT_KERNEL_AGGREGATE] = k;
-        if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch;
+        if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch, e->fused_pack = e->pack;
         e->last_kernel[KT_KERNEL_REDUCE] = e->fused_pending ? "(in kt_reduce_finalize_packed)" : sc.launched_packed ? "kt_reduce_packed_slabs" : "kt_reduce_bitmap_slabs";
       }
     }
@@ -2127,7 +2128,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
   {
     TimedLaunch tl(e, KT_KERNEL_FINALIZE, s);
     if (e->fused_pending) {
-      kt::launch_reduce_finalize_packed(e->tt, e->sp, e->D, e->dindex, e->pack, e->d_slab.p, e->fused_nb, e->d_slab_tag.p, e->fused_epoch, e->partial(),
+      kt::launch_reduce_finalize_packed(e->tt, e->sp, e->D, e->dindex, e->fused_pack, e->d_slab.p, e->fused_nb, e->d_slab_tag.p, e->fused_epoch, e->partial(),
                                         consume, now_s, now_ns, apply, out, apply ? e->d_recs2[wbuf].p : nullptr, rec_DT, e->recs_eq, req_bound(e), s,
                                         row_mask, e->dindex.n_slow != 0 || e->n_overflow != 0);
       e->last_kernel[KT_KERNEL_FINALIZE] = "kt_reduce_finalize_packed";
@@ -2311,6 +2312,25 @@ int32_t kt_reconcile_fetch_next_override(kt_engine* e, int32_t n, int64_t* next_
 // check
 // ---------------------------------------------------------------------------------------------------
 // allow_small: false for callers that go on working on the device-side rows / summaries (kt_admit_launch)
+// The CheckRecs only depend on (stored status, reserved amounts, isThrottledOnEqual): rebuilt when one of them changed
+// since they were last built (by kt_prepare_check or by kt_finalize with APPLY)
+static int32_t ensure_check_recs(kt_engine* e, int32_t on_equal, int DT, hipStream_t s) {
+  if (e->recs_valid && e->recs_eq == (on_equal != 0) && e->recs_DT == DT) return KT_OK;
+  recs_invalidate_and_drain(e);  // rebuilt in place
+  {
+    TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
+    kt::launch_prepare_check(e->tt, e->thr_rows_hi, e->D, DT, on_equal != 0, e->recs_ptr(), req_bound(e), s);
+  }
+  if (e->few_ready) KT_HIP(e, hipEventRecord(e->recs_ev[e->recs_cur], s));
+  std::lock_guard<std::mutex> g(e->recs_mu);
+  e->recs_ev_pending[e->recs_cur] = e->few_ready;
+  e->recs_prev_valid = false;  // records of an older status / other on_equal: not a substitute any more
+  e->recs_valid = true;
+  e->recs_eq = on_equal != 0;
+  e->recs_DT = DT;
+  return KT_OK;
+}
+
 static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint32_t flags,
                                    hipStream_t s, bool allow_small = true) {
   if (pod_rows) {
@@ -2353,22 +2373,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
   }
   // the record layout follows the scan kernel that will read it
   const int DT = e->cfg.kernel_variant == 1 ? kt::dt_bucket(e->D) : kt::dt_bucket_ix(e->D);
-  // the CheckRecs only depend on (stored status, reserved amounts, isThrottledOnEqual): rebuilt when one of them
-  // changed since they were last built (by kt_prepare_check or by kt_finalize with APPLY)
-  if (!(e->recs_valid && e->recs_eq == (on_equal != 0) && e->recs_DT == DT)) {
-    recs_invalidate_and_drain(e);  // rebuilt in place
-    {
-      TimedLaunch tl(e, KT_KERNEL_PREPARE, s);
-      kt::launch_prepare_check(e->tt, (int)T, e->D, DT, on_equal != 0, e->recs_ptr(), req_bound(e), s);
-    }
-    if (e->few_ready) KT_HIP(e, hipEventRecord(e->recs_ev[e->recs_cur], s));
-    std::lock_guard<std::mutex> g(e->recs_mu);
-    e->recs_ev_pending[e->recs_cur] = e->few_ready;
-    e->recs_prev_valid = false;  // records of an older status / other on_equal: not a substitute any more
-    e->recs_valid = true;
-    e->recs_eq = on_equal != 0;
-    e->recs_DT = DT;
-  }
+  if ((rc = ensure_check_recs(e, on_equal, DT, s)) != KT_OK) return rc;
   {
     TimedLaunch tl(e, KT_KERNEL_CHECK, s);
     if (e->cfg.kernel_variant == 1)
@@ -2422,6 +2427,70 @@ int32_t kt_check_launch(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_
   LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   return check_launch_locked(e, n, pod_rows, on_equal, flags, pick_stream(e, stream));
+}
+
+// kt_sweep_launch — the PreFilter sweep of every pod row against the STORED status and the reconcile of every throttle
+// as one pass over the pod tables (kt_check_bitmap's AGG instantiation: one chunk prologue and one selector scan per pod
+// where kt_check_launch + kt_reconcile_launch make two), then kt_reduce_finalize_packed.  Results are read with
+// kt_check_fetch / kt_reconcile_fetch and are bit for bit those of kt_check_launch(all rows) followed by
+// kt_reconcile_launch — which is also what runs when the fused kernel does not apply (several index chunks, a slow list,
+// pods whose atoms overflow their row, requests that do not pack, wide sums, an incremental engine, the dense variant).
+int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t on_equal, void* stream) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  LaunchLock lk(e);
+  KT_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = pick_stream(e, stream);
+  int32_t rc = ensure_ready(e, s);
+  if (rc != KT_OK) return rc;
+  const int64_t n = e->pod_rows_hi;
+  auto one_after_the_other = [&]() -> int32_t {
+    int32_t r = check_launch_locked(e, n, nullptr, on_equal, 0u, s);
+    if (r != KT_OK) return r;
+    if ((r = aggregate_locked(e, s, /*allow_fused=*/true)) != KT_OK) return r;
+    return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
+  };
+  bool fused = e->cfg.kernel_variant != 1 && !e->incremental && e->dindex.n_chunks == 1 && e->dindex.n_slow == 0 && !e->hindex.has_slow &&
+               e->n_overflow == 0 && e->thr_rows_hi > 0 && n > 0 && kt::dt_bucket_ix(e->D) == 8 && !getenv_flag("KT_NO_SWEEP") &&
+               !getenv_flag("KT_NO_FUSED") && !getenv_flag("KT_NO_PACK");
+  if (!fused) return one_after_the_other();
+  if ((rc = request_sums_in_range(e, s)) != KT_OK) return rc;
+  if (e->wide) return one_after_the_other();
+  // the packed fold's plan for THIS scan: every row of [0, n) in row order, aggregate_blocks(n) workgroups
+  const int nb = kt::aggregate_blocks(n);
+  kt::PackPlan plan = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, kt::aggregate_slab_pods(n, nb), /*pad_odd=*/true);
+  if (!plan.nw || plan.rec_bytes > kt::agg_rec_bytes(e->D, false)) return one_after_the_other();  // (slab areas hold plain records)
+  const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
+  if (e->ext_partial && (int64_t)words > e->ext_partial_words)
+    return e->fail(KT_ERR_OUT_OF_RANGE, "caller partial buffer holds %lld words, %lld needed", (long long)e->ext_partial_words, (long long)words);
+  if (e->d_summary.cap < (size_t)n + 1) {
+    if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));  // the buffer may still be in use
+    KT_HIP(e, e->d_summary.reserve((size_t)n + 1));
+  }
+  const int DT = kt::dt_bucket_ix(e->D);
+  if ((rc = ensure_check_recs(e, on_equal, DT, s)) != KT_OK) return rc;
+  e->fused_pending = false;
+  e->agg_wide = false;
+  if (words && e->clean_partial != (const void*)e->partial()) KT_HIP(e, hipMemsetAsync(e->partial(), 0, words * 8, s));
+  e->clean_partial = nullptr;
+  kt::AggScan sc;
+  if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
+  int launched = 0;
+  const char* k;
+  {
+    TimedLaunch tl(e, KT_KERNEL_CHECK, s);
+    k = kt::launch_sweep_indexed(e->pods, n, e->sp, e->d_sp.p, e->dindex, e->recs_ptr(), e->d_summary.p, plan, e->d_slab.p, sc.slab_tag, sc.epoch,
+                                 &launched, s);
+  }
+  if (!k) return one_after_the_other();  // (LDS: check tables + fold tables of this program do not fit one workgroup)
+  KT_HIP(e, hipGetLastError());
+  e->last_kernel[KT_KERNEL_CHECK] = k;
+  e->last_kernel[KT_KERNEL_AGGREGATE] = "(in kt_sweep_bitmap)";
+  e->last_kernel[KT_KERNEL_REDUCE] = "(in kt_reduce_finalize_packed)";
+  e->check_n = n, e->check_in_h_small = false, e->check_T = e->thr_rows_hi, e->check_has_status = false, e->check_ready = true;
+  e->fused_pending = true, e->fused_nb = launched, e->fused_epoch = sc.epoch, e->fused_pack = plan;
+  e->agg_pending = true, e->agg_words = words, e->agg_gen = e->program_gen;
+  e->last_stream = s;
+  return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/true);
 }
 
 // ---------------------------------------------------------------------------------------------------

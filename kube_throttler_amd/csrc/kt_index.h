@@ -329,6 +329,13 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,
                           const CheckByNs* by_ns = nullptr);
+// kt_sweep: the PreFilter sweep of pod rows [0, n) and the packed reconcile scan of the same rows as ONE launch
+// (kt_check_bitmap's AGG instantiation: single-chunk programs without a slow list; pk sized for aggregate_slab_pods(n,
+// aggregate_blocks(n))).  The slabs are left for launch_reduce_finalize_packed (*launched_blocks of them).  nullptr: not
+// dispatchable — the caller runs launch_check_indexed and launch_aggregate_indexed one after the other.
+const char* launch_sweep_indexed(const PodTable& pods, int64_t n, const SelProgram& sp, const SelProgram* sp_dev, const IndexDev& ix,
+                                 const void* recs, uint64_t* summary, const PackPlan& pk, void* slab, uint32_t* slab_tag, uint32_t epoch,
+                                 int* launched_blocks, hipStream_t s);
 // PreFilter of n <= 8 pods without staging, copies or a stream synchronisation (kt_kernels_few.hip): one wave per index
 // chunk, summaries + sequence number to pinned host memory.  false: not dispatched (slow-list throttles; the caller
 // also keeps programs with `slow` term shapes and overflow pods away).

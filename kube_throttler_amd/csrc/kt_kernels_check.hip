@@ -50,12 +50,13 @@ constexpr uint32_t kTiAdj = 0x00100000u, kTiTight = 0x10000000u;
 constexpr int kTiShActive = 16, kTiShIdle = 22;
 
 // what a tile needs of its 64 pods before it can start (kt_check_bitmap's fetch_tile)
-template <int LA>
+template <int LA, int NV = 1>
 struct TileRec {
   uint32_t p;                  // pod row
   uint64_t meta;
   u32x4 raw[LA / 8];           // atom row
   unsigned long long carried;  // class counters of the earlier chunks
+  int64_t v[NV];               // AGG (kt_sweep): the request row — ResourceAmountOfPod of the reconcile half
 };
 // Requesting a tile's records early — the first tile's before the chunk is staged, every later one's behind the scan of
 // the tile before it — was measured and NOT kept (round 4: check 28.0 -> 31.6 us at 1M pods, 79.9 -> 85.3 at 4M; the
@@ -95,11 +96,19 @@ struct BmCheckArgs {
   uint64_t* carry;         // [n] class counters between chunks
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
+  // AGG instantiation (kt_sweep_launch: the PreFilter sweep AND the reconcile scan in one pass over the pod rows): the
+  // packed fold of kt_aggregate_bitmap (kt_kernels_aggregate.hip) rides on the check's scan
+  unsigned char* slab;
+  uint32_t* slab_tag;
+  uint32_t epoch;
+  uint32_t off_rank, off_tab;
+  uint32_t pk_nw, pk_rec;  // PackPlan::nw / rec_bytes
+  uint32_t pk_dim[8];      // per dimension: shift | pos << 8 | word << 16 | (width != 0) << 24
 };
 
 static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int64_t* rows, const SelProgram& sp,
                                       const SelProgram* sp_dev, const IndexDev& ix, const void* recs,
-                                      uint64_t* summary, uint8_t* status, uint32_t* total) {
+                                      uint64_t* summary, uint8_t* status, uint32_t* total, const PackPlan* agg_pk = nullptr) {
   BmCheckArgs a{};
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.lpair = pods.lpair, a.lkey = pods.lkey;
   a.n = n, a.rows = rows, a.recs = recs, a.summary = summary, a.status = status;
@@ -112,6 +121,13 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   a.off_tinfo = take(ix.bm_max_words * 64u * 8u);
   a.off_wv = take(ix.bm_max_words * (uint32_t)(pods.D <= 8 ? sizeof(WordVerdict<8>) : sizeof(WordVerdict<16>)));
   plan_bitmap_index(ix, a.ix, take);
+  if (agg_pk) {  // the reconcile half's tables: ranks of the term numbers, one packed record per throttle of the chunk
+    a.pk_nw = agg_pk->nw, a.pk_rec = agg_pk->rec_bytes;
+    for (int d = 0; d < 8; ++d)
+      a.pk_dim[d] = (uint32_t)agg_pk->shift[d] | (uint32_t)agg_pk->pos[d] << 8 | (uint32_t)agg_pk->word[d] << 16 | (agg_pk->width[d] ? 1u << 24 : 0u);
+    a.off_rank = take(ix.bm_max_words * 64u * 2u);
+    a.off_tab = take(ix.bm_max_thr * agg_pk->rec_bytes);
+  }
   *total = o;
   return a;
 }
@@ -132,8 +148,14 @@ uint32_t check_word_lds(int D) { return 64u * 8u + (uint32_t)(D <= 8 ? sizeof(Wo
 // ONE:  the index is ONE chunk and the sweep runs in row order (the two-per-CU sweep of programs that fit half the LDS:
 //       BASELINE configs 1-3) — no chunk loop, no carry words, no namespace-ordered views: none of their registers either
 //       (the 64-VGPR instantiation spilled a handful of them, and a reload in the chunk prologue is a trip to memory)
-template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL, bool ONE = false>
+// AGG:  kt_sweep — the ONE lean sweep also IS the reconcile scan: a lane whose pod is counted (shouldCountIn,
+//       throttle_controller.go:217-219) folds its packed request words (PackPlan) into the record of every throttle it
+//       matches, exactly as kt_aggregate_bitmap's packed instantiation does, and the workgroup spills its table of records
+//       as a slab for kt_reduce_finalize_packed.  One pass over the pod rows, one chunk prologue, one scan per pod where
+//       check + aggregate made two; the check's verdicts are those against the status stored BEFORE this reconcile.
+template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL, bool ONE = false, bool AGG = false>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
+  static_assert(!AGG || (ONE && !FULL && !SMALL && WPE < 8), "the fused sweep is the lean single-chunk form, one workgroup per CU");
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;  // drains in the middle of a scan (the list ran full)
 #ifndef KT_DRAIN_FINAL_8
 #define KT_DRAIN_FINAL_8 2  // (4 = the whole rows at once costs the 64-VGPR instantiation 80 B of scratch inside the scan)
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     const uint32_t wt0 = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : by_ns ? t_lo + wave : blockIdx.x * (kBlockIx / kWave) + wave;
     const uint32_t wt_step = SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
     auto fetch_tile = [&](uint32_t wt) {
-      TileRec<LA> r;
+      TileRec<LA, AGG ? DT : 1> r;
       const uint32_t i = wt * kWave + lane;
       const uint32_t ic = min(i, n - 1u);
       r.p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
@@ -203,12 +225,18 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
       const unsigned long long* carry_w = by_ns ? (const unsigned long long*)a.carry + ic : (const unsigned long long*)a.summary + (by_ns ? r.p : i);
       r.carried = (!SMALL && !first && i < n) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if constexpr (AGG) load_requests<DT>(a.req, DS, (int64_t)r.p, r.v);  // every lane's: the row does not hang off the meta word
       return r;
     };
-    TileRec<LA> cur{};
+    TileRec<LA, AGG ? DT : 1> cur{};
     if (kTilePrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     __syncthreads();  // nobody reads the previous image any more
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
+    if constexpr (AGG) {  // the reconcile half: chunk-local throttle rank of every term number, the table of packed records zeroed
+      const uint32_t tab_bytes = (ch.n_thr * a.pk_rec + 15u) & ~15u;
+      for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
+      lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
+    }
     {  // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
       const uint32_t* term_t = (const uint32_t*)(a.ix.blob + ch.img_off + ch.off_term_t);
       for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx) {
@@ -281,6 +309,28 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       atom_row_offsets<LA>(raw, bm.row_bytes, ro);
       uint32_t n_list = 0;  // wave-uniform
       uint32_t last_t = 0xFFFFFFFFu;
+      // AGG: is the pod counted (shouldCountIn && isNotFinished: throttle_controller.go:217-219, pod_util.go:26-28), and
+      // ResourceAmountOfPod as the packed words of the fold — what kt_build_scan_view stores per record of the aggregate's
+      // view, built here from the request row: pod count 1 from bit 0 of word 0, every request as its field
+      bool counted = false;
+      uint32_t zero_keys = 0u;
+      unsigned long long pw[4] = {0ull, 0ull, 0ull, 0ull};
+      if constexpr (AGG) {
+        const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
+        counted = in && (st & (kPodValid | kPodSchedMatch | kPodScheduled | kPodFinished)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+        const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
+        zero_keys = present & ~nz & 0xFFFFu;  // keys carried with the value 0
+        pw[0] = 1ull;
+        static_assert(!AGG || DT == 8, "pk_dim holds eight dimensions");
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const uint32_t pd = a.pk_dim[d];  // (wave-uniform: scalar decode)
+          const uint64_t f = (uint64_t)cur.v[d] >> (pd & 63u);
+          const uint64_t piece = (pd >> 24) ? f << ((pd >> 8) & 63u) : 0ull;  // (dimensions without a field: width 0)
+          const uint32_t k = (pd >> 16) & 3u;
+          pw[0] |= k == 0u ? piece : 0ull, pw[1] |= k == 1u ? piece : 0ull, pw[2] |= k == 2u ? piece : 0ull, pw[3] |= k == 3u ? piece : 0ull;
+        }
+      }
 
       // UNROLL (a std::integral_constant): pieces of the request row / thr[] / head[] requested per batch.  The drain behind
       // the scan (nothing of the scan is live any more) asks for the whole rows at once in every instantiation: with two
@@ -427,11 +477,35 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         for (int k = 0; k < DT / 4; ++k) r.nib[k] = *(KT_LDS const unsigned long long*)(q + (PREFETCH ? nib_off[k] : nib_offset(k)));
         return r;
       };
-      auto settle = [&](uint64_t x, const VerdictRegs& q) -> uint64_t {
+      // AGG: the fold of kt_aggregate_bitmap's packed instantiation over the word's matches (one per throttle: x is past
+      // the run rule below) — counted pods only, lane = pod, one LDS atomic per packed word
+      KT_LDS const uint16_t* trank = (KT_LDS const uint16_t*)(lds + a.off_rank);
+      KT_LDS unsigned char* tab = lds + a.off_tab;
+      const uint32_t pk_rec = AGG ? a.pk_rec : 0u, pk_nw = AGG ? a.pk_nw : 0u;
+      auto fold = [&](uint32_t w, uint64_t x) {
+        uint64_t xf = counted ? x : 0ull;
+        while (__ballot(xf != 0ull) != 0ull) {
+          const bool has = xf != 0ull;
+          const uint32_t c = has ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+          xf &= xf - 1ull;
+          const uint32_t r = trank[c] & 0x7FFFu;  // chunk-local throttle rank
+          if (has) {
+            KT_LDS unsigned char* rp = tab + __umul24(r, pk_rec);
+            lds_u64wp tv = (lds_u64wp)rp;
+            lds_add64(tv, pw[0]);
+            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+            if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + pk_nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      };
+      auto settle = [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
         if (seg_on) {  // a throttle with several terms is reported once: the lowest match of every run
           const uint64_t v = x | q.seg.y;
           x = andn_64(x, v - q.seg.x);  // (= x & (v ^ (v - seg_lo)) & v, x being part of v)
         }
+        if constexpr (AGG) fold(w, x);
         uint64_t act = q.nib[0];  // (act-by-count is part of every entry of nibble 0's table)
 #pragma unroll
         for (int k = 1; k < DT / 4; ++k) act |= q.nib[k];
@@ -450,19 +524,19 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       if constexpr (PREFETCH) {
         scan_tile<LA, VETO, NEED, VETO>(
             bm, scan_on, ns, ro, peel_tight, confirm_slow,
-            [&](uint32_t, uint64_t x, const VerdictRegs& q) -> uint64_t { return settle(x, q); },
+            [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t { return settle(w, x, q); },
             [&](uint32_t w) -> VerdictRegs { return fetch(w); });
       } else {
         scan_tile<LA, VETO, NEED, false>(
             bm, scan_on, ns, ro, peel_tight, confirm_slow,
             [&](uint32_t w, uint64_t x, int) -> uint64_t {
               if (__ballot(x != 0ull) == 0ull) return 0ull;  // nobody of the tile matched a term of this word
-              return settle(x, fetch(w));
+              return settle(w, x, fetch(w));
             });
       }
       my = (unsigned long long)n_exc << 4 | (unsigned long long)n_act << 24 | (unsigned long long)n_ins << 44;
       }
-      TileRec<LA> nxt{};  // (only looked at when there is a next tile)
+      TileRec<LA, AGG ? DT : 1> nxt{};  // (only looked at when there is a next tile)
       if (kTilePrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);  // (wave-uniform)
       if (n_list) drain(std::integral_constant<int, kDrainFinalUnroll>());
       pod_err |= on & (ns_ok_raw == 0u);
@@ -501,6 +575,14 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         }
       }
       cur = nxt;
+    }
+    if constexpr (AGG) {  // this workgroup's table as its slab (coalesced 16-byte stores), stamped with the launch's epoch
+      __syncthreads();
+      const uint32_t tab_bytes = (ch.n_thr * a.pk_rec + 15u) & ~15u;
+      u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
+      lds_u4p src = (lds_u4p)(lds + a.off_tab);
+      for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+      if (threadIdx.x == 0) a.slab_tag[ci * kSlabTagStride + blockIdx.x] = a.epoch;
     }
   }
 }
@@ -567,6 +649,36 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   else { if (DT <= 8) KT_BM_CASE(8, 32, true, 3) else KT_BM_CASE(16, 32, true, 3) }
 #endif
   return small ? "kt_check_bitmap_small" : ix.n_chunks == 1 ? "kt_check_bitmap" : "kt_check_bitmap_chunked";
+}
+
+// kt_sweep: PreFilter sweep of rows [0, n) + the packed reconcile scan of the same rows in one launch (AGG instantiation).
+// nullptr: not dispatchable (several chunks, a slow list, LDS) — the caller runs check and aggregate one after the other.
+#define KT_SWEEP_CASE(DT_, LA_, VETO_, NEED_)                                                                   \
+  {                                                                                                             \
+    auto kfn = kt_check_bitmap<DT_, LA_, VETO_, NEED_, 4, false, false, true, true>;                            \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bytes, s, bm_args);                                                     \
+  }
+const char* launch_sweep_indexed(const PodTable& pods, int64_t n, const SelProgram& sp, const SelProgram* sp_dev, const IndexDev& ix,
+                                 const void* recs, uint64_t* summary, const PackPlan& pk, void* slab, uint32_t* slab_tag, uint32_t epoch,
+                                 int* launched_blocks, hipStream_t s) {
+  if (n <= 0 || ix.n_chunks != 1 || ix.n_slow != 0 || pk.nw == 0) return nullptr;
+  const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
+  if (DT != 8) return nullptr;  // (the packed fold's records are planned for the 8-dimension instantiation, as in kt_aggregate_bitmap)
+  uint32_t bm_total = 0;
+  BmCheckArgs bm_args = make_bm_check_args(pods, n, nullptr, sp, sp_dev, ix, recs, summary, nullptr, &bm_total, &pk);
+  if (bm_total > (uint32_t)kMaxLds) return nullptr;
+  bm_args.slab = (unsigned char*)slab, bm_args.slab_tag = slab_tag, bm_args.epoch = epoch;
+  const size_t lds_bytes = bm_total;
+  int64_t nb = (n + kBlockIx - 1) / kBlockIx;
+  if (nb > kCUs) nb = kCUs;  // one slab per workgroup, at most kSlabTagStride of them
+  dim3 g_((unsigned)nb), b_(kBlockIx);
+  if (!ix.rich) KT_SWEEP_CASE(8, 8, false, 2)
+  else if (LA <= 8) KT_SWEEP_CASE(8, 8, true, 3)
+  else if (LA <= 16) KT_SWEEP_CASE(8, 16, true, 3)
+  else KT_SWEEP_CASE(8, 32, true, 3)
+  *launched_blocks = (int)nb;
+  return "kt_sweep_bitmap";
 }
 
 }  // namespace kt

@@ -34,7 +34,7 @@ EXPORTS = [
     "kt_version", "kt_engine_create", "kt_engine_destroy", "kt_last_error", "kt_upsert_namespaces", "kt_upsert_pods",
     "kt_upsert_throttles", "kt_delete_namespaces", "kt_delete_pods", "kt_delete_throttles", "kt_load_snapshot",
     "kt_set_reserved", "kt_set_status", "kt_reconcile_launch", "kt_aggregate_launch", "kt_partial_used_buffer",
-    "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows",
+    "kt_use_partial_buffer", "kt_finalize_launch", "kt_reconcile_fetch", "kt_check_launch", "kt_check_fetch", "kt_throttle_rows", "kt_sweep_launch",
     "kt_check_device_summary", "kt_fetch_pod_requests", "kt_timing_enable", "kt_timing_read", "kt_timing_reset",
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
@@ -106,6 +106,7 @@ def lib():
         L.kt_finalize_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p]
         L.kt_reconcile_fetch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KtStatus)]
         L.kt_check_launch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
+        L.kt_sweep_launch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p]
         L.kt_check_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.kt_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.kt_comm_unique_id.argtypes = [C.c_void_p]
@@ -345,6 +346,11 @@ class Engine:
     def check_launch(self, n, rows=None, on_equal=False, want_status=False, stream=None):
         a, p = self._rows(rows, np.int64)
         self._ck(lib().kt_check_launch(self._h, n, p, int(on_equal), CHECK_STATUS_MATRIX if want_status else 0, stream))
+
+    def sweep_launch(self, now, apply=True, on_equal=False, stream=None):
+        """kt_sweep_launch: PreFilter sweep of every pod row against the stored status + reconcile of every throttle, one pass
+        over the pod tables; read the results with check_fetch(pod rows) / reconcile_fetch()."""
+        self._ck(lib().kt_sweep_launch(self._h, int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, int(on_equal), stream))
 
     def check_fetch(self, n, want_status=False):
         T = self.throttle_rows()

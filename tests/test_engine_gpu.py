@@ -68,6 +68,17 @@ def responsible_rows(snap):
     return np.nonzero((snap.thr_flags[:snap.n_thr] & need) == need)[0]
 
 
+def _rows_of(rec_all, rows, D):
+    """the listed throttle rows of a whole-engine reconcile result, in the oracle's layout"""
+    got = E.ReconcileResult(len(rows), D)
+    for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
+        getattr(got, name)[:len(rows)] = getattr(rec_all, name)[rows]
+    for tab in ("used", "calc"):
+        for f in ("v", "present", "count", "has_count"):
+            getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(rec_all, tab), f)[rows]
+    return got
+
+
 def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True), nthreads=8):
     """reconcile -> store status -> check, oracle vs engine, everything compared."""
     T = snap.n_thr
@@ -83,12 +94,7 @@ def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True),
         rows = responsible_rows(snap)
         want = o.reconcile(now, rows=rows, nthreads=nthreads)
         got_all = eng.reconcile(now, apply=True)
-        got = E.ReconcileResult(len(rows), snap.D)
-        for name in ("calc_updated", "thrl_flag", "thrl_has", "thrl_pod", "error"):
-            getattr(got, name)[:len(rows)] = getattr(got_all, name)[rows]
-        for tab in ("used", "calc"):
-            for f in ("v", "present", "count", "has_count"):
-                getattr(getattr(got, tab), f)[:len(rows)] = getattr(getattr(got_all, tab), f)[rows]
+        got = _rows_of(got_all, rows, snap.D)
         assert_reconcile_equal(got, want, len(rows))
         # NextOverrideHappensIn (the controller's enqueueAfter instant) of every reconciled throttle
         ws, wn, wh = o.next_override(now)
@@ -108,7 +114,20 @@ def run_full_parity(snap, oracle_mod, variant, now=NOW, on_equals=(False, True),
             # the PreFilter sweep proper (summary words only: the lean / wordwise instantiations of the check kernel)
             _, sm_l = eng.check(n=snap.n_pods, on_equal=on_equal, want_status=False)
             np.testing.assert_array_equal(sm_l, sm_w, err_msg=f"summary of the lean sweep on_equal={on_equal}")
-        return st_w, sm_w, want
+        ret = (st_w, sm_w, want)
+        # kt_sweep_launch: that sweep (against the status stored so far) AND a reconcile as one pass over the pod tables —
+        # the fused kernel where the program allows it, the two launches one after the other otherwise; either way the
+        # results of the pair
+        for on_equal in on_equals:
+            _, sm_w2 = o.check(on_equal=on_equal, want_status=False, nthreads=nthreads)
+            want2 = o.reconcile(now, rows=rows, nthreads=nthreads)
+            eng.sweep_launch(now, apply=True, on_equal=on_equal)
+            _, sm_s = eng.check_fetch(snap.n_pods, False)
+            np.testing.assert_array_equal(sm_s, sm_w2, err_msg=f"summary of kt_sweep_launch on_equal={on_equal}")
+            assert_reconcile_equal(_rows_of(eng.reconcile_fetch(), rows, snap.D), want2, len(rows))
+            snap.apply_status(want2.used, want2.calc, want2.calc_updated, want2.thrl_flag, want2.thrl_has, want2.thrl_pod,
+                              want2.error, rows=rows)
+        return ret
     finally:
         eng.close()
 
@@ -993,6 +1012,17 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None):
         _, sm_w = o.check(want_status=False, nthreads=nthreads)
         _, sm_all = eng.check(n=P, want_status=False)
         np.testing.assert_array_equal(sm_all, sm_w)
+        #     ... kt_sweep_launch: the same sweep AND a reconcile in one pass over the pod tables (the fused kernel for
+        #     single-chunk programs, the pair of launches otherwise): every summary word and every `used` once more
+        eng.sweep_launch(now, apply=True)
+        _, sm_sw = eng.check_fetch(P, False)
+        np.testing.assert_array_equal(sm_sw, sm_w, err_msg="kt_sweep_launch: summaries")
+        rec_sw = eng.reconcile_fetch()
+        for f in ("v", "present", "count", "has_count"):
+            np.testing.assert_array_equal(getattr(rec_sw.used, f)[:T], getattr(got.used, f)[:T], err_msg=f"kt_sweep_launch: used.{f}")
+        np.testing.assert_array_equal(rec_sw.thrl_flag[:T], got.thrl_flag[:T])
+        np.testing.assert_array_equal(rec_sw.thrl_pod[:T], got.thrl_pod[:T])
+        assert not rec_sw.calc_updated[:T].any()
         #     ... and a pod sample with full status rows (the matrix of all P x T pairs would be 1-12 GB)
         sample = np.unique(np.linspace(0, P - 1, 16384).astype(np.int64))
         st_w, sm_s = o.check(rows=sample, nthreads=nthreads)
