@@ -253,10 +253,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       if (kAggPrefetch && EARLY && more) nxt = fetch_tile(wt + wt_step);
       uint32_t last_r = 0xFFFFFFFFu;
       const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
-      scan_tile<LA, VETO, NEED, VETO>(
-          bm, scan_counted, ns, ro,
-          [&](bool has, uint32_t c) {
-            const uint32_t tr = trank[c];
+      // one matched term number of the lane's pod, given its rank word
+      auto add_match = [&](bool has, uint32_t tr) {
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
             // a throttle with several terms is counted once
             const bool ok = has && !((tr & kRankAdj) && r == last_r);
@@ -289,10 +287,40 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
                 lds_add(tu + 1, 1u);
               }
             }
-          },
-          [&](uint32_t c) {
-            return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
-          });
+      };
+      auto confirm_slow = [&](uint32_t c) {
+        return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
+      };
+#ifndef KT_AGG_PEEL_ONE
+      constexpr bool kFoldPairs = PK;
+#else
+      constexpr bool kFoldPairs = false;
+#endif
+      if constexpr (kFoldPairs) {
+        // the packed fold takes a word's matches where the scan produced them (scan_tile's post hook), TWO per step: both
+        // rank reads are in flight together and the wave steps ceil(matches / 2) times per word instead of once per match
+        // through scan_tile's peel (ascending term numbers per lane, as the run rule of add_match needs)
+        scan_tile<LA, VETO, NEED, VETO>(
+            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
+            [&](uint32_t w, uint64_t x, int) -> uint64_t {
+              uint64_t xf = x;
+              while (__ballot(xf != 0ull) != 0ull) {
+                const bool h1 = xf != 0ull;
+                const uint32_t c1 = h1 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+                xf &= xf - 1ull;
+                const bool h2 = xf != 0ull;
+                const uint32_t c2 = h2 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+                xf &= xf - 1ull;
+                const uint32_t tr1 = trank[c1], tr2 = trank[c2];
+                add_match(h1, tr1);
+                add_match(h2, tr2);
+              }
+              return 0ull;
+            });
+      } else {
+        scan_tile<LA, VETO, NEED, VETO>(
+            bm, scan_counted, ns, ro, [&](bool has, uint32_t c) { add_match(has, trank[c]); }, confirm_slow);
+      }
       if (kAggPrefetch && !EARLY && more) nxt = fetch_tile(wt + wt_step);
       cur = nxt;
     }

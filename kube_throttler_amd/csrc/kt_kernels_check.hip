@@ -484,11 +484,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       const uint32_t pk_rec = AGG ? a.pk_rec : 0u, pk_nw = AGG ? a.pk_nw : 0u;
       auto fold = [&](uint32_t w, uint64_t x) {
         uint64_t xf = counted ? x : 0ull;
-        while (__ballot(xf != 0ull) != 0ull) {
-          const bool has = xf != 0ull;
-          const uint32_t c = has ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
-          xf &= xf - 1ull;
-          const uint32_t r = trank[c] & 0x7FFFu;  // chunk-local throttle rank
+        auto add = [&](bool has, uint32_t r) {
           if (has) {
             KT_LDS unsigned char* rp = tab + __umul24(r, pk_rec);
             lds_u64wp tv = (lds_u64wp)rp;
@@ -498,6 +494,17 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
             if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
             if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + pk_nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
+        };
+        while (__ballot(xf != 0ull) != 0ull) {  // two matches per step: both rank reads in flight together
+          const bool h1 = xf != 0ull;
+          const uint32_t c1 = h1 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+          xf &= xf - 1ull;
+          const bool h2 = xf != 0ull;
+          const uint32_t c2 = h2 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+          xf &= xf - 1ull;
+          const uint32_t r1 = trank[c1] & 0x7FFFu, r2 = trank[c2] & 0x7FFFu;  // chunk-local throttle ranks
+          add(h1, r1);
+          add(h2, r2);
         }
       };
       auto settle = [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {

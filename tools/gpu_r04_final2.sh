@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 4, last call: the -m gpu suite on the final sources (configs[4]: shard 0 — shards 3 and 7 ran on the same kernels
-# in tools/gpu_r04_final.sh and are left to the driver's own run), the round's evidence with the quoted bench lines
+# Round 4, last call: the -m gpu suite on the final sources (without the configs[4] shards: shard 0 ran on these very sources
+# in tools/gpu_r04_r.sh, all three on the kernels of tools/gpu_r04_final.sh), the round's evidence with the quoted bench lines
 # (tools/gpu_r04_evidence2.sh), and the bench lines of the two step forms that were measured and not made the default
 # (--sweep: the fused kernel; --overlap: two streams).
 set -u
@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
-timeout 1300 python -m pytest tests -m gpu -q --deselect "tests/test_engine_gpu.py::test_config4_one_shard[3]" --deselect "tests/test_engine_gpu.py::test_config4_one_shard[7]" > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu: exit $?"; tail -5 $OUT/${TAG}_pytest_gpu.log
+timeout 1300 python -m pytest tests -m gpu -q --deselect "tests/test_engine_gpu.py::test_config4_one_shard[0]" --deselect "tests/test_engine_gpu.py::test_config4_one_shard[3]" --deselect "tests/test_engine_gpu.py::test_config4_one_shard[7]" > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu: exit $?"; tail -5 $OUT/${TAG}_pytest_gpu.log
 bash tools/gpu_r04_evidence2.sh $TAG
 B="--steps 1000 --warmup 20 --no-cpu-baseline --no-latency"
 for c in 1 2 3; do
