@@ -2,7 +2,7 @@
 # Round 4: the evidence once more on the FINAL source hash (a header comment moved it), then — profiles/pmc_summary.json
 # rebuilt on the box from these very passes — the bench lines with traffic / bound_by quoted.
 set -u
-TAG=${1:-r04y}
+TAG=${1:-r04z}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
