@@ -1,6 +1,12 @@
 // kt_anchor.cpp — see kt_anchor.h
 #include "kt_anchor.h"
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
 #include <algorithm>
 #include <map>
 
@@ -172,8 +178,17 @@ void build_anchored_index(AnchoredIndex& out, const std::vector<uint32_t>& thr_t
     }
   }
   out = AnchoredIndex();
+  const bool dbg = getenv("KT_DEBUG_COMPILE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    const auto t = std::chrono::steady_clock::now();
+    if (dbg) fprintf(stderr, "build_anchored_index: %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  lap("anchorable / kept terms");
   const std::vector<AnchorSubProgram> subs = anchor_split(thr_term_off, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, anchorable, &out.stats, &kept);
   out.n_ns = n_ns;
+  lap("anchor_split");
   HostIndex& ox = out.ix;
   ox.atoms = classic.atoms, ox.atom_key = classic.atom_key, ox.atom_table = classic.atom_table;
   ox.bm_rows = classic.bm_rows, ox.la = classic.la, ox.rich = true;
@@ -182,23 +197,46 @@ void build_anchored_index(AnchoredIndex& out, const std::vector<uint32_t>& thr_t
   ox.ns_words = ((size_t)n_blocks * n_ns + 31) / 32;
   if (!ox.ns_words) ox.ns_words = 1;
   uint64_t slab_run = 0;
-  std::vector<uint32_t> term_thr_unused;
+  // the sub-indexes are independent of one another: built side by side (build_index keeps its scratch per thread and stays
+  // single-threaded at these sizes), concatenated in block order afterwards
+  std::vector<HostIndex> sxs(n_blocks);
+  {
+    uint32_t n_thr = std::min<uint32_t>(std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())), std::max(1u, n_blocks / 4u));
+    if (const char* ev = getenv("KT_ANCHOR_THREADS")) n_thr = std::max(1, atoi(ev));  // (measurements)
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+      std::vector<uint32_t> term_thr_unused;
+      for (uint32_t c = next.fetch_add(1); c < n_blocks; c = next.fetch_add(1)) {
+        const AnchorSubProgram& sp = subs[c];
+        // the namespace side of the copied terms: the original term's
+        const uint32_t G = (uint32_t)sp.term_orig.size(), gws = (G + 31) / 32 + 1;
+        std::vector<uint32_t> ok((size_t)n_ns * gws, 0u);
+        for (uint32_t g = 0; g < G; ++g) {
+          const uint32_t og = sp.term_orig[g];
+          for (uint32_t n = 0; n < n_ns; ++n)
+            if ((ns_term_ok[(size_t)n * gw + (og >> 5)] >> (og & 31)) & 1u) ok[(size_t)n * gws + (g >> 5)] |= 1u << (g & 31);
+        }
+        build_index(sxs[c], sp.thr_term_off, term_thr_unused, sp.term_flags, sp.term_req_off, sp.req_op, sp.req_key, sp.req_val_off, sp.req_val,
+                    [&](uint32_t v) { return thr_info(sp.thr_orig[v]); }, n_ns, ok, gws, agg_budget, chk_budget, thr_bytes, max_labels, nullptr, 0u,
+                    chk_word, &classic);
+      }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 1; k < n_thr; ++k) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  lap("sub-index builds");
+  // which block a pod's atom opens: the anchors are pairs some kept term names, i.e. atoms of the classic numbering
+  out.atom_block.assign(classic.bm_rows, 0u);
+  for (uint32_t c = 1; c < n_blocks; ++c)
+    for (const AtomId& a : classic.atoms)
+      if (a.atom == subs[c].anchor) out.atom_block[a.id] = c;
   for (uint32_t c = 0; c < n_blocks; ++c) {
     const AnchorSubProgram& sp = subs[c];
     out.block_anchor.push_back(sp.anchor);
     out.blk_chunk0.push_back((uint32_t)ox.bm_chunks.size());
-    // the namespace side of the copied terms: the original term's
-    const uint32_t G = (uint32_t)sp.term_orig.size(), gws = (G + 31) / 32 + 1;
-    std::vector<uint32_t> ok((size_t)n_ns * gws, 0u);
-    for (uint32_t g = 0; g < G; ++g) {
-      const uint32_t og = sp.term_orig[g];
-      for (uint32_t n = 0; n < n_ns; ++n)
-        if ((ns_term_ok[(size_t)n * gw + (og >> 5)] >> (og & 31)) & 1u) ok[(size_t)n * gws + (g >> 5)] |= 1u << (g & 31);
-    }
-    HostIndex sx;
-    build_index(sx, sp.thr_term_off, term_thr_unused, sp.term_flags, sp.term_req_off, sp.req_op, sp.req_key, sp.req_val_off, sp.req_val,
-                [&](uint32_t v) { return thr_info(sp.thr_orig[v]); }, n_ns, ok, gws, agg_budget, chk_budget, thr_bytes, max_labels, nullptr, 0u,
-                chk_word, &classic);
+    const HostIndex& sx = sxs[c];
     const uint32_t rank_base = (uint32_t)ox.bm_rank_t.size();
     for (uint32_t r : sx.bm_rank_t) ox.bm_rank_t.push_back(sp.thr_orig[r]);
     for (uint32_t v : sx.slow_thr) ox.slow_thr.push_back(sp.thr_orig[v]);
@@ -236,6 +274,7 @@ void build_anchored_index(AnchoredIndex& out, const std::vector<uint32_t>& thr_t
   }
   out.blk_chunk0.push_back((uint32_t)ox.bm_chunks.size());
   ox.bm_slab_bytes = slab_run;
+  lap("concatenation");
 }
 
 }  // namespace kt

@@ -62,6 +62,8 @@ std::vector<AnchorSubProgram> anchor_split(const std::vector<uint32_t>& thr_term
 struct AnchoredIndex {
   HostIndex ix;                        // chunks of all blocks back to back; atoms / atom_table = classic's
   std::vector<uint32_t> block_anchor;  // block -> anchor pair id (block 0: 0)
+  std::vector<uint32_t> atom_block;    // [ix.bm_rows] atom id (a pod's atom row holds these) -> the block it opens, 0 = none:
+                                       // a pod's items are block 0 and atom_block[id] of its atoms
   std::vector<uint32_t> blk_chunk0;    // [blocks + 1] first chunk of every block
   uint32_t n_ns = 0;                   // real namespaces per block
   AnchorSplitStats stats;

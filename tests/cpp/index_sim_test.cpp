@@ -445,8 +445,23 @@ static std::map<uint32_t, int> scan_anchored(const AnchoredIndexes& A, const Pod
 }
 // the same walk through the CONCATENATED anchored index (kt_anchor.h: build_anchored_index — the structure the device will
 // get): an item (pod, block) is a virtual pod of namespace block * n_ns + pod.ns walking the block's chunks
+static long g_items = 0;
 static std::map<uint32_t, int> scan_concat(const Program& p, const AnchoredIndex& AX, const std::map<uint32_t, uint32_t>& block_of, const PodLabels& pod) {
   std::map<uint32_t, int> out;
+  // the pod's items as the device finds them: from its translated atom row through AnchoredIndex::atom_block — the same
+  // blocks as "the anchors among the pairs it carries"
+  {
+    bool overflow = false;
+    std::set<uint32_t> by_row, by_pair;
+    for (uint32_t id : translate(AX.ix, pod, &overflow))
+      if (id && AX.atom_block[id]) by_row.insert(AX.atom_block[id]);
+    for (uint32_t pr : pod.pairs) {
+      const auto it = block_of.find(pr);
+      if (it != block_of.end()) by_pair.insert(it->second);
+    }
+    EXPECT(by_row == by_pair, "items through the atom row (%zu) and through the pairs (%zu) differ", by_row.size(), by_pair.size());
+    g_items += 1 + (long)by_row.size();
+  }
   auto walk = [&](uint32_t c) {
     PodLabels item = pod;
     item.ns = c * AX.n_ns + pod.ns;
@@ -858,6 +873,7 @@ static int run_anchored(int argc, char** argv) {
     std::map<uint32_t, uint32_t> block_of;
     for (uint32_t c = 1; c < AX.block_anchor.size(); ++c) block_of[AX.block_anchor[c]] = c;
     long vc = 0, va = 0, vx = 0, matches = 0, v_max = 0;
+    g_items = 0;
     std::vector<long> useful(pods.size()), hit(pods.size()), visited(pods.size());
     const size_t T = p.thr.size();
     for (size_t i = 0; i < pods.size(); ++i) {
@@ -906,6 +922,7 @@ static int run_anchored(int argc, char** argv) {
       printf("  classic index, words with an admitted atom bit per pod: %.2f (with a match: %.2f); per tile of 64 pods in namespace order, max over lanes: visited %.1f, useful %.1f, with a match %.1f\n",
              su / pods.size(), sh / pods.size(), tmax_v / tiles, tmax_u / tiles, tmax_h / tiles);
     }
+    printf("  items per pod (block 0 + one per anchor atom it carries): %.2f\n", (double)g_items / (double)pods.size());
     printf("  concatenated (shared atom numbering, one chunked index over %zu virtual namespaces): %zu chunks, %u words, images %.1f MB, largest LDS part %u B / %u throttles / %u words per chunk, slab scratch %.0f MB; %.2f word visits per pod; built in %.1f ms\n",
            (size_t)AX.block_anchor.size() * AX.n_ns, AX.ix.bm_chunks.size(), AX.ix.bm_words, AX.ix.bm_images.size() / 1048576.0, AX.ix.bm_max_lds, AX.ix.bm_max_thr,
            AX.ix.bm_max_words, AX.ix.bm_slab_bytes / 1048576.0, (double)vx / (double)pods.size(), ms2);
