@@ -167,6 +167,26 @@ static std::vector<uint32_t> translate(const HostIndex& ix, const PodLabels& pod
 
 // replays scan_tile (kt_scan.h) for one pod -> per-throttle result (1 match / 2 error), checks "reported once"
 static long g_matches_exact = 0, g_slow_confirms = 0, g_word_steps = 0, g_admitted = 0;
+static long g_word_veto = 0, g_word_m3 = 0, g_word_plain = 0;  // visited words that hold a veto bit in some row / a need-3 term / neither
+// per index: does word w of chunk ci hold a veto bit in ANY row (the rich image's second family)
+static const std::vector<std::vector<uint8_t>>& word_veto_flags(const HostIndex& ix) {
+  static std::map<const HostIndex*, std::vector<std::vector<uint8_t>>> cache;
+  static std::map<const HostIndex*, size_t> stamp;
+  auto it = cache.find(&ix);
+  if (it != cache.end() && stamp[&ix] == ix.bm_images.size() + ix.bm_chunks.size() * 7919u) return it->second;
+  std::vector<std::vector<uint8_t>> f(ix.bm_chunks.size());
+  for (size_t ci = 0; ci < ix.bm_chunks.size(); ++ci) {
+    const BmChunk& ch = ix.bm_chunks[ci];
+    f[ci].assign(ch.n_words, 0);
+    if (!ix.rich) continue;
+    const uint64_t* rows = (const uint64_t*)(ix.bm_images.data() + ch.img_off);
+    for (uint32_t r = 0; r < ix.bm_rows; ++r)
+      for (uint32_t w = 0; w < ch.n_words; ++w)
+        if (rows[((size_t)r * ch.stride + w) * 2 + 1]) f[ci][w] = 1;
+  }
+  stamp[&ix] = ix.bm_images.size() + ix.bm_chunks.size() * 7919u;
+  return cache[&ix] = f;
+}
 static long g_word_useful = 0, g_word_hit = 0;  // visited words in which some atom of the pod (or a term without positive requirement) has an admitted bit / that hold a match
 // c0 / c1: the chunks walked (an anchored index: those of the item's block); walk_slow: the slow list too
 static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const PodLabels& pod, size_t c0 = 0, size_t c1 = ~(size_t)0,
@@ -196,6 +216,10 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       EXPECT(prev_w == ~0u || w > prev_w, "word list of ns %u not ascending", pod.ns);
       prev_w = w;
       ++g_word_steps;
+      if (getenv("KT_SIM_WORD_FORMS")) {
+        const bool wv = word_veto_flags(ix)[ci][w] != 0, w3 = hdr[w].m3 != 0;
+        g_word_veto += wv, g_word_m3 += w3, g_word_plain += !wv && !w3;
+      }
       g_admitted += __builtin_popcountll(nsl[k].mask);
       uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0;
       for (uint32_t id : ids) {
@@ -661,6 +685,9 @@ static int run_file(const char* path, uint32_t chk_budget) {
          ix.bm_max_lds + ix.bm_max_words * kCheckWordLds + check_fixed_lds(), ix.bm_max_lds + ix.bm_max_words * 128 + ix.bm_max_thr * thr_bytes);
   printf("  %ld pods: %.2f matches per pod (exact, no candidates), %.2f word steps per pod (%.1f admitted term copies per visited word), %ld slow confirmations\n", pods,
          (double)matches / (double)pods, (double)g_word_steps / (double)pods, (double)g_admitted / (double)std::max(1L, g_word_steps), g_slow_confirms);
+  if (getenv("KT_SIM_WORD_FORMS"))
+    printf("  visited words by form: %.1f %% hold a veto bit in some row, %.1f %% a term with three positive keys, %.1f %% neither\n",
+           100.0 * g_word_veto / std::max(1L, g_word_steps), 100.0 * g_word_m3 / std::max(1L, g_word_steps), 100.0 * g_word_plain / std::max(1L, g_word_steps));
   if (tiles)
     printf("  per 64-pod tile (all chunks): %.1f advance rounds, %.1f peel steps at %.1f %% busy lanes\n", (double)adv_rounds / tiles,
            (double)peel_steps / tiles, peel_steps ? 100.0 * (double)peel_busy / (64.0 * (double)peel_steps) : 0.0);
