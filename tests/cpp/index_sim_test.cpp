@@ -950,6 +950,29 @@ static int run_anchored(int argc, char** argv) {
              su / pods.size(), sh / pods.size(), tmax_v / tiles, tmax_u / tiles, tmax_h / tiles);
     }
     printf("  items per pod (block 0 + one per anchor atom it carries): %.2f\n", (double)g_items / (double)pods.size());
+    {
+      // rows a block's image really needs: the atoms with a bit in some word of the block (an item record could carry
+      // block-local row numbers, translated when the item view is built — the image then holds these rows only)
+      size_t sum_rows = 0, max_rows = 0, sum_bytes = 0, max_bytes = 0;
+      for (size_t c = 0; c + 1 < AX.blk_chunk0.size(); ++c) {
+        std::set<uint32_t> live;
+        size_t bytes = 0;
+        for (uint32_t ci = AX.blk_chunk0[c]; ci < AX.blk_chunk0[c + 1]; ++ci) {
+          const BmChunk& ch = AX.ix.bm_chunks[ci];
+          const uint64_t* rows = (const uint64_t*)(AX.ix.bm_images.data() + ch.img_off);
+          for (uint32_t r = 1; r < AX.ix.bm_rows; ++r)
+            for (uint32_t w = 0; w < ch.n_words; ++w)
+              if (rows[((size_t)r * ch.stride + w) * 2] | rows[((size_t)r * ch.stride + w) * 2 + 1]) { live.insert(r); break; }
+          bytes += (size_t)ch.stride * 16u;
+        }
+        sum_rows += live.size(), max_rows = std::max(max_rows, live.size());
+        const size_t b = (live.size() + 1) * bytes;
+        sum_bytes += b, max_bytes = std::max(max_bytes, b);
+      }
+      const size_t nb = AX.blk_chunk0.size() - 1;
+      printf("  atoms with a bit in a block: %.1f on average, %zu at most (of %u rows) -> rows of a block-local image %.1f KB on average, %.1f KB at most\n",
+             (double)sum_rows / nb, max_rows, AX.ix.bm_rows, sum_bytes / 1024.0 / nb, max_bytes / 1024.0);
+    }
     printf("  concatenated (shared atom numbering, one chunked index over %zu virtual namespaces): %zu chunks, %u words, images %.1f MB, largest LDS part %u B / %u throttles / %u words per chunk, slab scratch %.0f MB; %.2f word visits per pod; built in %.1f ms\n",
            (size_t)AX.block_anchor.size() * AX.n_ns, AX.ix.bm_chunks.size(), AX.ix.bm_words, AX.ix.bm_images.size() / 1048576.0, AX.ix.bm_max_lds, AX.ix.bm_max_thr,
            AX.ix.bm_max_words, AX.ix.bm_slab_bytes / 1048576.0, (double)vx / (double)pods.size(), ms2);
