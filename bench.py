@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i], i in 1..4 (default 2)")
     ap.add_argument("--pods-per-gpu", type=int, default=0, help="override the per-GPU pod rows")
     ap.add_argument("--variant", choices=["indexed", "dense"], default="indexed")
+    ap.add_argument("--throttles", type=int, default=0,
+                    help="measurements only: scale the config's throttle count (ClusterThrottles in proportion) — NOT a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
@@ -99,6 +101,9 @@ def main():
 
     # ---- workload: this rank's pod shard of a job with P_total = world x pods_per_gpu pods
     cfg = W.preset(args.config)
+    if args.throttles:
+        cfg.n_cluster = max(0, int(round(cfg.n_cluster * args.throttles / cfg.n_thr)))
+        cfg.n_thr = args.throttles
     if args.scaling == "strong":  # total work fixed: the config's pods (or --pods-per-gpu x 1 as the total) over N ranks
         total = args.pods_per_gpu or cfg.n_pods_total
         per_gpu = (total + world - 1) // world
@@ -437,7 +442,8 @@ def main():
             "metric": "pod_throttle_decisions_per_sec", "value": value, "unit": "decisions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config], "pods_total": P_total, "pods_per_gpu": per_gpu,
+            "config": {"workload": WORKLOADS[args.config] + (" — throttle count overridden (--throttles): not a BASELINE config" if args.throttles else ""),
+                       "pods_total": P_total, "pods_per_gpu": per_gpu,
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
                        "step": "sweep(check all pods against the stored status + aggregate, one pass)+finalize(apply)" if args.sweep
                                else "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",

@@ -187,6 +187,35 @@ static const std::vector<std::vector<uint8_t>>& word_veto_flags(const HostIndex&
   stamp[&ix] = ix.bm_images.size() + ix.bm_chunks.size() * 7919u;
   return cache[&ix] = f;
 }
+// per index: the keys whose atoms hold a bit (either family) in word w of chunk ci, as a bit mask over key ranks
+static long g_word_keys = 0;
+static const std::vector<std::vector<uint32_t>>& word_key_masks(const HostIndex& ix) {
+  static std::map<const HostIndex*, std::vector<std::vector<uint32_t>>> cache;
+  static std::map<const HostIndex*, size_t> stamp;
+  auto it = cache.find(&ix);
+  if (it != cache.end() && stamp[&ix] == ix.bm_images.size() + ix.bm_chunks.size() * 7919u) return it->second;
+  std::map<uint32_t, uint32_t> key_rank;
+  for (uint32_t k : ix.atom_key) key_rank.emplace(k, 0u);
+  uint32_t nk = 0;
+  for (auto& kv : key_rank) kv.second = nk++;
+  std::vector<std::vector<uint32_t>> f(ix.bm_chunks.size());
+  const size_t fam = ix.rich ? 2 : 1;
+  for (size_t ci = 0; ci < ix.bm_chunks.size(); ++ci) {
+    const BmChunk& ch = ix.bm_chunks[ci];
+    f[ci].assign(ch.n_words, 0u);
+    const uint64_t* rows = (const uint64_t*)(ix.bm_images.data() + ch.img_off);
+    for (size_t a = 0; a < ix.atoms.size(); ++a) {
+      const uint32_t r = ix.atoms[a].id, kr = std::min(31u, key_rank[ix.atom_key[a]]);
+      for (uint32_t w = 0; w < ch.n_words; ++w) {
+        uint64_t any = 0;
+        for (size_t q = 0; q < fam; ++q) any |= rows[((size_t)r * ch.stride + w) * fam + q];
+        if (any) f[ci][w] |= 1u << kr;
+      }
+    }
+  }
+  stamp[&ix] = ix.bm_images.size() + ix.bm_chunks.size() * 7919u;
+  return cache[&ix] = f;
+}
 static long g_word_useful = 0, g_word_hit = 0;  // visited words in which some atom of the pod (or a term without positive requirement) has an admitted bit / that hold a match
 // c0 / c1: the chunks walked (an anchored index: those of the item's block); walk_slow: the slow list too
 static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const PodLabels& pod, size_t c0 = 0, size_t c1 = ~(size_t)0,
@@ -219,6 +248,7 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       if (getenv("KT_SIM_WORD_FORMS")) {
         const bool wv = word_veto_flags(ix)[ci][w] != 0, w3 = hdr[w].m3 != 0;
         g_word_veto += wv, g_word_m3 += w3, g_word_plain += !wv && !w3;
+        g_word_keys += __builtin_popcount(word_key_masks(ix)[ci][w]);
       }
       g_admitted += __builtin_popcountll(nsl[k].mask);
       uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0;
@@ -688,6 +718,9 @@ static int run_file(const char* path, uint32_t chk_budget) {
   if (getenv("KT_SIM_WORD_FORMS"))
     printf("  visited words by form: %.1f %% hold a veto bit in some row, %.1f %% a term with three positive keys, %.1f %% neither\n",
            100.0 * g_word_veto / std::max(1L, g_word_steps), 100.0 * g_word_m3 / std::max(1L, g_word_steps), 100.0 * g_word_plain / std::max(1L, g_word_steps));
+  if (getenv("KT_SIM_WORD_FORMS"))
+    printf("  keys with a bit in a visited word: %.2f on average (a pod reads one atom row per key it carries: %u atom slots)\n",
+           (double)g_word_keys / std::max(1L, g_word_steps), ix.la);
   if (tiles)
     printf("  per 64-pod tile (all chunks): %.1f advance rounds, %.1f peel steps at %.1f %% busy lanes\n", (double)adv_rounds / tiles,
            (double)peel_steps / tiles, peel_steps ? 100.0 * (double)peel_busy / (64.0 * (double)peel_steps) : 0.0);
