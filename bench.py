@@ -250,6 +250,18 @@ def main():
         tot, n = eng.timing_read(fam)
         k_ms[name] = tot / max(n, 1)
 
+    # a fingerprint of what the step left behind (every summary word, every throttle's used / flags): two builds that claim
+    # the same results can be compared on full-size runs without an oracle pass (tools/gpu_r04_t.sh)
+    results_sha1 = None
+    if world == 1:
+        import hashlib
+        h = hashlib.sha1()
+        rec_f = eng.reconcile_fetch()
+        _, sm_f = eng.check_fetch(per_gpu, False)
+        for a in (rec_f.used.v, rec_f.used.count, rec_f.used.present, rec_f.thrl_flag, rec_f.thrl_has, rec_f.thrl_pod, rec_f.error, sm_f):
+            h.update(np.ascontiguousarray(a).tobytes())
+        results_sha1 = h.hexdigest()[:16]
+
     per_rank_kernel_ms = None
     if world > 1:  # every rank's kernel times, so that the first multi-GPU run explains itself
         gathered = [None] * world
@@ -448,7 +460,7 @@ def main():
                        "step": "sweep(check all pods against the stored status + aggregate, one pass)+finalize(apply)" if args.sweep
                                else "reconcile(aggregate+allreduce+finalize,apply)+check(all pods)",
                        "streams": "check(i) on a second stream beside reconcile(i+1); check(i) after finalize(i)" if overlap else "one",
-                       "overlap_identical_to_serial": overlap_identical,
+                       "overlap_identical_to_serial": overlap_identical, "results_sha1": results_sha1,
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
                        "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},

@@ -485,15 +485,23 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       for (uint32_t wi = 0; wi < nsw; ++wi) pc += (uint32_t)__builtin_popcount(a[wi]);
       keyed[g] = {(uint64_t)(0xFFFFFFFFu - pc) << 32 | (nsw >= 1 ? a[0] : 0u), g};
     }
-    if (nsw <= 1) {
-      std::sort(keyed.begin(), keyed.end());
-    } else {
-      std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
-        if (x.first != y.first) return x.first < y.first;
-        const int c = memcmp_words(adm_of(x.second) + 1, adm_of(y.second) + 1, nsw - 1);
-        return c != 0 ? c < 0 : x.second < y.second;
-      });
-    }
+    // inside a class: by FORM (kNsWord*, kt_index.h) — groups without a negative requirement first, inside those the groups
+    // without a need-3 term first — so that the words of a rich program come out (mostly) pure and the scans can take the
+    // cheaper path per word; a program of the simple form has one form and keeps its order
+    std::vector<uint8_t> form(NG, 0);
+    for (uint32_t g = 0; g < NG; ++g)
+      for (uint32_t q = grp_first[g]; q < grp_first[g + 1]; ++q) {
+        const BT& b = bts[tcs[q].bt];
+        if (b.neg_cnt != 0u || b.nk_cnt != 0u) form[g] |= 2u;
+        if (!b.slow && b.need >= 3u) form[g] |= 1u;
+      }
+    std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+      if (x.first != y.first) return x.first < y.first;
+      const int c = nsw > 1 ? memcmp_words(adm_of(x.second) + 1, adm_of(y.second) + 1, nsw - 1) : 0;
+      if (c != 0) return c < 0;
+      if (form[x.second] != form[y.second]) return form[x.second] < form[y.second];
+      return x.second < y.second;
+    });
     for (uint32_t g = 0; g < NG; ++g) gorder[g] = keyed[g].second;
   }
   std::vector<uint32_t>& order = scratch.order;
@@ -734,6 +742,13 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   for (uint32_t n = 0; n < n_ns; ++n)
     for (uint32_t w = 0; w < W; ++w) ns_per_word[w] += nsrows[(size_t)n * W + w] != 0;
   const size_t fam = veto ? 2 : 1;
+  // the form of every word (NsWord::flags): does some atom row hold a veto bit in it, does some term need three hits
+  std::vector<uint32_t> word_form(W, 0u);
+  for (uint32_t w = 0; w < W; ++w) word_form[w] = hdr[w].m3 != 0ull ? kNsWordNeed3 : 0u;
+  if (veto)
+    for (uint32_t r = 0; r < R; ++r)
+      for (uint32_t w = 0; w < W; ++w)
+        if (vet[(size_t)r * W + w]) word_form[w] |= kNsWordVeto;
   uint64_t slab_run = 0;
   out.bm_chunks.clear();
   out.bm_images.clear();
@@ -795,7 +810,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
     for (uint32_t n = 0; n < n_ns; ++n) {
       for (uint32_t w = 0; w < ch.n_words; ++w) {
         const uint64_t m = nsrows[(size_t)n * W + w0 + w];
-        if (m) nsl.push_back(NsWord{w, 0u, m});
+        if (m) nsl.push_back(NsWord{w, word_form[w0 + w], m});
       }
       nsl_off[n + 1] = (uint32_t)nsl.size();
     }

@@ -68,9 +68,17 @@ struct alignas(16) WordHdr {
 };
 // one entry of a namespace's word list
 struct alignas(16) NsWord {
-  uint32_t w, pad;
-  uint64_t mask;  // terms of word w whose namespace side admits the namespace
+  uint32_t w;
+  uint32_t flags;  // kNsWord*: the FORM of word w (the same in every namespace's entry of it)
+  uint64_t mask;   // terms of word w whose namespace side admits the namespace
 };
+// Inside a class (groups with one admission set) the groups are numbered by form — without / with a term of three
+// positive keys, without / with a negative requirement — so that most words of a rich program are pure: a word without
+// veto bits is scanned by reading the `any` half of every atom row only (8 bytes instead of 16 per atom: the scans of large
+// programs are bound by these LDS gathers), a word without need-3 terms takes the OR / XOR accumulation of the simple form
+// instead of the counting tree.  configs[4] shard: 54 % of the visited words carry no veto bit, 54 % no need-3 term.
+constexpr uint32_t kNsWordVeto = 1u;   // some atom row holds a veto bit in this word
+constexpr uint32_t kNsWordNeed3 = 2u;  // some term of this word needs three positive hits (WordHdr::m3 != 0)
 
 // One LDS-sized slice of the bitmap form: 64-bit words [w0, w0 + n_words) of every row.  The terms of a throttle never
 // straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers.

@@ -219,38 +219,70 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
       KT_LDS const unsigned char* col = b.rows + w * (VETO ? 16u : 8u);
       uint64_t xx, vet = 0;
       if (NEED >= 3) {
+        // The FORM of the word (NsWord::flags — inside a class the groups are numbered by form, so most words are pure),
+        // wave-uniform: the lanes of a tile in namespace order visit the same words; a tile whose lanes visit words of
+        // different forms takes the general path, which is right for every word.
+        //   no veto bit in any row  : only the `any` half of every atom row is read (8 bytes per atom instead of 16: these
+        //                             gathers are what the scans of large programs wait for)
+        //   no need-3 term          : the OR / XOR accumulation of the simple form (below) instead of the counting tree
+        // (only in the instantiations with room for it — the PIPE ones with eight atom slots: the 64-VGPR forms and the
+        //  16 / 32-slot ones spill over the second path)
+#ifndef KT_NO_WORD_FORMS
+        constexpr bool FORMS = PIPE && LA == 8;
+        const bool w_veto = VETO && (!FORMS || __ballot(adv && (e.y & kNsWordVeto) != 0u) != 0ull);
+#ifdef KT_WORD_FORM_NEED3
+        const bool w_need3 = __ballot(adv && (e.y & kNsWordNeed3) != 0u) != 0ull;
+#else
+        const bool w_need3 = true;  // (the OR / XOR path saves VALU only, and the instantiations with 128 VGPRs spill over it)
+#endif
+#else
+        const bool w_veto = VETO, w_need3 = true;
+#endif
         // hits per term as a 2-bit number (c1 c0): a pod carries at most one atom of any requirement and an exactly
         // indexed term has at most three positive keys, so the count never passes 3.  Eight rows at a time through a
         // small adder tree of three-input operations (count8); the groups of eight are added as 2-bit numbers.
         static_assert(LA % 8 == 0, "atom slots come in eights");
-        uint64_t c0 = 0, c1 = 0;
+        // (c0 / c1: the 2-bit counter of the counting form — or, in a word without need-3 terms, the OR and the XOR of the rows)
+        uint64_t c0 = w_need3 ? 0ull : h0.x, c1 = 0;
 #pragma unroll
         for (int g8 = 0; g8 < LA / 8; ++g8) {
+          // (one set of registers for both forms: the veto halves of a veto-free word are zeroed instead of read)
           uint64_t r[8], v8[8];
+          if (w_veto) {
 #pragma unroll
-          for (int l = 0; l < 8; ++l) {
-            if (VETO) {
+            for (int l = 0; l < 8; ++l) {
               const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[8 * g8 + l]);
               r[l] = rv.x, v8[l] = rv.y;
-            } else {
-              r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
-              v8[l] = 0;
             }
+          } else {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]), v8[l] = 0ull;  // (the `any` half of the cell)
           }
           if (VETO) vet |= or3_64(or3_64(v8[0], v8[1], v8[2]), or3_64(v8[3], v8[4], v8[5]), v8[6] | v8[7]);
-          uint64_t ones, twos;
-          count8(r, ones, twos);
-          if (g8 == 0) {
-            c0 = ones, c1 = twos;
-          } else {  // (the total still does not pass 3: at most one carry)
-            c1 |= twos | (c0 & ones);
-            c0 ^= ones;
+          if (w_need3) {
+            uint64_t ones, twos;
+            count8(r, ones, twos);
+            if (g8 == 0) {
+              c0 = ones, c1 = twos;
+            } else {  // (the total still does not pass 3: at most one carry)
+              c1 |= twos | (c0 & ones);
+              c0 ^= ones;
+            }
+          } else {
+            c0 = or3_64(or3_64(r[0], r[1], r[2]), or3_64(r[3], r[4], r[5]), or3_64(r[6], r[7], c0));
+            c1 = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], c1));
           }
         }
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
-        const uint64_t any = or3_64(h0.x, c0, c1), two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
-        xx = mux_64(any, two, h0.y);    // (any & ~m2) | (two & m2)
-        xx = mux_64(xx, three, h1.x);   // (xx & ~m3) | (three & m3)
+        if (w_need3) {
+          const uint64_t any = or3_64(h0.x, c0, c1), two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
+          xx = mux_64(any, two, h0.y);    // (any & ~m2) | (two & m2)
+          xx = mux_64(xx, three, h1.x);   // (xx & ~m3) | (three & m3)
+        } else {
+          // at most two positive keys per term, each met by at most one of the pod's atoms: under m2 "both met" = "met, and in
+          // an even number of rows"
+          xx = and_nand_64(c0, c1, h0.y);
+        }
         xx = and_not_and_64(xx, vet, (uint64_t)e.z | (uint64_t)e.w << 32);
         xx = adv ? xx : 0ull;
         if (b.has_slow) {

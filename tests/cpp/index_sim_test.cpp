@@ -246,12 +246,13 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       prev_w = w;
       ++g_word_steps;
       if (getenv("KT_SIM_WORD_FORMS")) {
-        const bool wv = word_veto_flags(ix)[ci][w] != 0, w3 = hdr[w].m3 != 0;
+        const bool wv = (nsl[k].flags & kNsWordVeto) != 0, w3 = hdr[w].m3 != 0;
+        EXPECT(!ix.rich || wv == (word_veto_flags(ix)[ci][w] != 0), "veto flag of word %u", w);
         g_word_veto += wv, g_word_m3 += w3, g_word_plain += !wv && !w3;
         g_word_keys += __builtin_popcount(word_key_masks(ix)[ci][w]);
       }
       g_admitted += __builtin_popcountll(nsl[k].mask);
-      uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0;
+      uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0, par = 0;
       for (uint32_t id : ids) {
         EXPECT(id < ix.bm_rows, "row %u of %u", id, ix.bm_rows);
         const uint64_t r = rows[((size_t)id * ch.stride + w) * fam];
@@ -259,6 +260,16 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
         three |= two & r;
         two |= any & r;
         any |= r;
+        par ^= r;
+      }
+      // the word's form (NsWord::flags): what scan_tile's cheaper paths rely on
+      const uint32_t fl = nsl[k].flags;
+      EXPECT(((fl & kNsWordNeed3) != 0u) == (hdr[w].m3 != 0ull), "need-3 flag of word %u", w);
+      EXPECT(ix.rich || fl == 0u, "a simple image has one form");
+      if (!(fl & kNsWordVeto)) EXPECT(vet == 0ull, "word %u is flagged veto-free, yet a row of the pod holds veto bits", w);
+      if (!(fl & kNsWordNeed3)) {
+        const uint64_t general = (any & ~hdr[w].m2) | (two & hdr[w].m2), simple = any & ~(par & hdr[w].m2);
+        EXPECT(general == simple, "word %u without need-3 terms: OR / XOR accumulation disagrees with the counting form", w);
       }
       if (any & nsl[k].mask) ++g_word_useful;
       uint64_t x = (any & ~hdr[w].m2) | (two & hdr[w].m2);

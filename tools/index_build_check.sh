@@ -8,7 +8,7 @@
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
-WANT="0f45a244af442de0 c3790c66eb17b27c 35ccbc1446a588e2"
+WANT="a028203c41407067 c3790c66eb17b27c 3d1100d72a10dfd5"
 make -C kube_throttler_amd/csrc 2>&1 | grep -E "error|warning"
 make -C kube_throttler_amd/host index_sim_test 2>&1 | grep -E "error|warning"
 for c in 2 4; do
