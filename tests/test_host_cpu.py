@@ -198,6 +198,26 @@ def test_anchor_split_against_brute_force(tool, tmp_path):
     assert m2 and abs(float(m2.group(1)) - float(m.group(2))) < 1e-9, out.stdout[-800:]
 
 
+def test_word_forms_of_the_configs4_program(tool, tmp_path):
+    """Inside a class the index builder numbers the groups by form (kt_index.h: kNsWord*), so that most 64-bit words of a
+    rich program hold no veto bit in any atom row — the scans then read half the bytes for them.  The CPU replay checks,
+    for every pod and visited word of the random suite and of the real program of a BASELINE configs[4] shard, that a word
+    flagged veto-free shows no veto bit in the pod's rows and that a word flagged need-3-free gives the same matches through
+    the OR / XOR accumulation as through the counting form; here: the statistic the layout exists for."""
+    import re
+    subprocess.check_call(["make", "-C", HOST, "index_sim_test"], stdout=subprocess.DEVNULL)
+    dump = str(tmp_path / "cfg4.bin")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "4", "--pods", "1024", dump],
+                          stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "index_sim_test"), dump], capture_output=True, text=True, env=dict(os.environ, KT_SIM_WORD_FORMS="1"))
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-1000:]
+    m = re.search(r"visited words by form: ([0-9.]+) % hold a veto bit in some row, ([0-9.]+) % a term with three positive keys", out.stdout)
+    assert m, out.stdout[-800:]
+    assert float(m.group(1)) < 60.0 and float(m.group(2)) < 60.0, out.stdout[-800:]   # (every word was mixed before: 100 % / 99.9 %)
+    v = re.search(r"([0-9.]+) word steps per pod", out.stdout)
+    assert v and float(v.group(1)) < 80.0, out.stdout[-800:]                           # (the order inside a class costs no visits)
+
+
 def test_label_key_value_validation(tool):
     """What makes LabelSelectorAsSelector fail on a key / value (validation.IsQualifiedName, IsValidLabelValue of
     apimachinery v0.26.4, restated — parity unpinned: no reference test feeds a malformed label): known answers, and the
