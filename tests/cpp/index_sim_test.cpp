@@ -859,7 +859,9 @@ int main(int argc, char** argv) {
     if (r >= 500000000L) r -= 500000000L, ++simple_seen;
     chunks_seen = std::max(chunks_seen, r / 1000000L), matches += r % 1000000L;
   };
-  for (uint32_t seed = 1; seed <= 40; ++seed) {
+  // KT_SIM_SEED_OFFSET=n: the same suite on other random programs (the pinned fingerprint belongs to offset 0)
+  const uint32_t seed_off = getenv("KT_SIM_SEED_OFFSET") ? (uint32_t)atoi(getenv("KT_SIM_SEED_OFFSET")) * 100u : 0u;
+  for (uint32_t seed = 1 + seed_off; seed <= 40 + seed_off; ++seed) {
     // everything resident in one chunk
     acc(run_case(seed, 40 + seed % 60, 1 + seed % 9, 6, 4, 3, 3, seed % 5 == 0 ? 0.05 : 0.0, 160 << 10, 160 << 10, 160, 300));
     // tight budgets: a few words per chunk, different for the two kernels
