@@ -315,6 +315,12 @@ struct kt_engine {
   // consistent status: the one before the reconcile) instead of waiting for — or racing with — kt_finalize
   DevBuf<uint8_t> d_recs2[2];
   int recs_cur = 0;
+  // per CheckRecs buffer: how often it was rewritten, and the per-word check tables (TermInfo + WordVerdict of every word of
+  // the index: kt_build_verdict_images) built from it — valid while (recs_seq, program_gen, DT) are those of the build
+  uint64_t recs_seq[2] = {0, 0};
+  DevBuf<uint8_t> d_wvimg[2];
+  uint64_t wvimg_seq[2] = {~0ull, ~0ull}, wvimg_gen[2] = {~0ull, ~0ull};
+  int wvimg_DT[2] = {0, 0};
   hipEvent_t recs_ev[2] = {nullptr, nullptr};
   bool recs_ev_pending[2] = {false, false};
   int32_t wide_mode = 0;  // kt_set_wide_sums: 0 = decided per engine (single rank only), 1 = always two blocks
@@ -1101,7 +1107,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
                               &e->d_ovr_off, &e->d_out_thrl_flag, &e->d_out_thrl_has};
   for (auto* b : u32s) b->release();
   DevBuf<uint8_t>* u8s[] = {&e->d_term_flags, &e->d_req_op, &e->d_ns_valid, &e->d_ovr_flags, &e->d_out_calc_updated,
-                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_status, &e->d_stage, &e->d_ev_stage, &e->d_slab, &e->d_admit};
+                            &e->d_out_thrl_pod, &e->d_out_error, &e->d_recs2[0], &e->d_recs2[1], &e->d_wvimg[0], &e->d_wvimg[1], &e->d_status, &e->d_stage, &e->d_ev_stage, &e->d_slab, &e->d_admit};
   for (auto* b : u8s) b->release();
   e->d_status_fp.release(); e->d_spec_fp.release(); e->d_summary.release(); e->d_rows.release();
   e->d_used_hi.release(); e->d_out_used_hi.release();
@@ -2146,6 +2152,7 @@ static int32_t finalize_locked(kt_engine* e, int64_t now_s, int32_t now_ns, uint
     e->recs_ev_pending[wbuf] = e->few_ready;
     e->recs_prev_valid = keep_prev;
     e->recs_cur = wbuf;
+    ++e->recs_seq[wbuf];
     e->recs_valid = true;  // e->recs_eq unchanged
     e->recs_DT = rec_DT;
   }
@@ -2325,6 +2332,7 @@ static int32_t ensure_check_recs(kt_engine* e, int32_t on_equal, int DT, hipStre
   std::lock_guard<std::mutex> g(e->recs_mu);
   e->recs_ev_pending[e->recs_cur] = e->few_ready;
   e->recs_prev_valid = false;  // records of an older status / other on_equal: not a substitute any more
+  ++e->recs_seq[e->recs_cur];
   e->recs_valid = true;
   e->recs_eq = on_equal != 0;
   e->recs_DT = DT;
@@ -2404,7 +2412,19 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
         e->view_rows_a = e->pod_rows_hi;
         e->order_all_valid = true;
       }
-      const kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
+      kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
+      if (by_ns && !want_status && e->dindex.n_slow == 0 && e->n_overflow == 0 && e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_VERDICT_IMAGES")) {
+        // the lean sweep of a multi-chunk program: TermInfo + WordVerdict of every word once per generation of CheckRecs
+        // (one small launch) instead of once per (workgroup, chunk) — 256 x ~15 rebuilds of the same words
+        const int b = e->recs_cur;
+        if (e->wvimg_seq[b] != e->recs_seq[b] || e->wvimg_gen[b] != e->program_gen || e->wvimg_DT[b] != DT) {
+          KT_HIP(e, e->d_wvimg[b].reserve(kt::verdict_images_bytes(e->dindex.bm_words, e->D)));
+          TimedLaunch tl2(e, KT_KERNEL_PREPARE, s);
+          kt::launch_build_verdict_images(e->dindex, e->dindex.bm_words, e->recs_ptr(), e->thr_rows_hi, e->D, e->d_wvimg[b].p, s);
+          e->wvimg_seq[b] = e->recs_seq[b], e->wvimg_gen[b] = e->program_gen, e->wvimg_DT[b] = DT;
+        }
+        view.wv_img = e->d_wvimg[b].p, view.wv_total_words = e->dindex.bm_words;
+      }
       const char* k = kt::launch_check_indexed(e->pods, n, by_ns ? e->d_order_all.p : pod_rows ? e->d_rows.p : nullptr, e->sp, e->d_sp.p, e->dindex,
                                                e->recs_ptr(), e->d_summary.p, want_status ? e->d_status.p : nullptr, s,
                                                small ? &sm : nullptr, e->n_overflow != 0, by_ns ? &view : nullptr);

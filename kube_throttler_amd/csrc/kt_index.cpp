@@ -776,8 +776,10 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
       const size_t lds_hi = std::max(lds, (size_t)out.bm_max_lds);
       const size_t thr_hi = std::max((size_t)nthr, (size_t)out.bm_max_thr);
       const size_t nw_hi = std::max(nw, (size_t)out.bm_max_words);
-      const bool fits = lds_hi + nw_hi * chk_word <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + thr_hi * thr_bytes + 16 <= agg_budget &&
-                        nthr < 0x8000u;
+      // (aggregate: ranks u16[64] + the run masks {seg_lo, seg_hi} per word; nw < 1024: the packed fold queues chunk-local
+      //  term numbers as 16-bit values)
+      const bool fits = lds_hi + nw_hi * chk_word <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + nw_hi * 16 + thr_hi * thr_bytes + 16 <= agg_budget &&
+                        nthr < 0x8000u && nw < 1024;
       if (!fits && w1 != 0) break;
       if (cand == W || splittable[cand]) {
         w1 = cand;
@@ -907,6 +909,7 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.h_chunks = h.bm_chunks;
   d.n_chunks = (uint32_t)h.bm_chunks.size();
   d.bm_max_lds = h.bm_max_lds, d.bm_max_thr = h.bm_max_thr, d.bm_max_words = h.bm_max_words, d.bm_rows = h.bm_rows;
+  d.bm_words = h.bm_words;
   d.bm_slab_bytes = h.bm_slab_bytes;
   d.has_veto = h.has_veto ? 1u : 0u;
   d.max_need = h.max_need;

@@ -229,13 +229,14 @@ struct IndexDev {
   uint32_t n_chunks = 0, bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0, bm_rows = 0;
   uint64_t bm_slab_bytes = 0;
   uint32_t has_veto = 0, max_need = 0, n_atoms = 0, has_key_atoms = 0, la = 8;
+  uint32_t bm_words = 0;  // 64-bit words of the numbered program (all chunks)
   bool rich = false;
   size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_chunk_ns = 0, cap_atom_table = 0, cap_slow = 0;
 };
 
 // LDS budgets: a chunk must satisfy
 //   check     : lds_bytes + n_words*chk_word (term info + verdict masks: check_word_lds(D)) <= chk_budget
-//   aggregate : lds_bytes + n_words*64*2 (ranks) + n_thr * thr_bytes      <= agg_budget
+//   aggregate : lds_bytes + n_words*(64*2 + 16) (ranks, run masks) + n_thr * thr_bytes <= agg_budget
 // (both kernels lay LDS out once, for the maxima over all chunks, so the maxima have to fit too).
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
@@ -332,7 +333,15 @@ struct CheckByNs {
   const uint64_t* v_meta;
   const uint16_t* v_latom;
   uint64_t* carry;
+  // TermInfo + WordVerdict of every word (launch_build_verdict_images, for the CheckRecs this launch reads), or nullptr:
+  // every workgroup then rebuilds them per chunk
+  const unsigned char* wv_img = nullptr;
+  uint32_t wv_total_words = 0;
 };
+// the per-word check tables of the whole index in global memory: TermInfo [total_words][64], then WordVerdict [total_words]
+// (total_words = HostIndex::bm_words) — built once per generation of CheckRecs instead of once per (workgroup, chunk)
+size_t verdict_images_bytes(uint32_t total_words, int D);
+void launch_build_verdict_images(const IndexDev& ix, uint32_t total_words, const void* recs, int T, int D, void* out, hipStream_t s);
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,

@@ -39,6 +39,7 @@ struct BmAggArgs {
   int64_t row0, n_rows;
   BmIndexArgs ix;
   uint32_t off_rank, off_tab;
+  uint32_t off_seg;  // packed fold: per word {seg_lo, seg_hi}, the run masks of throttles with several terms (built per chunk)
   uint32_t n_slow;
   int32_t D, DS, LS, T;
   int32_t counts;  // table keeps per-key pod counts instead of the presence mask
@@ -70,6 +71,7 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
   a.off_tab = take(packed ? ix.bm_max_thr * a.pk.rec_bytes : agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
+  a.off_seg = take(packed ? ix.bm_max_words * 16u : 0u);
   plan_bitmap_index(ix, a.ix, take);
   a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && (sc.v_req || packed)) ? 1u : 0u;
   *total = o;
@@ -126,6 +128,17 @@ __device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram
 template <int DT, int LA, bool VETO, int NEED, bool PK>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
+  // QUEUED FOLD (round 5, the packed instantiations): an LDS atomic costs per INSTRUCTION (~11.5 cycles of the CU's one LDS
+  // pipe whatever the number of active lanes), and folding a word's matches where the scan produced them steps as often as
+  // the lane with the MOST matches of that word has matches — lanes 21 % (configs[2]) to 38 % (configs[4]) busy.  The
+  // matches are therefore first peeled into a lane-private queue of 16-bit term numbers in registers (plain VALU steps),
+  // and folded — three atomics per step — only when some lane's queue is full or the tile is done: a step of the fold then
+  // serves a match of nearly every lane that has any left.  -DKT_AGG_NO_QUEUE restores the word-by-word fold (A/B).
+#ifndef KT_AGG_NO_QUEUE
+  constexpr bool kFoldQueue = PK && LA <= 16;  // (32 atom slots: the queue does not fit the registers)
+#else
+  constexpr bool kFoldQueue = false;
+#endif
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
@@ -190,6 +203,23 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
     lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
+    if constexpr (kFoldQueue) {
+      // the run masks of the chunk's words, by ballot from the rank words (a wave per word, lane = term number): lowest /
+      // highest number of every run of one group's terms — a throttle with several terms is counted once, and with the
+      // masks that rule is applied to a whole word at a time (as kt_check_bitmap's WordVerdict does), so that the order
+      // in which a lane's matches are folded no longer matters
+      if (ch.has_adj) {
+        const uint16_t* g_rank = (const uint16_t*)(a.ix.blob + ch.img_off + ch.off_term_rank);
+        for (uint32_t w = wave; w < ch.n_words; w += (uint32_t)(kBlockIx / kWave)) {
+          const uint32_t tr = g_rank[w * 64u + lane];
+          const uint32_t tp = (uint32_t)__shfl_up((int)tr, 1), tn = (uint32_t)__shfl_down((int)tr, 1);
+          const bool adj = (tr & kRankAdj) != 0u;
+          const bool same_prev = lane > 0u && adj && tp == tr, same_next = lane < 63u && adj && tn == tr;
+          const uint64_t m_lo = __ballot(!same_prev), m_hi = __ballot(!same_next);
+          if (lane < 2u) ((lds_u64wp)(lds + a.off_seg))[w * 2u + lane] = lane == 0u ? m_lo : m_hi;
+        }
+      }
+    }
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
     for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
@@ -252,7 +282,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       constexpr bool EARLY = PK && LA <= 16;  // (32 atom slots: the second record does not fit the registers)
       if (kAggPrefetch && EARLY && more) nxt = fetch_tile(wt + wt_step);
       uint32_t last_r = 0xFFFFFFFFu;
+#ifdef KT_PROBE_FOLD_WORDS  // timing probe (results are wrong): only the first words of the plan are added
+      const uint32_t pk_nw = min((uint32_t)KT_PROBE_FOLD_WORDS, __builtin_amdgcn_readfirstlane(a.pk.nw));
+#else
       const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
+#endif
       // one matched term number of the lane's pod, given its rank word
       auto add_match = [&](bool has, uint32_t tr) {
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
@@ -266,6 +300,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
                 // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
                 // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
                 // testing the words lane by lane only bought exec-mask juggling
+#ifdef KT_PROBE_FOLD_WORDS
+                if (pk_nw > 0u)
+#endif
                 lds_add64(tv, pw[0]);
                 if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
                 if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
@@ -296,7 +333,77 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
 #else
       constexpr bool kFoldPairs = false;
 #endif
-      if constexpr (kFoldPairs) {
+      if constexpr (kFoldQueue) {
+        // lane-private queue: kQueueCap 16-bit chunk-local term numbers, newest in the low half of q[0] (entries past qn are zero)
+#ifndef KT_AGG_QUEUE_CAP
+#define KT_AGG_QUEUE_CAP 12
+#endif
+        constexpr uint32_t kQueueCap = KT_AGG_QUEUE_CAP;
+        constexpr int NQ = (int)kQueueCap / 2;
+        static_assert(kQueueCap % 2 == 0 && kQueueCap >= 4, "queue entries come in pairs");
+        uint32_t q[NQ], qn = 0u;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) q[k] = 0u;
+        auto add_rank = [&](bool has, uint32_t r) {
+          if (has) {
+            KT_LDS unsigned char* rp = tab + __umul24(r, rec);
+            lds_u64wp tv = (lds_u64wp)rp;
+#ifdef KT_PROBE_FOLD_WORDS
+            if (pk_nw > 0u)
+#endif
+            lds_add64(tv, pw[0]);
+            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+            if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+        auto flush = [&]() {
+#ifdef KT_PROBE_NO_FLUSH  // timing probe (results are wrong): the queue is filled and thrown away
+          if (qn < 1000000u) { qn = 0u; return; }
+#endif  // two queued matches per step: both rank reads in flight together
+          while (__ballot(qn != 0u) != 0ull) {
+            const bool h1 = qn >= 1u, h2 = qn >= 2u;
+            const uint32_t c1 = q[0] & 0xFFFFu, c2 = q[0] >> 16;
+#pragma unroll
+            for (int k = 0; k + 1 < NQ; ++k) q[k] = q[k + 1];
+            q[NQ - 1] = 0u;
+            qn = h2 ? qn - 2u : 0u;
+            const uint32_t r1 = trank[c1] & 0x7FFFu, r2 = trank[c2] & 0x7FFFu;
+            add_rank(h1, r1);
+            add_rank(h2, r2);
+          }
+        };
+        const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
+        KT_LDS const u64x2* segp = (KT_LDS const u64x2*)(lds + a.off_seg);
+        scan_tile<LA, VETO, NEED, VETO>(
+            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
+            [&](uint32_t w, uint64_t x, const u64x2& seg) -> uint64_t {
+              if (seg_on) {  // a throttle with several terms is counted once: the lowest match of every run
+                const uint64_t v = x | seg.y;
+                x = andn_64(x, v - seg.x);
+              }
+#ifdef KT_PROBE_NO_FOLD  // timing probe (results are wrong): the scan without the fold
+              if (x == 0x123456789ull) qn = 1u;
+              return 0ull;
+#endif
+              while (__ballot(x != 0ull) != 0ull) {
+                if (__ballot(qn >= kQueueCap) != 0ull) flush();
+                const bool has = x != 0ull;
+                const uint32_t c = w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u;
+                x &= x - 1ull;
+                if (has) {
+#pragma unroll
+                  for (int k = NQ - 1; k > 0; --k) q[k] = __builtin_amdgcn_alignbit(q[k], q[k - 1], 16);
+                  q[0] = q[0] << 16 | c;
+                  qn += 1u;
+                }
+              }
+              return 0ull;
+            },
+            [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
+        flush();
+      } else if constexpr (kFoldPairs) {
         // the packed fold takes a word's matches where the scan produced them (scan_tile's post hook), TWO per step: both
         // rank reads are in flight together and the wave steps ceil(matches / 2) times per word instead of once per match
         // through scan_tile's peel (ascending term numbers per lane, as the run rule of add_match needs)

@@ -49,6 +49,74 @@ struct alignas(16) WordVerdict {
 constexpr uint32_t kTiAdj = 0x00100000u, kTiTight = 0x10000000u;
 constexpr int kTiShActive = 16, kTiShIdle = 22;
 
+// TermInfo + (WORDWISE) the WordVerdict masks of ONE term number c: the 64 lanes of a wave hold the 64 numbers of word c / 64
+// (c = 64 * word + lane), the masks are ballots.  tinfo / wv: where the tables go — LDS in the scan kernels' chunk prologue,
+// global memory in kt_build_verdict_images.
+template <int DT, bool WORDWISE, class TI, class WV>
+__device__ __forceinline__ void build_term_verdicts(uint32_t tt, uint32_t c, const u32x2* g_rflags, TI* tinfo, WV* wv) {
+  const bool real = (tt & kTermReal) != 0;
+  const uint32_t t = tt & kTermRowMask;
+  const u32x2 rf = real ? g_rflags[t] : u32x2{0u, 0u};  // {flags, active_mask}
+  u32x2 ti = {0u, 0u};
+  if (real) {
+    const uint32_t sh_act = (rf.x & kRecExceedsByCount) ? 4u : 24u;
+    const uint32_t sh_idle = (rf.x & kRecExceedsByCount) ? 4u : (rf.x & kRecActiveByCount) ? 24u : (rf.x & kRecInsufficientByCount) ? 44u : 0u;
+    ti.x = t | ((tt & kTermAdj) ? kTiAdj : 0u);
+    ti.y = (rf.y & 0xFFFFu) | sh_act << kTiShActive | sh_idle << kTiShIdle | ((rf.x & kRecTight) ? kTiTight : 0u);
+  }
+  tinfo[c] = ti;
+  if (WORDWISE) {  // this wave holds the 64 numbers of word c / 64: their verdict masks by ballot
+    const uint32_t ln = c & 63u;
+    const uint32_t tp = (uint32_t)__shfl_up((int)tt, 1), tn = (uint32_t)__shfl_down((int)tt, 1);
+    const bool adj = (tt & kTermAdj) != 0;
+    const bool same_prev = ln > 0u && adj && (tp & kTermReal) && (tp & kTermAdj) && (tp & kTermRowMask) == t;
+    const bool same_next = ln < 63u && adj && (tn & kTermReal) && (tn & kTermAdj) && (tn & kTermRowMask) == t;
+    const bool xc = (rf.x & kRecExceedsByCount) != 0;
+    const uint64_t m_lo = __ballot(real && !same_prev), m_hi = __ballot(real && !same_next);
+    const uint64_t m_tight = __ballot(real && (rf.x & kRecTight) != 0), m_exc = __ballot(real && xc);
+    const uint64_t m_act = __ballot(real && (rf.x & kRecActiveByCount) != 0), m_ins = __ballot(real && (rf.x & kRecInsufficientByCount) != 0);
+    WV* wvp = wv + (c >> 6);
+    const uint64_t mine = ln == 0u ? m_lo : ln == 1u ? m_hi : ln == 2u ? m_tight : ln == 3u ? m_exc : ln == 4u ? m_act : m_ins;
+    // act_nib[q][v], entry e = 16 q + v: lane e (and lane e - 64 ... : DT = 16 has 64 entries, one per lane)
+    const uint32_t eq = ln >> 4, ev = ln & 15u;
+    uint64_t tab = m_act;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const uint64_t m = __ballot(real && ((rf.y >> d) & 1u) != 0);
+      tab |= ((uint32_t)(d >> 2) == eq && ((ev >> (d & 3)) & 1u)) ? m : 0ull;
+    }
+    typedef decltype(&wvp->seg_lo) u64p;  // (pointer to uint64_t in the address space of wv)
+    if (ln < 6u) ((u64p)wvp)[ln] = mine;
+    if (ln < 4u * (uint32_t)DT) ((u64p)wvp)[6u + ln] = tab;
+  }
+}
+template <int DT>
+__host__ __device__ constexpr uint32_t verdict_image_word_bytes() { return 64u * 8u; }  // TermInfo block; the WordVerdicts follow ALL TermInfo blocks
+
+// kt_build_verdict_images — TermInfo + WordVerdict of every word of the index, in global memory: grid = (word groups, chunks),
+// a wave per word.  Layout: TermInfo [total_words][64] (8 bytes each, global word order), then WordVerdict<DT> [total_words].
+template <int DT>
+__global__ __launch_bounds__(256) void kt_build_verdict_images(const unsigned char* blob, const BmChunk* chunks, const void* recs, int T,
+                                                               uint32_t total_words, unsigned char* out) {
+  const BmChunk ch = chunks[blockIdx.y];
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (w >= ch.n_words) return;  // wave-uniform
+  const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)recs, T);
+  const uint32_t* term_t = (const uint32_t*)(blob + ch.img_off + ch.off_term_t);
+  const uint32_t c_local = w * 64u + (threadIdx.x & 63u);
+  const uint32_t c_glob = (ch.w0 + w) * 64u + (threadIdx.x & 63u);
+  build_term_verdicts<DT, true>(term_t[c_local], c_glob, g_rflags, (u32x2*)out, (WordVerdict<DT>*)(out + (size_t)total_words * 64u * 8u));
+}
+size_t verdict_images_bytes(uint32_t total_words, int D) {
+  return (size_t)total_words * (64u * 8u + (D <= 8 ? sizeof(WordVerdict<8>) : sizeof(WordVerdict<16>))) + 64;
+}
+void launch_build_verdict_images(const IndexDev& ix, uint32_t total_words, const void* recs, int T, int D, void* out, hipStream_t s) {
+  if (!ix.n_chunks || !ix.bm_max_words) return;
+  const dim3 g_((ix.bm_max_words + 3u) / 4u, ix.n_chunks), b_(256);
+  if (dt_bucket_ix(D) <= 8) hipLaunchKernelGGL(kt_build_verdict_images<8>, g_, b_, 0, s, ix.bm_blob, ix.bm_chunks, recs, T, total_words, (unsigned char*)out);
+  else hipLaunchKernelGGL(kt_build_verdict_images<16>, g_, b_, 0, s, ix.bm_blob, ix.bm_chunks, recs, T, total_words, (unsigned char*)out);
+}
+
 // what a tile needs of its 64 pods before it can start (kt_check_bitmap's fetch_tile)
 template <int LA, int NV = 1>
 struct TileRec {
@@ -96,6 +164,11 @@ struct BmCheckArgs {
   uint64_t* carry;         // [n] class counters between chunks
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
+  // namespace-ordered lean sweeps of multi-chunk programs: TermInfo + WordVerdict of EVERY word, built once per generation
+  // of CheckRecs by kt_build_verdict_images (below) — the chunk prologue then is a straight copy into LDS (nullable: the
+  // other forms build their chunk's tables in place)
+  const unsigned char* wv_img;
+  uint32_t wv_total_words;
   // AGG instantiation (kt_sweep_launch: the PreFilter sweep AND the reconcile scan in one pass over the pod rows): the
   // packed fold of kt_aggregate_bitmap (kt_kernels_aggregate.hip) rides on the check's scan
   unsigned char* slab;
@@ -237,48 +310,22 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
       lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
     }
-    {  // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
+#ifndef KT_PROBE_NO_PROLOGUE  // (timing probe, results wrong: the chunk prologue without the TermInfo / WordVerdict build)
+    if (!SMALL && !ONE && !FULL && a.wv_img) {
+      // the tables of this chunk's words as kt_build_verdict_images left them: [TermInfo x 64 | WordVerdict] per word, the
+      // chunk's words back to back from word w0 — two straight copies
+      const unsigned char* img = a.wv_img + (size_t)ch.w0 * verdict_image_word_bytes<DT>();
+      lds_stage16((KT_LDS u32x4*)(lds + a.off_tinfo), (const u32x4*)img, ch.n_words * (64u * 8u / 16u));
+      if (WORDWISE)
+        lds_stage16((KT_LDS u32x4*)(lds + a.off_wv), (const u32x4*)(a.wv_img + (size_t)a.wv_total_words * 64u * 8u + (size_t)ch.w0 * sizeof(WordVerdict<DT>)),
+                    ch.n_words * (uint32_t)(sizeof(WordVerdict<DT>) / 16u));
+    } else {
+      // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
       const uint32_t* term_t = (const uint32_t*)(a.ix.blob + ch.img_off + ch.off_term_t);
-      for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx) {
-        const uint32_t tt = term_t[c];
-        u32x2 ti = {0u, 0u};
-        if (tt & kTermReal) {
-          const uint32_t t = tt & kTermRowMask;
-          const u32x2 rf = g_rflags[t];  // {flags, active_mask}
-          const uint32_t sh_act = (rf.x & kRecExceedsByCount) ? 4u : 24u;
-          const uint32_t sh_idle = (rf.x & kRecExceedsByCount) ? 4u : (rf.x & kRecActiveByCount) ? 24u : (rf.x & kRecInsufficientByCount) ? 44u : 0u;
-          ti.x = t | ((tt & kTermAdj) ? kTiAdj : 0u);
-          ti.y = (rf.y & 0xFFFFu) | sh_act << kTiShActive | sh_idle << kTiShIdle | ((rf.x & kRecTight) ? kTiTight : 0u);
-        }
-        tinfo[c] = ti;
-        if (WORDWISE) {  // this wave holds the 64 numbers of word c / 64: their verdict masks by ballot
-          const uint32_t ln = c & 63u;
-          const bool real = (tt & kTermReal) != 0;
-          const uint32_t t = tt & kTermRowMask;
-          const u32x2 rf = real ? g_rflags[t] : u32x2{0u, 0u};
-          const uint32_t tp = (uint32_t)__shfl_up((int)tt, 1), tn = (uint32_t)__shfl_down((int)tt, 1);
-          const bool adj = (tt & kTermAdj) != 0;
-          const bool same_prev = ln > 0u && adj && (tp & kTermReal) && (tp & kTermAdj) && (tp & kTermRowMask) == t;
-          const bool same_next = ln < 63u && adj && (tn & kTermReal) && (tn & kTermAdj) && (tn & kTermRowMask) == t;
-          const bool xc = (rf.x & kRecExceedsByCount) != 0;
-          const uint64_t m_lo = __ballot(real && !same_prev), m_hi = __ballot(real && !same_next);
-          const uint64_t m_tight = __ballot(real && (rf.x & kRecTight) != 0), m_exc = __ballot(real && xc);
-          const uint64_t m_act = __ballot(real && (rf.x & kRecActiveByCount) != 0), m_ins = __ballot(real && (rf.x & kRecInsufficientByCount) != 0);
-          KT_LDS WordVerdict<DT>* wvp = (KT_LDS WordVerdict<DT>*)(lds + a.off_wv) + (c >> 6);
-          const uint64_t mine = ln == 0u ? m_lo : ln == 1u ? m_hi : ln == 2u ? m_tight : ln == 3u ? m_exc : ln == 4u ? m_act : m_ins;
-          // act_nib[q][v], entry e = 16 q + v: lane e (and lane e - 64 ... : DT = 16 has 64 entries, one per lane)
-          const uint32_t eq = ln >> 4, ev = ln & 15u;
-          uint64_t tab = m_act;
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const uint64_t m = __ballot(real && ((rf.y >> d) & 1u) != 0);
-            tab |= ((uint32_t)(d >> 2) == eq && ((ev >> (d & 3)) & 1u)) ? m : 0ull;
-          }
-          if (ln < 6u) ((KT_LDS uint64_t*)wvp)[ln] = mine;
-          if (ln < 4u * (uint32_t)DT) ((KT_LDS uint64_t*)wvp)[6u + ln] = tab;
-        }
-      }
+      for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx)
+        build_term_verdicts<DT, WORDWISE>(term_t[c], c, g_rflags, tinfo, (KT_LDS WordVerdict<DT>*)(lds + a.off_wv));
     }
+#endif
     __syncthreads();
     for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
       // ---- the tile's records (requested before the chunk was staged / behind the previous tile's scan: fetch_tile)
@@ -469,6 +516,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       auto fetch = [&](uint32_t w) -> VerdictRegs {
         KT_LDS const unsigned char* q = wv + __umul24(w, (uint32_t)sizeof(WordVerdict<DT>));
         VerdictRegs r;
+#ifdef KT_PROBE_NO_SETTLE
+        r.seg = r.te = r.ai = u64x2{0ull, 0ull};
+        for (int k = 0; k < DT / 4; ++k) r.nib[k] = 0ull;
+        return r;
+#endif
         r.seg = u64x2{0ull, 0ull};
         if (seg_on) r.seg = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, seg_lo));  // {seg_lo, seg_hi}
         r.te = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, tight));              // {tight, exc}
@@ -508,6 +560,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         }
       };
       auto settle = [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
+#ifdef KT_PROBE_NO_SETTLE  // timing probe (results are wrong): the scan without the verdicts
+        n_exc += (uint32_t)(x == 0x123456789ull);
+        return 0ull;
+#endif
         if (seg_on) {  // a throttle with several terms is reported once: the lowest match of every run
           const uint64_t v = x | q.seg.y;
           x = andn_64(x, v - q.seg.x);  // (= x & (v ^ (v - seg_lo)) & v, x being part of v)
@@ -522,6 +578,9 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         n_exc = (uint32_t)__popc((uint32_t)xe) + ((uint32_t)__popc((uint32_t)(xe >> 32)) + n_exc);
         n_act = (uint32_t)__popc((uint32_t)xa) + ((uint32_t)__popc((uint32_t)(xa >> 32)) + n_act);
         n_ins = (uint32_t)__popc((uint32_t)xi) + ((uint32_t)__popc((uint32_t)(xi >> 32)) + n_ins);
+#ifdef KT_PROBE_NO_TIGHT  // timing probe (results are wrong): no match goes through the comparison
+        return x & q.te.x & 0x8000000000000000ull & (uint64_t)(n_exc == 0x12345u);
+#endif
         return x & q.te.x;
       };
       auto confirm_slow = [&](uint32_t c) {
@@ -635,6 +694,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   if (by_ns && !small && rows_dev) {
     bm_args.ix.by_ns = 1u;
     bm_args.v_meta = by_ns->v_meta, bm_args.v_latom = by_ns->v_latom, bm_args.carry = by_ns->carry;
+    bm_args.wv_img = by_ns->wv_img, bm_args.wv_total_words = by_ns->wv_total_words;
   }
   const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);

@@ -158,8 +158,13 @@ __device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uin
     const uint32_t w[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#ifdef KT_PROBE_ROW0  // timing probe (results are wrong): every lane reads row 0 — the gathers without their bank conflicts
+      ro[8 * q + 2 * k] = __umul24(w[k] & 0x0u, row_bytes);
+      ro[8 * q + 2 * k + 1] = __umul24(w[k] >> 31 >> 1, row_bytes);
+#else
       ro[8 * q + 2 * k] = __umul24(w[k] & 0xFFFFu, row_bytes);  // (16-bit id x row bytes < 2^24: the full-rate multiply)
       ro[8 * q + 2 * k + 1] = __umul24(w[k] >> 16, row_bytes);
+#endif
     }
   }
 }
