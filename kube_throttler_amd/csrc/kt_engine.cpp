@@ -229,6 +229,10 @@ struct kt_engine {
   DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
   bool order_all_valid = false;
   DevBuf<unsigned long long> d_ns_cursor;        // counting-sort scratch (one word per namespace row)
+  // record ranges of the workgroups of a namespace-ordered scan, ends at namespace boundaries (kt_plan_wg_ranges): the all-rows
+  // list (check sweep) and the countable list (aggregate); *_G = the grid they were planned for (0: none)
+  DevBuf<uint32_t> d_range_a, d_range_c;
+  int range_a_G = 0, range_c_G = 0;
   // scan-ordered copies of the listed pods' records (kt_build_scan_view): countable list / all-rows list
   DevBuf<uint64_t> d_vc_meta, d_va_meta, d_carry;
   DevBuf<uint16_t> d_vc_latom, d_va_latom;
@@ -1083,7 +1087,7 @@ int32_t kt_engine_destroy(kt_engine* e) {
   e->d_vc_meta.release(); e->d_va_meta.release(); e->d_carry.release();
   e->d_vc_latom.release(); e->d_va_latom.release(); e->d_vc_req.release(); e->d_vc_pk.release();
   e->d_pos_c.release(); e->d_pos_a.release(); e->d_view_dirty.release(); e->d_n_all.release();
-  e->d_ns_cursor.release();
+  e->d_ns_cursor.release(); e->d_range_a.release(); e->d_range_c.release();
   e->d_slab_tag.release();
   e->d_row_mask.release();
   e->d_req_sums.release();
@@ -1994,6 +1998,12 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
+    e->range_c_G = 0;
+    if (by_ns && e->n_countable > 0 && !getenv_flag("KT_NO_WG_RANGES")) {
+      e->range_c_G = kt::aggregate_blocks((int64_t)e->n_countable);
+      KT_HIP(e, e->d_range_c.reserve((size_t)e->range_c_G + 2));
+      kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, (int64_t)e->n_countable, e->range_c_G, e->d_range_c.p, s);
+    }
     e->pack = kt::PackPlan();
     if (!getenv_flag("KT_NO_SCAN_VIEW")) {
       // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
@@ -2006,7 +2016,9 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
       if (!e->incremental && !e->wide && !getenv_flag("KT_NO_PACK")) {
-        const uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
+        uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
+        // (planned ranges hold up to wg_range_cap records)
+        if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
         e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true);
         if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
       }
@@ -2060,6 +2072,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
         if (sc.by_ns) sc.n += e->view_extra;
         if (sc.by_ns) sc.v_meta = e->d_vc_meta.p, sc.v_latom = e->d_vc_latom.p, sc.v_req = e->pack.nw ? nullptr : e->d_vc_req.p;
         if (sc.by_ns && e->pack.nw) sc.pk = &e->pack, sc.v_pk = e->d_vc_pk.p;
+        if (sc.by_ns && e->countable_by_ns && e->range_c_G) sc.wg_range = e->d_range_c.p, sc.wg_range_G = e->range_c_G;
         if ((rc = slab_tags(e, sc, s)) != KT_OK) return rc;
         sc.defer_reduce = defer && sc.pk != nullptr;
         const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, target, e->d_slab.p, s,
@@ -2399,6 +2412,12 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
         kt::launch_order_rows_by_ns(e->pods, e->pod_rows_hi, /*countable_only=*/false, (uint32_t)e->sp.n_ns,
                                     e->d_ns_cursor.p, e->d_order_all.p, e->d_n_all.p, s);
         KT_HIP(e, hipGetLastError());
+        e->range_a_G = 0;
+        if (!getenv_flag("KT_NO_WG_RANGES")) {  // every row is listed: the list holds pod_rows_hi records
+          e->range_a_G = kt::check_sweep_blocks(e->pod_rows_hi);
+          KT_HIP(e, e->d_range_a.reserve((size_t)e->range_a_G + 2));
+          kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, e->pod_rows_hi, e->range_a_G, e->d_range_a.p, s);
+        }
         const size_t na = (size_t)e->pod_rows_hi + 1;
         KT_HIP(e, e->d_va_meta.reserve(na));
         KT_HIP(e, e->d_va_latom.reserve(na * (size_t)e->pods.LA));
@@ -2413,6 +2432,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
         e->order_all_valid = true;
       }
       kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
+      if (by_ns && e->range_a_G) view.wg_range = e->d_range_a.p, view.wg_range_G = e->range_a_G;
       if (by_ns && !want_status && e->dindex.n_slow == 0 && e->n_overflow == 0 && e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_VERDICT_IMAGES")) {
         // the lean sweep of a multi-chunk program: TermInfo + WordVerdict of every word once per generation of CheckRecs
         // (one small launch) instead of once per (workgroup, chunk) — 256 x ~15 rebuilds of the same words

@@ -293,6 +293,8 @@ struct AggScan {
   const int64_t* v_req = nullptr;
   uint32_t* slab_tag = nullptr;  // [chunks][kSlabTagStride] epoch of the last launch that spilled this (chunk, workgroup) slab
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
+  const uint32_t* wg_range = nullptr;  // by_ns: record range of every workgroup (launch_plan_wg_ranges for aggregate_blocks(n) workgroups)
+  int wg_range_G = 0;                  //        ... and the number of workgroups they were planned for
   const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
   const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
   int limb = 0;                  // wide sums: the limb of every request this scan adds (limb_of, kt_device.h)
@@ -337,7 +339,12 @@ struct CheckByNs {
   // every workgroup then rebuilds them per chunk
   const unsigned char* wv_img = nullptr;
   uint32_t wv_total_words = 0;
+  // record range of every workgroup of the sweep (launch_plan_wg_ranges for check_sweep_blocks(n) workgroups), or nullptr:
+  // fixed ranges of ceil(tiles / workgroups) tiles
+  const uint32_t* wg_range = nullptr;
+  int wg_range_G = 0;  // the workgroups the ranges were planned for (a launch with another grid ignores them)
 };
+int check_sweep_blocks(int64_t n);  // workgroups of a namespace-ordered lean sweep over n pod rows (one per CU)
 // the per-word check tables of the whole index in global memory: TermInfo [total_words][64], then WordVerdict [total_words]
 // (total_words = HostIndex::bm_words) — built once per generation of CheckRecs instead of once per (workgroup, chunk)
 size_t verdict_images_bytes(uint32_t total_words, int D);

@@ -317,6 +317,60 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
   hipLaunchKernelGGL(kt_ns_scatter, g, b, lds_scat, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
 }
 
+// kt_plan_wg_ranges — which records of a namespace-ordered list every workgroup of a scan owns: contiguous ranges of about
+// n / G records whose ends are moved to a namespace boundary when one lies close enough.  A workgroup walks the index chunks
+// that hold words of ITS namespaces; with ranges cut at fixed multiples of tiles nearly every workgroup straddled two
+// namespaces and opened the chunks of both (configs[4]: 14.6 chunk passes per workgroup where one namespace needs 8).
+// ns_end[k] = end of namespace k's records in the list (what kt_ns_scatter leaves in its cursor words); cap = the most
+// records one workgroup may own (the packed fold's fields are proven for it).  range[g] .. range[g + 1]; range[G + 1] = the
+// largest range handed out.
+__global__ void kt_plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, uint64_t n, uint32_t G, uint32_t cap, uint32_t* range) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint64_t pos = 0, largest = 0;
+  range[0] = 0u;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint64_t left = n - pos, wgs = G - g;
+    uint64_t end = pos;
+    if (left > 0) {
+      const uint64_t share = (left + wgs - 1) / wgs;
+      // what the workgroups behind this one can still take bounds how little this one may take
+      const uint64_t must = left > (wgs - 1) * (uint64_t)cap ? left - (wgs - 1) * (uint64_t)cap : 1;
+      const uint64_t lo = pos + (must > share / 2 ? must : (share / 2 ? share / 2 : 1)), hi = pos + (left < cap ? left : cap);
+      const uint64_t ideal = pos + share > hi ? hi : pos + share;
+      end = ideal < lo ? lo : ideal;
+      if (wgs > 1) {
+        // the namespace boundaries around `ideal`: first k with ns_end[k] >= ideal
+        uint32_t a = 0, b = n_keys;
+        while (a < b) {
+          const uint32_t m = (a + b) / 2;
+          if (ns_end[m] < ideal) a = m + 1; else b = m;
+        }
+        uint64_t best = 0, best_d = ~0ull;
+        for (uint32_t k = (a > 2 ? a - 2 : 0); k < n_keys && k <= a + 1; ++k) {
+          const uint64_t e = ns_end[k];
+          if (e < lo || e > hi) continue;
+          const uint64_t d = e > ideal ? e - ideal : ideal - e;
+          if (d < best_d) best_d = d, best = e;
+        }
+        if (best_d != ~0ull) end = best;
+      } else {
+        end = n;
+      }
+    }
+    largest = end - pos > largest ? end - pos : largest;
+    pos = end;
+    range[g + 1] = (uint32_t)pos;
+  }
+  range[G + 1] = (uint32_t)largest;
+}
+uint32_t wg_range_cap(int64_t n, int G) {
+  const int64_t share = (n + G - 1) / (G > 0 ? G : 1);
+  return (uint32_t)(share + share / 4 + 64);
+}
+void launch_plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range, hipStream_t s) {
+  hipLaunchKernelGGL(kt_plan_wg_ranges, dim3(1), dim3(64), 0, s, ns_end, n_keys, (uint64_t)(n > 0 ? n : 0), (uint32_t)G, wg_range_cap(n, G), range);
+}
+
 // kt_build_scan_view — the records the namespace-ordered scans stream, copied into scan order once per ordering so that
 // a tile reads 64 consecutive records instead of gathering them through the row list on every chunk visit:
 // meta word, atom row, and (aggregate view) the request row of every listed pod.

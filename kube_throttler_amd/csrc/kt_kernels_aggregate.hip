@@ -39,6 +39,7 @@ struct BmAggArgs {
   int64_t row0, n_rows;
   BmIndexArgs ix;
   uint32_t off_rank, off_tab;
+  uint32_t off_next;  // scan views: the workgroup's next tile (its waves take tiles as they get free)
   uint32_t off_seg;  // packed fold: per word {seg_lo, seg_hi}, the run masks of throttles with several terms (built per chunk)
   uint32_t n_slow;
   int32_t D, DS, LS, T;
@@ -49,6 +50,7 @@ struct BmAggArgs {
   const uint64_t* v_meta;  // namespace order (ix.by_ns): scan-ordered copies, record j belongs to pod rows[j]
   const uint16_t* v_latom;
   const int64_t* v_req;
+  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (kt_plan_wg_ranges)
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
   int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
@@ -65,6 +67,7 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.D = pods.D, a.DS = pods.DS, a.LS = pods.LS, a.T = sp.T;
   a.slab_tag = sc.slab_tag, a.epoch = sc.epoch, a.limb = sc.limb;
   a.v_meta = sc.v_meta, a.v_latom = sc.v_latom, a.v_req = sc.v_req;
+  a.wg_range = sc.by_ns && sc.wg_range_G == aggregate_blocks(sc.n) ? sc.wg_range : nullptr;
   const bool packed = sc.pk && sc.pk->nw && sc.v_pk;
   if (packed) a.pk = *sc.pk, a.v_pk = sc.v_pk;
   uint32_t o = 0;
@@ -72,6 +75,7 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
   a.off_tab = take(packed ? ix.bm_max_thr * a.pk.rec_bytes : agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
   a.off_seg = take(packed ? ix.bm_max_words * 16u : 0u);
+  a.off_next = take(16);
   plan_bitmap_index(ix, a.ix, take);
   a.ix.by_ns = (sc.by_ns && sc.rows && sc.v_meta && sc.v_latom && (sc.v_req || packed)) ? 1u : 0u;
   *total = o;
@@ -155,7 +159,17 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   const bool by_ns = PK || a.ix.by_ns != 0u;
   uint32_t t_lo = 0, t_hi = n_wtiles;
   uint32_t ns_lo = 0, ns_hi = 0;
-  if (by_ns) {
+  // the records the workgroup's tiles are cut from: [rec0, rec_end) — everything, or this workgroup's planned range of a
+  // namespace-ordered view (ends at a namespace boundary where one lies close: see kt_plan_wg_ranges)
+  uint32_t rec0 = 0, rec_end = n_rows;
+  if (by_ns && a.wg_range) {
+    rec0 = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x]), rec_end = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x + 1u]);
+    if (rec0 >= rec_end) return;  // (multi-chunk programs only: their reductions skip a slab nobody tagged)
+    t_lo = 0u, t_hi = (rec_end - rec0 + kWave - 1u) / kWave;
+    ns_lo = (uint32_t)(a.v_meta[rec0] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.v_meta[rec_end - 1u] & kMetaNsMask);
+    ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
+  } else if (by_ns) {
     const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
     t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
     // A workgroup without tiles must NOT return: the reductions of single-chunk programs read every launched
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const uint32_t wt_step = by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
     auto fetch_tile = [&](uint32_t wt) {
       TileRecAgg<DT, LA, PK> r;
-      const uint32_t ic = min(wt * kWave + lane, n_rows - 1u);
+      const uint32_t ic = min(rec0 + wt * kWave + lane, rec_end - 1u);
       r.p = a.rows ? (uint32_t)a.rows[ic] : (uint32_t)a.row0 + ic;
       r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
       load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
@@ -202,7 +216,14 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     if (kAggPrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
-    lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
+#ifdef KT_DYN_TILES
+    if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
+#endif
+    {  // the image and the ranks of the chunk's term numbers: one batch of loads
+      const StageSeg segs[2] = {chunk_image_segment(a.ix, ch),
+                                StageSeg{a.off_rank, (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u}};
+      lds_stage_segments<2>(lds, segs);
+    }
     if constexpr (kFoldQueue) {
       // the run masks of the chunk's words, by ballot from the rank words (a wave per word, lane = term number): lowest /
       // highest number of every run of one group's terms — a throttle with several terms is counted once, and with the
@@ -222,12 +243,22 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     }
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
+#ifdef KT_DYN_TILES
+    auto next_tile = [&](uint32_t prev) -> uint32_t {  // (see kt_check_bitmap)
+      if (!by_ns) return prev + wt_step;
+      uint32_t t = 0u;
+      if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
+      return __builtin_amdgcn_readfirstlane(t);
+    };
+    for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
+#else
     for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
+#endif
       // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
       //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
       if (!kAggPrefetch) cur = fetch_tile(wt);
-      const uint32_t i = wt * kWave + lane;
-      const bool in = i < n_rows;
+      const uint32_t i = rec0 + wt * kWave + lane;
+      const bool in = i < rec_end;
       const uint32_t p = cur.p;
       const uint64_t meta = cur.meta;
       u32x4 raw[LA / 8];
@@ -594,7 +625,12 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
                       bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false);
   if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
   int nb = aggregate_blocks(n_rows);
-  if (bm_args.ix.by_ns) {
+  if (bm_args.ix.by_ns && bm_args.wg_range) {
+    // planned ranges: one per workgroup of the full grid (a workgroup whose range is empty returns: multi-chunk programs only,
+    // whose reductions go by the slab tags)
+    if (ix.n_chunks == 1) bm_args.wg_range = nullptr;
+  }
+  if (bm_args.ix.by_ns && !bm_args.wg_range) {
     // contiguous tile ranges of ceil(tiles / nb) tiles: launch exactly the workgroups that own at least one tile (with
     // 10 163 tiles and 256 workgroups the last one would own none).  ceil(tiles / nb) is the same for the smaller grid.
     const int64_t tiles = (n_rows + kWave - 1) / kWave, tpb = (tiles + nb - 1) / nb;

@@ -3,6 +3,21 @@
 
 #include "kt_scan.h"
 
+#ifdef KT_PROFILE_PHASES
+// Development aid (tools/prof_phases.py, -DKT_PROFILE_PHASES builds only): cycles per phase, summed over the waves of every launch
+__device__ unsigned long long kt_prof_check[16];
+extern "C" int kt_debug_prof_check(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kt_prof_check), 16 * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(kt_prof_check), z, 16 * 8); }
+  return 0;
+}
+#define KT_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define KT_PROF_ADD(slot, dt) prof_acc[slot] += (dt)
+#else
+#define KT_PROF_T(var)
+#define KT_PROF_ADD(slot, dt)
+#endif
+
 namespace kt {
 
 // ---------------------------------------------------------------------------------------------------
@@ -152,6 +167,7 @@ struct BmCheckArgs {
   int64_t n;
   BmIndexArgs ix;
   uint32_t off_cnt, off_list, off_tinfo, off_wv;
+  uint32_t off_next;  // namespace-ordered sweeps: the workgroup's next tile (its waves take tiles as they get free)
   uint32_t n_slow;
   int32_t DS, LS, T;
   // small launches (SMALL instantiation: one workgroup per (chunk, tile), results met by atomics)
@@ -162,6 +178,7 @@ struct BmCheckArgs {
   const uint64_t* v_meta;
   const uint16_t* v_latom;
   uint64_t* carry;         // [n] class counters between chunks
+  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (kt_plan_wg_ranges)
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
   // namespace-ordered lean sweeps of multi-chunk programs: TermInfo + WordVerdict of EVERY word, built once per generation
@@ -191,6 +208,7 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_cnt = take(kBlockIx * 8);
   a.off_list = take((kBlockIx / kWave) * kListCap * 4);
+  a.off_next = take(16);
   a.off_tinfo = take(ix.bm_max_words * 64u * 8u);
   a.off_wv = take(ix.bm_max_words * (uint32_t)(pods.D <= 8 ? sizeof(WordVerdict<8>) : sizeof(WordVerdict<16>)));
   plan_bitmap_index(ix, a.ix, take);
@@ -205,6 +223,10 @@ static BmCheckArgs make_bm_check_args(const PodTable& pods, int64_t n, const int
   return a;
 }
 
+int check_sweep_blocks(int64_t n) {
+  const int64_t nb = (n + kBlockIx - 1) / kBlockIx;
+  return (int)(nb > kCUs ? kCUs : nb < 1 ? 1 : nb);
+}
 uint32_t check_fixed_lds() { return kBlockIx * 8 + (kBlockIx / kWave) * kListCap * 4 + 64; }
 static_assert(sizeof(WordVerdict<16>) == 560 && 64u * 8u + sizeof(WordVerdict<16>) == kCheckWordLds, "kCheckWordLds (kt_index.h) follows WordVerdict");
 static_assert(sizeof(WordVerdict<8>) == 304, "WordVerdict<8>");
@@ -253,6 +275,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   // the verdict masks of a word are requested together with its atom rows (scan_tile's pre hook) where registers allow;
   // the 64-VGPR instantiation reads them when the rows have been consumed
   constexpr bool PREFETCH = WPE < 8;
+#ifdef KT_PROFILE_PHASES
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  KT_PROF_T(t_kernel0);
+#endif
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
   const u32x2* g_rflags = (const u32x2*)rec_flags<DT>((void*)a.recs, a.T);
@@ -272,12 +298,21 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   // tiles [t_lo, t_hi) and only walks the chunks that hold words of their namespaces
   const bool by_ns = !SMALL && !ONE && a.ix.by_ns != 0u;
   uint32_t t_lo = 0, t_hi = n_wtiles, ns_lo = 0, ns_hi = 0, last_ci = n_chunks - 1u;
+  // the records the workgroup's tiles are cut from: [rec0, rec_end) — tile wt holds records rec0 + 64 wt .. (everything, or
+  // this workgroup's range of a namespace-ordered list: planned ranges end at namespace boundaries where one lies close)
+  uint32_t rec0 = 0, rec_end = n;
   if (by_ns) {
-    const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
-    t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
-    if (t_lo >= t_hi) return;
-    ns_lo = (uint32_t)(a.v_meta[(uint64_t)t_lo * kWave] & kMetaNsMask);
-    ns_hi = (uint32_t)(a.v_meta[min((uint64_t)t_hi * kWave, (uint64_t)n) - 1u] & kMetaNsMask);
+    if (a.wg_range) {
+      rec0 = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x]), rec_end = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x + 1u]);
+      if (rec0 >= rec_end) return;
+      t_lo = 0u, t_hi = (rec_end - rec0 + kWave - 1u) / kWave;
+    } else {
+      const uint32_t tpb = (n_wtiles + gridDim.x - 1u) / gridDim.x;
+      t_lo = min(blockIdx.x * tpb, n_wtiles), t_hi = min(t_lo + tpb, n_wtiles);
+      if (t_lo >= t_hi) return;
+    }
+    ns_lo = (uint32_t)(a.v_meta[(uint64_t)rec0 + (uint64_t)t_lo * kWave] & kMetaNsMask);
+    ns_hi = (uint32_t)(a.v_meta[min((uint64_t)rec0 + (uint64_t)t_hi * kWave, (uint64_t)rec_end) - 1u] & kMetaNsMask);
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
     last_ci = last_relevant_chunk(a.ix, ns_lo, ns_hi);
   }
@@ -291,48 +326,89 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     const uint32_t wt_step = SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
     auto fetch_tile = [&](uint32_t wt) {
       TileRec<LA, AGG ? DT : 1> r;
-      const uint32_t i = wt * kWave + lane;
-      const uint32_t ic = min(i, n - 1u);
+      const uint32_t i = rec0 + wt * kWave + lane;
+      const uint32_t ic = min(i, rec_end - 1u);
       r.p = (SMALL && a.n_inline) ? (uint32_t)a.inline_rows[ic & 7u] : a.rows ? (uint32_t)a.rows[ic] : ic;
       r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
       load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
       const unsigned long long* carry_w = by_ns ? (const unsigned long long*)a.carry + ic : (const unsigned long long*)a.summary + (by_ns ? r.p : i);
-      r.carried = (!SMALL && !first && i < n) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      r.carried = (!SMALL && !first && i < rec_end) ? __hip_atomic_load(carry_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       if constexpr (AGG) load_requests<DT>(a.req, DS, (int64_t)r.p, r.v);  // every lane's: the row does not hang off the meta word
       return r;
     };
     TileRec<LA, AGG ? DT : 1> cur{};
     if (kTilePrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
+    KT_PROF_T(t_b0);
     __syncthreads();  // nobody reads the previous image any more
+    KT_PROF_T(t_b1);
+    KT_PROF_ADD(0, t_b1 - t_b0);
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
-    if constexpr (AGG) {  // the reconcile half: chunk-local throttle rank of every term number, the table of packed records zeroed
+#ifdef KT_DYN_TILES
+    if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
+#endif
+    const bool from_images = !SMALL && !ONE && !FULL && a.wv_img != nullptr;  // (kernel argument: uniform)
+    // (tables built in place: the first term word of every thread is requested AHEAD of the image — it arrives with that batch,
+    //  and the dependent read of the CheckRec flags is the prologue's second trip to memory instead of its third)
+    const uint32_t* term_t = (const uint32_t*)(a.ix.blob + ch.img_off + ch.off_term_t);
+    uint32_t tt_first = 0u;
+    if (!from_images && threadIdx.x < ch.n_words * 64u) tt_first = term_t[threadIdx.x];
+    {  // everything that is a straight copy into LDS goes out as ONE batch of loads: the image, the fold's ranks (AGG), and
+       // — sweeps of multi-chunk programs — the chunk's words of the TermInfo / WordVerdict tables kt_build_verdict_images left
+      const u32x4* img0 = (const u32x4*)(a.ix.blob + ch.img_off);
+      StageSeg segs[4] = {chunk_image_segment(a.ix, ch), StageSeg{0u, img0, 0u}, StageSeg{0u, img0, 0u}, StageSeg{0u, img0, 0u}};
+      if constexpr (AGG) segs[1] = StageSeg{a.off_rank, (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u};
+      if (from_images) {
+        segs[2] = StageSeg{a.off_tinfo, (const u32x4*)(a.wv_img + (size_t)ch.w0 * verdict_image_word_bytes<DT>()), ch.n_words * (64u * 8u / 16u)};
+        if (WORDWISE)
+          segs[3] = StageSeg{a.off_wv, (const u32x4*)(a.wv_img + (size_t)a.wv_total_words * 64u * 8u + (size_t)ch.w0 * sizeof(WordVerdict<DT>)),
+                             ch.n_words * (uint32_t)(sizeof(WordVerdict<DT>) / 16u)};
+      }
+      lds_stage_segments<4>(lds, segs);
+    }
+    if constexpr (AGG) {  // the reconcile half: the table of packed records zeroed
       const uint32_t tab_bytes = (ch.n_thr * a.pk_rec + 15u) & ~15u;
       for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
-      lds_stage16((KT_LDS u32x4*)(lds + a.off_rank), (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u);
     }
 #ifndef KT_PROBE_NO_PROLOGUE  // (timing probe, results wrong: the chunk prologue without the TermInfo / WordVerdict build)
-    if (!SMALL && !ONE && !FULL && a.wv_img) {
-      // the tables of this chunk's words as kt_build_verdict_images left them: [TermInfo x 64 | WordVerdict] per word, the
-      // chunk's words back to back from word w0 — two straight copies
-      const unsigned char* img = a.wv_img + (size_t)ch.w0 * verdict_image_word_bytes<DT>();
-      lds_stage16((KT_LDS u32x4*)(lds + a.off_tinfo), (const u32x4*)img, ch.n_words * (64u * 8u / 16u));
-      if (WORDWISE)
-        lds_stage16((KT_LDS u32x4*)(lds + a.off_wv), (const u32x4*)(a.wv_img + (size_t)a.wv_total_words * 64u * 8u + (size_t)ch.w0 * sizeof(WordVerdict<DT>)),
-                    ch.n_words * (uint32_t)(sizeof(WordVerdict<DT>) / 16u));
+    if (from_images) {
+      // (the tables of this chunk's words came with the image: kt_build_verdict_images built them once per generation of CheckRecs)
     } else {
       // TermInfo of the chunk's term numbers: throttle row + the pod-independent verdict bits of its CheckRec
-      const uint32_t* term_t = (const uint32_t*)(a.ix.blob + ch.img_off + ch.off_term_t);
       for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx)
-        build_term_verdicts<DT, WORDWISE>(term_t[c], c, g_rflags, tinfo, (KT_LDS WordVerdict<DT>*)(lds + a.off_wv));
+        build_term_verdicts<DT, WORDWISE>(c == threadIdx.x ? tt_first : term_t[c], c, g_rflags, tinfo, (KT_LDS WordVerdict<DT>*)(lds + a.off_wv));
     }
 #endif
+    KT_PROF_T(t_b2);
     __syncthreads();
+    KT_PROF_T(t_b3);
+    KT_PROF_ADD(1, t_b2 - t_b1);
+    KT_PROF_ADD(2, t_b3 - t_b2);
+    KT_PROF_ADD(6, 1ull);
+#ifdef KT_DYN_TILES
+    // namespace-ordered sweeps: the waves of the workgroup take the tiles of its range as they get free (a counter in LDS) —
+    // with a fixed stride every chunk pass ended with the waves that own five tiles while those that own four waited
+    auto next_tile = [&](uint32_t prev) -> uint32_t {
+      if (!by_ns) return prev + wt_step;
+      uint32_t t = 0u;
+      if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
+      return __builtin_amdgcn_readfirstlane(t);
+    };
+    for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
+#else
     for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
+#endif
       // ---- the tile's records (requested before the chunk was staged / behind the previous tile's scan: fetch_tile)
+      KT_PROF_T(t_f0);
       if (!kTilePrefetch) cur = fetch_tile(wt);
-      const uint32_t i = wt * kWave + lane;
-      const bool in = i < n;
-      const uint32_t ic = min(i, n - 1u);
+#ifdef KT_PROFILE_PHASES
+      __builtin_amdgcn_s_waitcnt(0);  // (vmcnt / lgkmcnt / expcnt = 0: the wait for the records is charged to the fetch)
+      KT_PROF_T(t_f1);
+      KT_PROF_ADD(3, t_f1 - t_f0);
+      KT_PROF_ADD(7, 1ull);
+#endif
+      const uint32_t i = rec0 + wt * kWave + lane;
+      const bool in = i < rec_end;
+      const uint32_t ic = min(i, rec_end - 1u);
       const uint32_t p = cur.p;
       const uint32_t si = by_ns ? p : i;  // the pod's index in the summary words / status matrix
       const uint64_t meta = cur.meta;
@@ -604,6 +680,10 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
       TileRec<LA, AGG ? DT : 1> nxt{};  // (only looked at when there is a next tile)
       if (kTilePrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);  // (wave-uniform)
+#ifdef KT_PROFILE_PHASES
+      KT_PROF_T(t_s1);
+      KT_PROF_ADD(4, t_s1 - t_f1);
+#endif
       if (n_list) drain(std::integral_constant<int, kDrainFinalUnroll>());
       pod_err |= on & (ns_ok_raw == 0u);
       // ---- lane = pod: the 8-byte summary word
@@ -641,6 +721,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         }
       }
       cur = nxt;
+#ifdef KT_PROFILE_PHASES
+      __builtin_amdgcn_s_waitcnt(0);
+      KT_PROF_T(t_d1);
+      KT_PROF_ADD(5, t_d1 - t_s1);
+#endif
     }
     if constexpr (AGG) {  // this workgroup's table as its slab (coalesced 16-byte stores), stamped with the launch's epoch
       __syncthreads();
@@ -651,6 +736,14 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       if (threadIdx.x == 0) a.slab_tag[ci * kSlabTagStride + blockIdx.x] = a.epoch;
     }
   }
+#ifdef KT_PROFILE_PHASES
+  if (!SMALL && lane == 0) {
+    KT_PROF_T(t_kernel1);
+    for (int k = 0; k < 8; ++k) atomicAdd(&kt_prof_check[k], prof_acc[k]);
+    atomicAdd(&kt_prof_check[8], t_kernel1 - t_kernel0);
+    atomicAdd(&kt_prof_check[9], 1ull);
+  }
+#endif
 }
 
 #define KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, WPE_, FULL_, SMALL_, ONE_)                                         \
@@ -695,12 +788,14 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     bm_args.ix.by_ns = 1u;
     bm_args.v_meta = by_ns->v_meta, bm_args.v_latom = by_ns->v_latom, bm_args.carry = by_ns->carry;
     bm_args.wv_img = by_ns->wv_img, bm_args.wv_total_words = by_ns->wv_total_words;
+    bm_args.wg_range = by_ns->wg_range_G == check_sweep_blocks(n) ? by_ns->wg_range : nullptr;
   }
   const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
   const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;
+  if (nb != check_sweep_blocks(n)) bm_args.wg_range = nullptr;  // (two workgroups per CU: the ranges were planned for one)
   dim3 g_((unsigned)nb), b_(kBlockIx);
   if (small) g_ = dim3(ix.n_chunks, (unsigned)((n + kWave - 1) / kWave));
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;

@@ -33,6 +33,11 @@ void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows
 // n_keys = namespace capacity; out_n: device counter receiving the number of listed rows
 void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
                              int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
+// contiguous record ranges of a namespace-ordered list for the G workgroups of a scan, ends moved to namespace boundaries
+// (kt_plan_wg_ranges): range[0 .. G], range[G + 1] = the largest range; no range holds more than wg_range_cap(n, G) records.
+// ns_end = the cursor words launch_order_rows_by_ns leaves behind (end of every namespace's records)
+uint32_t wg_range_cap(int64_t n, int G);
+void launch_plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range, hipStream_t s);
 // scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
 struct PackPlan;  // kt_index.h
 // pk + v_pk (nullable): also the packed request words of every listed pod

@@ -22,6 +22,14 @@
 #pragma once
 #include "kt_index_device.h"
 
+// Namespace-ordered scans hand the tiles of a workgroup's range to its waves as they get free (a counter in LDS) — with a fixed
+// stride every chunk pass ended with the waves that own one tile more (configs[4] check: 12.8 % of the wave cycles at the
+// barrier, 6.6 % with the counter; 0.532 -> 0.494 ms).  -DKT_STATIC_TILES restores the stride (A/B); the tile prefetch
+// experiment (-DKT_TILE_PREFETCH) needs it.
+#if !defined(KT_STATIC_TILES) && !defined(KT_TILE_PREFETCH) && !defined(KT_DYN_TILES)
+#define KT_DYN_TILES 1
+#endif
+
 namespace kt {
 
 // What the kernels need of the index (IndexDev)
@@ -88,10 +96,67 @@ __device__ __forceinline__ void lds_stage16(KT_LDS u32x4* dst, const u32x4* src,
   }
 }
 
-// Makes chunk `ch` resident (the caller barriers before — nobody still reads the previous image — and after)
+// Several copies into LDS as ONE batch: all threads of the workgroup, up to DEPTH 16-byte pieces per thread in flight over
+// ALL segments before the first is stored.  A chunk prologue used to be three or four lds_stage16 calls one after the other —
+// image, ranks / TermInfo, WordVerdict — each a full round trip to L2 for a few kilobytes per thread-pass: measured on the
+// configs[4] shard at ~9.6 us per chunk a workgroup opens (15 of them per launch), most of it those dependent round trips.
+struct StageSeg {
+  uint32_t dst;        // byte offset in the workgroup's LDS
+  const u32x4* src;
+  uint32_t n16;
+};
+template <int NS, int DEPTH = 8>
+__device__ __forceinline__ void lds_stage_segments(KT_LDS unsigned char* lds, const StageSeg (&sg)[NS]) {
+  uint32_t total = 0;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) total += sg[k].n16;
+  if (total == 0u) return;
+  // piece i of the batch -> (segment, piece of the segment): the segments back to back
+  auto locate = [&](uint32_t i, uint32_t& seg_dst, uint64_t& seg_src) -> uint32_t {
+    uint32_t off = i;
+    seg_dst = sg[0].dst, seg_src = (uint64_t)sg[0].src;
+#pragma unroll
+    for (int k = 1; k < NS; ++k) {
+      uint32_t before = 0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) before += sg[j].n16;
+      const bool later = i >= before && sg[k].n16 != 0u;
+      seg_dst = later ? sg[k].dst : seg_dst;
+      seg_src = later ? (uint64_t)sg[k].src : seg_src;
+      off = later ? i - before : off;
+    }
+    return off;
+  };
+  for (uint32_t base = threadIdx.x; base < total; base += DEPTH * kBlockIx) {
+    u32x4 v[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      uint32_t d;
+      uint64_t sp;
+      const uint32_t off = locate(min(base + (uint32_t)j * kBlockIx, total - 1u), d, sp);
+      v[j] = ((const u32x4*)sp)[off];
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const uint32_t i = base + (uint32_t)j * kBlockIx;
+      if (i < total) {
+        uint32_t d;
+        uint64_t sp;
+        const uint32_t off = locate(i, d, sp);
+        *(KT_LDS u32x4*)(lds + d + off * 16u) = v[j];
+      }
+    }
+  }
+}
+
+// The tables of chunk `ch` as they will sit in LDS, and the copy that makes the image resident (the caller stages it — alone
+// or batched with its own tables: lds_stage_segments — after a barrier: nobody still reads the previous image — and barriers
+// again before the first read)
+__device__ __forceinline__ StageSeg chunk_image_segment(const BmIndexArgs& a, const BmChunk& ch) {
+  return StageSeg{a.lds_img, (const u32x4*)(a.blob + ch.img_off), ch.lds_bytes / 16u};
+}
 template <bool VETO>
 __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const BmIndexArgs& a, const BmChunk& ch) {
-  lds_stage16((KT_LDS u32x4*)(lds + a.lds_img), (const u32x4*)(a.blob + ch.img_off), ch.lds_bytes / 16u);
   KT_LDS unsigned char* base = lds + a.lds_img;
   BmView v;
   v.rows = base;

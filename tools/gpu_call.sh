@@ -1,5 +1,6 @@
 #!/bin/bash
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO; mkdir -p gpurun_out
-bash tools/gpu_ab.sh r05h "q12 q12@KT_CHUNK_BUDGET=110000 q12@KT_CHUNK_BUDGET=80000" "4"
-for b in 163000 110000 80000; do KT_CHUNK_BUDGET=$b KT_DEBUG_LDS=1 KT_ENGINE_LIB=tools/ab/libkt_engine_q12.so python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extra 2>&1 >/dev/null | grep -E "bitmap index" | head -1; done
+timeout 600 python -m pytest tests/test_engine_gpu.py -m gpu -x -q -k "multi_chunk or random_small_rich or golden or lean_sweep or edge_shapes or namespace_order or few_pod or pod_events_between or incremental_event" > gpurun_out/r05k_pytest.log 2>&1; echo "pytest subset: exit $?"; tail -5 gpurun_out/r05k_pytest.log
+bash tools/gpu_ab.sh r05k "dyn rng rng@KT_NO_WG_RANGES=1" "4"
+bash tools/gpu_ab.sh r05k "stage rng" "2"
