@@ -371,6 +371,28 @@ def main():
             h.update(np.ascontiguousarray(a).tobytes())
         results_sha1 = h.hexdigest()[:16]
 
+    # what every rank's exchange and scans looked like — and the ranks must agree on the words of the partial buffer (the
+    # all-reduce sums them position by position: a rank with another throttle set or another sum form would corrupt every
+    # other rank's `used` silently)
+    index_stats = eng.index_stats()
+    per_rank_index = None
+    try:
+        eng.aggregate_launch(stream)
+        torch.cuda.synchronize()
+        pending = eng.pending_partial_words()
+    except Exception as ex:
+        pending = (-1, repr(ex))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "partial_words": pending[0], "wide": pending[1], **index_stats})
+        per_rank_index = gathered
+        if len({(g["partial_words"], g["wide"]) for g in gathered}) != 1:
+            if rank == 0:
+                print(json.dumps({"error": "the ranks disagree on kt_partial_words: the all-reduce would mix different buffers",
+                                  "per_rank": gathered}))
+            dist.destroy_process_group()
+            sys.exit(2)
+
     per_rank_kernel_ms = None
     if world > 1:  # every rank's kernel times, so that the first multi-GPU run explains itself
         gathered = [None] * world
@@ -577,6 +599,7 @@ def main():
             "per_rank_ms_per_step": [round(x, 6) for x in rank_ms],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 6),
             "per_rank_kernel_ms": per_rank_kernel_ms,
+            "index": index_stats, "partial_words": pending[0], "per_rank_index": per_rank_index,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "latency": latency,
         }
     if args.native_comm:

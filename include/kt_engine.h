@@ -196,6 +196,15 @@ int32_t kt_set_wide_sums(kt_engine* e, int32_t mode);
 /* Words (int64) of the aggregate that is pending, and whether they are the two-block form: what a caller's own
  * collective has to sum.  KT_ERR_NOT_READY without a pending kt_aggregate_launch. */
 int32_t kt_partial_words(kt_engine* e, int64_t* n_int64, int32_t* wide);
+/* The layout of one throttle's row of the partial buffer, for n_dims resource dimensions (int64 words): `stride` words per
+ * throttle row; the summed request values start at off_values (n_dims words), the per-key contributor counts — presence
+ * travels as counts so that it can be summed — at off_presence (n_dims words), then the counted pods at off_pods and the
+ * pods whose selector evaluation failed at off_errors (one word each).  With wide sums the buffer holds two such blocks of
+ * throttle_rows x stride words (low 32-bit limbs, then the rest: kt_partial_words).  No engine and no device needed: a host
+ * that exchanges the buffer with its own collective — or a test that builds one by hand — lays it out by THIS query, which
+ * returns what the kernels compile against (partial_stride / partial_off_* in csrc/kt_device.h). */
+int32_t kt_partial_layout(int32_t n_dims, int32_t* stride, int32_t* off_values, int32_t* off_presence, int32_t* off_pods,
+                          int32_t* off_errors);
 int32_t kt_comm_destroy(kt_engine* e);
 
 /* Copies the last reconcile's result for throttle rows [0, n) into caller arrays (synchronises). */
@@ -292,6 +301,10 @@ const char* kt_kernel_name(kt_engine* e, int32_t kernel);
 #define KT_COUNTER_COMPILES 1   /* selector program compiles + index builds so far (a Throttle event that leaves every
                                    selector, namespace and flag of its rows as stored — a threshold edit, a status update —
                                    only re-uploads the throttle tables and does not count) */
+#define KT_COUNTER_INDEX_CHUNKS 2 /* LDS-sized chunks of the compiled selector index (0 before the first compile) */
+#define KT_COUNTER_INDEX_WORDS 3  /* 64-bit words of term numbers of the compiled program (all chunks) */
+#define KT_COUNTER_NS_WORD_VISITS 4 /* sum over the namespace rows in use of the words a pod of that namespace visits */
+#define KT_COUNTER_NS_ROWS 5      /* namespace rows the compiled program covers */
 int64_t kt_counter(kt_engine* e, int32_t which);
 
 #ifdef __cplusplus

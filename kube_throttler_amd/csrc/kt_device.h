@@ -163,5 +163,10 @@ __host__ __device__ inline int64_t limb_of(int64_t v, int limb) {
 
 // layout of one throttle's row in the partial-used buffer (int64 words): v[D], present_count[D], pods, errors
 __host__ __device__ inline int partial_stride(int D) { return 2 * D + 2; }
+// ... and where its parts start (every kernel that writes or reads a partial row, and kt_partial_layout — the C-ABI query a
+// host that runs its own collective lays its buffers out by — go through these)
+__host__ __device__ inline int partial_off_presence(int D) { return D; }     // per-key contributor counts, after the D values
+__host__ __device__ inline int partial_off_pods(int D) { return 2 * D; }     // pods counted
+__host__ __device__ inline int partial_off_errors(int D) { return 2 * D + 1; }  // pods whose selector evaluation failed
 
 }  // namespace kt

@@ -793,7 +793,8 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const char* hook = getenv("KT_CHUNK_BUDGET");
     const uint32_t lds_all = 160u * 1024u;
     const uint32_t agg_budget = hook ? (uint32_t)atoi(hook) : lds_all - kt::aggregate_fixed_lds();
-    const uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
+    uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
+    if (const char* tb = getenv("KT_CUT_THR_BYTES")) thr_bytes = (uint32_t)atoi(tb);  // (experiment: cut for the packed fold's records)
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();
@@ -2785,8 +2786,27 @@ int64_t kt_counter(kt_engine* e, int32_t which) {
   switch (which) {
     case KT_COUNTER_FEW_CHECKS: return e->few_served.load(std::memory_order_relaxed);
     case KT_COUNTER_COMPILES: return e->n_compiles.load(std::memory_order_relaxed);
+    case KT_COUNTER_INDEX_CHUNKS: return (int64_t)e->hindex.bm_chunks.size();
+    case KT_COUNTER_INDEX_WORDS: return (int64_t)e->hindex.bm_words;
+    case KT_COUNTER_NS_ROWS: return (int64_t)e->hindex.n_ns;
+    case KT_COUNTER_NS_WORD_VISITS: {  // the word lists of all chunk images: their entries are (namespace, visited word) pairs
+      int64_t n = 0;
+      for (const kt::BmChunk& ch : e->hindex.bm_chunks) n += (int64_t)((ch.off_term_t - ch.off_nsl) / sizeof(kt::NsWord));
+      return n;
+    }
     default: return -1;
   }
+}
+
+int32_t kt_partial_layout(int32_t n_dims, int32_t* stride, int32_t* off_values, int32_t* off_presence, int32_t* off_pods,
+                          int32_t* off_errors) {
+  if (n_dims < 1 || n_dims > KT_MAX_DIMS) return KT_ERR_INVALID_ARGUMENT;
+  if (stride) *stride = kt::partial_stride(n_dims);
+  if (off_values) *off_values = 0;
+  if (off_presence) *off_presence = kt::partial_off_presence(n_dims);
+  if (off_pods) *off_pods = kt::partial_off_pods(n_dims);
+  if (off_errors) *off_errors = kt::partial_off_errors(n_dims);
+  return KT_OK;
 }
 
 const char* kt_kernel_name(kt_engine* e, int32_t kernel) {

@@ -793,15 +793,15 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense(PodTable pods, int6
       bool matched, err;
       walk_terms<LT, KEYS>(sp, t, ns_row, countable, r.lp, r.lk, cur_w, cur_wi, matched, err);
       unsigned long long* row = partial + (size_t)t * stride;
-      if (err) atomicAdd(row + 2 * D + 1, 1ull);
+      if (err) atomicAdd(row + partial_off_errors(D), 1ull);
       if (matched && not_finished) {
 #pragma unroll
         for (int d = 0; d < DT; ++d)
           if (d < D && ((present >> d) & 1u)) {
             if (r.v[d] != 0) atomicAdd(row + d, (unsigned long long)r.v[d]);
-            atomicAdd(row + D + d, 1ull);
+            atomicAdd(row + partial_off_presence(D) + d, 1ull);
           }
-        atomicAdd(row + 2 * D, 1ull);
+        atomicAdd(row + partial_off_pods(D), 1ull);
       }
     }
   }
@@ -1143,9 +1143,9 @@ __global__ __launch_bounds__(kFinalizeBlock) void kt_finalize(ThrTables tt, int 
   load_thr(tt, t, D, d, r);
   unsigned long long* prow = partial + (size_t)t * stride;
   const int dd = d < D ? d : 0;
-  const unsigned long long a = prow[dd], b = prow[D + dd];
+  const unsigned long long a = prow[dd], b = prow[partial_off_presence(D) + dd];
   const unsigned long long pv = d < D ? a : 0ull, pc = d < D ? b : 0ull;
-  const unsigned long long pods = prow[2 * D], errs = prow[2 * D + 1];
+  const unsigned long long pods = prow[partial_off_pods(D)], errs = prow[partial_off_errors(D)];
   unsigned long long pv_hi = 0;
   if (partial_hi) {
     const unsigned long long h = partial_hi[(size_t)t * stride + dd];
@@ -1267,10 +1267,10 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_finalize_packed(const Fus
     unsigned long long* prow = partial + (size_t)t * stride;
     unsigned long long seen = 0;
     if (multi && rec_pods) {
-      if (d == 0) seen |= atomicAdd(prow + 2 * D, rec_pods);
+      if (d == 0) seen |= atomicAdd(prow + partial_off_pods(D), rec_pods);
       if (d < D) {
         if (mine) seen |= atomicAdd(prow + d, mine);
-        if ((zero_keys >> d) & 1u) seen |= atomicAdd(prow + D + d, 1ull);
+        if ((zero_keys >> d) & 1u) seen |= atomicAdd(prow + partial_off_presence(D) + d, 1ull);
       }
     }
     // (the previous values are sums far below 2^64: the comparison is false, but only the hardware knows)
@@ -1309,8 +1309,8 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_finalize_packed(const Fus
         return consume ? __hip_atomic_exchange(prow + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                        : __hip_atomic_fetch_add(prow + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      if (d < D) pv += take(d), pc += take(D + d);
-      if (d == 0) p0 = take(2 * D), e0 = take(2 * D + 1);
+      if (d < D) pv += take(d), pc += take(partial_off_presence(D) + d);
+      if (d == 0) p0 = take(partial_off_pods(D)), e0 = take(partial_off_errors(D));
     }
     const int leader = (int)((x & 63u) & ~(uint32_t)(DT - 1));
     p0 = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)p0, leader) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(p0 >> 32), leader) << 32;
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_finalize_packed(const Fus
     // rows only the scan kernel wrote (slow list, overflow pods, errors) are plain data of the previous launch
     if (from_row && !met) {
       const int dd = d < D ? d : 0;
-      const unsigned long long a = prow[dd], b = prow[D + dd], pp = prow[2 * D], ee = prow[2 * D + 1];
+      const unsigned long long a = prow[dd], b = prow[partial_off_presence(D) + dd], pp = prow[partial_off_pods(D)], ee = prow[partial_off_errors(D)];
       pv += d < D ? a : 0ull, pc += d < D ? b : 0ull, pods += pp, errs += ee;
       if (consume && valid)
         for (int j = d; j < stride; j += DT) prow[j] = 0ull;
@@ -1441,15 +1441,15 @@ __global__ __launch_bounds__(kBlock) void kt_aggregate_dense_mem(PodTable pods, 
     for (int t = 0; t < sp.T; ++t) {
       const uint32_t res = walk_slow_mem(sp, t, ns_row, true, lp, lk, pods.LS);
       unsigned long long* row = partial + (size_t)t * stride;
-      if (res & kSlowError) atomicAdd(row + 2 * D + 1, 1ull);
+      if (res & kSlowError) atomicAdd(row + partial_off_errors(D), 1ull);
       if ((res & kSlowMatched) && not_finished) {
 #pragma unroll
         for (int d = 0; d < DT; ++d)
           if (d < D && ((present >> d) & 1u)) {
             if (v[d] != 0) atomicAdd(row + d, (unsigned long long)v[d]);
-            atomicAdd(row + D + d, 1ull);
+            atomicAdd(row + partial_off_presence(D) + d, 1ull);
           }
-        atomicAdd(row + 2 * D, 1ull);
+        atomicAdd(row + partial_off_pods(D), 1ull);
       }
     }
   }

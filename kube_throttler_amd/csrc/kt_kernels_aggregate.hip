@@ -99,15 +99,15 @@ __device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram
   auto walk_one = [&](uint32_t t, bool lane_on) {
     const uint32_t res = walk_slow_mem(sp, (int)t, sp.ns_term_ok + (size_t)ns * sp.gw, lane_on, lp, lk, LS);
     unsigned long long* pr = partial + (size_t)t * pstride;
-    if (res & kSlowError) atomicAdd(pr + 2 * D + 1, (unsigned long long)(long long)sign);
+    if (res & kSlowError) atomicAdd(pr + partial_off_errors(D), (unsigned long long)(long long)sign);
     if ((res & kSlowMatched) && counted) {
       for (int d = 0; d < D; ++d)
         if ((present >> d) & 1u) {
           const int64_t vd = limb_of(req[(uint64_t)p * (uint32_t)DS + d], limb);
           if (vd != 0) atomicAdd(pr + d, (unsigned long long)(sign * vd));
-          atomicAdd(pr + D + d, (unsigned long long)(long long)sign);
+          atomicAdd(pr + partial_off_presence(D) + d, (unsigned long long)(long long)sign);
         }
-      atomicAdd(pr + 2 * D, (unsigned long long)(long long)sign);
+      atomicAdd(pr + partial_off_pods(D), (unsigned long long)(long long)sign);
     }
   };
   for (uint32_t ks = 0; ks < n_slow; ++ks) walk_one(slow_thr[ks], countable && !overflow);
@@ -537,10 +537,10 @@ __global__ __launch_bounds__(256) void kt_reduce_bitmap_slabs(const unsigned cha
         atomicAdd(prow + dw / 2u, (unsigned long long)((long long)sign * (long long)sum));
       } else if (kind[k] == 2u) {  // presence mask: key seen by some slab of this split
         for (int d = 0; d < D; ++d)
-          if ((sum >> d) & 1ull) atomicAdd(prow + D + d, 1ull);
+          if ((sum >> d) & 1ull) atomicAdd(prow + partial_off_presence(D) + d, 1ull);
       } else {
         const uint32_t u = dw - n_val;  // counts mode: u < D per-key pod counts, u == D pods; mask mode: u == 1 pods
-        const int j = counts ? (u < (uint32_t)D ? D + (int)u : 2 * D) : 2 * D;
+        const int j = counts ? (u < (uint32_t)D ? partial_off_presence(D) + (int)u : partial_off_pods(D)) : partial_off_pods(D);
         atomicAdd(prow + j, (unsigned long long)((long long)sign * (long long)sum));
       }
     }
@@ -574,12 +574,12 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_packed_slabs(const unsign
   const unsigned long long pods = packed_pods(lds, ub, pk);
   if (pods == 0ull) return;  // nobody matched this throttle
   unsigned long long* prow = partial + (size_t)t * partial_stride(D);
-  if (d == 0u) atomicAdd(prow + 2 * D, pods);
+  if (d == 0u) atomicAdd(prow + partial_off_pods(D), pods);
   if (d < (uint32_t)D) {
     const unsigned long long mine = packed_field(lds, ub, packed_desc_of(pk, (int)d, D));
     if (mine) atomicAdd(prow + d, mine);
     // key seen: a non-zero sum says so by itself (kt_finalize); a key only ever carried with the value 0 is marked here
-    if ((packed_zero_keys(lds, ub, pk) >> d) & 1u) atomicAdd(prow + D + d, 1ull);
+    if ((packed_zero_keys(lds, ub, pk) >> d) & 1u) atomicAdd(prow + partial_off_presence(D) + d, 1ull);
   }
 }
 

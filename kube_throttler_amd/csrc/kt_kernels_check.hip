@@ -258,7 +258,11 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 #ifdef KT_DRAIN_SERIAL
   constexpr int kDrainFinalUnroll = kDrainUnroll;
 #else
+#ifdef KT_DRAIN_PREFETCH
+  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : (!SMALL && !ONE && !AGG && !FULL) ? 2 : DT / 2;  // (the next tile's record is live across it)
+#else
   constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : DT / 2;  // the drain behind the scan
+#endif
 #endif
   // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
   // being peeled one by one: three popcounts per visited word, and only the matches of tight throttles go through the
@@ -275,6 +279,14 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   // the verdict masks of a word are requested together with its atom rows (scan_tile's pre hook) where registers allow;
   // the 64-VGPR instantiation reads them when the rows have been consumed
   constexpr bool PREFETCH = WPE < 8;
+  // PF: the NEXT tile's records are requested behind this tile's scan, ahead of its drain and summary write — the wait for them
+  // (a trip to memory per (tile, chunk): 12 % of the wave cycles of the configs[4] sweep) then lies behind the drain's own
+  // trips.  Only where the scan's registers are dead by then and 128 are available: the lean multi-chunk form.
+#if defined(KT_DRAIN_PREFETCH)
+  constexpr bool PF = kTilePrefetch || (!SMALL && !ONE && !AGG && !FULL && WPE < 8);
+#else
+  constexpr bool PF = kTilePrefetch;
+#endif
 #ifdef KT_PROFILE_PHASES
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   KT_PROF_T(t_kernel0);
@@ -384,22 +396,29 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     KT_PROF_ADD(1, t_b2 - t_b1);
     KT_PROF_ADD(2, t_b3 - t_b2);
     KT_PROF_ADD(6, 1ull);
-#ifdef KT_DYN_TILES
     // namespace-ordered sweeps: the waves of the workgroup take the tiles of its range as they get free (a counter in LDS) —
     // with a fixed stride every chunk pass ended with the waves that own five tiles while those that own four waited
     auto next_tile = [&](uint32_t prev) -> uint32_t {
-      if (!by_ns) return prev + wt_step;
-      uint32_t t = 0u;
-      if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
-      return __builtin_amdgcn_readfirstlane(t);
-    };
-    for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
-#else
-    for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
+#ifdef KT_DYN_TILES
+      if (by_ns) {
+        uint32_t t = 0u;
+        if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+      }
 #endif
-      // ---- the tile's records (requested before the chunk was staged / behind the previous tile's scan: fetch_tile)
+      return prev + wt_step;
+    };
+#ifdef KT_DYN_TILES
+    uint32_t wt = by_ns ? next_tile(0u) : wt0;
+#else
+    uint32_t wt = wt0;
+#endif
+    if (PF && !kTilePrefetch && wt < t_hi) cur = fetch_tile(wt);
+    uint32_t wt_next = 0u;
+    for (; wt < t_hi; wt = wt_next) {
+      // ---- the tile's records (PF: requested behind the previous tile's scan)
       KT_PROF_T(t_f0);
-      if (!kTilePrefetch) cur = fetch_tile(wt);
+      if (!PF) cur = fetch_tile(wt);
 #ifdef KT_PROFILE_PHASES
       __builtin_amdgcn_s_waitcnt(0);  // (vmcnt / lgkmcnt / expcnt = 0: the wait for the records is charged to the fetch)
       KT_PROF_T(t_f1);
@@ -679,7 +698,8 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       my = (unsigned long long)n_exc << 4 | (unsigned long long)n_act << 24 | (unsigned long long)n_ins << 44;
       }
       TileRec<LA, AGG ? DT : 1> nxt{};  // (only looked at when there is a next tile)
-      if (kTilePrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);  // (wave-uniform)
+      wt_next = next_tile(wt);
+      if (PF && wt_next < t_hi) nxt = fetch_tile(wt_next);  // (wave-uniform)
 #ifdef KT_PROFILE_PHASES
       KT_PROF_T(t_s1);
       KT_PROF_ADD(4, t_s1 - t_f1);

@@ -39,8 +39,19 @@ EXPORTS = [
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
     "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter", "kt_reconcile_fetch_used_hi",
-    "kt_set_wide_sums", "kt_partial_words",
+    "kt_set_wide_sums", "kt_partial_words", "kt_partial_layout",
 ]
+COUNTER_FEW_CHECKS, COUNTER_COMPILES, COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS, COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS = range(6)
+
+
+def partial_layout(n_dims: int) -> dict:
+    """kt_partial_layout(): the layout of one throttle's row of the partial-`used` buffer as the library's kernels are
+    compiled (no engine, no GPU needed) -> {stride, values, presence, pods, errors} in int64 words."""
+    v = [C.c_int32() for _ in range(5)]
+    rc = lib().kt_partial_layout(int(n_dims), *[C.byref(x) for x in v])
+    if rc != KT_OK:
+        raise EngineError(rc, f"kt_partial_layout({n_dims})")
+    return dict(zip(("stride", "values", "presence", "pods", "errors"), (int(x.value) for x in v)))
 
 
 def version() -> str:
@@ -116,6 +127,7 @@ def lib():
         L.kt_set_exchange_world.argtypes = [C.c_void_p, C.c_int32]
         L.kt_set_wide_sums.argtypes = [C.c_void_p, C.c_int32]
         L.kt_partial_words.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.kt_partial_layout.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 5
         L.kt_counter.argtypes = [C.c_void_p, C.c_int32]
         L.kt_reconcile_fetch_used_hi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_counter.restype = C.c_int64
@@ -302,8 +314,16 @@ class Engine:
         """Ranks whose partials the CALLER sums with its own collective (kt_comm_init declares it by itself)."""
         self._ck(lib().kt_set_exchange_world(self._h, world))
 
+    def index_stats(self) -> dict:
+        """The compiled selector index (after the first launch): LDS-sized chunks, 64-bit words of term numbers, namespace rows,
+        and the words a pod visits on average over the namespace rows in use."""
+        ch, words, visits, rows = (int(lib().kt_counter(self._h, k)) for k in (COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS,
+                                                                                COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS))
+        return {"chunks": ch, "words": words, "namespace_rows": rows,
+                "word_visits_per_namespace": round(visits / rows, 3) if rows > 0 else None}
+
     def partial_words(self) -> int:
-        return self.throttle_rows() * (2 * self.D + 2)
+        return self.throttle_rows() * partial_layout(self.D)["stride"]
 
     def set_wide_sums(self, mode: int):
         """1: always the two-block (limb sums) form of the partial buffer — what every rank of a multi-rank exchange must

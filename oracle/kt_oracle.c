@@ -319,9 +319,24 @@ static bool cterm_matches_to_namespace(const kt_snapshot* s, uint32_t term, uint
   return selector_matches(&sel, ns_labels(s, ns));
 }
 
+/* TEST-MODE memo of cterm_matches_to_namespace (kto_enable_ns_memo): the namespace side of a term is a pure function of
+ * (term, namespace object), and the literal loop re-evaluates it for every pod of the namespace — 1.25M x 15k times on a
+ * configs[4] shard.  memo[term * n_ns + ns]: 0 = not evaluated yet, 1 = false, 2 = true (filled on first use; concurrent
+ * threads can only store the same value).  NULL = the literal evaluation (the timed CPU baseline always passes NULL). */
+static bool cterm_ns_ok(const kt_snapshot* s, uint8_t* memo, uint32_t term, uint32_t ns) {
+  if (!memo) return cterm_matches_to_namespace(s, term, ns);
+  uint8_t* m = memo + (size_t)term * (size_t)s->n_ns + ns;
+  uint8_t v = *m;
+  if (v == 0) {
+    v = cterm_matches_to_namespace(s, term, ns) ? 2 : 1;
+    *m = v;
+  }
+  return v == 2;
+}
+
 /* ClusterThrottleSelectorTerm.MatchesToPod — clusterthrottle_selector.go:71-87. */
-static bool cterm_matches_to_pod(const kt_snapshot* s, uint32_t term, pod_t p, uint32_t ns, bool* err) {
-  bool match_ns = cterm_matches_to_namespace(s, term, ns);
+static bool cterm_matches_to_pod(const kt_snapshot* s, uint32_t term, pod_t p, uint32_t ns, bool* err, uint8_t* memo) {
+  bool match_ns = cterm_ns_ok(s, memo, term, ns);
   if (!match_ns) return false;
   bool match = term_matches_to_pod(s, term, p, err);
   if (*err) return false;
@@ -329,17 +344,17 @@ static bool cterm_matches_to_pod(const kt_snapshot* s, uint32_t term, pod_t p, u
 }
 
 /* ClusterThrottleSelector.MatchesToNamespace — clusterthrottle_selector.go:30-42. */
-static bool cluster_selector_matches_to_namespace(const kt_snapshot* s, int32_t t, uint32_t ns) {
+static bool cluster_selector_matches_to_namespace(const kt_snapshot* s, int32_t t, uint32_t ns, uint8_t* memo) {
   for (uint32_t term = s->thr_term_off[t]; term < s->thr_term_off[t + 1]; ++term)
-    if (cterm_matches_to_namespace(s, term, ns)) return true;
+    if (cterm_ns_ok(s, memo, term, ns)) return true;
   return false;
 }
 
 /* ClusterThrottleSelector.MatchesToPod — clusterthrottle_selector.go:44-56. */
 static bool cluster_selector_matches_to_pod(const kt_snapshot* s, int32_t t, pod_t p, uint32_t ns,
-                                            bool* err) {
+                                            bool* err, uint8_t* memo) {
   for (uint32_t term = s->thr_term_off[t]; term < s->thr_term_off[t + 1]; ++term) {
-    bool match = cterm_matches_to_pod(s, term, p, ns, err);
+    bool match = cterm_matches_to_pod(s, term, p, ns, err, memo);
     if (*err) return false;
     if (match) return true;
   }
@@ -481,7 +496,16 @@ struct kto_ctx {
    * kto_reconcile writes the high words of what it computes there when asked to (both set by kto_set_wide). */
   const int64_t* status_used_hi;
   int64_t* out_used_hi; /* [n][D] by output position */
+  uint8_t* ns_memo;     /* test mode (kto_enable_ns_memo): [terms][n_ns] memo of cterm_matches_to_namespace, or NULL */
 };
+
+int kto_enable_ns_memo(kto_ctx* c) {
+  const kt_snapshot* s = c->s;
+  const uint64_t cells = (uint64_t)s->thr_term_off[s->n_thr] * (uint64_t)(s->n_ns > 0 ? s->n_ns : 1);
+  if (c->ns_memo || cells == 0 || cells > (1ull << 29)) return c->ns_memo != NULL;
+  c->ns_memo = (uint8_t*)calloc((size_t)cells, 1);
+  return c->ns_memo != NULL;
+}
 
 void kto_set_wide(kto_ctx* c, const int64_t* status_used_hi, int64_t* out_used_hi) {
   c->status_used_hi = status_used_hi;
@@ -544,6 +568,7 @@ void kto_destroy(kto_ctx* c) {
   free(c->cluster_thr);
   free(c->ns_pod_off);
   free(c->ns_pod);
+  free(c->ns_memo);
   free(c);
 }
 
@@ -594,7 +619,7 @@ static bool check_throttled(kto_ctx* c, pod_t pod, bool cluster, bool on_equal, 
     int32_t t = cand[i];
     if (!is_responsible_for(s, t)) continue;
     bool err = false;
-    bool match = cluster ? cluster_selector_matches_to_pod(s, t, pod, ns, &err)
+    bool match = cluster ? cluster_selector_matches_to_pod(s, t, pod, ns, &err, mimic_log_args ? NULL : c->ns_memo)
                          : throttle_selector_matches_to_pod(s, t, pod, &err);
     if (err) return false;
     if (match) row[t] = KTO_NOT_THROTTLED; /* provisional: "affected" */
@@ -798,12 +823,12 @@ static bool reconcile_one(kto_ctx* c, int32_t t, int64_t now_s, int32_t now_ns, 
   } else {
     for (int32_t ns = 0; ns < s->n_ns; ++ns) {
       if (!s->ns_valid[ns]) continue;
-      if (!cluster_selector_matches_to_namespace(s, t, (uint32_t)ns)) continue;
+      if (!cluster_selector_matches_to_namespace(s, t, (uint32_t)ns, c->ns_memo)) continue;
       for (uint64_t k = c->ns_pod_off[ns]; k < c->ns_pod_off[ns + 1]; ++k) {
         int64_t p = c->ns_pod[k];
         if (!should_count_in(s, p)) continue;
         pod_t pod = {s, p};
-        bool match = cluster_selector_matches_to_pod(s, t, pod, (uint32_t)ns, &err);
+        bool match = cluster_selector_matches_to_pod(s, t, pod, (uint32_t)ns, &err, c->ns_memo);
         if (err) return false;
         if (!match) continue;
         if (is_not_finished(s, p)) {
@@ -911,7 +936,7 @@ int kto_unit_calculate_threshold(const kt_snapshot* s, int32_t t, int64_t now_s,
 int kto_unit_selector_matches(const kt_snapshot* s, int32_t t, int64_t pod_row) {
   bool err = false;
   pod_t p = {s, pod_row};
-  bool m = (s->thr_flags[t] & KT_THR_CLUSTER) ? cluster_selector_matches_to_pod(s, t, p, s->pod_ns[pod_row], &err)
+  bool m = (s->thr_flags[t] & KT_THR_CLUSTER) ? cluster_selector_matches_to_pod(s, t, p, s->pod_ns[pod_row], &err, NULL)
                                               : throttle_selector_matches_to_pod(s, t, p, &err);
   return err ? -1 : (m ? 1 : 0);
 }

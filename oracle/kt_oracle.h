@@ -45,6 +45,11 @@ typedef struct kto_ctx kto_ctx;
 /* Builds the per-namespace indexes the informer caches provide (listers/.../throttle.go:49-100). */
 kto_ctx* kto_create(const kt_snapshot* s);
 void kto_destroy(kto_ctx* c);
+/* TEST MODE: memoise ClusterThrottleSelectorTerm.MatchesToNamespace per (term, namespace) — a pure function of the two
+ * objects that the literal loops re-evaluate for every pod.  Results are unchanged; only kto_check(mimic_log_args = 0),
+ * kto_reconcile and kto_admit use it — the timed CPU baseline (mimic_log_args = 1) always runs the literal evaluation.
+ * Returns 1 when the table is in place (0: too large / no terms: the literal evaluation stays). */
+int kto_enable_ns_memo(kto_ctx* c);
 
 /* resourcelist.PodRequestResourceList for n pods (rows NULL => 0..n-1). out_v [n][D]. */
 int kto_pod_requests(kto_ctx* c, int64_t n, const int64_t* rows, int64_t* out_v, uint32_t* out_present);

@@ -39,6 +39,7 @@ def lib():
         _LIB.kto_create.restype = C.c_void_p
         _LIB.kto_create.argtypes = [C.POINTER(S.KtSnapshot)]
         _LIB.kto_destroy.argtypes = [C.c_void_p]
+        _LIB.kto_enable_ns_memo.argtypes = [C.c_void_p]
         _LIB.kto_check.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _LIB.kto_admit.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S.KtAmounts)]
         _LIB.kto_next_override.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -61,10 +62,15 @@ class ReconcileResult:
 
 
 class Oracle:
-    def __init__(self, snap: S.Snapshot):
+    def __init__(self, snap: S.Snapshot, memo: bool = True):
+        """memo: test mode — the namespace side of every ClusterThrottle term is evaluated once per (term, namespace)
+        instead of once per (term, pod) (kto_enable_ns_memo: same results; check(mimic_log_args=True), the timed CPU
+        baseline, never uses it)."""
         self.snap = snap
         self._struct = snap.as_struct()
         self._ctx = lib().kto_create(C.byref(self._struct))
+        if memo:
+            lib().kto_enable_ns_memo(self._ctx)
 
     def close(self):
         if self._ctx:

@@ -16,7 +16,7 @@
 #include <set>
 #include <vector>
 
-#include "../../kube_throttler_amd/host/kt_anchor.h"
+#include "../../tools/study/kt_anchor.h"
 #include "kt_index.h"
 #include "../../include/kt_snapshot.h"
 
@@ -447,7 +447,7 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
   return (long)chunks_first * 1000000L + matches % 1000000L + (ix.rich ? 0 : 500000000L);
 }
 
-// ---- anchored mode (groundwork of the inverted scan, kube_throttler_amd/host/kt_anchor.h): the program split by anchor
+// ---- anchored mode (groundwork of the inverted scan, tools/study/kt_anchor.h): the program split by anchor
 //      atom, one index per anchor built by the SAME kt::build_index, a pod walked through the sub-indexes of anchor 0 and of
 //      the pairs it carries — the union must be exactly the brute-force result of the ORIGINAL program, every throttle
 //      reported once.  Returns word visits over all pods (g_word_steps delta).

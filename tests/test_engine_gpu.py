@@ -968,7 +968,7 @@ def test_partials_must_match_the_throttle_set(oracle_mod):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full-size configurations: parity on samples + size-independent properties
 # ---------------------------------------------------------------------------------------------------
-def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None):
+def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="full"):
     """NOTHING is sampled: every responsible throttle's reconcile result and every pod's summary word are compared with
     the oracle (the C restatement runs the whole configuration in seconds on the GPU box's host cores), a pod sample
     additionally with full status rows, and the dense (reference-shaped) kernels must agree with the indexed ones."""
@@ -1023,6 +1023,8 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None):
         np.testing.assert_array_equal(rec_sw.thrl_flag[:T], got.thrl_flag[:T])
         np.testing.assert_array_equal(rec_sw.thrl_pod[:T], got.thrl_pod[:T])
         assert not rec_sw.calc_updated[:T].any()
+        if level == "core":  # every `used`, every summary word, the sweep: the other shards of a sharded configuration
+            return sm_all
         #     ... and a pod sample with full status rows (the matrix of all P x T pairs would be 1-12 GB)
         sample = np.unique(np.linspace(0, P - 1, 16384).astype(np.int64))
         st_w, sm_s = o.check(rows=sample, nthreads=nthreads)
@@ -1070,14 +1072,61 @@ def test_config3_overrides_full_size(oracle_mod):
     assert snap.n_ovr > 2 * snap.n_thr
 
 
-@pytest.mark.parametrize("shard", [0, 3, 7] + [pytest.param(k, marks=pytest.mark.slow) for k in (1, 2, 4, 5, 6)])
+@pytest.mark.parametrize("shard", range(8))
 def test_config4_one_shard(oracle_mod, shard):
-    """configs[4]: 10M pods x 10k throttles with multi-term OR-of-AND selectors — the rows of one 1/8 shard (the per-GPU
-    slice of the 8-GPU configuration), NOTHING sampled: all 1.25M summary words (1.25e10 decisions) and all 10k throttles'
-    `used` against the oracle.  Shards 0, 3 and 7 run by default, the other five with `-m slow`.  The dense kernels
-    (1.25e10 pair evaluations in the reference loop shape) cross-check shard 3 only."""
+    """configs[4]: 10M pods x 10k throttles with multi-term OR-of-AND selectors — the rows of EVERY 1/8 shard (the per-GPU
+    slices of the 8-GPU configuration), NOTHING sampled: all 1.25M summary words (1.25e10 decisions) and all 10k throttles'
+    `used` of each shard against the oracle, and kt_sweep_launch once more.  Shards 0, 3 and 7 also compare 16 384 pods with
+    full status rows and every summary word under isThrottledOnEqual; the dense kernels (1.25e10 pair evaluations in the
+    reference loop shape) cross-check shard 3.  (Round 5: the oracle's test mode evaluates the namespace side of a
+    ClusterThrottle term once per (term, namespace) — kto_enable_ns_memo — which is what made all eight affordable.)"""
     cfg = W.preset(4).shard(shard, 8)
-    _full_size_checks(cfg, oracle_mod, with_dense=(shard == 3))
+    _full_size_checks(cfg, oracle_mod, with_dense=(shard == 3), level="full" if shard in (0, 3, 7) else "core")
+
+
+@pytest.mark.parametrize("n_terms", [65, 130])
+def test_throttles_with_more_than_64_terms(n_terms, oracle_mod):
+    """The reference takes any number of selector terms (throttle_selector.go:30-42); the index keeps a throttle's terms
+    inside one 64-bit word, so a throttle with more than 64 terms leaves the bitmap path: it joins the slow list and is
+    walked term by term, in order, by the FULL instantiations (and by the aggregate's out-of-line walk).  Every throttle of
+    this cluster has 65 / 130 terms; everything is compared with the oracle."""
+    cfg = W.small(seed=700 + n_terms, n_pods=3000, n_thr=12, n_cluster=6, K=16, V=8, L=6, terms=(n_terms, n_terms), reqs=(1, 3))
+    snap = W.generate(cfg)
+    assert int(np.diff(snap.thr_term_off[:snap.n_thr + 1]).min()) >= n_terms
+    st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    assert (st != S.NOT_AFFECTED).any()
+    # ... and beside ordinary throttles (the slow list next to indexed ones, several chunks)
+    mixed = W.generate(W.small(seed=710 + n_terms, n_pods=3000, n_thr=48, n_cluster=24, K=16, V=8, L=6, terms=(1, n_terms), reqs=(1, 3)))
+    assert int(np.diff(mixed.thr_term_off[:mixed.n_thr + 1]).max()) > 64
+    run_full_parity(mixed, oracle_mod, E.VARIANT_INDEXED)
+
+
+def test_terms_with_four_and_five_positive_keys_100k(oracle_mod):
+    """A term with more than three positive keys is indexed by its anchor requirement only and confirmed by the generic
+    requirement walk (`slow` in the word header, confirm() in kt_scan.h).  100k pods against throttles whose terms carry
+    three to five requirements: at least a tenth of the terms have four or five POSITIVE keys; everything against the
+    oracle (status matrix included)."""
+    cfg = W.small(seed=4545, n_pods=100000, n_thr=160, n_cluster=80, n_ns=16, K=16, V=3, L=10, terms=(1, 3), reqs=(3, 5))
+    snap = W.generate(cfg)
+    n_terms = int(snap.thr_term_off[snap.n_thr])
+    many = 0
+    for g in range(n_terms):
+        ops = snap.preq.op[snap.term_preq_off[g]:snap.term_preq_off[g + 1]]
+        many += int(((ops == 0) | (ops == 2)).sum() >= 4)  # In / Exists (distinct keys inside a term: the generator's rule)
+    assert many * 10 >= n_terms, f"{many} of {n_terms} terms with >= 4 positive keys"
+    st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    assert (st == S.NOT_THROTTLED).any() or (st == S.ACTIVE).any()
+
+
+def test_sixteen_dims_sixteen_labels_1m(oracle_mod):
+    """D = 16 resource names and L = 16 labels per pod are a product path (resourcelist.go:27-54: any number of names), not a
+    3000-pod shape: configs[2]'s cluster at full size — 1M pods x 1k throttles — with 16 dimensions and 16 labels over 32
+    keys (the <16, 16, rich> instantiations of both scans): every `used`, every summary word (both isThrottledOnEqual values),
+    16 384 pods with full status rows."""
+    cfg = W.preset(2)
+    cfg.D, cfg.L, cfg.K = 16, 16, 32
+    cfg.terms_min, cfg.terms_max, cfg.reqs_min, cfg.reqs_max, cfg.rich_ops = 1, 2, 1, 3, 1
+    _full_size_checks(cfg, oracle_mod, with_dense=False)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -171,7 +171,7 @@ def test_index_builder_against_cpu_scan_replay(tool):
 
 
 def test_anchor_split_against_brute_force(tool, tmp_path):
-    """The selector program split by anchor atom (kube_throttler_amd/host/kt_anchor.h — groundwork of the inverted scan,
+    """The selector program split by anchor atom (tools/study/kt_anchor.h — groundwork of the inverted scan,
     not wired into the engine): per throttle one copy per anchor value of its terms' `In` requirements, each copy vetoing
     the earlier anchors; one index per anchor from the SAME kt::build_index.  A pod walked through the sub-indexes of
     anchor 0 and of the pairs it carries must give exactly the brute-force result of the ORIGINAL program, every throttle

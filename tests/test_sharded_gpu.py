@@ -107,6 +107,55 @@ def test_eight_shards_of_config2(oracle_mod):
     _sharded_pipeline(W.preset(2), 8, oracle_mod, n_thr_sample=200, n_pod_sample=8192, nthreads=64)
 
 
+def test_partial_buffer_is_laid_out_as_the_query_says(oracle_mod):
+    """What kt_aggregate_launch leaves in the partial buffer, decoded by tests/partial_layout.py — whose stride and offsets
+    come from kt_partial_layout, the query the gloo world-size-2 test (tests/test_distributed_cpu.py) lays its buffers out
+    by — must be the oracle's `used` of the same pods; and the other way round: the oracle's `used` packed by the same helper
+    and handed to kt_finalize_launch gives the oracle's reconcile result.  Both kernel variants, 8 and 12 dimensions."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import partial_layout as KD
+    for D, variant in ((8, E.VARIANT_INDEXED), (12, E.VARIANT_INDEXED), (8, E.VARIANT_DENSE)):
+        cfg = W.small(seed=90 + D, n_pods=3000, n_thr=64, n_cluster=32, D=D, n_invalid_pod_sel=2, n_missing_ns=1)
+        snap = W.generate(cfg)
+        now = (cfg.now_s, 0)
+        T = snap.n_thr
+        lo = E.partial_layout(D)
+        assert lo["stride"] >= 2 * D + 2 and len({lo["values"], lo["presence"], lo["pods"], lo["errors"]}) == 4
+        want = oracle_mod.Oracle(snap).reconcile(now)
+        eng = E.Engine.for_snapshot(snap, variant)
+        try:
+            words = eng.partial_words()
+            assert words == T * lo["stride"]
+            part = torch.zeros(words, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(part.data_ptr(), words)
+            eng.aggregate_launch()
+            eng.synchronize()
+            v, present, count, has_count, err = KD.unpack_partial(part.cpu().numpy(), D)
+            rows = _responsible(snap)
+            ok = rows[want.error[rows] == 0]
+            np.testing.assert_array_equal(err[rows], want.error[rows] != 0)
+            np.testing.assert_array_equal(v[ok], want.used.v[ok])
+            np.testing.assert_array_equal(present[ok], want.used.present[ok])
+            np.testing.assert_array_equal(count[ok], want.used.count[ok])
+            # the oracle's `used`, packed by the helper, through the engine's finalize
+            packed = torch.from_numpy(KD.pack_partial(want.used.v, want.used.present, want.used.count, want.error, D).reshape(-1).copy()).cuda()
+            torch.cuda.synchronize()
+            eng.use_partial_buffer(packed.data_ptr(), words)
+            eng.finalize_launch(now, apply=False)
+            got = eng.reconcile_fetch()
+            np.testing.assert_array_equal(got.used.v[ok], want.used.v[ok])
+            np.testing.assert_array_equal(got.used.present[ok], want.used.present[ok])
+            np.testing.assert_array_equal(got.thrl_flag[ok], want.thrl_flag[ok])
+            np.testing.assert_array_equal(got.thrl_pod[ok], want.thrl_pod[ok])
+            eng.use_partial_buffer(None, 0)
+        finally:
+            eng.close()
+
+
 def test_three_uneven_shards_with_selector_errors(oracle_mod):
     """Shards of different length (2001 pods over 3 ranks), unconvertible selectors and missing Namespace objects:
     the error words of the partial buffer travel through the sum as well."""

@@ -15,7 +15,7 @@ Layout studied (throttle-level anchoring; everything else as in kt_index.h):
   * copies are numbered by (anchor, admission class); a pod visits, per atom it carries, the words of that anchor that hold
     a copy admitted for its namespace — nothing else.
 
-    python tools/anchor_study.py --config 4 --pods 4096
+    python tools/study/anchor_study.py --config 4 --pods 4096
 """
 import argparse
 import collections
@@ -24,7 +24,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kube_throttler_amd import snapshot as S, workload as W  # noqa: E402
 from dump_program import ns_selector_matches  # noqa: E402
 

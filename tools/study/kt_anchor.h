@@ -23,7 +23,7 @@
 #include <functional>
 #include <vector>
 
-#include "../csrc/kt_index.h"
+#include "kt_index.h"  // (kube_throttler_amd/csrc, on the include path of index_sim_test)
 
 namespace kt {
 
