@@ -527,7 +527,7 @@ def main():
         rec = eng.reconcile_fetch()
         snap.apply_status(rec.used, rec.calc, rec.calc_updated, rec.thrl_flag, rec.thrl_has, rec.thrl_pod, rec.error)
         o = O.Oracle(snap)
-        cores = os.cpu_count() or 1
+        cores = O.effective_cpus()  # the affinity mask capped by the cgroup CPU quota: the threads that really run side by side
         # bounded sample: grow it until one pass costs a few seconds of wall time, then repeat to ~cpu_seconds
         n_sample = min(per_gpu, 16384)
         while True:

@@ -254,6 +254,14 @@ int32_t kt_check_fetch(kt_engine* e, int64_t n, uint64_t* out_summary, uint8_t* 
  * launched (while those run it sees the status as stored before that reconcile: the CheckRecs are double-buffered). */
 int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary,
                  uint8_t* out_status);
+/* affectedPods for pods the caller names — pkg/controllers/throttle_controller.go:221-246, clusterthrottle_controller.go:224-270
+ * restricted to n pod rows x m throttle rows: out[i * m + j] = 1 when throttle_rows[j]'s selector (its namespace side
+ * included) matches pod_rows[i] as the engine holds it now, 0 when not, KT_STATUS_ERROR when the pod's PreFilter is an
+ * error (unknown namespace object, an unconvertible selector reached first).  The caller adds shouldCountIn
+ * (throttle_controller.go:217-219: it knows scheduler name and node of its pods).  This is what unreserveAffectedPods
+ * (throttle_controller.go:135-155) iterates over: behind a reconcile, a reservation is released only for a pod that is in the
+ * reconciled throttle's affected set — a pod whose labels changed after Reserve is not.  Cost: one small check launch. */
+int32_t kt_affected_pods(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t m, const int32_t* throttle_rows, uint8_t* out);
 /* ---- sequential admission with reservation: for i = 0..n-1 IN ORDER,
  *      PreFilter(pod_rows[i]) (plugin.go:148-215) and, on Success, Reserve(pod_rows[i]) (plugin.go:217-239 ->
  *      [Cluster]ThrottleController.Reserve, throttle_controller.go:271-300 -> reservedResourceAmounts.addPod,
@@ -306,6 +314,28 @@ const char* kt_kernel_name(kt_engine* e, int32_t kernel);
 #define KT_COUNTER_NS_WORD_VISITS 4 /* sum over the namespace rows in use of the words a pod of that namespace visits */
 #define KT_COUNTER_NS_ROWS 5      /* namespace rows the compiled program covers */
 int64_t kt_counter(kt_engine* e, int32_t which);
+/* ---- More resource names than one engine has dimensions (KT_MAX_DIMS): PAGES.  The reference sums and compares any resource
+ *      name (pkg/resourcelist/resourcelist.go:27-54, resource_amount.go:127-159).  The host builds the same cluster once per
+ *      page of <= KT_MAX_DIMS names — every page engine holds every pod row and every throttle row, with the requests /
+ *      thresholds of ITS names — and these two calls run a step on every page and combine the results.  The combination is
+ *      exact: every step of CheckThrottledFor (throttle_types.go:128-153) is `count part OR exists a resource name ...`; the
+ *      count part needs no name (every page computes it alike) and the name part of the cluster is the OR over the pages:
+ *          exceeds <=> some page says exceeds; else active <=> some page says active; else insufficient <=> some page says so;
+ *      a pod-level Error shows in every page.  (kube_throttler_amd/paging.py is the same statement in Python.) -------------- */
+/* kt_check on every page, combined: out_status [n][throttle rows] (nullable) and out_summary [n] (nullable; verdict and the
+ * three class counts of the COMBINED row).  The engines are called one after the other (each call is its own critical section). */
+int32_t kt_paged_check(kt_engine* const* pages, int32_t n_pages, int64_t n, const int64_t* pod_rows, int32_t on_equal,
+                       uint64_t* out_summary, uint8_t* out_status);
+/* kt_reconcile_launch + kt_reconcile_fetch on every page: page_out[k] receives page k's result for throttle rows [0, n) —
+ * `used`, calculatedThreshold and `throttled` are per resource name, each name comes from the page that owns it; the pod
+ * counts and the pod flag are the same in every page.  replaced_any[i] (nullable) = calculatedThreshold replaced in some
+ * page (it is replaced as a whole), error_any[i] (nullable) = the reconcile of row i failed. */
+int32_t kt_paged_reconcile(kt_engine* const* pages, int32_t n_pages, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
+                           const kt_status* page_out, uint8_t* replaced_any, uint8_t* error_any);
+
+/* Development aid: the engine reads its A/B switches (KT_NO_* / KT_SYNC_INGEST ... environment variables, all off by default)
+ * once, at kt_engine_create; a tool that flips one on a live engine calls this afterwards. */
+int32_t kt_debug_reload_env(kt_engine* e);
 
 #ifdef __cplusplus
 }

@@ -153,7 +153,14 @@ struct TimingFamily {
 
 }  // namespace
 
+// The A/B switches of the engine (environment variables, all off by default): read ONCE per engine — at kt_engine_create
+// and again on kt_debug_reload_env, which tools/latency_bench.py calls after it flips one on a live engine — instead of by
+// getenv on every pod event and launch (getenv is not safe beside a setenv of another thread, and the pod event
+// path is tuned to a few microseconds).
+enum EnvSwitch { kSw_FEED_NO_STAGE, kSw_FORCE_NS_ORDER, kSw_INGEST_EVENT_WAIT, kSw_NO_FEED_FEW, kSw_NO_FEED_FUSION, kSw_NO_FUSED, kSw_NO_NS_ORDER, kSw_NO_PACK, kSw_NO_SCAN_VIEW, kSw_NO_SWEEP, kSw_NO_VERDICT_IMAGES, kSw_NO_WG_RANGES, kSw_SYNC_INGEST, kSwCount };
+static const char* const kEnvSwitchName[kSwCount] = {"KT_FEED_NO_STAGE", "KT_FORCE_NS_ORDER", "KT_INGEST_EVENT_WAIT", "KT_NO_FEED_FEW", "KT_NO_FEED_FUSION", "KT_NO_FUSED", "KT_NO_NS_ORDER", "KT_NO_PACK", "KT_NO_SCAN_VIEW", "KT_NO_SWEEP", "KT_NO_VERDICT_IMAGES", "KT_NO_WG_RANGES", "KT_SYNC_INGEST"};
 struct kt_engine {
+  bool sw[kSwCount] = {};  // EnvSwitch values (load_env_switches)
   kt_config cfg{};
   // writers (state feed, launches, fetches) hold it exclusively for the duration of the call; the single-pod PreFilter
   // path (kt_check with n <= 8, summaries only) holds it SHARED: it reads device tables nobody may rewrite meanwhile,
@@ -202,6 +209,8 @@ struct kt_engine {
   int ev_next = 0;
   std::atomic<bool> ingest_pending{false};
   hipEvent_t ingest_ev = nullptr;            // the event behind the newest asynchronous feed call
+  std::atomic<hipEvent_t> ingest_unretired{nullptr};  // ... while its kernel may not have retired yet (settle_ingest returned on the spin)
+  hipStream_t ingest_stream = nullptr;       // the stream the feed kernels run on
   unsigned long long* h_overflow = nullptr;  // pinned: n_overflow as the newest asynchronous translate left it; word 1: the
                                              // sequence number of the last event kernel (kt_feed_small / kt_unfeed_small) that finished
   bool overflow_in_flight = false;
@@ -392,6 +401,9 @@ static bool getenv_flag(const char* name) {
   const char* v = getenv(name);
   return v && *v && *v != '0';
 }
+static void load_env_switches(kt_engine* e) {
+  for (int k = 0; k < kSwCount; ++k) e->sw[k] = getenv_flag(kEnvSwitchName[k]);
+}
 // what asynchronous pod feed calls left in flight: wait for it (any thread; idempotent)
 inline void settle_ingest(kt_engine* e) {
   if (!e->ingest_pending.load(std::memory_order_acquire)) return;
@@ -411,8 +423,24 @@ inline void settle_ingest(kt_engine* e) {
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!done) (void)hipEventSynchronize(e->ingest_ev);
+  // The spin returns when the feed kernel has STORED its sequence number (behind a system-scope release of everything it
+  // wrote), not when it has retired.  Measured sufficient on gfx950 (tools/microbench/meet_litmus.hip), but HIP does not
+  // promise it for coarse-grained allocations: every stream other than the feed's own is therefore also ordered behind the
+  // kernel's event on the DEVICE side before it reads the pod tables (order_behind_ingest: one hipStreamWaitEvent per such
+  // launch until the event has completed — no host wait).
+  e->ingest_unretired = done ? e->ingest_ev : nullptr;
   if (e->overflow_in_flight) e->n_overflow = *e->h_overflow, e->overflow_in_flight = false;
   e->ingest_pending.store(false, std::memory_order_release);
+}
+// a launch on `s` that reads what the newest feed kernel wrote: behind that kernel on the device (see settle_ingest)
+inline void order_behind_ingest(kt_engine* e, hipStream_t s) {
+  hipEvent_t ev = e->ingest_unretired.load(std::memory_order_acquire);
+  if (!ev) return;
+  if (hipEventQuery(ev) == hipSuccess) {  // retired meanwhile: nothing to order any more
+    e->ingest_unretired.compare_exchange_strong(ev, nullptr);
+    return;
+  }
+  if (s != e->ingest_stream) (void)hipStreamWaitEvent(s, ev, 0);
 }
 // state feed: nobody else inside
 struct StateLock {
@@ -445,7 +473,11 @@ void recs_invalidate_and_drain(kt_engine* e) {
   if (e->few_ready) std::lock_guard<std::mutex> drain(e->small_mu);
 }
 
-hipStream_t pick_stream(kt_engine* e, void* s) { return s ? (hipStream_t)s : e->own_stream; }
+hipStream_t pick_stream(kt_engine* e, void* s) {
+  hipStream_t st = s ? (hipStream_t)s : e->own_stream;
+  order_behind_ingest(e, st);
+  return st;
+}
 
 struct TimedLaunch {
   kt_engine* e;
@@ -1028,6 +1060,7 @@ int32_t kt_engine_create(const kt_config* cfg, kt_engine** out) {
   }
   kt_engine* e = new kt_engine();
   e->cfg = *cfg;
+  load_env_switches(e);
   e->device = dev;
   e->D = cfg->n_dims;
   e->L = cfg->max_labels;
@@ -1317,7 +1350,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     // an informer event or a coalesced handful of them (the whole batch fits one pinned slot): no device staging copy —
     // the kernels read the slot where it lies — and no stream synchronisation: an event behind the kernels, and
     // settle_ingest() in every entry point that is not a pod feed call
-    const bool slot_path = n <= chunk && off + 16 <= kt_engine::kEvSlotBytes && !e->incremental && !getenv_flag("KT_SYNC_INGEST");
+    const bool slot_path = n <= chunk && off + 16 <= kt_engine::kEvSlotBytes && !e->incremental && !e->sw[kSw_SYNC_INGEST];
     kt_engine::EvSlot* slot = nullptr;
     if (slot_path) {
       slot = &e->ev_slots[e->ev_next];
@@ -1337,11 +1370,22 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     }
     // ONE launch (kt_feed_small) for an event batch: the workgroup first pulls the whole slot over the link with all its
     // threads, the batch pointers name that device copy (KT_FEED_NO_STAGE=1: the kernel walks the slot over the link)
-    const bool fused = slot_path && cn <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION");
+    // A batch that names a row twice does not go through the fused kernels: they run ingest, translation and view patch of
+    // a row in one thread / wave with no barrier between the phases across the workgroup, so entry A could patch the scan
+    // view while entry B is still rewriting the same table row — the view record would keep A's content, the table B's.  The
+    // separate launches below see the final table content in every phase.
+    bool row_twice = false;
+    if (slot_path && rows && cn > 1 && cn <= kt::kFeedSmallMax) {
+      int64_t sorted[kt::kFeedSmallMax];
+      std::copy(rows + c0, rows + c0 + cn, sorted);
+      std::sort(sorted, sorted + cn);
+      row_twice = std::adjacent_find(sorted, sorted + cn) != sorted + cn;
+    }
+    const bool fused = slot_path && cn <= kt::kFeedSmallMax && !row_twice && !e->sw[kSw_NO_FEED_FUSION];
     // an informer event proper — a pod or a few: one wave per pod, the slot pulled into LDS (kt_feed_few); the batch
     // pointers are then byte offsets into the slot (KT_NO_FEED_FEW=1: kt_feed_small's thread per pod, A/B)
-    const bool few = fused && cn <= kt::kFeedFewMax && off <= kt::kFeedFewSlotMax && !getenv_flag("KT_NO_FEED_FEW");
-    const bool dev_copy = fused && !few && !getenv_flag("KT_FEED_NO_STAGE");
+    const bool few = fused && cn <= kt::kFeedFewMax && off <= kt::kFeedFewSlotMax && !e->sw[kSw_NO_FEED_FEW];
+    const bool dev_copy = fused && !few && !e->sw[kSw_FEED_NO_STAGE];
     if (dev_copy) KT_HIP(e, e->d_ev_stage.reserve(kt_engine::kEvSlotBytes));
     uint8_t* st = few ? (uint8_t*)nullptr : dev_copy ? e->d_ev_stage.p : slot_path ? slot->h : e->d_stage.p;
     // a small batch is packed in pinned host memory and crosses in ONE copy; a bulk load copies its sections straight
@@ -1393,7 +1437,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       const bool tr = !e->program_dirty && e->pods.latom;
       kt::ViewPatch v{};
       if (patch) v = view_patch_of(e, cn);
-      const bool spin = !getenv_flag("KT_INGEST_EVENT_WAIT");  // (A/B: wait on the event as the first form of this path did)
+      const bool spin = !e->sw[kSw_INGEST_EVENT_WAIT];  // (A/B: wait on the event as the first form of this path did)
       const unsigned long long seq = ++e->ingest_seq;
       if (few)
         kt::launch_feed_few(e->pods, pb, rows != nullptr, e->dindex, e->d_overflow.p, tr, patch ? &v : nullptr, e->h_overflow, slot->h, (uint32_t)off,
@@ -1407,6 +1451,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       slot->used = true;
       std::lock_guard<std::mutex> g(e->ingest_mu);
       e->ingest_ev = slot->ev;
+      e->ingest_stream = s;
       e->ingest_spin_seq = spin ? seq : 0ull;
       e->ingest_pending.store(true, std::memory_order_release);
       continue;
@@ -1432,6 +1477,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
       slot->used = true;
       std::lock_guard<std::mutex> g(e->ingest_mu);
       e->ingest_ev = slot->ev;
+      e->ingest_stream = s;
       e->ingest_spin_seq = 0ull;  // several kernels: the event says when the last one is done
       e->ingest_pending.store(true, std::memory_order_release);
     } else {
@@ -1463,7 +1509,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   for (int64_t i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= e->cfg.pod_capacity) return e->fail(KT_ERR_OUT_OF_RANGE, "pod row %lld", (long long)rows[i]);
   if (n <= 0) return KT_OK;
-  const bool slot_path = (size_t)n * 8 <= kt_engine::kEvSlotBytes && !e->incremental && !getenv_flag("KT_SYNC_INGEST");
+  const bool slot_path = (size_t)n * 8 <= kt_engine::kEvSlotBytes && !e->incremental && !e->sw[kSw_SYNC_INGEST];
   if (!slot_path || (e->last_stream && e->last_stream != e->own_stream)) {
     settle_ingest(e);
     if (e->last_stream) KT_HIP(e, hipStreamSynchronize(e->last_stream));
@@ -1494,14 +1540,14 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
   }
   if (e->incremental && e->program_dirty) e->agg_valid = false;
   unsigned long long spin_seq = 0ull;
-  if (slot_path && n <= kt::kFeedSmallMax && !getenv_flag("KT_NO_FEED_FUSION")) {
+  if (slot_path && n <= kt::kFeedSmallMax && !e->sw[kSw_NO_FEED_FUSION]) {
     kt::ViewPatch v{};
     if (patch) v = view_patch_of(e, n);
     if (!e->h_overflow) {
       KT_HIP(e, hipHostMalloc((void**)&e->h_overflow, 64, hipHostMallocDefault));
       memset(e->h_overflow, 0, 64);  // (word 1 is the sequence number settle_ingest compares with)
     }
-    if (!getenv_flag("KT_INGEST_EVENT_WAIT")) spin_seq = ++e->ingest_seq;
+    if (!e->sw[kSw_INGEST_EVENT_WAIT]) spin_seq = ++e->ingest_seq;
     kt::launch_unfeed_small(e->pods, n, rows_dev, patch ? &v : nullptr, spin_seq ? e->h_overflow + 1 : nullptr, spin_seq, e->own_stream);
     KT_HIP(e, hipGetLastError());
   } else {
@@ -1518,6 +1564,7 @@ int32_t kt_delete_pods(kt_engine* e, int64_t n, const int64_t* rows) {
     slot->used = true;
     std::lock_guard<std::mutex> g(e->ingest_mu);
     e->ingest_ev = slot->ev;
+    e->ingest_stream = e->own_stream;
     e->ingest_spin_seq = spin_seq;
     e->ingest_pending.store(true, std::memory_order_release);
   } else {
@@ -1978,11 +2025,11 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     return KT_OK;
   }
   // a multi-chunk index is scanned in namespace order (tiles share their word lists, workgroups skip foreign chunks)
-  const bool by_ns = (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
+  const bool by_ns = (e->dindex.n_chunks > 1 || e->sw[kSw_FORCE_NS_ORDER]) && !e->sw[kSw_NO_NS_ORDER];
   if ((rc = settle_view_patches(e, s)) != KT_OK) return rc;
   // pod events appended records behind the listed ones; a scan that will gather through the row list instead of streaming
   // the view cannot tell them from the list's zeroed padding: list again
-  if (e->countable_valid && e->view_extra && !(!getenv_flag("KT_NO_SCAN_VIEW") && (by_ns || e->dindex.n_chunks == 1))) e->countable_valid = false;
+  if (e->countable_valid && e->view_extra && !(!e->sw[kSw_NO_SCAN_VIEW] && (by_ns || e->dindex.n_chunks == 1))) e->countable_valid = false;
   if (e->cfg.kernel_variant != 1 && (!e->countable_valid || e->countable_by_ns != by_ns)) {  // pods changed since the last scan: which rows does a reconcile look at
     if (e->last_stream && e->last_stream != s) KT_HIP(e, hipStreamSynchronize(e->last_stream));
     KT_HIP(e, e->d_countable.reserve((size_t)e->cfg.pod_capacity + 1));
@@ -2000,13 +2047,13 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
     KT_HIP(e, hipStreamSynchronize(s));
     e->range_c_G = 0;
-    if (by_ns && e->n_countable > 0 && !getenv_flag("KT_NO_WG_RANGES")) {
+    if (by_ns && e->n_countable > 0 && !e->sw[kSw_NO_WG_RANGES]) {
       e->range_c_G = kt::aggregate_blocks((int64_t)e->n_countable);
       KT_HIP(e, e->d_range_c.reserve((size_t)e->range_c_G + 2));
       kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, (int64_t)e->n_countable, e->range_c_G, e->d_range_c.p, s);
     }
     e->pack = kt::PackPlan();
-    if (!getenv_flag("KT_NO_SCAN_VIEW")) {
+    if (!e->sw[kSw_NO_SCAN_VIEW]) {
       // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
       // (namespace order for a multi-chunk index, ascending rows otherwise)
       // room for the pods that become countable before the next rebuild (kt_patch_scan_views appends them)
@@ -2016,7 +2063,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       const size_t nc = (size_t)e->view_cap_c + 1;
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
-      if (!e->incremental && !e->wide && !getenv_flag("KT_NO_PACK")) {
+      if (!e->incremental && !e->wide && !e->sw[kSw_NO_PACK]) {
         uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
         // (planned ranges hold up to wg_range_cap records)
         if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
@@ -2048,7 +2095,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     // reconcile in one call: the slab reduction of a packed scan is done by kt_reduce_finalize_packed
     // (single-chunk programs: with a chunked index most slabs are skipped and most throttles have several groups that meet
     // in the partial rows anyway — measured on the configs[4] shard: 111 us fused against 72 + 9 us)
-    const bool defer = allow_fused && !e->incremental && !e->wide && e->dindex.n_chunks == 1 && !getenv_flag("KT_NO_FUSED");
+    const bool defer = allow_fused && !e->incremental && !e->wide && e->dindex.n_chunks == 1 && !e->sw[kSw_NO_FUSED];
     auto after_scan = [&]() {  // the slab reduction is its own kernel: time it as its own family
       tl.stop_now();
       if (!(defer && e->pack.nw)) tr.reset(new TimedLaunch(e, KT_KERNEL_REDUCE, s));
@@ -2067,7 +2114,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
         sc.overflow_pods = e->n_overflow != 0;
         sc.limb = limb;
         // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
-        sc.by_ns = !getenv_flag("KT_NO_SCAN_VIEW") && (e->countable_by_ns || e->dindex.n_chunks == 1);
+        sc.by_ns = !e->sw[kSw_NO_SCAN_VIEW] && (e->countable_by_ns || e->dindex.n_chunks == 1);
         // (records appended behind the listed ones by pod events exist in the VIEW only: a scan that gathers through the
         //  row list — KT_NO_NS_ORDER on a multi-chunk index — must not run over the list's zeroed padding = pod row 0)
         if (sc.by_ns) sc.n += e->view_extra;
@@ -2404,7 +2451,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
           e->last_kernel[KT_KERNEL_CHECK] = "kt_check_dense";
     else {
       // a sweep over every row of a multi-chunk index runs in namespace order (results stay indexed by pod row)
-      const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && (e->dindex.n_chunks > 1 || getenv_flag("KT_FORCE_NS_ORDER")) && !getenv_flag("KT_NO_NS_ORDER");
+      const bool by_ns = !pod_rows && !small && n == e->pod_rows_hi && (e->dindex.n_chunks > 1 || e->sw[kSw_FORCE_NS_ORDER]) && !e->sw[kSw_NO_NS_ORDER];
       if (by_ns && (rc = settle_view_patches(e, s)) != KT_OK) return rc;
       if (by_ns && (!e->order_all_valid || e->view_rows_a != e->pod_rows_hi)) {
         KT_HIP(e, e->d_order_all.reserve((size_t)e->pod_rows_hi + 1));
@@ -2414,7 +2461,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
                                     e->d_ns_cursor.p, e->d_order_all.p, e->d_n_all.p, s);
         KT_HIP(e, hipGetLastError());
         e->range_a_G = 0;
-        if (!getenv_flag("KT_NO_WG_RANGES")) {  // every row is listed: the list holds pod_rows_hi records
+        if (!e->sw[kSw_NO_WG_RANGES]) {  // every row is listed: the list holds pod_rows_hi records
           e->range_a_G = kt::check_sweep_blocks(e->pod_rows_hi);
           KT_HIP(e, e->d_range_a.reserve((size_t)e->range_a_G + 2));
           kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, e->pod_rows_hi, e->range_a_G, e->d_range_a.p, s);
@@ -2434,7 +2481,7 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
       }
       kt::CheckByNs view{e->d_va_meta.p, e->d_va_latom.p, e->d_carry.p};
       if (by_ns && e->range_a_G) view.wg_range = e->d_range_a.p, view.wg_range_G = e->range_a_G;
-      if (by_ns && !want_status && e->dindex.n_slow == 0 && e->n_overflow == 0 && e->dindex.n_chunks > 1 && !getenv_flag("KT_NO_VERDICT_IMAGES")) {
+      if (by_ns && !want_status && e->dindex.n_slow == 0 && e->n_overflow == 0 && e->dindex.n_chunks > 1 && !e->sw[kSw_NO_VERDICT_IMAGES]) {
         // the lean sweep of a multi-chunk program: TermInfo + WordVerdict of every word once per generation of CheckRecs
         // (one small launch) instead of once per (workgroup, chunk) — 256 x ~15 rebuilds of the same words
         const int b = e->recs_cur;
@@ -2491,8 +2538,8 @@ int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t fl
     return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
   };
   bool fused = e->cfg.kernel_variant != 1 && !e->incremental && e->dindex.n_chunks == 1 && e->dindex.n_slow == 0 && !e->hindex.has_slow &&
-               e->n_overflow == 0 && e->thr_rows_hi > 0 && n > 0 && kt::dt_bucket_ix(e->D) == 8 && !getenv_flag("KT_NO_SWEEP") &&
-               !getenv_flag("KT_NO_FUSED") && !getenv_flag("KT_NO_PACK");
+               e->n_overflow == 0 && e->thr_rows_hi > 0 && n > 0 && kt::dt_bucket_ix(e->D) == 8 && !e->sw[kSw_NO_SWEEP] &&
+               !e->sw[kSw_NO_FUSED] && !e->sw[kSw_NO_PACK];
   if (!fused) return one_after_the_other();
   if ((rc = request_sums_in_range(e, s)) != KT_OK) return rc;
   if (e->wide) return one_after_the_other();
@@ -2523,6 +2570,7 @@ int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t fl
                                  &launched, s);
   }
   if (!k) return one_after_the_other();  // (LDS: check tables + fold tables of this program do not fit one workgroup)
+  if (launched != nb) return e->fail(KT_ERR_DEVICE, "kt_sweep_launch: %d workgroups launched, the packed fields were planned for %d", launched, nb);
   KT_HIP(e, hipGetLastError());
   e->last_kernel[KT_KERNEL_CHECK] = k;
   e->last_kernel[KT_KERNEL_AGGREGATE] = "(in kt_sweep_bitmap)";
@@ -2634,6 +2682,7 @@ static int32_t check_few_shared(kt_engine* e, int64_t n, const int64_t* pod_rows
     }
   }
   if (wait_cur) KT_HIP(e, hipStreamWaitEvent(e->small_stream, e->recs_ev[b], 0));
+  order_behind_ingest(e, e->small_stream);  // (a pod event right before this PreFilter: behind its kernel on the device)
   const uint64_t seq = ++e->few_seq;
   if (!kt::launch_check_few(e->pods, (int)n, pod_rows, e->sp, e->dindex, e->d_recs2[b].p, e->d_few_acc.p, e->d_few_ticket.p, e->h_few, e->h_few + 8,
                             seq, e->small_stream))
@@ -2694,6 +2743,32 @@ static int32_t check_fetch_locked(kt_engine* e, int64_t n, uint64_t* out_summary
     KT_HIP(e, hipMemcpyAsync(out_status, e->d_status.p, (size_t)n * (size_t)e->check_T, hipMemcpyDeviceToHost, s));
   KT_HIP(e, hipStreamSynchronize(s));
   if (n && out_summary && from_pinned) memcpy(out_summary, e->h_small, (size_t)n * 8);
+  return KT_OK;
+}
+
+// affectedPods restricted to the pods a caller names (throttle_controller.go:221-246 / clusterthrottle_controller.go:224-270):
+// for each of the n pod rows and each of the m throttle rows — does the throttle's selector (namespace side included) match
+// the pod as the engine holds it NOW.  What unreserveAffectedPods (throttle_controller.go:135-155) needs: a reservation is
+// released behind a reconcile only for a pod that is IN the reconciled throttle's affected set — one whose labels moved on
+// after Reserve is not.  One status-matrix check of those rows (a small launch), read by column.
+int32_t kt_affected_pods(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t m, const int32_t* throttle_rows, uint8_t* out) {
+  if (!e || n < 0 || m < 0 || (n > 0 && !pod_rows) || (m > 0 && !throttle_rows) || (n > 0 && m > 0 && !out)) return KT_ERR_INVALID_ARGUMENT;
+  if (n == 0 || m == 0) return KT_OK;
+  LaunchLock lk(e);
+  KT_HIP(e, hipSetDevice(e->device));
+  int32_t rc = ensure_ready(e, e->own_stream);
+  if (rc != KT_OK) return rc;
+  const int32_t T = e->thr_rows_hi;
+  for (int32_t j = 0; j < m; ++j)
+    if (throttle_rows[j] < 0 || throttle_rows[j] >= T) return e->fail(KT_ERR_OUT_OF_RANGE, "throttle row %d", throttle_rows[j]);
+  if ((rc = check_launch_locked(e, n, pod_rows, 0, KT_CHECK_STATUS_MATRIX, e->own_stream)) != KT_OK) return rc;
+  std::vector<uint8_t> st((size_t)n * (size_t)T);
+  if ((rc = check_fetch_locked(e, n, nullptr, st.data())) != KT_OK) return rc;
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t j = 0; j < m; ++j) {
+      const uint8_t v = st[(size_t)i * (size_t)T + (size_t)throttle_rows[j]];
+      out[(size_t)i * (size_t)m + (size_t)j] = v == KT_STATUS_ERROR ? (uint8_t)KT_STATUS_ERROR : v != KT_STATUS_NOT_AFFECTED ? 1 : 0;
+    }
   return KT_OK;
 }
 
@@ -2778,6 +2853,72 @@ int32_t kt_synchronize(kt_engine* e, void* stream) {
   LaunchLock lk(e);
   KT_HIP(e, hipSetDevice(e->device));
   KT_HIP(e, hipStreamSynchronize(pick_stream(e, stream)));
+  return KT_OK;
+}
+
+// ---- pages: more resource names than KT_MAX_DIMS (include/kt_engine.h)
+int32_t kt_paged_check(kt_engine* const* pages, int32_t n_pages, int64_t n, const int64_t* pod_rows, int32_t on_equal,
+                       uint64_t* out_summary, uint8_t* out_status) {
+  if (!pages || n_pages < 1 || n < 0) return KT_ERR_INVALID_ARGUMENT;
+  for (int32_t k = 0; k < n_pages; ++k)
+    if (!pages[k]) return KT_ERR_INVALID_ARGUMENT;
+  int32_t T = 0;
+  int32_t rc = kt_throttle_rows(pages[0], &T);
+  if (rc != KT_OK) return rc;
+  for (int32_t k = 1; k < n_pages; ++k) {
+    int32_t Tk = 0;
+    if ((rc = kt_throttle_rows(pages[k], &Tk)) != KT_OK) return rc;
+    if (Tk != T) return pages[k]->fail(KT_ERR_INVALID_ARGUMENT, "page %d holds %d throttle rows, page 0 %d: every page holds every throttle", k, Tk, T);
+  }
+  if (n == 0) return KT_OK;
+  // CheckThrottleStatus precedence (first hit wins, throttle_types.go:128-153): exceeds > active > insufficient > not throttled
+  auto rank = [](uint8_t v) -> uint8_t {
+    return v == KT_STATUS_ERROR ? 5 : v == KT_STATUS_POD_REQUESTS_EXCEEDS_THRESHOLD ? 4 : v == KT_STATUS_ACTIVE ? 3 : v == KT_STATUS_INSUFFICIENT ? 2 : v == KT_STATUS_NOT_THROTTLED ? 1 : 0;
+  };
+  static const uint8_t code[6] = {KT_STATUS_NOT_AFFECTED, KT_STATUS_NOT_THROTTLED, KT_STATUS_INSUFFICIENT, KT_STATUS_ACTIVE, KT_STATUS_POD_REQUESTS_EXCEEDS_THRESHOLD, KT_STATUS_ERROR};
+  const size_t cells = (size_t)n * (size_t)(T > 0 ? T : 1);
+  std::vector<uint8_t> acc(cells, 0), page(cells);
+  for (int32_t k = 0; k < n_pages; ++k) {
+    if ((rc = kt_check(pages[k], n, pod_rows, on_equal, nullptr, page.data())) != KT_OK) return rc;
+    for (size_t i = 0; i < (size_t)n * (size_t)T; ++i) acc[i] = std::max(acc[i], rank(page[i]));
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t n_exc = 0, n_act = 0, n_ins = 0;
+    bool err = false;
+    for (int32_t t = 0; t < T; ++t) {
+      const uint8_t r = acc[(size_t)i * T + t];
+      err |= r == 5, n_exc += r == 4, n_act += r == 3, n_ins += r == 2;
+      if (out_status) out_status[(size_t)i * T + t] = code[r];
+    }
+    if (out_summary) out_summary[i] = err ? 2ull : ((n_exc | n_act | n_ins) ? 1ull : 0ull) | n_exc << 4 | n_act << 24 | n_ins << 44;
+  }
+  return KT_OK;
+}
+
+int32_t kt_paged_reconcile(kt_engine* const* pages, int32_t n_pages, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
+                           const kt_status* page_out, uint8_t* replaced_any, uint8_t* error_any) {
+  if (!pages || n_pages < 1 || n < 0 || !page_out) return KT_ERR_INVALID_ARGUMENT;
+  for (int32_t k = 0; k < n_pages; ++k)
+    if (!pages[k]) return KT_ERR_INVALID_ARGUMENT;
+  int32_t rc;
+  for (int32_t k = 0; k < n_pages; ++k)  // (enqueued on every page's own stream: the pages run side by side on the device)
+    if ((rc = kt_reconcile_launch(pages[k], now_s, now_ns, flags, nullptr)) != KT_OK) return rc;
+  if (replaced_any) memset(replaced_any, 0, (size_t)n);
+  if (error_any) memset(error_any, 0, (size_t)n);
+  for (int32_t k = 0; k < n_pages; ++k) {
+    if ((rc = kt_reconcile_fetch(pages[k], n, &page_out[k])) != KT_OK) return rc;
+    for (int32_t i = 0; i < n; ++i) {
+      if (replaced_any && page_out[k].calc_at_nonzero) replaced_any[i] |= page_out[k].calc_at_nonzero[i] != 0;
+      if (error_any && page_out[k].error) error_any[i] |= page_out[k].error[i] != 0;
+    }
+  }
+  return KT_OK;
+}
+
+int32_t kt_debug_reload_env(kt_engine* e) {
+  if (!e) return KT_ERR_INVALID_ARGUMENT;
+  StateLock lk(e);  // nobody else inside: the switches are plain fields
+  load_env_switches(e);
   return KT_OK;
 }
 

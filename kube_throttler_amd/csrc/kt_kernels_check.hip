@@ -852,8 +852,8 @@ const char* launch_sweep_indexed(const PodTable& pods, int64_t n, const SelProgr
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
   bm_args.slab = (unsigned char*)slab, bm_args.slab_tag = slab_tag, bm_args.epoch = epoch;
   const size_t lds_bytes = bm_total;
-  int64_t nb = (n + kBlockIx - 1) / kBlockIx;
-  if (nb > kCUs) nb = kCUs;  // one slab per workgroup, at most kSlabTagStride of them
+  // (the grid the caller sized the PackPlan's fields for: one slab per workgroup, at most kSlabTagStride of them)
+  const int64_t nb = aggregate_blocks(n);
   dim3 g_((unsigned)nb), b_(kBlockIx);
   if (!ix.rich) KT_SWEEP_CASE(8, 8, false, 2)
   else if (LA <= 8) KT_SWEEP_CASE(8, 8, true, 3)

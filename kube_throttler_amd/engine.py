@@ -39,7 +39,7 @@ EXPORTS = [
     "kt_synchronize", "kt_kernel_name", "kt_admit_launch", "kt_fetch_reserved", "kt_reconcile_fetch_next_override",
     "kt_check", "kt_upsert_namespace", "kt_upsert_pod", "kt_upsert_throttle", "kt_comm_unique_id", "kt_comm_init",
     "kt_comm_allreduce_partial", "kt_comm_destroy", "kt_reconcile_rows_launch", "kt_set_exchange_world", "kt_counter", "kt_reconcile_fetch_used_hi",
-    "kt_set_wide_sums", "kt_partial_words", "kt_partial_layout",
+    "kt_set_wide_sums", "kt_partial_words", "kt_partial_layout", "kt_debug_reload_env", "kt_affected_pods", "kt_paged_check", "kt_paged_reconcile",
 ]
 COUNTER_FEW_CHECKS, COUNTER_COMPILES, COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS, COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS = range(6)
 
@@ -57,6 +57,36 @@ def partial_layout(n_dims: int) -> dict:
 def version() -> str:
     """kt_version(): library version + hash of the kernel sources it was built from."""
     return lib().kt_version().decode()
+
+
+def paged_check(engines, n, rows=None, on_equal=False):
+    """kt_paged_check: kt_check on every page engine (one per page of <= 16 resource names), combined in the library ->
+    (status matrix [n][T], summary words [n])."""
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    T = engines[0].throttle_rows()
+    rows_a = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+    if rows_a is None:
+        rows_a = np.arange(n, dtype=np.int64)
+    status = np.zeros((max(n, 1), max(T, 1)), np.uint8)
+    summary = np.zeros(max(n, 1), np.uint64)
+    rc = lib().kt_paged_check(hs, len(engines), n, rows_a.ctypes.data, int(on_equal), summary.ctypes.data, status.ctypes.data)
+    if rc != KT_OK:
+        raise EngineError(rc, "kt_paged_check: " + "; ".join(lib().kt_last_error(e._h).decode() for e in engines))
+    return status[:n, :T], summary[:n]
+
+
+def paged_reconcile(engines, now, apply=True):
+    """kt_paged_reconcile: a reconcile on every page engine -> (per-page ReconcileResult list, replaced_any [T], error_any [T])."""
+    hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    T = engines[0].throttle_rows()
+    results = [ReconcileResult(T, e.D) for e in engines]
+    structs = (KtStatus * len(engines))(*[r.as_struct() for r in results])
+    replaced, err = np.zeros(max(T, 1), np.uint8), np.zeros(max(T, 1), np.uint8)
+    rc = lib().kt_paged_reconcile(hs, len(engines), int(now[0]), int(now[1]), RECONCILE_APPLY if apply else 0, T, structs,
+                                  replaced.ctypes.data, err.ctypes.data)
+    if rc != KT_OK:
+        raise EngineError(rc, "kt_paged_reconcile: " + "; ".join(lib().kt_last_error(e._h).decode() for e in engines))
+    return results, replaced[:T], err[:T]
 
 
 class EngineError(RuntimeError):
@@ -128,6 +158,11 @@ def lib():
         L.kt_set_wide_sums.argtypes = [C.c_void_p, C.c_int32]
         L.kt_partial_words.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.kt_partial_layout.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 5
+        L.kt_debug_reload_env.argtypes = [C.c_void_p]
+        L.kt_affected_pods.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.kt_paged_check.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.kt_paged_reconcile.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32, C.c_uint32, C.c_int32,
+                                         C.POINTER(KtStatus), C.c_void_p, C.c_void_p]
         L.kt_counter.argtypes = [C.c_void_p, C.c_int32]
         L.kt_reconcile_fetch_used_hi.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.kt_counter.restype = C.c_int64
@@ -313,6 +348,19 @@ class Engine:
     def set_exchange_world(self, world: int):
         """Ranks whose partials the CALLER sums with its own collective (kt_comm_init declares it by itself)."""
         self._ck(lib().kt_set_exchange_world(self._h, world))
+
+    def affected_pods(self, pod_rows, throttle_rows):
+        """kt_affected_pods: [n][m] — 1 where the throttle's selector matches the pod as held now (affectedPods restricted to
+        the named pods), 0 where not, 255 for a pod whose PreFilter is an error."""
+        pr = np.ascontiguousarray(pod_rows, dtype=np.int64)
+        tr = np.ascontiguousarray(throttle_rows, dtype=np.int32)
+        out = np.zeros((max(len(pr), 1), max(len(tr), 1)), np.uint8)
+        self._ck(lib().kt_affected_pods(self._h, len(pr), pr.ctypes.data, len(tr), tr.ctypes.data, out.ctypes.data))
+        return out[:len(pr), :len(tr)]
+
+    def reload_env(self):
+        """kt_debug_reload_env: re-read the A/B switches (KT_NO_* environment variables) — they are read once, at creation."""
+        self._ck(lib().kt_debug_reload_env(self._h))
 
     def index_stats(self) -> dict:
         """The compiled selector index (after the first launch): LDS-sized chunks, 64-bit words of term numbers, namespace rows,

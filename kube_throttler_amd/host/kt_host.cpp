@@ -1068,21 +1068,50 @@ bool KubeThrottler::ReconcileAll(const std::string& now_rfc3339, std::map<std::s
     if (err) *err = p.engine_error(rc);
     return false;
   }
-  // Once status is updated, counted pods are safe to un-reserve (throttle_controller.go:135-155)
-  for (auto& kv : p.reserved) {
-    // a reconcile that failed returned before unreserveAffectedPods (throttle_controller.go:103-106), and throttles of
-    // another throttler are never reconciled: their reservations stay
-    const int32_t t = kv.first;
-    if (t < 0 || t >= T || terr[(size_t)t] || !p.thr_live[(size_t)t] || p.thr_by_row[(size_t)t].throttlerName != p.args.name) continue;
-    bool changed = false;
-    for (auto it = kv.second.begin(); it != kv.second.end();) {
-      auto pit = p.pods.find(it->first);
-      const bool counted = pit != p.pods.end() && pit->second.schedulerName == p.args.targetSchedulerName &&
-                           !pit->second.nodeName.empty();
-      if (counted) it = kv.second.erase(it), changed = true;
-      else ++it;
+  // Once status is updated, the reconciled throttle's AFFECTED pods are safe to un-reserve (unreserveAffectedPods,
+  // throttle_controller.go:135-155 / clusterthrottle_controller.go:138-160: it walks affectedNonTerminatedPods +
+  // affectedTerminatedPods of the throttle — shouldCountIn AND the selector matches the pod as it is now).  A pod that was
+  // reserved on the throttle and whose labels moved on afterwards is NOT in that list: its reservation stays until the pod
+  // handlers move it (kt_affected_pods: one small check launch over the pods that hold reservations).
+  {
+    std::vector<int32_t> thr_list;   // reconciled throttles that hold reservations
+    std::vector<std::string> keys;   // counted pods that hold a reservation on one of them
+    std::map<std::string, size_t> key_ix;
+    for (auto& kv : p.reserved) {
+      // a reconcile that failed returned before unreserveAffectedPods (throttle_controller.go:103-106), and throttles of
+      // another throttler are never reconciled: their reservations stay
+      const int32_t t = kv.first;
+      if (t < 0 || t >= T || terr[(size_t)t] || !p.thr_live[(size_t)t] || p.thr_by_row[(size_t)t].throttlerName != p.args.name) continue;
+      bool any = false;
+      for (auto& r : kv.second) {
+        auto pit = p.pods.find(r.first);
+        const bool counted = pit != p.pods.end() && pit->second.schedulerName == p.args.targetSchedulerName && !pit->second.nodeName.empty();
+        if (!counted || p.pod_rows.find(r.first) < 0) continue;
+        if (!key_ix.count(r.first)) key_ix[r.first] = keys.size(), keys.push_back(r.first);
+        any = true;
+      }
+      if (any) thr_list.push_back(t);
     }
-    if (changed) p.push_reserved(kv.first, nullptr);
+    if (!keys.empty() && !thr_list.empty()) {
+      std::vector<int64_t> rows(keys.size());
+      for (size_t i = 0; i < keys.size(); ++i) rows[i] = p.pod_rows.find(keys[i]);
+      std::vector<uint8_t> aff(keys.size() * thr_list.size());
+      rc = kt_affected_pods(p.e, (int64_t)rows.size(), rows.data(), (int32_t)thr_list.size(), thr_list.data(), aff.data());
+      if (rc != KT_OK) {
+        if (err) *err = p.engine_error(rc);
+        return false;
+      }
+      for (size_t j = 0; j < thr_list.size(); ++j) {
+        auto& held = p.reserved[thr_list[j]];
+        bool changed = false;
+        for (auto it = held.begin(); it != held.end();) {
+          auto k = key_ix.find(it->first);
+          if (k != key_ix.end() && aff[k->second * thr_list.size() + j] == 1) it = held.erase(it), changed = true;
+          else ++it;
+        }
+        if (changed) p.push_reserved(thr_list[j], nullptr);
+      }
+    }
   }
   std::vector<std::string> dim_name((size_t)D);
   std::vector<int> dim_scale((size_t)D, 0);

@@ -107,12 +107,20 @@ class PagedEngine:
             e.close()
 
     def reconcile(self, now, apply=True):
-        """-> (combined rows, per-page ReconcileResult list)."""
-        results = [e.reconcile(now, apply=apply) for e in self.engines]
-        return combine_reconcile(self.pages, results), results
+        """-> (combined rows, per-page ReconcileResult list).  The step runs through the library's kt_paged_reconcile (what
+        a Go host calls); the rows are put together by resource NAME here, which only the host layer knows."""
+        results, replaced_any, error_any = E.paged_reconcile(self.engines, now, apply=apply)
+        rows = combine_reconcile(self.pages, results)
+        for i, r in enumerate(rows):  # the library's OR over the pages is the same statement
+            assert r["calc_updated"] == bool(replaced_any[i]) and r["error"] == bool(error_any[i])
+        return rows, results
 
     def check(self, on_equal=False):
-        """-> (status matrix [pods][throttles], verdict per pod) of the whole cluster."""
+        """-> (status matrix [pods][throttles], verdict per pod) of the whole cluster — combined inside the library
+        (kt_paged_check: the C-ABI entry point of this module's combination rule)."""
         n = self.pages[0].snapshot.n_pods
-        status = combine_status([e.check(n=n, on_equal=on_equal, want_status=True)[0] for e in self.engines])
-        return status, verdicts(status)
+        status, summary = E.paged_check(self.engines, n, on_equal=on_equal)
+        v = verdicts(status)
+        got = np.where(summary == 2, S.VERDICT_ERROR, np.where((summary & 1) != 0, S.VERDICT_BLOCK, S.VERDICT_ALLOW)).astype(np.uint8)
+        assert (got == v).all(), "kt_paged_check: summary words disagree with the combined status rows"
+        return status, v

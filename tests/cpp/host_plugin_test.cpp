@@ -325,11 +325,51 @@ static void TestPodUpdateAndDeleteHandlers() {
   EXPECT(k->PreFilter(z).IsSuccess());
 }
 
+// unreserveAffectedPods walks the reconciled throttle's affectedPods (throttle_controller.go:135-155): a pod that was reserved
+// on `ta` while pending, whose labels moved on before it was bound (the Update handler returns early for a pod that does not
+// count in before or after: :451-455), is NOT in ta's affected set once it is scheduled — its reservation on ta stays; the pod
+// that still matches is un-reserved.  (The mirror of rounds 3-4 released every counted reserved pod of a reconciled throttle.)
+static void TestUnreserveOnlyAffectedPods() {
+  auto k = Fresh();
+  std::string err;
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "ta", "grp", "a", 2, ""), &err));
+  EXPECT(k->OnThrottleAdd(MakeThrottle("default", "tb", "grp", "b", 5, ""), &err));
+  std::map<std::string, ThrottleStatus> st;
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  Pod w = MakePod("default", "w", "100m", {{"grp", "a"}});
+  Pod v = MakePod("default", "v", "100m", {{"grp", "a"}});
+  Pod z = MakePod("default", "z", "100m", {{"grp", "a"}});
+  EXPECT(k->OnPodAdd(w, &err) && k->OnPodAdd(v, &err));
+  EXPECT(k->PreFilter(w).IsSuccess() && k->Reserve(w).IsSuccess());
+  EXPECT(k->PreFilter(v).IsSuccess() && k->Reserve(v).IsSuccess());
+  EXPECT(k->PreFilter(z).code == UnschedulableAndUnresolvable);   // ta: reserved {pod 2} >= 2
+  // w is relabelled while still pending: no handler moves its reservation
+  Pod w2 = w;
+  w2.labels = {{"grp", "b"}};
+  EXPECT(k->OnPodUpdate(w, w2, &err));
+  // both get bound
+  Pod w3 = w2, v2 = v;
+  w3.nodeName = v2.nodeName = "node-1";
+  w3.phase = v2.phase = "Running";
+  EXPECT(k->OnPodUpdate(w2, w3, &err) && k->OnPodUpdate(v, v2, &err));
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  // ta counts v only (w carries grp=b now); v was in ta's affected pods and is un-reserved, w was not: ta = used {pod 1} +
+  // reserved {pod 1 (w)} >= 2 -> still active for z
+  EXPECT(st["default/ta"].usedPod == 1 && st["default/tb"].usedPod == 1);
+  Status sz = k->PreFilter(z);
+  EXPECT(sz.code == UnschedulableAndUnresolvable && sz.reasons.size() == 1 && sz.reasons[0] == "throttle[active]=default/ta");
+  // Unreserve (plugin.go:240-257) or the Delete handler releases it
+  EXPECT(k->OnPodDelete(w3.Key(), &err));
+  EXPECT(k->ReconcileAll(NOW, &st, &err));
+  EXPECT(k->PreFilter(z).IsSuccess());
+}
+
 int main(int argc, char** argv) {
   // no argument: the reference's scenarios; "extended": status write-back and the pod Update / Delete handlers
   if (argc > 1 && std::string(argv[1]) == "extended") {
     TestStatusWriteBack();
     TestPodUpdateAndDeleteHandlers();
+    TestUnreserveOnlyAffectedPods();
   } else {
     TestExampleWalkthrough();
     TestThrottleScenarios();

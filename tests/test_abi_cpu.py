@@ -103,3 +103,19 @@ def test_native_latency_shim_builds_against_the_header(tmp_path, built_lib):
     import ctypes
     lib = ctypes.CDLL(str(so))
     assert hasattr(lib, "kt_native_check_latency")
+
+
+def test_partial_layout_query_needs_no_gpu(built_lib):
+    """kt_partial_layout: what a host's own collective (and tests/partial_layout.py) lays the partial buffer out by — the
+    stride and offsets the kernels are compiled against, for every dimension count the engine takes."""
+    for D in range(1, 17):
+        lo = E.partial_layout(D)
+        assert lo["stride"] >= 2 * D + 2
+        spans = sorted([(lo["values"], D), (lo["presence"], D), (lo["pods"], 1), (lo["errors"], 1)])
+        end = 0
+        for off, n in spans:  # the four parts do not overlap and lie inside the row
+            assert off >= end
+            end = off + n
+        assert end <= lo["stride"]
+    with pytest.raises(E.EngineError):
+        E.partial_layout(17)

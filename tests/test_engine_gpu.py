@@ -972,7 +972,7 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="fu
     """NOTHING is sampled: every responsible throttle's reconcile result and every pod's summary word are compared with
     the oracle (the C restatement runs the whole configuration in seconds on the GPU box's host cores), a pod sample
     additionally with full status rows, and the dense (reference-shaped) kernels must agree with the indexed ones."""
-    nthreads = nthreads or os.cpu_count() or 8
+    nthreads = nthreads or oracle_mod.effective_cpus()  # (the cgroup quota, not the box's thread count)
     snap = W.generate(cfg)
     now = (cfg.now_s, 0)
     P, T = snap.n_pods, snap.n_thr
@@ -1163,7 +1163,7 @@ def test_reconcile_after_a_larger_scan_of_the_same_engine(oracle_mod):
         snap.pod_flags[:snap.n_pods] = flags0
         eng.load_snapshot(snap)
         got = eng.reconcile(now, apply=False)
-        want = oracle_mod.Oracle(snap).reconcile(now, rows=rows, nthreads=os.cpu_count() or 8)
+        want = oracle_mod.Oracle(snap).reconcile(now, rows=rows, nthreads=oracle_mod.effective_cpus())
         assert (big.used.count[rows] >= want.used.count[:len(rows)]).all() and (big.used.count[rows] > want.used.count[:len(rows)]).any()
         bad = np.argwhere(got.used.v[rows] != want.used.v[:len(rows)])
         assert len(bad) == 0, "used.v differs in %d entries of %d throttles (kernels: %s, %s)" % (
@@ -1188,7 +1188,7 @@ def test_reconcile_stress_fresh_engines(oracle_mod, preset):
     snap = W.generate(cfg)
     now = (cfg.now_s, 0)
     rows = responsible_rows(snap)
-    want = oracle_mod.Oracle(snap).reconcile(now, rows=rows, nthreads=os.cpu_count() or 8)
+    want = oracle_mod.Oracle(snap).reconcile(now, rows=rows, nthreads=oracle_mod.effective_cpus())
     hip = ctypes.CDLL("libamdhip64.so")
     rng = np.random.default_rng(11 + preset)
 

@@ -17,3 +17,13 @@ def test_host_plugin_scenarios():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all expectations held" in r.stdout
+
+
+def test_host_plugin_extended():
+    """Status write-back, the pod Update / Delete handlers, and unreserveAffectedPods by the reconciled throttle's own
+    affected-pod list (kt_affected_pods: a pod relabelled after Reserve keeps its reservation)."""
+    exe = os.path.join(HOST, "host_plugin_test")
+    subprocess.check_call(["make", "-C", HOST, "host_plugin_test"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe, "extended"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all expectations held" in r.stdout

@@ -14,7 +14,7 @@ def test_paged_engines_equal_the_manifest_model(seed):
     def reconcile_pages(pages, now):
         eng = paging.PagedEngine(pages)
         try:
-            return eng.reconcile(now, apply=False)[1]
+            return eng.reconcile(now, apply=False)[1]  # (kt_paged_reconcile; PagedEngine checks the library's OR-ed flags)
         finally:
             eng.close()
 
@@ -24,8 +24,14 @@ def test_paged_engines_equal_the_manifest_model(seed):
             if eng is not None:
                 eng.close()
             eng = state["eng"] = paging.PagedEngine(pages)
+        # ONE matrix: the pages combined inside the library (kt_paged_check, the C-ABI form of paging.combine_status) —
+        # check_against_model combines what it is handed, and the combination of a single matrix is that matrix
+        status, _ = eng.check(on_equal=on_equal)
+        # ... which must also be what the Python statement of the rule makes of the per-page matrices
         n = pages[0].snapshot.n_pods
-        return [e.check(n=n, on_equal=on_equal, want_status=True)[0] for e in eng.engines]
+        per_page = [e.check(n=n, on_equal=on_equal, want_status=True)[0] for e in eng.engines]
+        assert (paging.combine_status(per_page) == status).all()
+        return [status]
 
     try:
         check_against_model(wide_cluster(seed), reconcile_pages, check_pages, f"seed {seed}")

@@ -142,16 +142,21 @@ def measure(eng, snap, n_check=10000, n_upsert=300, now=(1767225600, 0)):
     out["upsert_pod1"] = feed(1, n_upsert)                           # one event, the call alone
     out["upsert_pod64_per_pod"] = feed(64, max(20, n_upsert // 4))   # a coalesced batch of 64 events, per pod
     out["upsert1_then_check1"] = feed(1, n_upsert, then_check=True)  # event + PreFilter of that pod (waits for the ingest)
+    # (the engine reads its A/B switches once: reload_env after every flip)
     os.environ["KT_NO_FEED_FUSION"] = "1"                            # three launches + a copy instead of kt_feed_small
+    eng.reload_env()
     try:
         out["upsert1_then_check1_unfused"] = feed(1, max(50, n_upsert // 2), then_check=True)
     finally:
         del os.environ["KT_NO_FEED_FUSION"]
+        eng.reload_env()
     os.environ["KT_SYNC_INGEST"] = "1"                               # the blocking form of rounds 1-3, for comparison
+    eng.reload_env()
     try:
         out["upsert_pod1_blocking"] = feed(1, max(50, n_upsert // 2))
     finally:
         del os.environ["KT_SYNC_INGEST"]
+        eng.reload_env()
     ts = []
     for r in rng.integers(0, P, size=max(50, n_upsert // 2)):
         rs = np.array([int(r)], dtype=np.int64)
