@@ -147,6 +147,10 @@ def main():
     ap.add_argument("--variant", choices=["indexed", "dense"], default="indexed")
     ap.add_argument("--throttles", type=int, default=0,
                     help="measurements only: scale the config's throttle count (ClusterThrottles in proportion) — NOT a BASELINE config")
+    ap.add_argument("--dims", type=int, default=0,
+                    help="measurements only: resource dimensions per pod / throttle (up to 16) — NOT a BASELINE config")
+    ap.add_argument("--labels", type=int, default=0,
+                    help="measurements only: labels per pod (the label keys grow to twice that) — NOT a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="also bit-compare a pod sample with the oracle")
@@ -195,6 +199,11 @@ def main():
     if args.throttles:
         cfg.n_cluster = max(0, int(round(cfg.n_cluster * args.throttles / cfg.n_thr)))
         cfg.n_thr = args.throttles
+    if args.dims:
+        cfg.D = args.dims
+    if args.labels:
+        cfg.L = args.labels
+        cfg.K = max(cfg.K, 2 * args.labels)
     if args.scaling == "strong":  # total work fixed: the config's pods (or --pods-per-gpu x 1 as the total) over N ranks
         total = args.pods_per_gpu or cfg.n_pods_total
         per_gpu = (total + world - 1) // world
@@ -433,6 +442,8 @@ def main():
             key = f"config{args.config}_{args.variant}"
             if args.pods_per_gpu:  # e.g. config2_indexed_4M: the point past the 256 MiB Infinity Cache
                 key += "_%dM" % (args.pods_per_gpu // 1000000) if args.pods_per_gpu % 1000000 == 0 else "_%d" % args.pods_per_gpu
+            if args.dims or args.labels or args.throttles:  # not a profiled configuration: no PMC figures are quoted
+                key += "_custom"
             src = pmc.get("_source", {}).get(key)
             if isinstance(src, dict) and src.get("engine_version") == engine_version:
                 pmc_kernels = pmc.get(key, {})
@@ -586,7 +597,8 @@ def main():
             "steps": args.steps, "steps_requested": steps_requested, "timed_region_s": round(elapsed, 6),
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.config] + (" — throttle count overridden (--throttles): not a BASELINE config" if args.throttles else ""),
+            "config": {"workload": WORKLOADS[args.config] + (" — throttle count overridden (--throttles): not a BASELINE config" if args.throttles else "")
+                                   + (" — dimensions / labels overridden (--dims / --labels): not a BASELINE config" if args.dims or args.labels else ""),
                        "pods_total": P_total, "pods_per_gpu": per_gpu,
                        "throttles": T, "dims": D, "labels_per_pod": L, "namespaces": snap.n_ns,
                        "step": "sweep(check all pods against the stored status + aggregate, one pass)+finalize(apply)" if args.sweep
@@ -608,7 +620,7 @@ def main():
     if rank == 0:
         # the other single-GPU BASELINE configurations, driver-observed instead of builder-claimed: after the headline leg
         # (its engine is closed), on this GPU, each for at least --min-seconds
-        if world == 1 and not args.no_extra and args.config == 2 and not args.pods_per_gpu and not args.throttles and args.variant == "indexed":
+        if world == 1 and not args.no_extra and args.config == 2 and not args.pods_per_gpu and not args.throttles and not args.dims and not args.labels and args.variant == "indexed":
             extra = {}
             for idx, key in ((3, "configs[3]"), (4, "configs[4] shard")):
                 try:

@@ -251,7 +251,9 @@ uint32_t check_word_lds(int D) { return 64u * 8u + (uint32_t)(D <= 8 ? sizeof(Wo
 template <int DT, int LA, bool VETO, int NEED, int WPE, bool FULL, bool SMALL, bool ONE = false, bool AGG = false>
 __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckArgs a) {
   static_assert(!AGG || (ONE && !FULL && !SMALL && WPE < 8), "the fused sweep is the lean single-chunk form, one workgroup per CU");
-  constexpr int kDrainUnroll = WPE >= 8 ? 1 : DT / 2;  // drains in the middle of a scan (the list ran full)
+  // (pieces of the three rows per batch: 12 registers each — the whole rows of a 16-dimension engine would be 96 registers
+  //  of a 128-register kernel: four pieces per batch at most, two batches there)
+  constexpr int kDrainUnroll = WPE >= 8 ? 1 : (DT / 2 > 4 ? 4 : DT / 2);  // drains in the middle of a scan (the list ran full)
 #ifndef KT_DRAIN_FINAL_8
 #define KT_DRAIN_FINAL_8 2  // (4 = the whole rows at once costs the 64-VGPR instantiation 80 B of scratch inside the scan)
 #endif
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 #ifdef KT_DRAIN_PREFETCH
   constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : (!SMALL && !ONE && !AGG && !FULL) ? 2 : DT / 2;  // (the next tile's record is live across it)
 #else
-  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : DT / 2;  // the drain behind the scan
+  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : (DT / 2 > 4 ? 4 : DT / 2);  // the drain behind the scan
 #endif
 #endif
   // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
