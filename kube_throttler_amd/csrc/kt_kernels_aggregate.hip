@@ -1,5 +1,6 @@
 // kt_kernels_aggregate.hip — kt_aggregate_bitmap + kt_reduce_bitmap_slabs: per-throttle `used` through the exact term bitmaps.
 #include <cstdio>
+#include <type_traits>
 
 #include "kt_scan.h"
 
@@ -132,12 +133,17 @@ __device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram
 template <int DT, int LA, bool VETO, int NEED, bool PK>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
-  // QUEUED FOLD (round 5, the packed instantiations): an LDS atomic costs per INSTRUCTION (~11.5 cycles of the CU's one LDS
-  // pipe whatever the number of active lanes), and folding a word's matches where the scan produced them steps as often as
-  // the lane with the MOST matches of that word has matches — lanes 21 % (configs[2]) to 38 % (configs[4]) busy.  The
-  // matches are therefore first peeled into a lane-private queue of 16-bit term numbers in registers (plain VALU steps),
-  // and folded — three atomics per step — only when some lane's queue is full or the tile is done: a step of the fold then
-  // serves a match of nearly every lane that has any left.  -DKT_AGG_NO_QUEUE restores the word-by-word fold (A/B).
+  // QUEUED FOLD (round 5, the packed instantiations).  Folding a word's matches where the scan produced them steps as often as
+  // the lane with the MOST matches of that word has matches — lanes 21 % (configs[2]) to 38 % (configs[4]) busy — and every
+  // step pays the bit extraction (~16 VALU instructions), a rank read and three LDS atomics.  Measured on the configs[4] shard
+  // (timing probes, profiles/r05_probe_breakdown.txt): of the aggregate's 0.70 ms the scan is 0.30, the extraction loop 0.18,
+  // the atomics 0.22.  The lane therefore QUEUES what the scan finds and the wave folds only when some lane's queue is full
+  // or the tile is done — a step of the fold then serves nearly every lane that has anything left:
+  //   * word queue (default): the match words themselves, (word number, 64 bits) x kWq — one predicated push per visit, the
+  //     extraction runs inside the balanced steps: 0.53 -> 0.48 ms on the shard with the namespace-aligned ranges in place;
+  //   * term-number queue (-DKT_AGG_TERM_QUEUE): 16-bit chunk-local term numbers, extracted per word — halves the atomic
+  //     instructions as well (0.22 -> 0.12 ms) but keeps the lopsided extraction loop (+0.04): 0.53 ms.
+  // -DKT_AGG_NO_QUEUE restores the word-by-word fold (A/B).
 #ifndef KT_AGG_NO_QUEUE
   constexpr bool kFoldQueue = PK && LA <= 16;  // (32 atom slots: the queue does not fit the registers)
 #else
@@ -363,6 +369,86 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       constexpr bool kFoldPairs = PK;
 #else
       constexpr bool kFoldPairs = false;
+#endif
+#ifndef KT_AGG_TERM_QUEUE
+      if constexpr (kFoldQueue) {
+        // WORD queue (the default; -DKT_AGG_TERM_QUEUE: the queue of term numbers below, -DKT_AGG_NO_QUEUE: the word-by-word fold): the lane keeps the match words of the last visits as they are — (word number, 64 match bits), kWq of them,
+        // newest first — and nothing is extracted while the scan runs: ONE predicated push per visit.  When some lane's queue is
+        // full (or the tile is done) the wave folds: every step each lane that has anything takes the lowest bit of its newest
+        // word, so a step serves nearly every lane that has matches left — and the bit extraction, which the term-number queue
+        // pays in a loop that runs as often as the BUSIEST lane of every single word has matches, runs in these balanced steps too.
+#ifndef KT_AGG_WQ
+#define KT_AGG_WQ 3
+#endif
+        constexpr int kWq = KT_AGG_WQ;
+        uint64_t qx[kWq];
+        // word numbers, 10 bits each (newest lowest: cut_chunks keeps a chunk below 1024 words); entries in use
+        typedef typename std::conditional<(kWq > 3), uint64_t, uint32_t>::type qw_t;
+        static_assert(kWq * 10 <= 64, "ten bits per queued word number");
+        qw_t qw = 0;
+        uint32_t qn = 0u;
+#pragma unroll
+        for (int k = 0; k < kWq; ++k) qx[k] = 0ull;
+        auto add_rank = [&](bool has, uint32_t r) {
+          if (has) {
+            KT_LDS unsigned char* rp = tab + __umul24(r, rec);
+            lds_u64wp tv = (lds_u64wp)rp;
+            lds_add64(tv, pw[0]);
+            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+            if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+        auto flush = [&]() {
+          while (__ballot(qn != 0u) != 0ull) {
+            const bool has = qn != 0u;
+            const uint32_t cw = ((uint32_t)qw & 1023u) * 64u;
+            const uint32_t c = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
+            qx[0] &= qx[0] - 1ull;
+#ifdef KT_AGG_WQ_PAIRS  // two matches of the newest word per step: both rank reads in flight together
+            const bool has2 = has && qx[0] != 0ull;
+            const uint32_t c2 = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
+            qx[0] &= qx[0] - 1ull;
+            const uint32_t r = trank[has ? c : 0u] & 0x7FFFu, r2 = trank[has2 ? c2 : 0u] & 0x7FFFu;
+#else
+            const uint32_t r = trank[has ? c : 0u] & 0x7FFFu;
+#endif
+            if (has && qx[0] == 0ull) {  // the newest word is used up: the older ones move up
+#pragma unroll
+              for (int k = 0; k + 1 < kWq; ++k) qx[k] = qx[k + 1];
+              qx[kWq - 1] = 0ull;
+              qw >>= 10;
+              qn -= 1u;
+            }
+            add_rank(has, r);
+#ifdef KT_AGG_WQ_PAIRS
+            add_rank(has2, r2);
+#endif
+          }
+        };
+        const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
+        KT_LDS const u64x2* segp = (KT_LDS const u64x2*)(lds + a.off_seg);
+        scan_tile<LA, VETO, NEED, VETO>(
+            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
+            [&](uint32_t w, uint64_t x, const u64x2& seg) -> uint64_t {
+              if (seg_on) {  // a throttle with several terms is counted once: the lowest match of every run
+                const uint64_t v = x | seg.y;
+                x = andn_64(x, v - seg.x);
+              }
+              if (__ballot(x != 0ull && qn >= (uint32_t)kWq) != 0ull) flush();
+              if (x != 0ull) {
+#pragma unroll
+                for (int k = kWq - 1; k > 0; --k) qx[k] = qx[k - 1];
+                qx[0] = x;
+                qw = (qw_t)(qw << 10) | (qw_t)w;
+                qn += 1u;
+              }
+              return 0ull;
+            },
+            [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
+        flush();
+      } else
 #endif
       if constexpr (kFoldQueue) {
         // lane-private queue: kQueueCap 16-bit chunk-local term numbers, newest in the low half of q[0] (entries past qn are zero)
