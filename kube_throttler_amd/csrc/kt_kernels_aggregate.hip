@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   //     instructions as well (0.22 -> 0.12 ms) but keeps the lopsided extraction loop (+0.04): 0.53 ms.
   // -DKT_AGG_NO_QUEUE restores the word-by-word fold (A/B).
 #ifndef KT_AGG_NO_QUEUE
-  constexpr bool kFoldQueue = PK && LA <= 16;  // (32 atom slots: the queue does not fit the registers)
+  constexpr bool kFoldQueue = PK && LA <= 8;  // (16 / 32 atom slots: the queue does not fit the registers — 40 B of scratch at 16)
 #else
   constexpr bool kFoldQueue = false;
 #endif
@@ -377,10 +377,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
         // full (or the tile is done) the wave folds: every step each lane that has anything takes the lowest bit of its newest
         // word, so a step serves nearly every lane that has matches left — and the bit extraction, which the term-number queue
         // pays in a loop that runs as often as the BUSIEST lane of every single word has matches, runs in these balanced steps too.
-#ifndef KT_AGG_WQ
-#define KT_AGG_WQ 3
-#endif
+#ifdef KT_AGG_WQ
         constexpr int kWq = KT_AGG_WQ;
+#else
+        constexpr int kWq = 4;  // (measured on the configs[4] shard: 2 words 0.512, 3: 0.484, 4: 0.476, 5: 0.483 ms)
+#endif
         uint64_t qx[kWq];
         // word numbers, 10 bits each (newest lowest: cut_chunks keeps a chunk below 1024 words); entries in use
         typedef typename std::conditional<(kWq > 3), uint64_t, uint32_t>::type qw_t;

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency $*"
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --min-seconds 0 --no-extra --no-cpu-baseline --no-latency $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.json 2> $OUT/fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.json 2> $OUT/write.err

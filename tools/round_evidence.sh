@@ -10,11 +10,15 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfg2_driver.json 2> $OUT/${TAG}_bench_cfg2_driver.err; echo "bench cfg2 (driver arguments): exit $?"
-timeout 300 python bench.py --config 2 --steps 2000 --warmup 20 --no-cpu-baseline --no-latency > $OUT/${TAG}_bench_cfg2.json 2> $OUT/${TAG}_bench_cfg2.err; echo "bench cfg2: exit $?"
+timeout 300 python bench.py --config 2 --steps 2000 --warmup 20 --no-cpu-baseline --no-latency --no-extra > $OUT/${TAG}_bench_cfg2.json 2> $OUT/${TAG}_bench_cfg2.err; echo "bench cfg2: exit $?"
 for cfg in 3 1 4; do
   timeout 400 python bench.py --config $cfg --steps 200 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_cfg${cfg}.json 2> $OUT/${TAG}_bench_cfg${cfg}.err; echo "bench cfg$cfg: exit $?"
 done
 timeout 400 python bench.py --config 2 --pods-per-gpu 4000000 --steps 200 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_cfg2_4M.json 2> $OUT/${TAG}_bench_cfg2_4M.err; echo "bench cfg2 4M pods: exit $?"
+# D = 16 resource names / L = 16 labels per pod (not BASELINE configurations: the product path beyond 8 of each)
+timeout 300 python bench.py --config 2 --dims 16 --steps 300 --warmup 10 --no-cpu-baseline --no-latency > $OUT/${TAG}_bench_cfg2_D16.json 2> $OUT/${TAG}_bench_cfg2_D16.err; echo "bench cfg2 D=16: exit $?"
+timeout 300 python bench.py --config 2 --labels 16 --steps 300 --warmup 10 --no-cpu-baseline --no-latency > $OUT/${TAG}_bench_cfg2_L16.json 2> $OUT/${TAG}_bench_cfg2_L16.err; echo "bench cfg2 L=16: exit $?"
+timeout 300 python bench.py --config 4 --sweep --steps 200 --warmup 10 --no-cpu-baseline --no-latency > $OUT/${TAG}_bench_cfg4_sweep.json 2> $OUT/${TAG}_bench_cfg4_sweep.err; echo "bench cfg4 (kt_sweep_launch): exit $?"
 for f in $OUT/${TAG}_bench_cfg*.json; do python - "$f" <<'PY'
 import json, sys
 try:
