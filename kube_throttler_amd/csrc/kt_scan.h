@@ -131,10 +131,13 @@ __device__ __forceinline__ void lds_stage_segments(KT_LDS unsigned char* lds, co
     u32x4 v[DEPTH];
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
-      uint32_t d;
-      uint64_t sp;
-      const uint32_t off = locate(min(base + (uint32_t)j * kBlockIx, total - 1u), d, sp);
-      v[j] = ((const u32x4*)sp)[off];
+      const uint32_t i = base + (uint32_t)j * kBlockIx;
+      if (i < total) {  // (no piece is requested twice: a 44 KB image is 2.75 pieces per thread, not eight)
+        uint32_t d;
+        uint64_t sp;
+        const uint32_t off = locate(i, d, sp);
+        v[j] = ((const u32x4*)sp)[off];
+      }
     }
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
