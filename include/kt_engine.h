@@ -121,7 +121,10 @@ int32_t kt_upsert_pod(kt_engine* e, int64_t pod_row, uint32_t ns, uint32_t flags
 /* amounts of the throttle as four rows — 0 spec.threshold, 1 status.calculatedThreshold.threshold, 2 status.used,
  * 3 reserved: amt_v [4][D], amt_present [4], amt_count [4], amt_has_count [4].  Overrides: n_ovr rows (ovr_v [n_ovr][D]).
  * Selector: n_terms terms; term_preq_off / term_nreq_off [n_terms+1] index the two requirement pools, each given as
- * (n, op [n], key [n], val_off [n+1], val []) like kt_reqs. */
+ * (n, op [n], key [n], val_off [n+1], val []) like kt_reqs.  The shapes are held against each other before anything is
+ * stored (offset arrays start at 0 and never decrease, operators are KT_OP_*, masks name dimensions below n_dims, term flags
+ * are KT_TERM_*): a slice passed in the wrong position answers KT_ERR_INVALID_ARGUMENT naming the argument (kt_last_error)
+ * instead of feeding a wrong selector silently. */
 int32_t kt_upsert_throttle(kt_engine* e, int32_t thr_row, uint32_t flags, uint32_t ns, const int64_t* amt_v,
                            const uint32_t* amt_present, const int64_t* amt_count, const uint8_t* amt_has_count,
                            uint32_t thrl_flag, uint32_t thrl_has, uint64_t status_msgs_fp, uint64_t spec_msgs_fp, int32_t n_ovr,

@@ -1743,6 +1743,33 @@ int32_t kt_upsert_throttle(kt_engine* e, int32_t thr_row, uint32_t flags, uint32
   if (n_terms > 0 && (term_preq_off[n_terms] > n_preq || term_nreq_off[n_terms] > n_nreq))
     return e->fail(KT_ERR_OUT_OF_RANGE, "selector terms reference %u / %u requirements, pools hold %u / %u", term_preq_off[n_terms],
                    term_nreq_off[n_terms], n_preq, n_nreq);
+  // 37 positional arguments: one slice in the wrong position is a silent mis-feed unless the shapes are held against each
+  // other here — offsets start at 0 and never decrease, every operator is one of the four, masks name existing dimensions
+  auto bad = [&](const char* what, long long i, long long v) {
+    return e->fail(KT_ERR_INVALID_ARGUMENT, "kt_upsert_throttle(row %d): %s[%lld] = %lld does not fit the other arguments", thr_row, what, i, v);
+  };
+  const uint32_t dmask = D >= 32 ? ~0u : (1u << D) - 1u;
+  for (int k = 0; k < 4; ++k)
+    if (amt_present[k] & ~dmask) return bad("amt_present", k, amt_present[k]);
+  if ((thrl_has | thrl_flag) & ~dmask) return bad("thrl_has | thrl_flag", 0, thrl_has | thrl_flag);
+  for (int32_t o = 0; o < n_ovr; ++o)
+    if (ovr_present[o] & ~dmask) return bad("ovr_present", o, ovr_present[o]);
+  if (n_terms > 0 && (term_preq_off[0] != 0u || term_nreq_off[0] != 0u)) return bad("term_preq_off / term_nreq_off", 0, term_preq_off[0] | term_nreq_off[0]);
+  for (int32_t t = 0; t < n_terms; ++t) {
+    if (term_preq_off[t + 1] < term_preq_off[t]) return bad("term_preq_off", t + 1, term_preq_off[t + 1]);
+    if (term_nreq_off[t + 1] < term_nreq_off[t]) return bad("term_nreq_off", t + 1, term_nreq_off[t + 1]);
+    if (term_flags[t] & ~(KT_TERM_POD_SEL_INVALID | KT_TERM_NS_SEL_INVALID)) return bad("term_flags", t, term_flags[t]);
+  }
+  struct Pool { const char* name; uint32_t n; const uint8_t* op; const uint32_t* val_off; const uint32_t* val; };
+  const Pool pools[2] = {{"preq", n_preq, preq_op, preq_val_off, preq_val}, {"nreq", n_nreq, nreq_op, nreq_val_off, nreq_val}};
+  for (const Pool& pl : pools) {
+    if (pl.n && pl.val_off[0] != 0u) return bad(pl.name, 0, pl.val_off[0]);
+    for (uint32_t r = 0; r < pl.n; ++r) {
+      if (pl.op[r] > KT_OP_DOES_NOT_EXIST) return bad(pl.name, r, pl.op[r]);
+      if (pl.val_off[r + 1] < pl.val_off[r]) return bad(pl.name, r + 1, pl.val_off[r + 1]);
+    }
+    if (pl.n && pl.val_off[pl.n] > 0u && !pl.val) return bad(pl.name, pl.n, pl.val_off[pl.n]);
+  }
   return kt_upsert_throttles(e, &b, &thr_row);
 }
 

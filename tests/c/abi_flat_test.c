@@ -133,6 +133,27 @@ int main(int argc, char** argv) {
         memcpy(av + (size_t)k * D, amt_v[k] + (size_t)i * D, (size_t)D * 8);
         ap[k] = amt_p[k][i], ac[k] = amt_c[k][i], ah[k] = amt_h[k][i];
       }
+      if (i == 0) { /* shapes that do not fit each other are refused (a slice in the wrong position must not be a silent mis-feed) */
+        const uint8_t one_flag[1] = {0}, bad_op[1] = {9}, in_op[1] = {KT_OP_IN};
+        const uint32_t one_term[2] = {0, 1}, no_req[2] = {0, 0}, key1[1] = {1}, dec_off[2] = {2, 1}, ok_off[2] = {0, 1}, val1[1] = {7};
+        const uint32_t late_start[2] = {1, 1};
+        int32_t rc;
+#define KT_EXPECT_INVALID(call)                                                              \
+  rc = (call);                                                                               \
+  if (rc != KT_ERR_INVALID_ARGUMENT) {                                                       \
+    fprintf(stderr, "abi_flat_test: %s -> %d, expected KT_ERR_INVALID_ARGUMENT\n", #call, rc); \
+    return 4;                                                                                \
+  }
+        KT_EXPECT_INVALID(kt_upsert_throttle(e, i, thr_flags[i], thr_ns[i], av, ap, ac, ah, 0, 0, 0, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                                             NULL, 1, one_flag, one_term, no_req, 1, in_op, key1, dec_off, val1, 0, NULL, NULL, NULL, NULL));
+        KT_EXPECT_INVALID(kt_upsert_throttle(e, i, thr_flags[i], thr_ns[i], av, ap, ac, ah, 0, 0, 0, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                                             NULL, 1, one_flag, one_term, no_req, 1, bad_op, key1, ok_off, val1, 0, NULL, NULL, NULL, NULL));
+        KT_EXPECT_INVALID(kt_upsert_throttle(e, i, thr_flags[i], thr_ns[i], av, ap, ac, ah, 0, 0, 0, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                                             NULL, 1, one_flag, late_start, no_req, 1, in_op, key1, ok_off, val1, 0, NULL, NULL, NULL, NULL));
+        KT_EXPECT_INVALID(kt_upsert_throttle(e, i, thr_flags[i], thr_ns[i], av, ap, ac, ah, 0xFFFF0000u, 0xFFFF0000u, 0, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL,
+                                             NULL, NULL, NULL, 1, one_flag, one_term, no_req, 1, in_op, key1, ok_off, val1, 0, NULL, NULL, NULL, NULL));
+#undef KT_EXPECT_INVALID
+      }
       CK(kt_upsert_throttle(e, i, thr_flags[i], thr_ns[i], av, ap, ac, ah, thrl_flag[i], thrl_has[i], status_fp[i], spec_fp[i], (int32_t)(o1 - o0),
                             ovr_begin_s + o0, ovr_begin_ns + o0, ovr_end_s + o0, ovr_end_ns + o0, ovr_flags + o0, ovr_v + (size_t)o0 * D,
                             ovr_present + o0, ovr_count + o0, ovr_hc + o0, (int32_t)nt, term_flags + t0, poff, noff, r1[0] - r0[0],
