@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -102,6 +103,44 @@ void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t 
       }
   }, nullptr);
 }
+
+// Atom ids and home slots.  A pod carries at most one atom per key, and the scans read, for every visited word, the pod's
+// atom rows slot by slot — one gather per slot, lane = pod.  LDS serves the lanes of a gather that fall into distinct
+// bank slots in one pass, and the cell of (row id, word w) sits in bank slot id mod 32 of the word's column (kt_index.h:
+// image layout).  Hence:
+//   * every KEY gets a home slot (the keys with the most atoms first, each to the slot with the fewest atoms so far) and
+//     kt_translate_pods puts a pod's atom of that key there when the slot is free: lane by lane, a gather reads atoms of
+//     the same few keys;
+//   * the atoms of a slot are numbered side by side (key by key): any 32 consecutive ids fall into 32 distinct bank slots,
+//     so the distinct atoms of one slot collide only where the slot holds more than 32 atoms.
+// A program that names no more keys than the pods have slots is scanned without bank conflicts this way.  The BASELINE
+// programs name 16 keys of which a pod carries 8 in 8 slots: two keys share a home, a quarter of the atoms sit in a foreign
+// slot, and the LDS bank model of tests/cpp/index_sim_test.cpp (KT_SIM_BANKS=1) counts 2.4 passes per gather in namespace
+// order where the numbering by pair id had 2.5 (profiles/r05_lds_bank_model.txt has the model and what the GPU said).
+static void number_atoms_by_home_slot(HostIndex& out) {
+  const uint32_t la = out.la;
+  std::map<uint32_t, std::vector<uint32_t>> of_key;  // key -> entries of out.atoms (ascending atom)
+  for (uint32_t i = 0; i < out.atoms.size(); ++i) of_key[out.atom_key[i]].push_back(i);
+  std::vector<std::pair<uint32_t, uint32_t>> keys;  // (atoms, key)
+  for (auto& kv : of_key) keys.emplace_back((uint32_t)kv.second.size(), kv.first);
+  std::sort(keys.begin(), keys.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+    return a.first != b.first ? a.first > b.first : a.second < b.second;
+  });
+  std::vector<uint32_t> load(la, 0u);
+  std::vector<std::vector<uint32_t>> keys_of_slot(la);
+  for (auto& k : keys) {
+    uint32_t best = 0;
+    for (uint32_t sl = 1; sl < la; ++sl)
+      if (load[sl] < load[best]) best = sl;
+    load[best] += k.first;
+    keys_of_slot[best].push_back(k.second);
+  }
+  uint32_t next = 1;
+  for (uint32_t sl = 0; sl < la; ++sl)
+    for (uint32_t key : keys_of_slot[sl])
+      for (uint32_t i : of_key[key]) out.atoms[i].id = next++, out.atoms[i].home = sl;
+}
+
 
 void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, const std::vector<uint32_t>& term_thr,
                  const std::vector<uint8_t>& term_flags, const std::vector<uint32_t>& term_req_off,
@@ -570,13 +609,15 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       for (auto& kv : pairs_of_key)
         for (uint32_t a : kv.second) key_of_pair.emplace(a, kv.first);
       for (uint32_t i = 0; i < atoms.size(); ++i) {
-        out.atoms.push_back(AtomId{atoms[i], i + 1});
+        out.atoms.push_back(AtomId{atoms[i], 0u, 0u});
         out.atom_key.push_back((atoms[i] & kKeyAtom) ? (atoms[i] & ~kKeyAtom) : key_of_pair[atoms[i]]);
       }
+      number_atoms_by_home_slot(out);
     }
   }
   const uint32_t A = (uint32_t)out.atoms.size();
-  const uint32_t R = A + 1;
+  uint32_t R = 1;  // (an imposed numbering may have holes)
+  for (const AtomId& ai : out.atoms) R = std::max(R, ai.id + 1u);
   out.bm_rows = R;
   std::unordered_map<uint32_t, uint32_t> row_of;
   row_of.reserve(A * 2 + 1);
@@ -588,7 +629,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     for (const AtomId& ai : out.atoms) {
       uint32_t s = atom_slot(ai.atom, (uint32_t)n - 1);
       while (out.atom_table[s] != 0ull) s = (s + 1) & ((uint32_t)n - 1);
-      out.atom_table[s] = (uint64_t)ai.atom | (uint64_t)ai.id << 32;
+      out.atom_table[s] = (uint64_t)ai.atom | (uint64_t)ai.id << 32 | (uint64_t)ai.home << kAtomHomeShift;
     }
   }
   lap("numbering + atom ids");
@@ -624,7 +665,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       while (out.atom_table[sl] != 0ull && (uint32_t)out.atom_table[sl] != atom_pool[q]) sl = (sl + 1) & mask;
       // (an imposed numbering may lack a pair this program names — an anchor veto on a value no term that can match names:
       //  no pod carries it as an atom, row 0 = "no row")
-      pool_row[q] = (uint32_t)(out.atom_table[sl] >> 32);
+      pool_row[q] = (uint32_t)(out.atom_table[sl] >> 32) & kAtomIdMask;
     }
   }, nullptr);
   {
@@ -708,7 +749,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   lap("hand-off of the scratch containers");
   // chunks for chk_budget (two check workgroups per CU) — unless the caller wants larger chunks when the program needs
   // several anyway (chk_budget_full) and it plainly does: then only that cut is made
-  const size_t rows_bytes = (size_t)R * W * 8u * (veto ? 2u : 1u);
+  const size_t rows_bytes = (size_t)image_col_rows(R) * W * 8u * (veto ? 2u : 1u);
   if (chk_budget_full && rows_bytes > (size_t)chk_budget) cut_chunks(out, agg_budget, chk_budget_full, thr_bytes, chk_word);
   else cut_chunks(out, agg_budget, chk_budget, thr_bytes, chk_word);
   lap("cut_chunks");
@@ -742,6 +783,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   for (uint32_t n = 0; n < n_ns; ++n)
     for (uint32_t w = 0; w < W; ++w) ns_per_word[w] += nsrows[(size_t)n * W + w] != 0;
   const size_t fam = veto ? 2 : 1;
+  const uint32_t Rp = image_col_rows(R);
   // the form of every word (NsWord::flags): does some atom row hold a veto bit in it, does some term need three hits
   std::vector<uint32_t> word_form(W, 0u);
   for (uint32_t w = 0; w < W; ++w) word_form[w] = hdr[w].m3 != 0ull ? kNsWordNeed3 : 0u;
@@ -752,7 +794,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   uint64_t slab_run = 0;
   out.bm_chunks.clear();
   out.bm_images.clear();
-  out.bm_images.reserve(((size_t)R * W * 8 * (veto ? 2 : 1) + (size_t)W * (sizeof(WordHdr) + 64 * 10 + 64)) * 5 / 4 + ((size_t)n_ns + 8) * 4 * 64);  // (one allocation instead of a regrowth per chunk)
+  out.bm_images.reserve(((size_t)image_col_rows(R) * W * 8 * (veto ? 2 : 1) + (size_t)W * (sizeof(WordHdr) + 64 * 10 + 64)) * 5 / 4 + ((size_t)n_ns + 8) * 4 * 64);  // (one allocation instead of a regrowth per chunk)
   out.bm_chunk_ns.clear();
   const uint32_t nsw = (n_ns + 31) / 32;
   out.ns_words = nsw ? nsw : 1u;
@@ -769,8 +811,7 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
         if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
       const uint32_t nthr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
       const size_t nw = cand - w0;
-      const size_t lds = align16((size_t)R * (nw | 1) * 8 * fam) + nw * sizeof(WordHdr) + align16(((size_t)n_ns + 1) * 4) +
-                         nsl_entries * sizeof(NsWord);
+      const size_t lds = (size_t)Rp * nw * 8 * fam + nw * sizeof(WordHdr) + align16(((size_t)n_ns + 1) * 4) + nsl_entries * sizeof(NsWord);
       // the kernels lay LDS out ONCE for all chunks — the largest image next to the tables of the largest chunk —
       // so a chunk has to fit together with the maxima of the chunks cut before it, not only on its own
       const size_t lds_hi = std::max(lds, (size_t)out.bm_max_lds);
@@ -790,21 +831,19 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
     BmChunk ch{};
     ch.w0 = w0, ch.n_words = w1 - w0;
     ch.ns_base = 0u, ch.ns_cnt = 0xFFFFFFFFu;
-    ch.stride = ch.n_words | 1u;
+    ch.col_rows = Rp;
     r_lo = ~0u, r_hi = 0;
     for (size_t c = (size_t)w0 * 64; c < (size_t)w1 * 64; ++c)
       if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
     ch.rank0 = r_lo == ~0u ? 0 : r_lo;
     ch.n_thr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
-    std::vector<uint64_t> irows((size_t)R * ch.stride * fam, 0ull);
+    // planes of word columns: any[w][Rp], then (rich) veto[w][Rp]
+    std::vector<uint64_t> irows((size_t)Rp * ch.n_words * fam, 0ull);
+    const size_t veto_plane = (size_t)Rp * ch.n_words;
     for (uint32_t r = 0; r < R; ++r)
       for (uint32_t w = 0; w < ch.n_words; ++w) {
-        if (veto) {
-          irows[((size_t)r * ch.stride + w) * 2] = any[(size_t)r * W + w0 + w];
-          irows[((size_t)r * ch.stride + w) * 2 + 1] = vet[(size_t)r * W + w0 + w];
-        } else {
-          irows[(size_t)r * ch.stride + w] = any[(size_t)r * W + w0 + w];
-        }
+        irows[(size_t)w * Rp + r] = any[(size_t)r * W + w0 + w];
+        if (veto) irows[veto_plane + (size_t)w * Rp + r] = vet[(size_t)r * W + w0 + w];
       }
     std::vector<WordHdr> ihdr(hdr.begin() + w0, hdr.begin() + w1);
     std::vector<uint32_t> nsl_off((size_t)n_ns + 1, 0u);

@@ -84,8 +84,12 @@ constexpr uint32_t kNsWordNeed3 = 2u;  // some term of this word needs three pos
 // straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers.
 // Image layout (all offsets relative to img_off, every section 16-byte aligned):
 //   [0, lds_bytes)        what the scan keeps in LDS:  rows | WordHdr[n_words] | nsl_off u32[n_ns+1] | NsWord[]
-//     rows: u64 [n_rows][stride]        (program without negative requirements)
-//           u64 [n_rows][stride][2]     {any, veto} interleaved (one 128-bit read per atom and word)
+//     rows: u64 any[n_words][col_rows]            one COLUMN per word: the cell of (row id, word w) at (w * col_rows + id) * 8
+//           u64 veto[n_words][col_rows] behind it  (programs with negative requirements: the rich form)
+//       col_rows = the rows rounded up to 32 (image_col_rows): a column is a whole number of LDS bank rounds, so the bank
+//       slot of a cell is id mod 32 whatever the word — what a gather's lanes collide on is decided by the atom numbering
+//       alone (kt_index.cpp: number_atoms_by_home_slot), for lanes that visit different words as for lanes that visit the
+//       same.  (Until round 4: [row][odd stride] cells of 8 or 16 {any, veto} bytes — 3.1-3.3 LDS passes per gather.)
 //   off_term_t            u32 [n_words*64]  throttle row | kTerm*       (check: staged into LDS next to the CheckRec flags)
 //   off_term_rank         u16 [n_words*64]  chunk-local rank | kRankAdj  (aggregate)
 //   off_term_g            u32 [n_words*64]  selector-program term of the number (only read for `slow` candidates)
@@ -95,7 +99,7 @@ struct BmChunk {
   uint32_t img_off, lds_bytes;
   uint32_t off_hdr, off_nsl_off, off_nsl;
   uint32_t off_term_t, off_term_rank, off_term_g;
-  uint32_t stride;    // 64-bit words per row and family inside the image (odd: column reads spread over LDS banks)
+  uint32_t col_rows;  // cells per word column of a plane (rows rounded up to 32)
   uint32_t slab_off;  // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
   uint32_t has_slow;  // some term of the chunk needs the generic walk
   uint32_t img_bytes;
@@ -107,9 +111,15 @@ struct BmChunk {
   uint32_t ns_base, ns_cnt;
 };
 
+inline uint32_t image_col_rows(uint32_t rows) { return (rows + 31u) & ~31u; }
+
 struct AtomId {
   uint32_t atom, id;
+  uint32_t home;  // the atom slot of a pod's row kt_translate_pods tries first (the home slot of the atom's key)
 };
+// atom_table entry: atom | id << 32 | home slot << 48 (0 = empty)
+constexpr int kAtomHomeShift = 48;
+constexpr uint32_t kAtomIdMask = 0xFFFFu;
 
 struct HostIndex {
   std::vector<uint32_t> slow_thr;
@@ -124,7 +134,7 @@ struct HostIndex {
   bool rich = false;      // image in the {any, veto} form, kernels in the <VETO, NEED 3> instantiation
   std::vector<AtomId> atoms;               // referenced atom -> id (1..A)
   std::vector<uint32_t> atom_key;          // key id of every entry of `atoms` (a pair's key; a key atom's own key)
-  std::vector<uint64_t> atom_table;        // open-addressing table for the device: atom | id << 32, 0 = empty
+  std::vector<uint64_t> atom_table;        // open-addressing table for the device: atom | id << 32 | home slot << 48, 0 = empty
   std::vector<BmChunk> bm_chunks;
   std::vector<unsigned char> bm_images;    // chunk images back to back
   std::vector<uint32_t> bm_rank_t;         // dense rank (one per group, number order) -> throttle row

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void kt_delete_pods(PodTable pods, int64_t 
 // are dropped.  Runs over all pods after a program change and over the ingested rows after an upsert.  One thread per
 // pod; the atom row is assembled in LDS and written with 16-byte stores.
 // ---------------------------------------------------------------------------------------------------
+// -> id | home slot << 16 (0: the program does not refer to the atom)
 __device__ __forceinline__ uint32_t atom_id_of(const uint64_t* table, uint32_t mask, uint32_t atom) {
   uint32_t s = atom_slot(atom, mask);
   for (;;) {
@@ -105,18 +106,36 @@ __device__ __forceinline__ void translate_one(const PodTable& pods, int64_t row,
                                               unsigned long long* n_overflow, uint16_t* out) {
   const int LS = pods.LS;
   uint32_t cnt = 0;
+  // Every atom goes to the HOME slot of its key when that is free (kt_index.cpp: number_atoms_by_home_slot — the lanes of a
+  // scan then read, slot by slot, atoms that were numbered side by side: distinct LDS banks); the few that find it taken
+  // (two keys of one pod with the same home: only programs that name more keys than there are slots) take the free slots
+  // in label order afterwards.  Any order is CORRECT: the scans accumulate the rows with symmetric functions.
+  uint32_t taken = 0;           // slots in use
+  unsigned long long late = 0;  // labels whose atom found its home taken
+#pragma unroll
+  for (int k = 0; k < LA; ++k) out[k] = 0;
   for (int l = 0; l < LS; ++l) {
     const uint32_t pr = pods.lpair[row * LS + l];
     if (pr == 0u) continue;  // empty slot
     // one atom per label: the pair when some selector names it, else the key atom when some selector names the key
-    uint32_t id = atom_id_of(table, mask, pr);
-    if (!id && key_atoms) id = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
-    if (id) {
-      if (cnt < (uint32_t)LA) out[cnt] = (uint16_t)id;
+    uint32_t e = atom_id_of(table, mask, pr);
+    if (!e && key_atoms) e = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
+    if (e) {
+      const uint32_t home = (e >> 16) & (uint32_t)(LA - 1);
+      if (!((taken >> home) & 1u)) out[home] = (uint16_t)e, taken |= 1u << home;
+      else late |= 1ull << l;  // (LS <= 64)
       ++cnt;
     }
   }
-  for (uint32_t k = cnt; k < (uint32_t)LA; ++k) out[k] = 0;
+  if (late != 0ull && cnt <= (uint32_t)LA) {
+    for (int l = 0; l < LS; ++l) {
+      if (!((late >> l) & 1ull)) continue;
+      uint32_t e = atom_id_of(table, mask, pods.lpair[row * LS + l]);
+      if (!e) e = atom_id_of(table, mask, kKeyAtom | pods.lkey[row * LS + l]);
+      const uint32_t free_slot = (uint32_t)__ffs((int)~taken) - 1u;  // (cnt <= LA: there is one)
+      out[free_slot] = (uint16_t)e, taken |= 1u << free_slot;
+    }
+  }
   const bool over = cnt > (uint32_t)LA;
   const uint64_t m = pods.meta[row];
   if (over) {

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       }
       const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
       uint32_t ro[LA];
-      atom_row_offsets<LA>(raw, bm.row_bytes, ro);
+      atom_row_offsets<LA>(raw, ro);
 
       // ---- throttles with unconvertible selectors have no rank: walked once (with the first chunk), straight to the
       //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).

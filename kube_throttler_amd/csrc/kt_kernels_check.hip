@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       const uint32_t ns_ok_raw = a.ns_valid[ns];
       bool pod_err = (carried & 2ull) != 0;
       uint32_t ro[LA];
-      atom_row_offsets<LA>(raw, bm.row_bytes, ro);
+      atom_row_offsets<LA>(raw, ro);
       uint32_t n_list = 0;  // wave-uniform
       uint32_t last_t = 0xFFFFFFFFu;
       // AGG: is the pod counted (shouldCountIn && isNotFinished: throttle_controller.go:217-219, pod_util.go:26-28), and

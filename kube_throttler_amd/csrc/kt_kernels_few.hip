@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
   u32x4 raw[LA / 8];
   load_atoms<LA>(a.latom, p, raw);
   uint32_t ro[LA];
-  atom_row_offsets<LA>(raw, ch.stride * (VETO ? 16u : 8u), ro);
+  atom_row_offsets<LA>(raw, ro);
   int64_t v[DT];
   load_requests<DT>(a.req, a.DS, p, v);
   const uint32_t* nsl_off = (const uint32_t*)(img + ch.off_nsl_off);
@@ -70,17 +70,12 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
     const uint32_t w = e.x;
     const WordHdr h = hdr[w];
     uint64_t any = h.univ, two = 0, three = 0, vet = 0;
-    const unsigned char* col = img + (size_t)w * (VETO ? 16u : 8u);
+    const unsigned char* col = img + (size_t)w * ch.col_rows * 8u;  // the word's column of the `any` plane
+    const unsigned char* colv = col + (size_t)ch.n_words * ch.col_rows * 8u;
 #pragma unroll
     for (int l = 0; l < LA; ++l) {
-      uint64_t r;
-      if (VETO) {
-        const u64x2 rv = *(const u64x2*)(col + ro[l]);
-        r = rv.x;
-        vet |= rv.y;
-      } else {
-        r = *(const unsigned long long*)(col + ro[l]);
-      }
+      const uint64_t r = *(const unsigned long long*)(col + ro[l]);
+      if (VETO) vet |= *(const unsigned long long*)(colv + ro[l]);
       if (NEED >= 3) three |= two & r;
       if (NEED >= 2) two |= any & r;
       any |= r;

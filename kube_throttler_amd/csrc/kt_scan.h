@@ -6,7 +6,8 @@
 //
 //   advance : every lane that still has words takes the next (word, namespace mask) entry of its namespace's list and
 //             accumulates its atom rows over that word: `any |= r`, `two |= any & r`, `three |= two & r`, `veto |= r'`
-//             (one ds_read per atom: 64 bits, or 128 bits {any, veto} when the program has negative requirements).
+//             (one 64-bit ds_read per atom from the word's column of the `any` plane, a second one from the veto plane
+//             when some row holds a veto bit in the word).
 //             A pod carries at most one atom of any requirement, so the accumulators count satisfied positive
 //             requirements per term and
 //                 x = select(need: any / two / three) & ~veto & nsmask
@@ -75,12 +76,13 @@ __device__ __forceinline__ uint32_t last_relevant_chunk(const BmIndexArgs& a, ui
 
 // The tables of the chunk that is resident in LDS
 struct BmView {
-  KT_LDS const unsigned char* rows;  // [n_rows][stride]{any} or [n_rows][stride]{any, veto}
+  KT_LDS const unsigned char* rows;  // any[n_words][col_rows], then (VETO) veto[n_words][col_rows]: 8-byte cells
   KT_LDS const WordHdr* hdr;         // [n_words]
   lds_u32p nsl_off;                  // [n_ns + 1]
   KT_LDS const NsWord* nsl;
   const uint32_t* term_g;            // (HBM) selector-program term of every number: `slow` candidates only
-  uint32_t row_bytes;                // bytes per atom row
+  uint32_t col_bytes;                // bytes per word column
+  uint32_t veto_off;                 // from a cell of the `any` plane to the same cell of the veto plane
   uint32_t has_slow;
 };
 
@@ -167,7 +169,8 @@ __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const Bm
   v.nsl_off = (lds_u32p)(base + ch.off_nsl_off);
   v.nsl = (KT_LDS const NsWord*)(base + ch.off_nsl);
   v.term_g = (const uint32_t*)(a.blob + ch.img_off + ch.off_term_g);
-  v.row_bytes = ch.stride * (VETO ? 16u : 8u);
+  v.col_bytes = ch.col_rows * 8u;
+  v.veto_off = VETO ? ch.n_words * ch.col_rows * 8u : 0u;
   v.has_slow = ch.has_slow;
   return v;
 }
@@ -211,8 +214,8 @@ __device__ __forceinline__ void count8(const uint64_t (&r)[8], uint64_t& ones, u
   twos = or3_64(c1, c2, c3) | maj3_64(s1, s2, s3);
 }
 
-// A pod's atom row (PodTable::latom, LA u16 ids) as byte offsets of its bitmap rows: LA/8 128-bit loads, issued from
-// an always-valid address.
+// A pod's atom row (PodTable::latom, LA u16 ids) as byte offsets of its cells inside a word column: LA/8 128-bit loads,
+// issued from an always-valid address.
 template <int LA>
 __device__ __forceinline__ void load_atoms(const uint16_t* latom, int64_t p, u32x4 (&raw)[LA / 8]) {
   const u32x4* a = (const u32x4*)(latom + p * LA);
@@ -220,18 +223,18 @@ __device__ __forceinline__ void load_atoms(const uint16_t* latom, int64_t p, u32
   for (int q = 0; q < LA / 8; ++q) raw[q] = a[q];
 }
 template <int LA>
-__device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uint32_t row_bytes, uint32_t (&ro)[LA]) {
+__device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uint32_t (&ro)[LA]) {
 #pragma unroll
   for (int q = 0; q < LA / 8; ++q) {
     const uint32_t w[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #ifdef KT_PROBE_ROW0  // timing probe (results are wrong): every lane reads row 0 — the gathers without their bank conflicts
-      ro[8 * q + 2 * k] = __umul24(w[k] & 0x0u, row_bytes);
-      ro[8 * q + 2 * k + 1] = __umul24(w[k] >> 31 >> 1, row_bytes);
+      ro[8 * q + 2 * k] = (w[k] & 0x0u) << 3;
+      ro[8 * q + 2 * k + 1] = w[k] >> 31 >> 1;
 #else
-      ro[8 * q + 2 * k] = __umul24(w[k] & 0xFFFFu, row_bytes);  // (16-bit id x row bytes < 2^24: the full-rate multiply)
-      ro[8 * q + 2 * k + 1] = __umul24(w[k] >> 16, row_bytes);
+      ro[8 * q + 2 * k] = (w[k] & 0xFFFFu) << 3;
+      ro[8 * q + 2 * k + 1] = (w[k] >> 16) << 3;
 #endif
     }
   }
@@ -289,7 +292,8 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
       w = e.x;
       const u64x2 h0 = *(KT_LDS const u64x2*)(b.hdr + w);  // {univ, m2}
       const auto pf = pre(w);
-      KT_LDS const unsigned char* col = b.rows + w * (VETO ? 16u : 8u);
+      KT_LDS const unsigned char* col = b.rows + __umul24(w, b.col_bytes);  // (word < 2^10, column bytes < 2^18)
+      KT_LDS const unsigned char* colv = col + b.veto_off;
       uint64_t xx, vet = 0;
       if (NEED >= 3) {
         // The FORM of the word (NsWord::flags — inside a class the groups are numbered by form, so most words are pure),
@@ -324,12 +328,12 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           if (w_veto) {
 #pragma unroll
             for (int l = 0; l < 8; ++l) {
-              const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[8 * g8 + l]);
-              r[l] = rv.x, v8[l] = rv.y;
+              r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
+              v8[l] = *(KT_LDS const unsigned long long*)(colv + ro[8 * g8 + l]);
             }
           } else {
 #pragma unroll
-            for (int l = 0; l < 8; ++l) r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]), v8[l] = 0ull;  // (the `any` half of the cell)
+            for (int l = 0; l < 8; ++l) r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]), v8[l] = 0ull;  // (the `any` plane only)
           }
           if (VETO) vet |= or3_64(or3_64(v8[0], v8[1], v8[2]), or3_64(v8[3], v8[4], v8[5]), v8[6] | v8[7]);
           if (w_need3) {
@@ -376,13 +380,8 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
           uint64_t r[8];
 #pragma unroll
           for (int l = 0; l < 8; ++l) {
-            if (VETO) {
-              const u64x2 rv = *(KT_LDS const u64x2*)(col + ro[8 * g8 + l]);
-              r[l] = rv.x;
-              vet |= rv.y;
-            } else {
-              r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
-            }
+            r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
+            if (VETO) vet |= *(KT_LDS const unsigned long long*)(colv + ro[8 * g8 + l]);
           }
           any = or3_64(or3_64(r[0], r[1], r[2]), or3_64(r[3], r[4], r[5]), or3_64(r[6], r[7], any));
           if (NEED >= 2) par = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], par));
