@@ -597,7 +597,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
     std::vector<uint32_t> atoms(distinct.begin(), distinct.end());
     out.la = atom_slots(out.n_keys, max_labels);
     // the simple instantiation <8 atoms, no veto family, need <= 2> covers matchLabels-style programs; everything else
-    // takes the rich one, whose images carry {any, veto} pairs
+    // takes the rich one, whose images carry a veto plane behind the `any` plane
     out.rich = out.has_veto || out.has_slow || out.max_need > 2 || out.la != 8;
     std::sort(atoms.begin(), atoms.end());
     atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());

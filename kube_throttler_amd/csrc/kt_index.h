@@ -74,7 +74,7 @@ struct alignas(16) NsWord {
 };
 // Inside a class (groups with one admission set) the groups are numbered by form — without / with a term of three
 // positive keys, without / with a negative requirement — so that most words of a rich program are pure: a word without
-// veto bits is scanned by reading the `any` half of every atom row only (8 bytes instead of 16 per atom: the scans of large
+// veto bits is scanned by reading the `any` plane only (8 bytes instead of 16 per atom: the scans of large
 // programs are bound by these LDS gathers), a word without need-3 terms takes the OR / XOR accumulation of the simple form
 // instead of the counting tree.  configs[4] shard: 54 % of the visited words carry no veto bit, 54 % no need-3 term.
 constexpr uint32_t kNsWordVeto = 1u;   // some atom row holds a veto bit in this word

@@ -299,7 +299,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
         // The FORM of the word (NsWord::flags — inside a class the groups are numbered by form, so most words are pure),
         // wave-uniform: the lanes of a tile in namespace order visit the same words; a tile whose lanes visit words of
         // different forms takes the general path, which is right for every word.
-        //   no veto bit in any row  : only the `any` half of every atom row is read (8 bytes per atom instead of 16: these
+        //   no veto bit in any row  : only the `any` plane is read (8 bytes per atom instead of 16: these
         //                             gathers are what the scans of large programs wait for)
         //   no need-3 term          : the OR / XOR accumulation of the simple form (below) instead of the counting tree
         // (only in the instantiations with room for it — the PIPE ones with eight atom slots: the 64-VGPR forms and the
