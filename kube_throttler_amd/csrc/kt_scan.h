@@ -81,6 +81,10 @@ struct BmView {
   lds_u32p nsl_off;                  // [n_ns + 1]
   KT_LDS const NsWord* nsl;
   const uint32_t* term_g;            // (HBM) selector-program term of every number: `slow` candidates only
+#ifdef KT_PROBE_UNIFORM
+  const unsigned char* img_g;        // (timing probe) the image in global memory: uniform per-word data through scalar loads
+  uint32_t off_nsl_g, off_hdr_g;
+#endif
   uint32_t col_bytes;                // bytes per word column
   uint32_t veto_off;                 // from a cell of the `any` plane to the same cell of the veto plane
   uint32_t has_slow;
@@ -169,6 +173,9 @@ __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const Bm
   v.nsl_off = (lds_u32p)(base + ch.off_nsl_off);
   v.nsl = (KT_LDS const NsWord*)(base + ch.off_nsl);
   v.term_g = (const uint32_t*)(a.blob + ch.img_off + ch.off_term_g);
+#ifdef KT_PROBE_UNIFORM
+  v.img_g = a.blob + ch.img_off, v.off_nsl_g = ch.off_nsl, v.off_hdr_g = ch.off_hdr;
+#endif
   v.col_bytes = ch.col_rows * 8u;
   v.veto_off = VETO ? ch.n_words * ch.col_rows * 8u : 0u;
   v.has_slow = ch.has_slow;
@@ -269,7 +276,17 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
   uint64_t x = 0;
   uint32_t w = 0;
   u32x4 e_next = {0u, 0u, 0u, 0u};
+#ifdef KT_PROBE_UNIFORM  // timing probe (wrong for tiles whose lanes differ in namespace): the list entry and the word header as
+                         // SCALAR loads from the image in L2, as if every lane of the tile walked the same list
+  typedef const __attribute__((address_space(4))) u32x4* cst_u4p;
+  auto entry_u = [&](uint32_t kk) -> u32x4 {
+    const uint32_t ku = __builtin_amdgcn_readfirstlane(kk);
+    return *(cst_u4p)(b.img_g + b.off_nsl_g + (size_t)ku * 16u);
+  };
+  if (PIPE) e_next = entry_u(k < k1 ? k : 0u);
+#else
   if (PIPE) e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));
+#endif
   for (;;) {
     const bool has = x != 0;
     if (__ballot(has) != 0ull) {
@@ -284,13 +301,23 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
       if (PIPE) {
         e = e_next;
         k += adv ? 1u : 0u;
+#ifdef KT_PROBE_UNIFORM
+        e_next = entry_u(k < k1 ? k : 0u);
+#else
         e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));  // the entry of the next advance, in flight behind this word's reads
+#endif
       } else {
         e = *(lds_u4p)(b.nsl + (adv ? k : 0u));
         k += adv ? 1u : 0u;
       }
       w = e.x;
+#ifdef KT_PROBE_UNIFORM
+      typedef const __attribute__((address_space(4))) u64x2* cst_u64x2p;
+      const uint32_t w_u = __builtin_amdgcn_readfirstlane(w);
+      const u64x2 h0 = *(cst_u64x2p)(b.img_g + b.off_hdr_g + (size_t)w_u * 32u);
+#else
       const u64x2 h0 = *(KT_LDS const u64x2*)(b.hdr + w);  // {univ, m2}
+#endif
       const auto pf = pre(w);
       KT_LDS const unsigned char* col = b.rows + __umul24(w, b.col_bytes);  // (word < 2^10, column bytes < 2^18)
       KT_LDS const unsigned char* colv = col + b.veto_off;
@@ -350,7 +377,11 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
             c1 = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], c1));
           }
         }
+#ifdef KT_PROBE_UNIFORM
+        const u64x2 h1 = *(cst_u64x2p)(b.img_g + b.off_hdr_g + (size_t)w_u * 32u + 16u);
+#else
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
+#endif
         if (w_need3) {
           const uint64_t any = or3_64(h0.x, c0, c1), two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
           xx = mux_64(any, two, h0.y);    // (any & ~m2) | (two & m2)
