@@ -335,7 +335,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
         constexpr bool FORMS = PIPE && LA == 8;
         const bool w_veto = VETO && (!FORMS || __ballot(adv && (e.y & kNsWordVeto) != 0u) != 0ull);
 #ifdef KT_WORD_FORM_NEED3
-        const bool w_need3 = __ballot(adv && (e.y & kNsWordNeed3) != 0u) != 0ull;
+        const bool w_need3 = !FORMS || __ballot(adv && (e.y & kNsWordNeed3) != 0u) != 0ull;
 #else
         const bool w_need3 = true;  // (the OR / XOR path saves VALU only, and the instantiations with 128 VGPRs spill over it)
 #endif
