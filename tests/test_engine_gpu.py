@@ -1183,7 +1183,7 @@ def test_reconcile_after_a_larger_scan_of_the_same_engine(oracle_mod):
 
 @pytest.mark.parametrize("preset", [2, 3])
 def test_reconcile_stress_fresh_engines(oracle_mod, preset):
-    """configs[2] / [3]: KT_STRESS_ROUNDS (default 60; tools/gpu_stress.sh runs 500) reconciles, each on a FRESH engine,
+    """configs[2] / [3]: KT_STRESS_ROUNDS (default 60; profiles/r05_stress.log: 300) reconciles, each on a FRESH engine,
     against ONE oracle result — between rounds device memory of many sizes is filled with 0xFF and freed, so that a read
     of memory no launch wrote cannot hide behind an allocator that hands back zeroed pages.  Every fifth engine
     reconciles three times more (the meeting of throttles with several groups runs again on warm caches)."""
