@@ -316,6 +316,10 @@ const char* kt_kernel_name(kt_engine* e, int32_t kernel);
 #define KT_COUNTER_INDEX_WORDS 3  /* 64-bit words of term numbers of the compiled program (all chunks) */
 #define KT_COUNTER_NS_WORD_VISITS 4 /* sum over the namespace rows in use of the words a pod of that namespace visits */
 #define KT_COUNTER_NS_ROWS 5      /* namespace rows the compiled program covers */
+#define KT_COUNTER_NS_CHUNK_VISITS 6  /* sum over the namespace rows of the index chunks that hold a word list of the row: the chunk
+                                         passes a namespace-ordered scan makes per namespace, summed */
+#define KT_COUNTER_INDEX_IMAGE_WORDS 7 /* words over all chunk images (>= INDEX_WORDS: the grouped plan keeps copies of a word in
+                                          the chunks of every group of namespaces that visits it) */
 int64_t kt_counter(kt_engine* e, int32_t which);
 /* ---- More resource names than one engine has dimensions (KT_MAX_DIMS): PAGES.  The reference sums and compares any resource
  *      name (pkg/resourcelist/resourcelist.go:27-54, resource_amount.go:127-159).  The host builds the same cluster once per

@@ -191,6 +191,9 @@ struct kt_engine {
   unsigned __int128 max_abs[KT_MAX_DIMS] = {0};  // max |effective request| bound per dimension
   uint64_t or_abs[KT_MAX_DIMS] = {0};            // OR of every |request| fed: its trailing zero bits are common to all of them
   kt::PackPlan pack;                             // packed fold of the current scan view (nw == 0: plain fold)
+  bool cut_plain = false;                        // a scan needed the plain fold: the index chunks stay cut for plain records
+  void* cur_launch_lock = nullptr;               // the LaunchLock of the launch-side call in progress (set and cleared under op_mu)
+  std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0};
   DevBuf<uint64_t> d_vc_pk;                      // packed request words of the countable list, scan order
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
@@ -456,13 +459,23 @@ struct StateLock {
 // recompile or re-upload state those checks read (the dirty flags are only written under op_mu + exclusive mu, so reading
 // them with op_mu held is safe)
 struct LaunchLock {
+  kt_engine* e;
   std::unique_lock<std::mutex> op;
   std::unique_lock<std::shared_mutex> ex;
   std::shared_lock<std::shared_mutex> sh;
-  explicit LaunchLock(kt_engine* e, bool force_exclusive = false) : op(e->op_mu) {
+  explicit LaunchLock(kt_engine* e_, bool force_exclusive = false) : e(e_), op(e_->op_mu) {
     if (force_exclusive || e->program_dirty || e->status_host_dirty) ex = std::unique_lock<std::shared_mutex>(e->mu);
     else sh = std::shared_lock<std::shared_mutex>(e->mu);
+    e->cur_launch_lock = this;  // (op_mu is held: one launch-side call at a time)
     settle_ingest(e);
+  }
+  ~LaunchLock() { e->cur_launch_lock = nullptr; }
+  // a launch that finds it has to change state a few-pod check reads after all (the index cut again for plain records):
+  // shared -> exclusive.  op_mu stays held, so no other launch / feed call comes between; few-pod checks may.
+  void upgrade() {
+    if (!sh.owns_lock()) return;
+    sh.unlock();
+    ex = std::unique_lock<std::shared_mutex>(e->mu);
   }
 };
 // CheckRecs about to be rewritten IN PLACE: no few-pod check may start on them (recs_valid = false under recs_mu) and
@@ -827,8 +840,12 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const char* hook = getenv("KT_CHUNK_BUDGET");
     const uint32_t lds_all = 160u * 1024u;
     const uint32_t agg_budget = hook ? (uint32_t)atoi(hook) : lds_all - kt::aggregate_fixed_lds();
-    uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
-    if (const char* tb = getenv("KT_CUT_THR_BYTES")) thr_bytes = (uint32_t)atoi(tb);  // (experiment: cut for the packed fold's records)
+    const uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
+    // a program of several chunks is cut for the packed fold's records (at most 40 bytes: PackPlan) while this engine's scans
+    // can pack — a chunk then holds more words, a namespace-ordered scan makes fewer chunk passes; the first scan that needs
+    // the plain fold (a negative request, sums beyond int64, KT_NO_PACK) has the program cut again for plain records
+    // (aggregate_locked: cut_plain)
+    const uint32_t thr_packed = (!e->incremental && !e->wide && !e->neg_seen && !e->cut_plain && !e->sw[kSw_NO_PACK]) ? kt::kPackedRecMax : 0u;
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();
@@ -836,14 +853,20 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const bool full_when_chunked = !hook && !getenv("KT_CHUNK_HALF");
     kt::build_index(e->hindex, thr_term_off, term_thr, term_flags, term_req_off, req_op, req_key, req_val_off, req_val, thr_info,
                     (uint32_t)NS, ns_term_ok, gw, agg_budget, chk_half, thr_bytes, e->L, &adm_all,
-                    full_when_chunked ? lds_all - kt::check_fixed_lds() : 0u, kt::check_word_lds(D));
+                    full_when_chunked ? lds_all - kt::check_fixed_lds() : 0u, kt::check_word_lds(D), nullptr, thr_packed);
     lap("build_index");
     // a program that fits half the LDS as rows but still came out in several chunks (per-term tables): larger chunks
     if (full_when_chunked && e->hindex.bm_chunks.size() > 1 && e->hindex.cut_chk_budget != lds_all - kt::check_fixed_lds())
-      kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, kt::check_word_lds(D));
+      kt::cut_chunks(e->hindex, agg_budget, lds_all - kt::check_fixed_lds(), thr_bytes, kt::check_word_lds(D), thr_packed);
     lap("cut_chunks (full LDS)");
   }
   kt::index_group_counts(e->hindex, (uint32_t)T);
+  e->ctr_index_chunks.store((int64_t)e->hindex.bm_chunks.size(), std::memory_order_relaxed);
+  e->ctr_index_words.store((int64_t)e->hindex.bm_words, std::memory_order_relaxed);
+  e->ctr_index_image_words.store((int64_t)e->hindex.img_words, std::memory_order_relaxed);
+  e->ctr_ns_rows.store((int64_t)e->hindex.n_ns, std::memory_order_relaxed);
+  e->ctr_ns_word_visits.store(e->hindex.ns_word_visits, std::memory_order_relaxed);
+  e->ctr_ns_chunk_visits.store(e->hindex.ns_chunk_visits, std::memory_order_relaxed);
   e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
@@ -2034,6 +2057,10 @@ static int32_t request_sums_in_range(kt_engine* e, hipStream_t s) {
   return KT_OK;
 }
 
+static void upgrade_launch_lock(kt_engine* e) {
+  if (e->cur_launch_lock) ((LaunchLock*)e->cur_launch_lock)->upgrade();
+}
+
 static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = false) {
   e->fused_pending = false;
   int32_t rc = ensure_ready(e, s);
@@ -2097,7 +2124,15 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
         // (planned ranges hold up to wg_range_cap records)
         if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
         e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true);
-        if (e->pack.nw && e->pack.rec_bytes > kt::agg_rec_bytes(e->D, false)) e->pack = kt::PackPlan();  // slab areas hold plain records
+        if (e->pack.nw && e->pack.rec_bytes > e->dindex.cut_thr_bytes) e->pack = kt::PackPlan();  // the slab areas hold records of that size
+      }
+      if (!e->pack.nw && kt::agg_rec_bytes(e->D, e->incremental) > e->dindex.cut_thr_bytes) {
+        // the plain fold is coming and the chunks were cut for the packed fold's records: cut again, for plain ones (once —
+        // the engine then stays with plain-sized chunks), and start over on the new index
+        upgrade_launch_lock(e);
+        e->cut_plain = true, e->program_dirty = true;
+        e->countable_valid = false;
+        return aggregate_locked(e, s, allow_fused);
       }
       KT_HIP(e, e->d_vc_meta.reserve(nc));
       KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
@@ -2956,14 +2991,13 @@ int64_t kt_counter(kt_engine* e, int32_t which) {
   switch (which) {
     case KT_COUNTER_FEW_CHECKS: return e->few_served.load(std::memory_order_relaxed);
     case KT_COUNTER_COMPILES: return e->n_compiles.load(std::memory_order_relaxed);
-    case KT_COUNTER_INDEX_CHUNKS: return (int64_t)e->hindex.bm_chunks.size();
-    case KT_COUNTER_INDEX_WORDS: return (int64_t)e->hindex.bm_words;
-    case KT_COUNTER_NS_ROWS: return (int64_t)e->hindex.n_ns;
-    case KT_COUNTER_NS_WORD_VISITS: {  // the word lists of all chunk images: their entries are (namespace, visited word) pairs
-      int64_t n = 0;
-      for (const kt::BmChunk& ch : e->hindex.bm_chunks) n += (int64_t)((ch.off_term_t - ch.off_nsl) / sizeof(kt::NsWord));
-      return n;
-    }
+    // (the index figures are copied into atomics at the end of every compile: a metrics thread may ask during a recompile)
+    case KT_COUNTER_INDEX_CHUNKS: return e->ctr_index_chunks.load(std::memory_order_relaxed);
+    case KT_COUNTER_INDEX_WORDS: return e->ctr_index_words.load(std::memory_order_relaxed);
+    case KT_COUNTER_NS_ROWS: return e->ctr_ns_rows.load(std::memory_order_relaxed);
+    case KT_COUNTER_NS_WORD_VISITS: return e->ctr_ns_word_visits.load(std::memory_order_relaxed);
+    case KT_COUNTER_NS_CHUNK_VISITS: return e->ctr_ns_chunk_visits.load(std::memory_order_relaxed);
+    case KT_COUNTER_INDEX_IMAGE_WORDS: return e->ctr_index_image_words.load(std::memory_order_relaxed);
     default: return -1;
   }
 }

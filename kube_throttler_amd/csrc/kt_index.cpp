@@ -148,7 +148,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::vector<uint32_t>& req_val_off, const std::vector<uint32_t>& req_val,
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
-                 int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full, uint32_t chk_word, const HostIndex* atoms_from) {
+                 int max_labels, const std::vector<uint32_t>* adm_in, uint32_t chk_budget_full, uint32_t chk_word, const HostIndex* atoms_from,
+                 uint32_t thr_bytes_packed) {
   {
     // a fresh index in the OLD index's storage: the full bitmaps and the chunk images are a few megabytes that would
     // otherwise be unmapped and faulted in again page by page on every build
@@ -750,156 +751,461 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   // chunks for chk_budget (two check workgroups per CU) — unless the caller wants larger chunks when the program needs
   // several anyway (chk_budget_full) and it plainly does: then only that cut is made
   const size_t rows_bytes = (size_t)image_col_rows(R) * W * 8u * (veto ? 2u : 1u);
-  if (chk_budget_full && rows_bytes > (size_t)chk_budget) cut_chunks(out, agg_budget, chk_budget_full, thr_bytes, chk_word);
-  else cut_chunks(out, agg_budget, chk_budget, thr_bytes, chk_word);
+  if (chk_budget_full && rows_bytes > (size_t)chk_budget) cut_chunks(out, agg_budget, chk_budget_full, thr_bytes, chk_word, thr_bytes_packed);
+  else cut_chunks(out, agg_budget, chk_budget, thr_bytes, chk_word, thr_bytes_packed);
   lap("cut_chunks");
 }
 
 // Cuts the numbered bitmaps of `out` (build_index) into chunk images for the given LDS budgets; callable again with
 // other budgets without renumbering (the engine first asks for half-LDS chunks — two check workgroups per CU — and
 // re-cuts for the full LDS when the program needs several chunks anyway).
-void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, uint32_t chk_word) {
-  out.cut_chk_budget = chk_budget;
-  const uint32_t W = out.bm_words, R = out.bm_rows, n_ns = out.n_ns;
-  const bool veto = out.rich;
-  const std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
-  const std::vector<WordHdr>& hdr = out.full_hdr;
-  const std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
-  const std::vector<uint8_t>& real = out.full_real;
-  // ---- chunks: word ranges whose LDS part (rows | headers | namespace word lists) plus the per-term / per-throttle
-  //      tables of the kernels fit the LDS budgets; a throttle's terms never straddle a chunk
-  std::vector<uint8_t> splittable(W + 1, 1);  // chunk may START at word w
-  for (uint32_t w = 1; w < W; ++w) {
-    // the last real term of word w-1 and the first real term of word w belong to different throttles?
-    int64_t a = -1, b2 = -1;
-    for (int k = 63; k >= 0 && a < 0; --k)
-      if (real[(size_t)(w - 1) * 64 + k]) a = (int64_t)(w - 1) * 64 + k;
-    for (int k = 0; k < 64 && b2 < 0; ++k)
-      if (real[(size_t)w * 64 + k]) b2 = (int64_t)w * 64 + k;
-    if (a >= 0 && b2 >= 0 && term_rank[a] == term_rank[b2]) splittable[w] = 0;
-  }
-  // namespace word-list entries per word (for the size estimate)
-  std::vector<uint32_t> ns_per_word(W, 0u);
-  for (uint32_t n = 0; n < n_ns; ++n)
-    for (uint32_t w = 0; w < W; ++w) ns_per_word[w] += nsrows[(size_t)n * W + w] != 0;
-  const size_t fam = veto ? 2 : 1;
-  const uint32_t Rp = image_col_rows(R);
-  // the form of every word (NsWord::flags): does some atom row hold a veto bit in it, does some term need three hits
-  std::vector<uint32_t> word_form(W, 0u);
-  for (uint32_t w = 0; w < W; ++w) word_form[w] = hdr[w].m3 != 0ull ? kNsWordNeed3 : 0u;
-  if (veto)
-    for (uint32_t r = 0; r < R; ++r)
+//
+// Two plans (round 6).  A chunk is a LIST of words of the numbered program plus the namespaces whose word lists it
+// carries; a word may sit in several chunks (the images are copies in HBM), a namespace meets every word it visits in
+// exactly ONE of the chunks that serve it.
+//   * global  : consecutive word ranges, every chunk serves every namespace that has a word in it (rounds 1-5) — the default;
+//   * grouped : the namespaces are grouped by the words they visit, and every group gets its own run of chunks that
+//               holds exactly the words its members visit — the words most of them share first.  A namespace-ordered
+//               scan (a workgroup = a range of namespaces) then stages as many images as the words of ITS namespaces
+//               need instead of every chunk of the global numbering that holds one of them.  Built to VERDICT r5 #1 and
+//               MEASURED on the configs[4] shard (256 namespaces in 4 zones, a namespace visits 75 of 606 words): chunk
+//               passes per namespace 7.0 -> 3.7 (126 chunks instead of 29), results identical — and the check went from
+//               0.379 to 0.365 ms, the aggregate from 0.458 to 0.454, while the slab reduction (a block per chunk and
+//               record tile) went from 0.024 to 0.100: the step 0.851 -> 0.908 ms (profiles/r06_cut_plans.txt).  The
+//               per-(tile, chunk) work — barrier, image staged, records fetched again, carry words — overlaps with the
+//               other waves' scans; what bounds both kernels is VALU issue in the scan itself (2.0e8 wave instructions per
+//               check launch = 0.33 ms at one instruction per four cycles and SIMD).  KT_CUT_PLAN=grouped selects the plan
+//               (A/B runs, tests/cpp/index_sim_test.cpp replays it on the host); the default stays global.
+// What IS kept of the round: the veto plane holds only the columns of words that have a veto bit (kt_index.h), namespaces
+// with the same word list share it, and a program of several chunks is cut for the packed fold's 40-byte records: 29
+// chunks instead of 35 on the shard, 0.884 -> 0.851 ms.
+namespace {
+
+struct ChunkPlan {
+  std::vector<uint32_t> words;   // words of the numbered program, in chunk-local order
+  std::vector<uint32_t> served;  // namespaces whose word lists the chunk carries, ascending; `all`: every namespace
+  bool all = true;
+};
+
+struct Cutter {
+  HostIndex& out;
+  const uint32_t W, R, Rp, n_ns;
+  const bool veto;
+  const size_t fam;
+  const uint32_t agg_budget, chk_budget, thr_bytes, chk_word;
+  std::vector<uint8_t> splittable;    // a chunk may START at word w
+  std::vector<uint32_t> word_form;    // NsWord::flags of every word
+  std::vector<uint32_t> word_groups;  // groups (= ranks = slab records) whose numbers start in word w
+  std::vector<std::vector<uint32_t>> ns_words;  // words every namespace visits, ascending
+  bool all_splittable = true;
+
+  Cutter(HostIndex& o, uint32_t agg, uint32_t chk, uint32_t tb, uint32_t cw)
+      : out(o), W(o.bm_words), R(o.bm_rows), Rp(image_col_rows(o.bm_rows)), n_ns(o.n_ns), veto(o.rich), fam(o.rich ? 2 : 1),
+        agg_budget(agg), chk_budget(chk), thr_bytes(tb), chk_word(cw) {
+    const std::vector<uint32_t>& term_rank = out.full_term_rank;
+    const std::vector<uint8_t>& real = out.full_real;
+    splittable.assign(W + 1, 1);
+    for (uint32_t w = 1; w < W; ++w) {
+      // the last real term of word w-1 and the first real term of word w belong to different throttles?
+      int64_t a = -1, b2 = -1;
+      for (int k = 63; k >= 0 && a < 0; --k)
+        if (real[(size_t)(w - 1) * 64 + k]) a = (int64_t)(w - 1) * 64 + k;
+      for (int k = 0; k < 64 && b2 < 0; ++k)
+        if (real[(size_t)w * 64 + k]) b2 = (int64_t)w * 64 + k;
+      if (a >= 0 && b2 >= 0 && term_rank[a] == term_rank[b2]) splittable[w] = 0, all_splittable = false;
+    }
+    // the form of every word (NsWord::flags): does some atom row hold a veto bit in it, does some term need three hits
+    word_form.assign(W, 0u);
+    for (uint32_t w = 0; w < W; ++w) word_form[w] = out.full_hdr[w].m3 != 0ull ? kNsWordNeed3 : 0u;
+    if (veto)
+      for (uint32_t r = 0; r < R; ++r)
+        for (uint32_t w = 0; w < W; ++w)
+          if (out.full_veto[(size_t)r * W + w]) word_form[w] |= kNsWordVeto;
+    word_groups.assign(W, 0u);
+    {
+      uint32_t last = ~0u;
+      for (size_t c = 0; c < (size_t)W * 64; ++c)
+        if (real[c] && term_rank[c] != last) last = term_rank[c], ++word_groups[c >> 6];
+    }
+    ns_words.assign(n_ns, {});
+    for (uint32_t n = 0; n < n_ns; ++n)
       for (uint32_t w = 0; w < W; ++w)
-        if (vet[(size_t)r * W + w]) word_form[w] |= kNsWordVeto;
-  uint64_t slab_run = 0;
-  out.bm_chunks.clear();
-  out.bm_images.clear();
-  out.bm_images.reserve(((size_t)image_col_rows(R) * W * 8 * (veto ? 2 : 1) + (size_t)W * (sizeof(WordHdr) + 64 * 10 + 64)) * 5 / 4 + ((size_t)n_ns + 8) * 4 * 64);  // (one allocation instead of a regrowth per chunk)
-  out.bm_chunk_ns.clear();
-  const uint32_t nsw = (n_ns + 31) / 32;
-  out.ns_words = nsw ? nsw : 1u;
-  out.bm_max_lds = 0, out.bm_max_thr = 0, out.bm_max_words = 0, out.bm_slab_bytes = 0;
-  uint32_t w0 = 0;
-  while (w0 < W) {
-    // grow the chunk word by word while it fits; cut at the last boundary that splits no throttle
-    uint32_t w1 = 0;
-    size_t nsl_entries = 0;
-    uint32_t r_lo = ~0u, r_hi = 0;
-    for (uint32_t cand = w0 + 1; cand <= W; ++cand) {
-      nsl_entries += ns_per_word[cand - 1];
-      for (size_t c = (size_t)(cand - 1) * 64; c < (size_t)cand * 64; ++c)
-        if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
-      const uint32_t nthr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
-      const size_t nw = cand - w0;
-      const size_t lds = (size_t)Rp * nw * 8 * fam + nw * sizeof(WordHdr) + align16(((size_t)n_ns + 1) * 4) + nsl_entries * sizeof(NsWord);
-      // the kernels lay LDS out ONCE for all chunks — the largest image next to the tables of the largest chunk —
-      // so a chunk has to fit together with the maxima of the chunks cut before it, not only on its own
-      const size_t lds_hi = std::max(lds, (size_t)out.bm_max_lds);
-      const size_t thr_hi = std::max((size_t)nthr, (size_t)out.bm_max_thr);
-      const size_t nw_hi = std::max(nw, (size_t)out.bm_max_words);
-      // (aggregate: ranks u16[64] + the run masks {seg_lo, seg_hi} per word; nw < 1024: the packed fold queues chunk-local
-      //  term numbers as 16-bit values)
-      const bool fits = lds_hi + nw_hi * chk_word <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + nw_hi * 16 + thr_hi * thr_bytes + 16 <= agg_budget &&
-                        nthr < 0x8000u && nw < 1024;
-      if (!fits && w1 != 0) break;
-      if (cand == W || splittable[cand]) {
-        w1 = cand;
-        if (!fits) break;  // a single stretch larger than the budget: the launchers notice
-      }
-    }
-    // ---- image of words [w0, w1)
-    BmChunk ch{};
-    ch.w0 = w0, ch.n_words = w1 - w0;
-    ch.ns_base = 0u, ch.ns_cnt = 0xFFFFFFFFu;
-    ch.col_rows = Rp;
-    r_lo = ~0u, r_hi = 0;
-    for (size_t c = (size_t)w0 * 64; c < (size_t)w1 * 64; ++c)
-      if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
-    ch.rank0 = r_lo == ~0u ? 0 : r_lo;
-    ch.n_thr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
-    // planes of word columns: any[w][Rp], then (rich) veto[w][Rp]
-    std::vector<uint64_t> irows((size_t)Rp * ch.n_words * fam, 0ull);
-    const size_t veto_plane = (size_t)Rp * ch.n_words;
-    for (uint32_t r = 0; r < R; ++r)
-      for (uint32_t w = 0; w < ch.n_words; ++w) {
-        irows[(size_t)w * Rp + r] = any[(size_t)r * W + w0 + w];
-        if (veto) irows[veto_plane + (size_t)w * Rp + r] = vet[(size_t)r * W + w0 + w];
-      }
-    std::vector<WordHdr> ihdr(hdr.begin() + w0, hdr.begin() + w1);
-    std::vector<uint32_t> nsl_off((size_t)n_ns + 1, 0u);
-    std::vector<NsWord> nsl;
-    for (uint32_t n = 0; n < n_ns; ++n) {
-      for (uint32_t w = 0; w < ch.n_words; ++w) {
-        const uint64_t m = nsrows[(size_t)n * W + w0 + w];
-        if (m) nsl.push_back(NsWord{w, word_form[w0 + w], m});
-      }
-      nsl_off[n + 1] = (uint32_t)nsl.size();
-    }
-    {  // which namespaces have words here (the sorted scans skip the chunk for workgroups without any of them)
-      const size_t b0 = out.bm_chunk_ns.size();
-      out.bm_chunk_ns.resize(b0 + out.ns_words, 0u);
-      for (uint32_t n = 0; n < n_ns; ++n)
-        if (nsl_off[n + 1] > nsl_off[n]) out.bm_chunk_ns[b0 + (n >> 5)] |= 1u << (n & 31);
-    }
-    std::vector<uint32_t> it(term_t.begin() + (size_t)w0 * 64, term_t.begin() + (size_t)w1 * 64);
-    std::vector<uint32_t> ig(term_g.begin() + (size_t)w0 * 64, term_g.begin() + (size_t)w1 * 64);
-    std::vector<uint16_t> ir((size_t)ch.n_words * 64, 0);
-    for (uint32_t k = 0; k < ch.n_words * 64; ++k) {
-      const size_t c = (size_t)w0 * 64 + k;
-      if (!real[c]) continue;
-      ir[k] = (uint16_t)((term_rank[c] - ch.rank0) | ((term_t[c] & kTermAdj) ? kRankAdj : 0u));
-      ch.has_slow |= (hdr[c >> 6].slow >> (c & 63)) & 1ull ? 1u : 0u;
-      ch.has_adj |= (term_t[c] & kTermAdj) ? 1u : 0u;
-    }
-    const void* src[7] = {irows.data(), ihdr.data(), nsl_off.data(), nsl.data(), it.data(), ir.data(), ig.data()};
-    const size_t bytes[7] = {irows.size() * 8, ihdr.size() * sizeof(WordHdr), nsl_off.size() * 4, nsl.size() * sizeof(NsWord),
-                             it.size() * 4,    ir.size() * 2,                 ig.size() * 4};
-    uint32_t* offs[7] = {nullptr, &ch.off_hdr, &ch.off_nsl_off, &ch.off_nsl, &ch.off_term_t, &ch.off_term_rank, &ch.off_term_g};
-    size_t o = 0;
-    const size_t img0 = out.bm_images.size();
-    for (int k = 0; k < 7; ++k) {
-      if (offs[k]) *offs[k] = (uint32_t)o;
-      if (k == 4) ch.lds_bytes = (uint32_t)o;  // everything before term_t lives in LDS
-      o += align16(bytes[k]);
-    }
-    out.bm_images.resize(img0 + o, 0);
-    size_t oo = 0;
-    for (int k = 0; k < 7; ++k) {
-      if (bytes[k]) memcpy(out.bm_images.data() + img0 + oo, src[k], bytes[k]);
-      oo += align16(bytes[k]);
-    }
-    ch.img_off = (uint32_t)img0, ch.img_bytes = (uint32_t)o;
-    ch.slab_off = (uint32_t)(slab_run / 16);  // one table per (chunk, workgroup), 256 workgroups at most
-    // ... or 512 workgroups with packed records of half the size (PackPlan): their rounding to 16 bytes needs the slack
-    slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull) + 8192ull;
-    out.bm_max_lds = std::max(out.bm_max_lds, ch.lds_bytes);
-    out.bm_max_thr = std::max(out.bm_max_thr, ch.n_thr);
-    out.bm_max_words = std::max(out.bm_max_words, ch.n_words);
-    out.bm_chunks.push_back(ch);
-    if (getenv("KT_DEBUG_CHUNKS")) fprintf(stderr, "chunk %zu: words [%u,%u) lds %u B thr %u\n", out.bm_chunks.size() - 1, w0, w1, ch.lds_bytes, ch.n_thr);
-    out.bm_slab_bytes = slab_run;
-    w0 = w1;
+        if (out.full_nsrows[(size_t)n * W + w]) ns_words[n].push_back(w);
   }
+
+  // LDS bytes of the image part of a chunk of nw words, nv of them with a veto column, whose word lists hold nsl_entries entries
+  size_t image_lds(size_t nw, size_t nv, size_t nsl_entries) const {
+    const size_t cols = nw + (veto ? nv + (nv < nw ? 1 : 0) : 0);
+    return (size_t)Rp * cols * 8 + nw * sizeof(WordHdr) + align16((size_t)n_ns * 8) + nsl_entries * sizeof(NsWord);
+  }
+  // does word w get a column in the veto plane (a program with a run of numbers across a word boundary keeps them all)
+  bool has_veto(uint32_t w) const { return veto && (!all_splittable || (word_form[w] & kNsWordVeto) != 0u); }
+  // does a chunk fit both kernels' budgets next to the maxima of the chunks planned so far?  The kernels lay LDS out ONCE
+  // for all chunks — the largest image next to the tables of the largest chunk — so a chunk has to fit together with those
+  // maxima, not only on its own.  (aggregate: ranks u16[64] + the run masks {seg_lo, seg_hi} per word; nw < 1024: the
+  // packed fold queues chunk-local word numbers as 10-bit values)
+  struct Maxima { size_t lds = 0, thr = 0, nw = 0; };
+  bool fits(size_t lds, size_t nw, size_t nthr, const Maxima& mx) const {
+    const size_t lds_hi = std::max(lds, mx.lds), thr_hi = std::max(nthr, mx.thr), nw_hi = std::max(nw, mx.nw);
+    return lds_hi + nw_hi * chk_word <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + nw_hi * 16 + thr_hi * thr_bytes + 16 <= agg_budget &&
+           nthr < 0x8000u && nw < 1024;
+  }
+
+  // ---- plan: consecutive word ranges, cut at the last boundary that splits no throttle
+  std::vector<ChunkPlan> plan_global() const {
+    std::vector<ChunkPlan> plan;
+    const std::vector<uint32_t>& term_rank = out.full_term_rank;
+    const std::vector<uint8_t>& real = out.full_real;
+    std::vector<uint32_t> ns_per_word(W, 0u);
+    for (uint32_t n = 0; n < n_ns; ++n)
+      for (uint32_t w : ns_words[n]) ++ns_per_word[w];
+    Maxima mx;
+    uint32_t w0 = 0;
+    while (w0 < W) {
+      // grow the chunk word by word while it fits; cut at the last boundary that splits no throttle
+      uint32_t w1 = 0;
+      size_t nsl_entries = 0, lds1 = 0, thr1 = 0, nv = 0;
+      uint32_t r_lo = ~0u, r_hi = 0;
+      for (uint32_t cand = w0 + 1; cand <= W; ++cand) {
+        nsl_entries += ns_per_word[cand - 1], nv += has_veto(cand - 1);
+        for (size_t c = (size_t)(cand - 1) * 64; c < (size_t)cand * 64; ++c)
+          if (real[c]) r_lo = std::min(r_lo, term_rank[c]), r_hi = std::max(r_hi, term_rank[c]);
+        const uint32_t nthr = r_lo == ~0u ? 0 : r_hi - r_lo + 1;
+        const size_t nw = cand - w0, lds = image_lds(nw, nv, nsl_entries);
+        const bool ok = fits(lds, nw, nthr, mx);
+        if (!ok && w1 != 0) break;
+        if (cand == W || splittable[cand]) {
+          w1 = cand, lds1 = lds, thr1 = nthr;
+          if (!ok) break;  // a single stretch larger than the budget: the launchers notice
+        }
+      }
+      ChunkPlan cp;
+      for (uint32_t w = w0; w < w1; ++w) cp.words.push_back(w);
+      mx.lds = std::max(mx.lds, lds1), mx.thr = std::max(mx.thr, thr1), mx.nw = std::max(mx.nw, (size_t)(w1 - w0));
+      plan.push_back(std::move(cp));
+      w0 = w1;
+    }
+    return plan;
+  }
+
+  // ---- plan: chunks per group of namespaces.  `cnt[w]` = members of the group that visit word w.  The group's words go
+  // into its chunks in the order (members that visit the word, descending; word number): what most members share comes
+  // first, the words of single members last.  chunks_of() cuts that sequence greedily; mx == nullptr: against the budgets
+  // alone (estimates), else against the maxima of the plan so far, which it then raises.
+  size_t chunks_of(const std::vector<uint32_t>& words, const std::vector<uint16_t>& cnt, size_t n_members, Maxima* mx, std::vector<uint32_t>* cuts) const {
+    // (word-list entries: the lists of namespaces that visit the same words of a chunk with the same masks are stored once —
+    //  a chunk of words ALL members visit is charged one list, any other chunk one entry per (member, visited word); emit()
+    //  measures the real image and splits a chunk that turns out larger)
+    size_t n_chunks = 0, nw = 0, nv = 0, sum = 0, nthr = 0;
+    bool full = true;
+    const Maxima none;
+    auto entries = [&](size_t nw_, size_t sum_, bool full_) { return full_ ? nw_ : sum_; };
+    for (size_t i = 0; i < words.size(); ++i) {
+      const uint32_t w = words[i];
+      const bool full1 = full && cnt[w] >= n_members;
+      if (nw && !fits(image_lds(nw + 1, nv + has_veto(w), entries(nw + 1, sum + cnt[w], full1)), nw + 1, nthr + word_groups[w], mx ? *mx : none)) {
+        if (mx) mx->lds = std::max(mx->lds, image_lds(nw, nv, entries(nw, sum, full))), mx->thr = std::max(mx->thr, nthr), mx->nw = std::max(mx->nw, nw);
+        if (cuts) cuts->push_back((uint32_t)i);
+        ++n_chunks, nw = 0, nv = 0, sum = 0, nthr = 0, full = true;
+      }
+      ++nw, nv += has_veto(w), sum += cnt[w], nthr += word_groups[w], full = full && cnt[w] >= n_members;
+    }
+    if (nw) {
+      if (mx) mx->lds = std::max(mx->lds, image_lds(nw, nv, entries(nw, sum, full))), mx->thr = std::max(mx->thr, nthr), mx->nw = std::max(mx->nw, nw);
+      if (cuts) cuts->push_back((uint32_t)words.size());
+      ++n_chunks;
+    }
+    return n_chunks;
+  }
+  std::vector<ChunkPlan> plan_grouped() const {
+    struct Group {
+      std::vector<uint32_t> members, words;  // words: those with cnt > 0, unordered
+      std::vector<uint16_t> cnt;
+      size_t ideal = ~(size_t)0;  // the FEWEST chunks a member would need by itself: nobody joins at the price of a pass a member would not make alone
+    };
+    std::vector<Group> groups;
+    std::vector<uint16_t> one(W, 0);
+    std::vector<uint32_t> seq;
+    auto ordered = [&](const std::vector<uint32_t>& words, const std::vector<uint16_t>& cnt) {
+      seq = words;
+      std::sort(seq.begin(), seq.end(), [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+    };
+    constexpr size_t kOpen = 24;  // groups a namespace is tried against (the most recent ones)
+    for (uint32_t n = 0; n < n_ns; ++n) {
+      const std::vector<uint32_t>& nw = ns_words[n];
+      if (nw.empty()) continue;
+      for (uint32_t w : nw) one[w] = 1;
+      ordered(nw, one);
+      const size_t ideal_n = chunks_of(seq, one, 1, nullptr, nullptr);
+      for (uint32_t w : nw) one[w] = 0;
+      // the open group that shares the most words with n among those n can join without costing ANY member a chunk pass
+      // it would not make alone (ties: the most recent group — neighbours in namespace order share workgroups)
+      size_t best = ~(size_t)0, best_shared = 0;
+      for (size_t k = groups.size(); k-- > 0 && groups.size() - k <= kOpen;) {
+        Group& g = groups[k];
+        if (g.members.size() >= 0xFFFFu) continue;
+        size_t shared = 0;
+        for (uint32_t w : nw) shared += g.cnt[w] != 0;
+        if (best != ~(size_t)0 && shared <= best_shared) continue;
+        std::vector<uint32_t> uni = g.words;
+        for (uint32_t w : nw)
+          if (!g.cnt[w]) uni.push_back(w);
+        for (uint32_t w : nw) ++g.cnt[w];
+        ordered(uni, g.cnt);
+        const size_t c = chunks_of(seq, g.cnt, g.members.size() + 1, nullptr, nullptr);
+        for (uint32_t w : nw) --g.cnt[w];
+        if (c <= std::min(g.ideal, ideal_n)) best = k, best_shared = shared;
+      }
+      if (best == ~(size_t)0) {
+        groups.emplace_back();
+        groups.back().cnt.assign(W, 0);
+        best = groups.size() - 1;
+      }
+      Group& g = groups[best];
+      g.members.push_back(n);
+      for (uint32_t w : nw)
+        if (g.cnt[w]++ == 0) g.words.push_back(w);
+      g.ideal = std::min(g.ideal, ideal_n);
+    }
+    std::vector<ChunkPlan> plan;
+    Maxima mx;
+    for (Group& g : groups) {
+      ordered(g.words, g.cnt);
+      std::vector<uint32_t> cuts;
+      (void)chunks_of(seq, g.cnt, g.members.size(), &mx, &cuts);
+      size_t i0 = 0;
+      for (uint32_t i1 : cuts) {
+        ChunkPlan cp;
+        cp.all = false, cp.served = g.members;
+        cp.words.assign(seq.begin() + i0, seq.begin() + i1);
+        std::sort(cp.words.begin(), cp.words.end());  // (chunk-local order = word order: the lists stay ascending)
+        plan.push_back(std::move(cp));
+        i0 = i1;
+      }
+    }
+    return plan;
+  }
+  // chunks a namespace-ordered scan stages per namespace, summed over the namespaces that visit anything
+  size_t visits(const std::vector<ChunkPlan>& plan) const {
+    size_t v = 0;
+    std::vector<uint8_t> in_chunk(W, 0);
+    for (const ChunkPlan& cp : plan) {
+      for (uint32_t w : cp.words) in_chunk[w] = 1;
+      auto touches = [&](uint32_t n) {
+        for (uint32_t w : ns_words[n])
+          if (in_chunk[w]) return true;
+        return false;
+      };
+      if (cp.all) {
+        for (uint32_t n = 0; n < n_ns; ++n) v += touches(n);
+      } else {
+        for (uint32_t n : cp.served) v += touches(n);
+      }
+      for (uint32_t w : cp.words) in_chunk[w] = 0;
+    }
+    return v;
+  }
+
+  // ---- images.  A chunk whose real image turns out larger than the plan's estimate allowed (word lists that could not
+  // be shared) is cut in two.
+  void emit(const std::vector<ChunkPlan>& plan_in) {
+    const std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
+    const std::vector<WordHdr>& hdr = out.full_hdr;
+    const std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
+    const std::vector<uint8_t>& real = out.full_real;
+    uint64_t slab_run = 0;
+    out.bm_chunks.clear();
+    out.bm_images.clear();
+    size_t total_words = 0;
+    for (const ChunkPlan& cp : plan_in) total_words += cp.words.size();
+    out.bm_images.reserve(((size_t)Rp * total_words * 8 * fam + total_words * (sizeof(WordHdr) + 64 * 10 + 64)) * 5 / 4 + plan_in.size() * ((size_t)n_ns + 8) * 4 * 4);  // (one allocation instead of a regrowth per chunk)
+    out.bm_chunk_ns.clear();
+    const uint32_t nsw = (n_ns + 31) / 32;
+    out.ns_words = nsw ? nsw : 1u;
+    out.bm_max_lds = 0, out.bm_max_thr = 0, out.bm_max_words = 0, out.bm_slab_bytes = 0;
+    out.bm_rank_t.clear();
+    out.ns_word_visits = 0, out.ns_chunk_visits = 0;
+    uint32_t w_run = 0;
+    Maxima mx;
+    std::vector<ChunkPlan> work(plan_in.rbegin(), plan_in.rend());  // (a stack: the next chunk on top)
+    std::vector<uint64_t> irows;
+    std::vector<uint32_t> words;
+    while (!work.empty()) {
+      ChunkPlan cp = std::move(work.back());
+      work.pop_back();
+      BmChunk ch{};
+      const uint32_t nw = (uint32_t)cp.words.size();
+      // chunk-local word order: the words with a veto column first (their columns are the veto plane), word order inside
+      // both kinds.  (A program with a run of numbers across a word boundary keeps its order and every veto column.)
+      words = cp.words;
+      uint32_t nv = 0;
+      if (veto) {
+        std::stable_partition(words.begin(), words.end(), [&](uint32_t w) { return has_veto(w); });  // (a no-op when every word has one)
+        for (uint32_t w : words) nv += has_veto(w);
+      }
+      const uint32_t veto_cols = veto ? nv + (nv < nw ? 1u : 0u) : 0u;
+      ch.n_words = nw, ch.n_veto = nv;
+      ch.zero_col = veto && nv < nw ? (nw + nv) * Rp * 8u : 0u;
+      ch.ns_base = 0u, ch.ns_cnt = 0xFFFFFFFFu;
+      ch.col_rows = Rp;
+      // the word lists; namespaces with the same list share it
+      std::vector<uint32_t> nsl_rng((size_t)n_ns * 2, 0u);
+      std::vector<NsWord> nsl, cur;
+      {
+        std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash;  // list hash -> begins of the lists stored so far
+        size_t si = 0;
+        for (uint32_t n = 0; n < n_ns; ++n) {
+          bool serve = cp.all;
+          if (!cp.all) {
+            while (si < cp.served.size() && cp.served[si] < n) ++si;
+            serve = si < cp.served.size() && cp.served[si] == n;
+          }
+          if (!serve) continue;
+          cur.clear();
+          uint64_t h = 1469598103934665603ull;
+          for (uint32_t w = 0; w < nw; ++w) {
+            const uint64_t m = nsrows[(size_t)n * W + words[w]];
+            if (!m) continue;
+            cur.push_back(NsWord{w, word_form[words[w]], m});
+            h = (h ^ w) * 1099511628211ull, h = (h ^ m) * 1099511628211ull;
+          }
+          if (cur.empty()) continue;
+          uint32_t begin = ~0u;
+          std::vector<uint32_t>& cands = by_hash[h];
+          for (uint32_t b0 : cands) {
+            // (a stored list that starts at b0 and equals `cur` entry by entry — its end is not stored: compare the length through
+            //  the entries themselves, the next list or the end of the array follows)
+            if ((size_t)b0 + cur.size() > nsl.size()) continue;
+            bool same = true;
+            for (size_t q = 0; q < cur.size() && same; ++q) same = nsl[b0 + q].w == cur[q].w && nsl[b0 + q].mask == cur[q].mask;
+            if (same) { begin = b0; break; }
+          }
+          if (begin == ~0u) {
+            begin = (uint32_t)nsl.size();
+            nsl.insert(nsl.end(), cur.begin(), cur.end());
+            cands.push_back(begin);
+          }
+          nsl_rng[(size_t)n * 2] = begin, nsl_rng[(size_t)n * 2 + 1] = begin + (uint32_t)cur.size();
+        }
+      }
+      // per-number tables; dense ranks of the chunk's groups in chunk-local number order
+      const uint32_t rank0 = (uint32_t)out.bm_rank_t.size();
+      std::vector<uint32_t> it((size_t)nw * 64, 0u), ig((size_t)nw * 64, 0u);
+      std::vector<uint16_t> ir((size_t)nw * 64, 0);
+      {
+        uint32_t last_rank = ~0u;
+        for (uint32_t w = 0; w < nw; ++w)
+          for (uint32_t k = 0; k < 64; ++k) {
+            const size_t c = (size_t)words[w] * 64 + k;
+            it[(size_t)w * 64 + k] = term_t[c], ig[(size_t)w * 64 + k] = term_g[c];
+            if (!real[c]) continue;
+            if (term_rank[c] != last_rank) last_rank = term_rank[c], out.bm_rank_t.push_back(term_t[c] & kTermRowMask);
+            ir[(size_t)w * 64 + k] = (uint16_t)(((uint32_t)out.bm_rank_t.size() - 1u - rank0) | ((term_t[c] & kTermAdj) ? kRankAdj : 0u));
+            ch.has_slow |= (hdr[c >> 6].slow >> (c & 63)) & 1ull ? 1u : 0u;
+            ch.has_adj |= (term_t[c] & kTermAdj) ? 1u : 0u;
+          }
+      }
+      ch.n_thr = (uint32_t)out.bm_rank_t.size() - rank0;
+      ch.rank0 = ch.n_thr ? rank0 : 0u;
+      const size_t lds = image_lds(nw, nv, nsl.size());
+      if (!fits(lds, nw, ch.n_thr, mx) && nw > 1 && all_splittable) {
+        // larger than the plan thought: two halves (of the plan's order) take its place
+        out.bm_rank_t.resize(rank0);
+        ChunkPlan lo = cp, hi = cp;
+        lo.words.assign(cp.words.begin(), cp.words.begin() + nw / 2), hi.words.assign(cp.words.begin() + nw / 2, cp.words.end());
+        work.push_back(std::move(hi)), work.push_back(std::move(lo));
+        continue;
+      }
+      ch.w0 = w_run;
+      w_run += nw;
+      // planes of word columns: any[nw][Rp], then (rich) veto[veto_cols][Rp] — the columns of local words [0, nv) and the zero column
+      irows.assign((size_t)Rp * (nw + veto_cols), 0ull);
+      const size_t veto_plane = (size_t)Rp * nw;
+      for (uint32_t r = 0; r < R; ++r)
+        for (uint32_t w = 0; w < nw; ++w) {
+          irows[(size_t)w * Rp + r] = any[(size_t)r * W + words[w]];
+          if (veto && w < nv) irows[veto_plane + (size_t)w * Rp + r] = vet[(size_t)r * W + words[w]];
+        }
+      std::vector<WordHdr> ihdr(nw);
+      for (uint32_t w = 0; w < nw; ++w) ihdr[w] = hdr[words[w]];
+      out.ns_word_visits += (int64_t)nsl.size();
+      {  // which namespaces have words here (the namespace-ordered scans skip the chunk for workgroups without any of them)
+        const size_t b0 = out.bm_chunk_ns.size();
+        out.bm_chunk_ns.resize(b0 + out.ns_words, 0u);
+        for (uint32_t n = 0; n < n_ns; ++n)
+          if (nsl_rng[(size_t)n * 2 + 1] > nsl_rng[(size_t)n * 2]) out.bm_chunk_ns[b0 + (n >> 5)] |= 1u << (n & 31), ++out.ns_chunk_visits;
+      }
+      const void* src[7] = {irows.data(), ihdr.data(), nsl_rng.data(), nsl.data(), it.data(), ir.data(), ig.data()};
+      const size_t bytes[7] = {irows.size() * 8, ihdr.size() * sizeof(WordHdr), nsl_rng.size() * 4, nsl.size() * sizeof(NsWord),
+                               it.size() * 4,    ir.size() * 2,                 ig.size() * 4};
+      uint32_t* offs[7] = {nullptr, &ch.off_hdr, &ch.off_nsl_rng, &ch.off_nsl, &ch.off_term_t, &ch.off_term_rank, &ch.off_term_g};
+      size_t o = 0;
+      const size_t img0 = out.bm_images.size();
+      for (int k = 0; k < 7; ++k) {
+        if (offs[k]) *offs[k] = (uint32_t)o;
+        if (k == 4) ch.lds_bytes = (uint32_t)o;  // everything before term_t lives in LDS
+        o += align16(bytes[k]);
+      }
+      out.bm_images.resize(img0 + o, 0);
+      size_t oo = 0;
+      for (int k = 0; k < 7; ++k) {
+        if (bytes[k]) memcpy(out.bm_images.data() + img0 + oo, src[k], bytes[k]);
+        oo += align16(bytes[k]);
+      }
+      ch.img_off = (uint32_t)img0, ch.img_bytes = (uint32_t)o;
+      ch.slab_off = (uint32_t)(slab_run / 16);  // one table per (chunk, workgroup), 256 workgroups at most
+      // ... or 512 workgroups with packed records of half the size (PackPlan): their rounding to 16 bytes needs the slack
+      slab_run += 256ull * (((uint64_t)ch.n_thr * thr_bytes + 15) & ~15ull) + 8192ull;
+      mx.lds = std::max(mx.lds, (size_t)ch.lds_bytes), mx.thr = std::max(mx.thr, (size_t)ch.n_thr), mx.nw = std::max(mx.nw, (size_t)nw);
+      out.bm_max_lds = std::max(out.bm_max_lds, ch.lds_bytes);
+      out.bm_max_thr = std::max(out.bm_max_thr, ch.n_thr);
+      out.bm_max_words = std::max(out.bm_max_words, ch.n_words);
+      out.bm_chunks.push_back(ch);
+      if (getenv("KT_DEBUG_CHUNKS"))
+        fprintf(stderr, "chunk %zu: %u words (%u with veto columns; first %u) lds %u B thr %u, serves %zu namespaces, %zu list entries\n", out.bm_chunks.size() - 1,
+                nw, nv, nw ? words[0] : 0u, ch.lds_bytes, ch.n_thr, cp.all ? (size_t)n_ns : cp.served.size(), nsl.size());
+      out.bm_slab_bytes = slab_run;
+    }
+    out.img_words = w_run;
+  }
+};
+
+}  // namespace
+
+void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, uint32_t chk_word, uint32_t thr_bytes_packed) {
+  out.cut_chk_budget = chk_budget;
+  out.cut_thr_bytes = thr_bytes;
+  out.cut_grouped = false;
+  const char* force = getenv("KT_CUT_PLAN");
+  const bool want_global = force && !strcmp(force, "global"), want_grouped = force && !strcmp(force, "grouped");
+  std::vector<ChunkPlan> plan;
+  {
+    Cutter cut(out, agg_budget, chk_budget, thr_bytes, chk_word);
+    plan = cut.plan_global();
+    if (plan.size() <= 1 || !cut.all_splittable) {
+      cut.emit(plan);
+      return;
+    }
+  }
+  // several chunks: the tables (and slabs) of the aggregate are sized for the packed fold's records where the caller offers
+  // that — more words per chunk, fewer chunk passes
+  const uint32_t tb = thr_bytes_packed && thr_bytes_packed < thr_bytes && !getenv("KT_CUT_PLAIN") ? thr_bytes_packed : thr_bytes;
+  out.cut_thr_bytes = tb;
+  Cutter cut(out, agg_budget, chk_budget, tb, chk_word);
+  if (tb != thr_bytes) plan = cut.plan_global();
+  (void)want_global;
+  if (want_grouped || getenv("KT_CUT_PLAN_AUTO")) {
+    std::vector<ChunkPlan> grouped = cut.plan_grouped();
+    const size_t v_global = cut.visits(plan), v_grouped = cut.visits(grouped);
+    if (getenv("KT_DEBUG_CHUNKS"))
+      fprintf(stderr, "cut_chunks: global %zu chunks / %zu namespace visits, grouped %zu chunks / %zu namespace visits\n", plan.size(), v_global,
+              grouped.size(), v_grouped);
+    // (the slab scratch — a table per chunk and workgroup — and the tag table grow with the chunk count: a plan of thousands
+    //  of chunks is not worth its visits)
+    if (want_grouped || (v_grouped * 5 <= v_global * 4 && grouped.size() <= std::max<size_t>(8 * plan.size(), 64) && grouped.size() <= 2048))
+      plan.swap(grouped), out.cut_grouped = true;
+  }
+  cut.emit(plan);
 }
 
 template <class T>
@@ -948,7 +1254,8 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.h_chunks = h.bm_chunks;
   d.n_chunks = (uint32_t)h.bm_chunks.size();
   d.bm_max_lds = h.bm_max_lds, d.bm_max_thr = h.bm_max_thr, d.bm_max_words = h.bm_max_words, d.bm_rows = h.bm_rows;
-  d.bm_words = h.bm_words;
+  d.bm_words = h.img_words;
+  d.cut_thr_bytes = h.cut_thr_bytes;
   d.bm_slab_bytes = h.bm_slab_bytes;
   d.has_veto = h.has_veto ? 1u : 0u;
   d.max_need = h.max_need;

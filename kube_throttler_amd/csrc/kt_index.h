@@ -80,16 +80,25 @@ struct alignas(16) NsWord {
 constexpr uint32_t kNsWordVeto = 1u;   // some atom row holds a veto bit in this word
 constexpr uint32_t kNsWordNeed3 = 2u;  // some term of this word needs three positive hits (WordHdr::m3 != 0)
 
-// One LDS-sized slice of the bitmap form: 64-bit words [w0, w0 + n_words) of every row.  The terms of a throttle never
-// straddle two chunks; `rank0 .. rank0 + n_thr` are the dense throttle ranks (term order) the chunk covers.
+// One LDS-sized slice of the bitmap form: n_words 64-bit words of every row — a run of consecutive words of the numbered
+// program (the global plan) or the words a group of namespaces visits (the grouped plan: kt_index.cpp, cut_chunks); w0 counts
+// the words of the chunks before this one (the position of the chunk's words in the per-word verdict images).  The terms of
+// a throttle never straddle two chunks; `rank0 .. rank0 + n_thr` are the dense ranks of the chunk's groups (chunk-local
+// number order) in HostIndex::bm_rank_t — a group that sits in several chunks (grouped plan) has a rank in each.
 // Image layout (all offsets relative to img_off, every section 16-byte aligned):
-//   [0, lds_bytes)        what the scan keeps in LDS:  rows | WordHdr[n_words] | nsl_off u32[n_ns+1] | NsWord[]
+//   [0, lds_bytes)        what the scan keeps in LDS:  rows | WordHdr[n_words] | nsl_rng u32[n_ns][2] | NsWord[]
 //     rows: u64 any[n_words][col_rows]            one COLUMN per word: the cell of (row id, word w) at (w * col_rows + id) * 8
-//           u64 veto[n_words][col_rows] behind it  (programs with negative requirements: the rich form)
+//           u64 veto[veto_cols][col_rows] behind it  (programs with negative requirements: the rich form)
 //       col_rows = the rows rounded up to 32 (image_col_rows): a column is a whole number of LDS bank rounds, so the bank
 //       slot of a cell is id mod 32 whatever the word — what a gather's lanes collide on is decided by the atom numbering
 //       alone (kt_index.cpp: number_atoms_by_home_slot), for lanes that visit different words as for lanes that visit the
 //       same.  (Until round 4: [row][odd stride] cells of 8 or 16 {any, veto} bytes — 3.1-3.3 LDS passes per gather.)
+//       The veto plane only holds the columns of words that HAVE a veto bit in some row (round 6; half of the words of the
+//       configs[4] program have none, and a chunk holds as many words as fit LDS): those words come first in the chunk —
+//       local words [0, n_veto), veto column of word w at the same distance behind its `any` column as before — and when
+//       there are others one all-zero column follows (column n_veto of the plane): a lane whose word carries no kNsWordVeto
+//       flag reads THAT column where a mixed tile reads veto cells (kt_scan.h).
+//     nsl_rng[n] = {begin, end} of namespace n's word list in NsWord[] — namespaces with the same list share it.
 //   off_term_t            u32 [n_words*64]  throttle row | kTerm*       (check: staged into LDS next to the CheckRec flags)
 //   off_term_rank         u16 [n_words*64]  chunk-local rank | kRankAdj  (aggregate)
 //   off_term_g            u32 [n_words*64]  selector-program term of the number (only read for `slow` candidates)
@@ -97,9 +106,11 @@ struct BmChunk {
   uint32_t w0, n_words;
   uint32_t rank0, n_thr;
   uint32_t img_off, lds_bytes;
-  uint32_t off_hdr, off_nsl_off, off_nsl;
+  uint32_t off_hdr, off_nsl_rng, off_nsl;
   uint32_t off_term_t, off_term_rank, off_term_g;
   uint32_t col_rows;  // cells per word column of a plane (rows rounded up to 32)
+  uint32_t n_veto;    // local words [0, n_veto) have a column in the veto plane (rich images; 0 otherwise)
+  uint32_t zero_col;  // byte offset (from the rows) of the all-zero column behind the veto plane's n_veto columns; 0: every word has a veto column
   uint32_t slab_off;  // (aggregate) byte offset of this chunk's tables in the slab scratch / 16
   uint32_t has_slow;  // some term of the chunk needs the generic walk
   uint32_t img_bytes;
@@ -145,6 +156,11 @@ struct HostIndex {
   uint32_t bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0;
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
   uint32_t cut_chk_budget = 0; // the check budget the chunks were last cut for
+  uint32_t cut_thr_bytes = 0;  // the record size the aggregate's tables and slabs were sized for (plain, or the packed fold's)
+  bool cut_grouped = false;    // the chunks are those of the grouped plan (kt_index.cpp: cut_chunks): per group of namespaces
+  uint32_t img_words = 0;      // words over all chunk images (>= bm_words: the grouped plan copies words); BmChunk::w0 counts in these
+  int64_t ns_word_visits = 0;  // entries of all word lists = (namespace, visited word) pairs
+  int64_t ns_chunk_visits = 0; // (namespace, chunk that serves it with at least one word) pairs
   // the numbered program before it is cut into chunks (host only; cut_chunks reads it): full bitmap rows [rows][W],
   // namespace rows [n_ns][W], per-word headers, per-number tables [W * 64]
   uint32_t n_ns = 0;
@@ -188,6 +204,7 @@ struct PackPlan {
   uint32_t cnt_desc = 0;
 };
 constexpr int kPackHeadroomBits = 8;
+constexpr uint32_t kPackedRecMax = 40;  // the largest packed record: nw <= 4 words + the zero-key word, padded to an odd count (make_pack_plan)
 constexpr int kPackClasses = 3;  // even fields, odd fields, the top field
 // desc: bits 0-3 = 4 * word + class (0: even mask, 1: odd, 2: top field — already shifted down), 8-13 = pos,
 // 16-22 = bits to keep (field + headroom; 0: no field), 24-29 = shift
@@ -239,7 +256,8 @@ struct IndexDev {
   uint32_t n_chunks = 0, bm_max_lds = 0, bm_max_thr = 0, bm_max_words = 0, bm_rows = 0;
   uint64_t bm_slab_bytes = 0;
   uint32_t has_veto = 0, max_need = 0, n_atoms = 0, has_key_atoms = 0, la = 8;
-  uint32_t bm_words = 0;  // 64-bit words of the numbered program (all chunks)
+  uint32_t bm_words = 0;  // 64-bit words over all chunk images (HostIndex::img_words): what the verdict images are sized for
+  uint32_t cut_thr_bytes = 0;  // HostIndex::cut_thr_bytes
   bool rich = false;
   size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_chunk_ns = 0, cap_atom_table = 0, cap_slow = 0;
 };
@@ -255,7 +273,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
                  const std::function<ThrInfo(uint32_t)>& thr_info, uint32_t n_ns,
                  const std::vector<uint32_t>& ns_term_ok, uint32_t gw, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes,
                  int max_labels, const std::vector<uint32_t>* adm_in = nullptr, uint32_t chk_budget_full = 0,
-                 uint32_t chk_word = kCheckWordLds, const HostIndex* atoms_from = nullptr);
+                 uint32_t chk_word = kCheckWordLds, const HostIndex* atoms_from = nullptr, uint32_t thr_bytes_packed = 0);
 // atoms_from (optional): the atom numbering is IMPOSED — that of another index (its atoms / atom_key / atom_table / la) —
 // instead of derived from this program: the sub-indexes of an anchored index (host/kt_anchor.h) share the numbering of the
 // full program, against which the pods' atom rows are translated once; the image form is then always the rich one
@@ -267,7 +285,11 @@ void transpose_term_ns_bits(const std::vector<uint32_t>& in, size_t G, uint32_t 
 void parallel_for(size_t n, size_t min_per_part, const std::function<void(size_t, size_t, size_t)>& f, size_t* parts_out);
 // chunk images of an index build_index numbered, for other LDS budgets (no renumbering)
 // chk_word: the check kernel's LDS bytes per word beside the image (check_word_lds(D); the default is the worst case)
-void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, uint32_t chk_word = kCheckWordLds);
+// thr_bytes_packed (optional, < thr_bytes): the record size to cut for when the program needs several chunks — the packed
+// fold's records (PackPlan) are smaller than the plain ones, a chunk then holds more words; the plain fold does not fit such
+// chunks (HostIndex::cut_thr_bytes tells; the engine cuts again for plain records when it needs that fold)
+void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes, uint32_t chk_word = kCheckWordLds,
+                uint32_t thr_bytes_packed = 0);
 // groups per throttle row and the rows without any, from bm_rank_t (after the final cut)
 void index_group_counts(HostIndex& h, uint32_t T);
 hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s);

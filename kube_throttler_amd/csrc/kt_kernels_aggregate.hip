@@ -188,8 +188,11 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     }
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
   }
-  for (uint32_t ci = 0; ci < a.ix.n_chunks; ++ci) {
-    if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
+  // (the walk without a rank — slow list, overflow pods — rides on the first chunk the workgroup stages)
+  uint32_t first_ci = 0u, last_ci = a.ix.n_chunks - 1u;
+  if (by_ns) relevant_chunk_span(a.ix, ns_lo, ns_hi, first_ci, last_ci), last_ci = max(last_ci, first_ci);
+  for (uint32_t ci = first_ci; ci <= last_ci; ++ci) {
+    if (by_ns && ci != first_ci && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
     const BmChunk ch = a.ix.chunks[ci];
     const uint32_t n_thr = ch.n_thr;
     const uint32_t rec = PK ? a.pk.rec_bytes : agg_rec_bytes(D, counts);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).
       const bool overflow = a.has_overflow && countable && (meta & kMetaOverflow) != 0;
       const bool scan_counted = counted && !overflow;
-      if (ci == 0 && (a.n_slow || a.has_overflow))
+      if (ci == first_ci && (a.n_slow || a.has_overflow))
         agg_walk_without_rank(a.sp, a.slow_thr, a.n_slow, a.T, a.lpair, a.lkey, a.LS, a.req, D, DS, a.partial, a.sign, a.limb, p, ns, countable,
                               counted, overflow, present);
 
@@ -708,9 +711,12 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   BmAggArgs bm_args = make_bm_agg_args(pods, sc, sp, sp_dev, ix, partial, slab, &bm_total);
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
   // the packed fold: full scans over the scan view, records no larger than the plain ones (the slab areas were sized for those)
+  // (ix.cut_thr_bytes: the record size the chunks' tables and slab areas were cut for — the plain record, or the packed fold's
+  //  for a program of several chunks; the engine cuts again before it launches a fold whose records are larger)
   const bool packed = bm_args.v_pk != nullptr && bm_args.ix.by_ns && !sc.counts && sc.sign == 1 && sc.nonneg &&
-                      bm_args.pk.rec_bytes <= agg_rec_bytes(pods.D, false);
+                      bm_args.pk.rec_bytes <= ix.cut_thr_bytes;
   if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
+  if (!packed && agg_rec_bytes(pods.D, sc.counts) > ix.cut_thr_bytes) return nullptr;
   int nb = aggregate_blocks(n_rows);
   if (bm_args.ix.by_ns && bm_args.wg_range) {
     // planned ranges: one per workgroup of the full grid (a workgroup whose range is empty returns: multi-chunk programs only,

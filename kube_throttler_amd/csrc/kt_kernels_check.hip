@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   // namespace order (a.ix.by_ns; rows[] sorted by namespace, results indexed by pod row): this workgroup owns the
   // tiles [t_lo, t_hi) and only walks the chunks that hold words of their namespaces
   const bool by_ns = !SMALL && !ONE && a.ix.by_ns != 0u;
-  uint32_t t_lo = 0, t_hi = n_wtiles, ns_lo = 0, ns_hi = 0, last_ci = n_chunks - 1u;
+  uint32_t t_lo = 0, t_hi = n_wtiles, ns_lo = 0, ns_hi = 0, first_ci = 0u, last_ci = n_chunks - 1u;
   // the records the workgroup's tiles are cut from: [rec0, rec_end) — tile wt holds records rec0 + 64 wt .. (everything, or
   // this workgroup's range of a namespace-ordered list: planned ranges end at namespace boundaries where one lies close)
   uint32_t rec0 = 0, rec_end = n;
@@ -328,11 +328,12 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     ns_lo = (uint32_t)(a.v_meta[(uint64_t)rec0 + (uint64_t)t_lo * kWave] & kMetaNsMask);
     ns_hi = (uint32_t)(a.v_meta[min((uint64_t)rec0 + (uint64_t)t_hi * kWave, (uint64_t)rec_end) - 1u] & kMetaNsMask);
     ns_lo = __builtin_amdgcn_readfirstlane(ns_lo), ns_hi = __builtin_amdgcn_readfirstlane(max(ns_hi, ns_lo));
-    last_ci = last_relevant_chunk(a.ix, ns_lo, ns_hi);
+    relevant_chunk_span(a.ix, ns_lo, ns_hi, first_ci, last_ci);
+    last_ci = max(last_ci, first_ci);
   }
-  for (uint32_t ci = c_lo; ci < c_hi; ++ci) {
-    if (by_ns && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
-    const bool first = ONE || ci == 0, last = ONE || ci == last_ci;
+  for (uint32_t ci = SMALL ? c_lo : first_ci; ci < (SMALL ? c_hi : last_ci + 1u); ++ci) {
+    if (by_ns && ci != first_ci && !chunk_relevant(a.ix, ci, ns_lo, ns_hi)) continue;
+    const bool first = ONE || ci == (SMALL ? 0u : first_ci), last = ONE || ci == last_ci;
     const BmChunk ch = a.ix.chunks[ci];
     // the tile's records, always from valid addresses: lanes past the end re-read the last pod and are switched off by
     // `on` (kTilePrefetch: requested ahead of the tile — measured, not kept)

@@ -57,13 +57,14 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
   atom_row_offsets<LA>(raw, ro);
   int64_t v[DT];
   load_requests<DT>(a.req, a.DS, p, v);
-  const uint32_t* nsl_off = (const uint32_t*)(img + ch.off_nsl_off);
+  const u32x2* nsl_rng = (const u32x2*)(img + ch.off_nsl_rng);
   const NsWord* nsl = (const NsWord*)(img + ch.off_nsl);
   const WordHdr* hdr = (const WordHdr*)(img + ch.off_hdr);
   const uint32_t* term_t = (const uint32_t*)(img + ch.off_term_t);
   const CheckRec<DT>* recs = (const CheckRec<DT>*)a.recs;
-  uint32_t k = nsl_off[ns] + j;
-  const uint32_t k1 = on ? nsl_off[ns + 1] : 0u;
+  const u32x2 rng = nsl_rng[ns];
+  uint32_t k = rng.x + j;
+  const uint32_t k1 = on ? rng.y : 0u;
   unsigned long long my = 0;
   for (; k < k1; k += W) {  // normally one trip: a namespace has a handful of words per chunk
     const u32x4 e = *(const u32x4*)(nsl + k);  // {w, -, mask lo, mask hi}
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
     const WordHdr h = hdr[w];
     uint64_t any = h.univ, two = 0, three = 0, vet = 0;
     const unsigned char* col = img + (size_t)w * ch.col_rows * 8u;  // the word's column of the `any` plane
-    const unsigned char* colv = col + (size_t)ch.n_words * ch.col_rows * 8u;
+    // (a word without a veto column reads the plane's all-zero column: kt_index.h, image layout)
+    const unsigned char* colv = (ch.zero_col == 0u || (e.y & kNsWordVeto) != 0u) ? col + (size_t)ch.n_words * ch.col_rows * 8u : img + ch.zero_col;
 #pragma unroll
     for (int l = 0; l < LA; ++l) {
       const uint64_t r = *(const unsigned long long*)(col + ro[l]);

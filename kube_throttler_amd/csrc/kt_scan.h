@@ -53,10 +53,12 @@ static inline void plan_bitmap_index(const IndexDev& ix, BmIndexArgs& a, Take&& 
   a.chunk_ns = ix.bm_chunk_ns, a.ns_words = ix.ns_words, a.by_ns = 0u;
 }
 
-// Scans in namespace order: does chunk ci hold words of some namespace in [ns_lo, ns_hi]?  Chunk 0 always counts (it
-// carries the once-per-pod work).  Wave-uniform arguments: scalar loads.
+// Scans in namespace order: does chunk ci hold words of some namespace in [ns_lo, ns_hi]?  Wave-uniform arguments: scalar
+// loads.  The workgroup walks the chunks first_ci .. last_ci that are relevant; the once-per-pod work (slow list, overflow
+// pods, the start of the carry) rides on first_ci, the summary words on last_ci — chunk 0 when no chunk holds a word of the
+// range's namespaces (round 6: with the grouped plan chunk 0 belongs to ONE group of namespaces; every other workgroup used
+// to stage and scan it for nothing).
 __device__ __forceinline__ bool chunk_relevant(const BmIndexArgs& a, uint32_t ci, uint32_t ns_lo, uint32_t ns_hi) {
-  if (ci == 0) return true;
   const uint32_t* m = a.chunk_ns + (size_t)ci * a.ns_words;
   const uint32_t w_lo = ns_lo >> 5, w_hi = ns_hi >> 5;
   for (uint32_t w = w_lo; w <= w_hi; ++w) {
@@ -67,18 +69,18 @@ __device__ __forceinline__ bool chunk_relevant(const BmIndexArgs& a, uint32_t ci
   }
   return false;
 }
-__device__ __forceinline__ uint32_t last_relevant_chunk(const BmIndexArgs& a, uint32_t ns_lo, uint32_t ns_hi) {
-  uint32_t last = 0;
-  for (uint32_t ci = 1; ci < a.n_chunks; ++ci)
-    if (chunk_relevant(a, ci, ns_lo, ns_hi)) last = ci;
-  return last;
+__device__ __forceinline__ void relevant_chunk_span(const BmIndexArgs& a, uint32_t ns_lo, uint32_t ns_hi, uint32_t& first, uint32_t& last) {
+  first = 0xFFFFFFFFu, last = 0u;
+  for (uint32_t ci = 0; ci < a.n_chunks; ++ci)
+    if (chunk_relevant(a, ci, ns_lo, ns_hi)) first = first == 0xFFFFFFFFu ? ci : first, last = ci;
+  if (first == 0xFFFFFFFFu) first = 0u;
 }
 
 // The tables of the chunk that is resident in LDS
 struct BmView {
   KT_LDS const unsigned char* rows;  // any[n_words][col_rows], then (VETO) veto[n_words][col_rows]: 8-byte cells
   KT_LDS const WordHdr* hdr;         // [n_words]
-  lds_u32p nsl_off;                  // [n_ns + 1]
+  KT_LDS const u32x2* nsl_rng;       // [n_ns] {begin, end} of the namespace's word list
   KT_LDS const NsWord* nsl;
   const uint32_t* term_g;            // (HBM) selector-program term of every number: `slow` candidates only
 #ifdef KT_PROBE_UNIFORM
@@ -86,7 +88,8 @@ struct BmView {
   uint32_t off_nsl_g, off_hdr_g;
 #endif
   uint32_t col_bytes;                // bytes per word column
-  uint32_t veto_off;                 // from a cell of the `any` plane to the same cell of the veto plane
+  uint32_t veto_off;                 // from a cell of the `any` plane to the same cell of the veto plane (words with a veto column)
+  uint32_t zero_col;                 // offset (from rows) of the veto plane's all-zero column: what a word WITHOUT a veto column reads
   uint32_t has_slow;
 };
 
@@ -170,7 +173,7 @@ __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const Bm
   BmView v;
   v.rows = base;
   v.hdr = (KT_LDS const WordHdr*)(base + ch.off_hdr);
-  v.nsl_off = (lds_u32p)(base + ch.off_nsl_off);
+  v.nsl_rng = (KT_LDS const u32x2*)(base + ch.off_nsl_rng);
   v.nsl = (KT_LDS const NsWord*)(base + ch.off_nsl);
   v.term_g = (const uint32_t*)(a.blob + ch.img_off + ch.off_term_g);
 #ifdef KT_PROBE_UNIFORM
@@ -178,6 +181,7 @@ __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const Bm
 #endif
   v.col_bytes = ch.col_rows * 8u;
   v.veto_off = VETO ? ch.n_words * ch.col_rows * 8u : 0u;
+  v.zero_col = VETO ? ch.zero_col : 0u;
   v.has_slow = ch.has_slow;
   return v;
 }
@@ -271,8 +275,9 @@ struct ScanNoPrefetch {
 template <int LA, bool VETO, int NEED, bool PIPE = true, class Match, class Confirm, class Post = ScanKeepAll, class Pre = ScanNoPrefetch>
 __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_t ns, const uint32_t (&ro)[LA], Match&& match,
                                           Confirm&& confirm, Post&& post = Post(), Pre&& pre = Pre()) {
-  uint32_t k = b.nsl_off[ns];
-  const uint32_t k1 = lane_on ? b.nsl_off[ns + 1] : k;
+  const u32x2 rng = b.nsl_rng[ns];
+  uint32_t k = rng.x;
+  const uint32_t k1 = lane_on ? rng.y : k;
   uint64_t x = 0;
   uint32_t w = 0;
   u32x4 e_next = {0u, 0u, 0u, 0u};
@@ -320,7 +325,9 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
 #endif
       const auto pf = pre(w);
       KT_LDS const unsigned char* col = b.rows + __umul24(w, b.col_bytes);  // (word < 2^10, column bytes < 2^18)
-      KT_LDS const unsigned char* colv = col + b.veto_off;
+      // (the veto plane holds the columns of the words that have a veto bit somewhere and one all-zero column: a lane whose word
+      //  has none — a tile that straddles namespaces, or an instantiation that reads both planes for every word — reads that)
+      KT_LDS const unsigned char* colv = (!VETO || b.zero_col == 0u || (e.y & kNsWordVeto) != 0u) ? col + b.veto_off : b.rows + b.zero_col;
       uint64_t xx, vet = 0;
       if (NEED >= 3) {
         // The FORM of the word (NsWord::flags — inside a class the groups are numbered by form, so most words are pure),

@@ -143,7 +143,12 @@ static Program random_program(std::mt19937& rng, uint32_t T, uint32_t n_ns, uint
 
 // a cell of a chunk image's planes (kt_index.h: any[n_words][col_rows], then veto[n_words][col_rows])
 static inline uint64_t cell_any(const BmChunk& ch, const uint64_t* rows, size_t id, size_t w) { return rows[w * ch.col_rows + id]; }
-static inline uint64_t cell_veto(const BmChunk& ch, const uint64_t* rows, size_t id, size_t w) { return rows[((size_t)ch.n_words + w) * ch.col_rows + id]; }
+// (the veto plane holds the columns of local words [0, n_veto) and — when there are others — one all-zero column, which is what
+//  the device reads for a word without a veto column: BmChunk::zero_col)
+static inline uint64_t cell_veto(const BmChunk& ch, const uint64_t* rows, size_t id, size_t w) {
+  if (w < ch.n_veto) return rows[((size_t)ch.n_words + w) * ch.col_rows + id];
+  return rows[(size_t)ch.zero_col / 8 + id];
+}
 
 // kt_translate_pods on the host: the pod's labels as ids of referenced atoms (open-addressing table of the index)
 static uint32_t atom_id_of(const HostIndex& ix, uint32_t atom) {
@@ -245,14 +250,15 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
     const unsigned char* img = ix.bm_images.data() + ch.img_off;
     const uint64_t* rows = (const uint64_t*)img;
     const WordHdr* hdr = (const WordHdr*)(img + ch.off_hdr);
-    const uint32_t* nsl_off = (const uint32_t*)(img + ch.off_nsl_off);
+    const uint32_t* nsl_rng = (const uint32_t*)(img + ch.off_nsl_rng);
     const NsWord* nsl = (const NsWord*)(img + ch.off_nsl);
     const uint32_t* term_t = (const uint32_t*)(img + ch.off_term_t);
     const uint16_t* term_rank = (const uint16_t*)(img + ch.off_term_rank);
     const uint32_t* term_g = (const uint32_t*)(img + ch.off_term_g);
     EXPECT(ch.off_term_t == ch.lds_bytes, "LDS part must end where term_t starts");
     uint32_t last_t = ~0u, last_r = ~0u, prev_w = ~0u;
-    for (uint32_t k = nsl_off[ns_rel]; k < nsl_off[ns_rel + 1]; ++k) {
+    EXPECT(ch.n_veto <= ch.n_words && (ch.zero_col == 0u) == (!ix.rich || ch.n_veto == ch.n_words), "veto columns of chunk %zu", ci);
+    for (uint32_t k = nsl_rng[2 * ns_rel]; k < nsl_rng[2 * ns_rel + 1]; ++k) {
       const uint32_t w = nsl[k].w;
       EXPECT(w < ch.n_words, "word %u of %u", w, ch.n_words);
       EXPECT(prev_w == ~0u || w > prev_w, "word list of ns %u not ascending", pod.ns);
@@ -261,6 +267,7 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       if (getenv("KT_SIM_WORD_FORMS")) {
         const bool wv = (nsl[k].flags & kNsWordVeto) != 0, w3 = hdr[w].m3 != 0;
         EXPECT(!ix.rich || wv == (word_veto_flags(ix)[ci][w] != 0), "veto flag of word %u", w);
+        EXPECT(!ix.rich || wv == (w < ch.n_veto), "word %u: veto flag %d, veto column %d", w, (int)wv, (int)(w < ch.n_veto));
         g_word_veto += wv, g_word_m3 += w3, g_word_plain += !wv && !w3;
         g_word_keys += __builtin_popcount(word_key_masks(ix)[ci][w]);
       }
@@ -320,7 +327,7 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       }
     }
     // the namespace's word list is exactly the words its admission can touch
-    for (uint32_t k = nsl_off[ns_rel]; k < nsl_off[ns_rel + 1]; ++k) EXPECT(nsl[k].mask != 0, "empty mask in the word list of ns %u", pod.ns);
+    for (uint32_t k = nsl_rng[2 * ns_rel]; k < nsl_rng[2 * ns_rel + 1]; ++k) EXPECT(nsl[k].mask != 0, "empty mask in the word list of ns %u", pod.ns);
   }
   for (uint32_t t : walk_slow ? ix.slow_thr : std::vector<uint32_t>()) {
     const int r = brute(p, t, pod);  // walk_slow_mem IS the in-order walk
@@ -333,9 +340,11 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
 static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
   uint32_t w = 0, rank = 0;
   std::set<uint32_t> seen_t;
+  EXPECT(ix.cut_thr_bytes != 0 && ix.cut_thr_bytes <= thr_bytes, "record size of the cut: %u (plain: %u)", ix.cut_thr_bytes, thr_bytes);
+  thr_bytes = ix.cut_thr_bytes;  // (the packed fold's record size when the caller offered it and the program needs several chunks)
   auto fits_one = [&](const BmChunk& ch) {
     return (size_t)ch.lds_bytes + (size_t)ch.n_words * kCheckWordLds <= chk_budget &&
-           (size_t)ch.lds_bytes + (((size_t)ch.n_words * 128 + 15) & ~(size_t)15) + (size_t)ch.n_thr * thr_bytes + 16 <= agg_budget;
+           (size_t)ch.lds_bytes + (((size_t)ch.n_words * 128 + 15) & ~(size_t)15) + (size_t)ch.n_words * 16 + (size_t)ch.n_thr * thr_bytes + 16 <= agg_budget;
   };
   for (size_t i = 0; i < ix.bm_chunks.size(); ++i) {
     const BmChunk& ch = ix.bm_chunks[i];
@@ -371,10 +380,11 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   for (const BmChunk& ch : ix.bm_chunks) all_fit &= fits_one(ch);
   if (all_fit) {
     EXPECT((size_t)ix.bm_max_lds + (size_t)ix.bm_max_words * kCheckWordLds <= chk_budget, "maxima exceed the check budget");
-    EXPECT((size_t)ix.bm_max_lds + (((size_t)ix.bm_max_words * 128 + 15) & ~(size_t)15) + (size_t)ix.bm_max_thr * thr_bytes + 16 <= agg_budget,
+    EXPECT((size_t)ix.bm_max_lds + (((size_t)ix.bm_max_words * 128 + 15) & ~(size_t)15) + (size_t)ix.bm_max_words * 16 + (size_t)ix.bm_max_thr * thr_bytes + 16 <= agg_budget,
            "maxima exceed the aggregate budget");
   }
-  EXPECT(w == ix.bm_words, "chunks cover %u of %u words", w, ix.bm_words);
+  EXPECT(w == ix.img_words && w >= ix.bm_words, "chunk images hold %u words, index says %u (program: %u)", w, ix.img_words, ix.bm_words);
+  EXPECT(ix.cut_grouped || w == ix.bm_words, "the global plan copies no word: %u of %u", w, ix.bm_words);
   EXPECT(rank == ix.bm_rank_t.size(), "ranks cover %u of %zu", rank, ix.bm_rank_t.size());
   for (uint32_t t : ix.bm_rank_t) {
     // a throttle has one rank per GROUP (namespace cell, kt_index.cpp): that a pod never meets two of them is what
@@ -440,6 +450,7 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
     }
   }
   const size_t chunks_first = ix.bm_chunks.size();
+  const int64_t visits_first = ix.ns_chunk_visits;
   {  // cut_chunks(): the same numbering cut again for other budgets (what the engine does when the half-LDS cut needs
      // several chunks) must describe the same matches
     const uint32_t agg2 = agg_budget * 2, chk2 = chk_budget * 2;
@@ -457,7 +468,11 @@ static long run_case(uint32_t seed, uint32_t T, uint32_t n_ns, uint32_t K, uint3
         EXPECT((it == got.end() ? 0 : it->second) == brute(p, t, pod), "seed %u re-cut pod %d throttle %u", seed, i, t);
       }
     }
-    EXPECT(ix.bm_chunks.size() <= chunks_first, "doubling the budgets gave %zu chunks instead of %zu", ix.bm_chunks.size(), chunks_first);
+    // (larger budgets never cost a namespace-ordered scan chunk passes; the grouped plan may well have MORE chunks than the
+    //  global one it replaces — what it lowers are the chunks per namespace, and it is only taken when it saves a fifth of them)
+    EXPECT(ix.ns_chunk_visits * 4 <= visits_first * 5 + 4, "doubling the budgets gave %lld chunk visits over the namespaces instead of %lld", (long long)ix.ns_chunk_visits,
+           (long long)visits_first);
+    EXPECT(ix.cut_grouped || ix.bm_chunks.size() <= chunks_first, "doubling the budgets gave %zu chunks instead of %zu", ix.bm_chunks.size(), chunks_first);
   }
   return (long)chunks_first * 1000000L + matches % 1000000L + (ix.rich ? 0 : 500000000L);
 }
@@ -721,7 +736,9 @@ static int run_file(const char* path, uint32_t chk_budget) {
   for (int rep = 0; rep < reps; ++rep) {
     const auto t0 = std::chrono::steady_clock::now();
     build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,
-                [&](uint32_t t) { return p.thr[t]; }, NS, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L, &adm_all);
+                [&](uint32_t t) { return p.thr[t]; }, NS, p.ns_term_ok, p.gw, agg_budget, chk_budget, thr_bytes, (int)L, &adm_all, 0u,
+                getenv("KT_SIM_CHK_WORD") ? (uint32_t)atoi(getenv("KT_SIM_CHK_WORD")) : kCheckWordLds, nullptr,
+                getenv("KT_SIM_PACKED") ? (uint32_t)atoi(getenv("KT_SIM_PACKED")) : 0u);  // (the engine: check_word_lds(D) = 816 at D <= 8, 40-byte packed records)
     if (reps > 1) fprintf(stderr, "build_index: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   check_structure(p, ix, agg_budget, chk_budget, thr_bytes);
@@ -758,7 +775,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
         const unsigned char* img = ix.bm_images.data() + ch.img_off;
         const uint64_t* rows = (const uint64_t*)img;
         const WordHdr* hd = (const WordHdr*)(img + ch.off_hdr);
-        const uint32_t* nsl_off = (const uint32_t*)(img + ch.off_nsl_off);
+        const uint32_t* nsl_rng = (const uint32_t*)(img + ch.off_nsl_rng);
         const NsWord* nsl = (const NsWord*)(img + ch.off_nsl);
         std::vector<uint32_t> k(64), k1(64);
         std::vector<uint64_t> x(64, 0);
@@ -766,7 +783,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
         for (int l = 0; l < 64; ++l) {
           bool ov;
           ids[l] = translate(ix, tile[l], &ov);
-          k[l] = nsl_off[tile[l].ns], k1[l] = nsl_off[tile[l].ns + 1];
+          k[l] = nsl_rng[2 * tile[l].ns], k1[l] = nsl_rng[2 * tile[l].ns + 1];
         }
         if (&ch == &ix.bm_chunks[0]) {  // atoms the pods of a tile carry (labels no selector refers to have none)
           size_t mx = 0;
@@ -850,6 +867,18 @@ static int run_file(const char* path, uint32_t chk_budget) {
     printf("  per 64-pod tile (all chunks): %.1f advance rounds, %.1f peel steps at %.1f %% busy lanes\n", (double)adv_rounds / tiles,
            (double)peel_steps / tiles, peel_steps ? 100.0 * (double)peel_busy / (64.0 * (double)peel_steps) : 0.0);
   if (tiles) printf("  chunks with any word for a tile: %.1f of %zu\n", (double)chunk_visits / tiles, ix.bm_chunks.size());
+  {  // chunk passes of a namespace-ordered scan: the chunks that hold a word list of the namespace
+    std::vector<uint32_t> per_ns(NS, 0u);
+    for (const BmChunk& ch : ix.bm_chunks) {
+      const uint32_t* nsl_rng = (const uint32_t*)(ix.bm_images.data() + ch.img_off + ch.off_nsl_rng);
+      for (uint32_t n = 0; n < NS; ++n) per_ns[n] += nsl_rng[2 * n + 1] > nsl_rng[2 * n];
+    }
+    uint64_t sum = 0;
+    uint32_t mx = 0, used = 0;
+    for (uint32_t n = 0; n < NS; ++n) sum += per_ns[n], mx = std::max(mx, per_ns[n]), used += per_ns[n] != 0;
+    printf("  %s plan: %zu chunks over %u image words (program: %u); chunks per namespace: %.2f on average, %u at most; images %.1f MB\n",
+           ix.cut_grouped ? "grouped" : "global", ix.bm_chunks.size(), ix.img_words, ix.bm_words, used ? (double)sum / used : 0.0, mx, ix.bm_images.size() / 1048576.0);
+  }
   if (atoms_tiles) printf("  atoms per pod: %.2f (largest of a tile: %.2f)\n", (double)atoms_sum / (64.0 * atoms_tiles), (double)atoms_tile_max / atoms_tiles);
   if (sim_banks && bank_instr)
     printf("  LDS passes of the atom-row gathers: %.2f per instruction and 32 lanes, %.1f per advance round of a tile (conflict-free: %.1f)\n",

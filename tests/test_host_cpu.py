@@ -162,12 +162,17 @@ def test_index_builder_against_cpu_scan_replay(tool):
     # is how the round-3 rewrite of the builder's phases was accepted, together with the fingerprints of the dumped
     # BASELINE programs); a change of the index LAYOUT moves it on purpose — then re-pin it here after the GPU parity
     # tests have passed on the new layout.
-    assert "fingerprint of all indexes 94a7baeaa78ce28f" in out.stdout, out.stdout[-400:]
+    assert "fingerprint of all indexes 2c88ef0baed90af9" in out.stdout, out.stdout[-400:]
     # the builder's phases on several host threads (only programs beyond 16k throttles split by themselves): parts built
     # side by side and joined must give the same indexes
     out3 = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_INDEX_THREADS="3"))
     assert out3.returncode == 0, out3.stderr[-2000:]
-    assert "fingerprint of all indexes 94a7baeaa78ce28f" in out3.stdout, out3.stdout[-400:]
+    assert "fingerprint of all indexes 2c88ef0baed90af9" in out3.stdout, out3.stdout[-400:]
+    # the GROUPED plan of cut_chunks (chunks per group of namespaces, words copied between groups: KT_CUT_PLAN=grouped — measured
+    # on the GPU in round 6 and not the default) must describe the same matches: every throttle reported once, nothing missed
+    outg = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_CUT_PLAN="grouped"))
+    assert outg.returncode == 0 and "all expectations held" in outg.stdout, outg.stdout[-400:] + outg.stderr[-2000:]
+    assert "fingerprint of all indexes 9aa4b03ca8ab825a" in outg.stdout, outg.stdout[-400:]
 
 
 def test_anchor_split_against_brute_force(tool, tmp_path):
@@ -273,11 +278,14 @@ def test_scan_replay_on_the_10k_throttle_program(tool, tmp_path):
     dump = tmp_path / "cfg4.bin"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_program.py"), "--config", "4", "--pods", "512", str(dump)],
                           stdout=subprocess.DEVNULL)
-    for budget, lo, hi in (("147000", 20, 45), ("65000", 50, 100)):  # one / two workgroups per CU
-        out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump), budget], capture_output=True, text=True)
+    # (round 6: the global plan — consecutive word ranges — with the veto columns of veto-free words elided; and the GROUPED
+    #  plan, KT_CUT_PLAN=grouped: chunks per group of namespaces, more of them and far fewer per namespace)
+    for budget, plan, lo, hi, per_ns in (("147000", "global", 20, 45, 9.0), ("65000", "global", 50, 100, 14.0), ("147000", "grouped", 60, 200, 5.5)):
+        out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump), budget], capture_output=True, text=True, env=dict(os.environ, KT_CUT_PLAN=plan))
         assert out.returncode == 0, out.stdout + out.stderr
         chunks = int(re.search(r"-> (\d+) chunks", out.stdout).group(1))
-        assert "10000 throttles" in out.stdout and lo <= chunks <= hi and "rich {any, veto}" in out.stdout
+        assert "10000 throttles" in out.stdout and lo <= chunks <= hi and "rich {any, veto}" in out.stdout, out.stdout
+        assert plan + " plan" in out.stdout and float(re.search(r"chunks per namespace: ([\d.]+) on average", out.stdout).group(1)) <= per_ns, out.stdout
         assert " 0 slow confirmations" in out.stdout
         matches = float(re.search(r"([\d.]+) matches per pod", out.stdout).group(1))
         assert 50.0 < matches < 500.0

@@ -3,12 +3,12 @@
 # everything the device gets must not move — on the random suite of index_sim_test and on the real selector programs of
 # BASELINE configs[2] and the configs[4] shard — and the phase times tell what the change bought (minimum of 12 builds,
 # single-threaded unless THREADS is set).       usage: tools/index_build_check.sh
-# The pinned values are those of the round-5 layout (word columns of 8-byte cells, atoms numbered by home slot: kt_index.h); a change of the index LAYOUT moves them on purpose (re-pin here and
+# The pinned values are those of the round-6 layout (veto plane of the words that have veto bits + a zero column, shared word lists as {begin, end} pairs: kt_index.h); a change of the index LAYOUT moves them on purpose (re-pin here and
 # in tests/test_host_cpu.py after the GPU parity tests have passed on the new layout).
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
-WANT="94a7baeaa78ce28f 97c462f0446346cb da948deea7f1f907"
+WANT="2c88ef0baed90af9 81e0ec977f2b20af 75dbd44a87782bd5"
 make -C kube_throttler_amd/csrc 2>&1 | grep -E "error|warning"
 make -C kube_throttler_amd/host index_sim_test 2>&1 | grep -E "error|warning"
 for c in 2 4; do
