@@ -51,12 +51,56 @@ def aggregate_bytes(snap, n_counted, L):
     return n_counted * (8 + 4 * L + 8 * D) + T * 16 + 16 * n_req + T * (2 * D + 1) * 8
 
 
+# ---- self-verification of a run.  The finalize is REPLICATED: after the exchange every rank computes `used`,
+# thresholds and throttled flags of every throttle from the same summed partials, so the fingerprints of those tables must be
+# EQUAL over the ranks; the summary words belong to a rank's own pod rows and are fingerprinted per rank.  These three functions
+# are what `bench.py --gpus N` runs after the timed region (and tests/test_bench_verify_cpu.py drives with fake ranks on CPU).
+REPLICATED_FIELDS = ("used.v", "used.count", "used.present", "thrl_flag", "thrl_has", "thrl_pod", "error")
+
+
+def result_hashes(rec, summary):
+    """{"replicated": sha1 of the post-finalize per-throttle tables, "own": sha1 of this rank's summary words, "both": the
+    fingerprint of the whole step as `results_sha1` has been since round 3}."""
+    import hashlib
+    import numpy as np
+    h_rep, h_own, h_both = hashlib.sha1(), hashlib.sha1(), hashlib.sha1()
+    for a in (rec.used.v, rec.used.count, rec.used.present, rec.thrl_flag, rec.thrl_has, rec.thrl_pod, rec.error):
+        b = np.ascontiguousarray(a).tobytes()
+        h_rep.update(b), h_both.update(b)
+    b = np.ascontiguousarray(summary).tobytes()
+    h_own.update(b), h_both.update(b)
+    return {"replicated": h_rep.hexdigest()[:16], "own": h_own.hexdigest()[:16], "both": h_both.hexdigest()[:16]}
+
+
+def ranks_agree(per_rank):
+    """per_rank: the result_hashes() of every rank (+ "rank").  The replicated finalize must have left the same tables everywhere."""
+    reps = {g["replicated"] for g in per_rank}
+    return len(reps) == 1
+
+
+def verify_against_oracle(full_snap, now, rec, throttle_rows, nthreads=None):
+    """`rec`: a rank's post-finalize result (replicated).  The oracle reconciles the sampled throttles on the UNSHARDED snapshot —
+    what the 8 ranks together must have computed; returns the list of mismatching (field, throttle row) pairs (empty = parity)."""
+    import numpy as np
+    from oracle import kt_oracle as O
+    o = O.Oracle(full_snap)
+    want = o.reconcile(now, rows=np.asarray(throttle_rows, dtype=np.int64), nthreads=nthreads or O.effective_cpus())
+    bad = []
+    for j, t in enumerate(throttle_rows):
+        for name, g, w in (("used.v", rec.used.v[t], want.used.v[j]), ("used.count", rec.used.count[t], want.used.count[j]),
+                           ("used.present", rec.used.present[t], want.used.present[j]), ("thrl_flag", rec.thrl_flag[t], want.thrl_flag[j]),
+                           ("thrl_has", rec.thrl_has[t], want.thrl_has[j]), ("thrl_pod", rec.thrl_pod[t], want.thrl_pod[j]),
+                           ("error", rec.error[t], want.error[j])):
+            if not np.array_equal(np.asarray(g), np.asarray(w)):
+                bad.append((name, int(t)))
+    return bad
+
+
 def extra_leg(index, min_seconds):
     """One more configuration timed on this GPU after the headline leg (N = 1 only): the same step — reconcile with APPLY +
     PreFilter sweep of every pod — for at least `min_seconds`, per-kernel HIP-event times from a second pass, the roofline
     fractions of both scans and the fingerprint of what the step left behind.  configs[4] is its first 1/8 shard (1.25M pod
     rows of the 10M-pod job's generator stream, all 10k throttles)."""
-    import hashlib
     import numpy as np
     import torch
     from kube_throttler_amd import engine as E, snapshot as S, workload as W
@@ -107,17 +151,30 @@ def extra_leg(index, min_seconds):
                       ("finalize", E.KERNEL_FINALIZE), ("prepare", E.KERNEL_PREPARE)):
         tot, n = eng.timing_read(fam)
         k_ms[name] = tot / max(n, 1)
-    h = hashlib.sha1()
     rec_f = eng.reconcile_fetch()
     _, sm_f = eng.check_fetch(per_gpu, False)
-    for a in (rec_f.used.v, rec_f.used.count, rec_f.used.present, rec_f.thrl_flag, rec_f.thrl_has, rec_f.thrl_pod, rec_f.error, sm_f):
-        h.update(np.ascontiguousarray(a).tobytes())
+    sha_both = result_hashes(rec_f, sm_f)["both"]
     flags = snap.pod_flags[:per_gpu]
     need = S.POD_VALID | S.POD_SCHED_MATCH | S.POD_SCHEDULED
     n_counted = int(((flags & need) == need).sum())
     chk_bytes, _, _ = algorithmic_bytes(snap, per_gpu, snap.L)
     agg_bytes = aggregate_bytes(snap, n_counted, snap.L)
     ms = elapsed * 1e3 / steps
+    # the rocprofv3 averages of the same leg, when profiles/pmc_summary.json holds them for THIS library's sources
+    prof_ms = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as fh:
+            pmc = json.load(fh)
+        key = "config%d_indexed" % index
+        if pmc.get("_source", {}).get(key, {}).get("engine_version") == E.version():
+            sym = lambda k: k.replace("_chunked", "").replace("_packed", "")
+            prof_ms = {}
+            for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("reduce", E.KERNEL_REDUCE), ("finalize", E.KERNEL_FINALIZE)):
+                ns = pmc.get(key, {}).get(sym(eng.kernel_name(fam)), {}).get("rocprof_avg_ns")
+                if ns and k_ms[name] > 0:
+                    prof_ms[name] = round(ns * 1e-6, 6)
+    except Exception:
+        prof_ms = None
     frac = lambda nbytes, t_ms: round(nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_ms > 0 else 0.0
     out = {
         "workload": WORKLOADS[index] + (" — shard 0 of 8 on this GPU" if index == 4 else ""),
@@ -130,7 +187,8 @@ def extra_leg(index, min_seconds):
         "reconcile_frac": frac(agg_bytes, k_ms["aggregate"] + k_ms["reduce"] + k_ms["finalize"]),
         "step_frac": frac(chk_bytes + agg_bytes, ms),
         "algorithmic_bytes": {"check": chk_bytes, "aggregate": agg_bytes},
-        "results_sha1": h.hexdigest()[:16], "setup_s": round(t_setup, 2),
+        "per_kernel_ms_rocprof": prof_ms or None,
+        "results_sha1": sha_both, "setup_s": round(t_setup, 2),
     }
     eng.close()
     del partial
@@ -369,16 +427,49 @@ def main():
         k_ms[name] = tot / max(n, 1)
 
     # a fingerprint of what the step left behind (every summary word, every throttle's used / flags): two builds that claim
-    # the same results can be compared on full-size runs without an oracle pass (tools/gpu_r04_t.sh)
-    results_sha1 = None
-    if world == 1:
-        import hashlib
-        h = hashlib.sha1()
-        rec_f = eng.reconcile_fetch()
-        _, sm_f = eng.check_fetch(per_gpu, False)
-        for a in (rec_f.used.v, rec_f.used.count, rec_f.used.present, rec_f.thrl_flag, rec_f.thrl_has, rec_f.thrl_pod, rec_f.error, sm_f):
-            h.update(np.ascontiguousarray(a).tobytes())
-        results_sha1 = h.hexdigest()[:16]
+    # the same results can be compared on full-size runs without an oracle pass (tools/gpu_ab.sh).  With several ranks the
+    # replicated tables of every rank are compared (result_hashes / ranks_agree above): the first multi-GPU run verifies itself.
+    rec_f = eng.reconcile_fetch()
+    _, sm_f = eng.check_fetch(per_gpu, False)
+    hashes = dict(result_hashes(rec_f, sm_f), rank=rank)
+    results_sha1 = hashes["both"] if world == 1 else None
+    per_rank_hashes = [hashes]
+    if world > 1:
+        per_rank_hashes = [None] * world
+        dist.all_gather_object(per_rank_hashes, hashes)
+    agree = ranks_agree(per_rank_hashes)
+    if not agree:
+        if rank == 0:
+            print(json.dumps({"error": "the ranks' replicated finalize left DIFFERENT per-throttle tables: the exchange or a rank's scan is wrong",
+                              "ranks_agree": False, "per_rank_hashes": per_rank_hashes}))
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
+    # --verify: a throttle sample of the (replicated) result against the oracle on the UNSHARDED snapshot — the partial sums of
+    # all ranks together must be what one pass over every pod of the job gives
+    oracle_verify = None
+    if args.verify and rank == 0:
+        vcfg = W.preset(args.config)
+        for k in ("n_thr", "n_cluster", "D", "L", "K"):
+            setattr(vcfg, k, getattr(cfg, k))
+        vcfg.n_pods_total, vcfg.pod_begin, vcfg.n_pods = P_total, 0, P_total
+        full = snap if world == 1 else W.generate(vcfg)
+        need_t = S.THR_VALID | S.THR_RESPONSIBLE
+        live = np.nonzero((full.thr_flags[:T] & need_t) == need_t)[0]
+        sample_t = live[np.linspace(0, len(live) - 1, min(len(live), 48)).astype(np.int64)]
+        t0v = time.time()
+        bad = verify_against_oracle(full, now, rec_f, sample_t)
+        oracle_verify = {"throttles": int(len(sample_t)), "pods": int(P_total), "mismatches": bad[:8], "ok": not bad, "seconds": round(time.time() - t0v, 1)}
+    if world > 1:
+        okv = [oracle_verify]
+        dist.broadcast_object_list(okv, src=0)
+        oracle_verify = okv[0]
+    if oracle_verify is not None and not oracle_verify["ok"]:
+        if rank == 0:
+            print(json.dumps({"error": "the reconciled status differs from the oracle on the unsharded snapshot", "oracle_verify": oracle_verify}))
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(4)
 
     # what every rank's exchange and scans looked like — and the ranks must agree on the words of the partial buffer (the
     # all-reduce sums them position by position: a rank with another throttle set or another sum form would corrupt every
@@ -611,6 +702,7 @@ def main():
             "per_rank_ms_per_step": [round(x, 6) for x in rank_ms],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 6),
             "per_rank_kernel_ms": per_rank_kernel_ms,
+            "ranks_agree": agree, "per_rank_hashes": per_rank_hashes, "oracle_verify": oracle_verify,
             "index": index_stats, "partial_words": pending[0], "per_rank_index": per_rank_index,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "latency": latency,
         }

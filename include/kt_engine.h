@@ -97,7 +97,9 @@ int32_t kt_upsert_namespaces(kt_engine* e, const kt_snapshot* batch, const int32
  * The arrays are copied during the call.  A batch that fits a 64 KB pinned slot (an informer event, or a few dozen
  * coalesced ones) does NOT wait for the device: the call enqueues one kernel and returns; every other entry point — a
  * kt_check issued right behind it included — first waits for the newest such call, so the order "feed the event, then
- * the next PreFilter sees it" holds (kt_delete_pods and kt_upsert_pod likewise).  Larger batches block as before. */
+ * the next PreFilter sees it" holds (kt_delete_pods and kt_upsert_pod likewise).  Larger batches block as before.
+ * A batch may name a pod row more than once (coalesced informer events — Add, then Update of one pod): the entries are applied
+ * in batch order, the LAST one wins, exactly as if they had arrived in separate calls (incremental engines included). */
 int32_t kt_upsert_pods(kt_engine* e, const kt_snapshot* batch, const int64_t* pod_rows);
 /* Throttles: spec (threshold, overrides, selector), stored status and reserved amounts of each row. */
 int32_t kt_upsert_throttles(kt_engine* e, const kt_snapshot* batch, const int32_t* thr_rows);

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/kt_engine.h"
@@ -191,6 +192,8 @@ struct kt_engine {
   unsigned __int128 max_abs[KT_MAX_DIMS] = {0};  // max |effective request| bound per dimension
   uint64_t or_abs[KT_MAX_DIMS] = {0};            // OR of every |request| fed: its trailing zero bits are common to all of them
   kt::PackPlan pack;                             // packed fold of the current scan view (nw == 0: plain fold)
+  std::vector<unsigned long long> h_ns_end;      // host copy of the namespace ends of a namespace-ordered list (plan_wg_ranges)
+  std::vector<uint32_t> h_range;                 // ... and the ranges planned from it, on their way to the device
   bool cut_plain = false;                        // a scan needed the plain fold: the index chunks stay cut for plain records
   void* cur_launch_lock = nullptr;               // the LaunchLock of the launch-side call in progress (set and cleared under op_mu)
   std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0};
@@ -1325,15 +1328,6 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
         }
     for (int d = 0; d < D; ++d) batch_max[d] = std::max(batch_max[d], sum[d]), batch_total[d] += sum[d];
   }
-  if (e->incremental && rows && n > 1) {
-    // the delta scans remove every row's old content and add its new one, once per occurrence: a row named twice in
-    // one batch would be applied twice
-    std::vector<int64_t> sorted(rows, rows + n);
-    std::sort(sorted.begin(), sorted.end());
-    for (int64_t i = 1; i < n; ++i)
-      if (sorted[(size_t)i] == sorted[(size_t)i - 1])
-        return e->fail(KT_ERR_INVALID_ARGUMENT, "pod row %lld appears twice in one batch (incremental engine)", (long long)sorted[(size_t)i]);
-  }
   // a single request beyond 2^60 is refused here; whether the requests of all pods still ADD UP inside the exact range
   // is checked against their actual sum when a reconcile scans them (request_sums_in_range)
   for (int d = 0; d < D; ++d)
@@ -1361,8 +1355,25 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
   // ---- stage + ingest in chunks
   hipStream_t s = e->own_stream;
   const int64_t chunk = 1 << 20;
-  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
-    const int64_t cn = std::min(chunk, n - c0);
+  // A batch may name a pod row more than once (coalesced informer events: Add, then Update of the same pod) and the LAST entry
+  // must win, as if the events had arrived one by one.  The kernels below run one thread / wave per entry, so two entries of one
+  // row inside one launch would race for the row (the unfused path wrote a torn mix of both).  A chunk therefore ends
+  // where a row would repeat: the chunks are launched in stream order, every launch sees unique rows, the later entry
+  // overwrites the earlier one — and an incremental engine's delta scans take the first entry out again before the second goes in.
+  std::unordered_set<int64_t> seen_rows;
+  auto unique_prefix = [&](int64_t c0, int64_t max_n) -> int64_t {
+    if (!rows || max_n <= 1) return max_n;
+    bool ascending = true;
+    for (int64_t i = 1; i < max_n && ascending; ++i) ascending = rows[c0 + i] > rows[c0 + i - 1];
+    if (ascending) return max_n;  // (the usual case: no table needed)
+    seen_rows.clear();
+    seen_rows.reserve((size_t)std::min<int64_t>(max_n, 1 << 16));
+    for (int64_t i = 0; i < max_n; ++i)
+      if (!seen_rows.insert(rows[c0 + i]).second) return i;
+    return max_n;
+  };
+  for (int64_t c0 = 0, cn = 0; c0 < n; c0 += cn) {
+    cn = unique_prefix(c0, std::min(chunk, n - c0));
     const uint32_t lb = b->pod_label_off[c0], le = b->pod_label_off[c0 + cn];
     const uint32_t kb = b->pod_ctr_off[c0], ke = b->pod_ctr_off[c0 + cn];
     // layout of the staging buffer (8-byte aligned sections)
@@ -1395,18 +1406,7 @@ static int32_t upsert_pods_locked(kt_engine* e, const kt_snapshot* b, const int6
     }
     // ONE launch (kt_feed_small) for an event batch: the workgroup first pulls the whole slot over the link with all its
     // threads, the batch pointers name that device copy (KT_FEED_NO_STAGE=1: the kernel walks the slot over the link)
-    // A batch that names a row twice does not go through the fused kernels: they run ingest, translation and view patch of
-    // a row in one thread / wave with no barrier between the phases across the workgroup, so entry A could patch the scan
-    // view while entry B is still rewriting the same table row — the view record would keep A's content, the table B's.  The
-    // separate launches below see the final table content in every phase.
-    bool row_twice = false;
-    if (slot_path && rows && cn > 1 && cn <= kt::kFeedSmallMax) {
-      int64_t sorted[kt::kFeedSmallMax];
-      std::copy(rows + c0, rows + c0 + cn, sorted);
-      std::sort(sorted, sorted + cn);
-      row_twice = std::adjacent_find(sorted, sorted + cn) != sorted + cn;
-    }
-    const bool fused = slot_path && cn <= kt::kFeedSmallMax && !row_twice && !e->sw[kSw_NO_FEED_FUSION];
+    const bool fused = slot_path && cn <= kt::kFeedSmallMax && !e->sw[kSw_NO_FEED_FUSION];
     // an informer event proper — a pod or a few: one wave per pod, the slot pulled into LDS (kt_feed_few); the batch
     // pointers are then byte offsets into the slot (KT_NO_FEED_FEW=1: kt_feed_small's thread per pod, A/B)
     const bool few = fused && cn <= kt::kFeedFewMax && off <= kt::kFeedFewSlotMax && !e->sw[kSw_NO_FEED_FEW];
@@ -2101,12 +2101,20 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
     e->countable_by_ns = by_ns;
     KT_HIP(e, hipGetLastError());
     KT_HIP(e, hipMemcpyAsync(&e->n_countable, e->d_n_countable.p, 8, hipMemcpyDeviceToHost, s));
+    const bool plan_ranges = by_ns && !e->sw[kSw_NO_WG_RANGES];
+    if (plan_ranges) {  // the ends of the namespaces' records travel with the row count: the ranges are planned on the host
+      e->h_ns_end.resize((size_t)e->sp.n_ns + 1);
+      KT_HIP(e, hipMemcpyAsync(e->h_ns_end.data(), e->d_ns_cursor.p, (size_t)e->sp.n_ns * 8, hipMemcpyDeviceToHost, s));
+    }
     KT_HIP(e, hipStreamSynchronize(s));
     e->range_c_G = 0;
-    if (by_ns && e->n_countable > 0 && !e->sw[kSw_NO_WG_RANGES]) {
+    if (plan_ranges && e->n_countable > 0) {
       e->range_c_G = kt::aggregate_blocks((int64_t)e->n_countable);
       KT_HIP(e, e->d_range_c.reserve((size_t)e->range_c_G + 2));
-      kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, (int64_t)e->n_countable, e->range_c_G, e->d_range_c.p, s);
+      e->h_range.resize((size_t)e->range_c_G + 2);
+      kt::plan_wg_ranges(e->h_ns_end.data(), (uint32_t)e->sp.n_ns, (int64_t)e->n_countable, e->range_c_G, e->h_range.data());
+      KT_HIP(e, hipMemcpyAsync(e->d_range_c.p, e->h_range.data(), e->h_range.size() * 4, hipMemcpyHostToDevice, s));
+      KT_HIP(e, hipStreamSynchronize(s));  // (1 KB; h_range is reused)
     }
     e->pack = kt::PackPlan();
     if (!e->sw[kSw_NO_SCAN_VIEW]) {
@@ -2526,9 +2534,17 @@ static int32_t check_launch_locked(kt_engine* e, int64_t n, const int64_t* pod_r
         KT_HIP(e, hipGetLastError());
         e->range_a_G = 0;
         if (!e->sw[kSw_NO_WG_RANGES]) {  // every row is listed: the list holds pod_rows_hi records
+          // (planned on the host from a copy of the namespace ends — a view build is not a per-step cost, and the one GPU
+          //  thread the plan used to run on took 388 us, longer than the synchronisation and the walk here)
           e->range_a_G = kt::check_sweep_blocks(e->pod_rows_hi);
           KT_HIP(e, e->d_range_a.reserve((size_t)e->range_a_G + 2));
-          kt::launch_plan_wg_ranges(e->d_ns_cursor.p, (uint32_t)e->sp.n_ns, e->pod_rows_hi, e->range_a_G, e->d_range_a.p, s);
+          e->h_ns_end.resize((size_t)e->sp.n_ns + 1);
+          KT_HIP(e, hipMemcpyAsync(e->h_ns_end.data(), e->d_ns_cursor.p, (size_t)e->sp.n_ns * 8, hipMemcpyDeviceToHost, s));
+          KT_HIP(e, hipStreamSynchronize(s));
+          e->h_range.resize((size_t)e->range_a_G + 2);
+          kt::plan_wg_ranges(e->h_ns_end.data(), (uint32_t)e->sp.n_ns, e->pod_rows_hi, e->range_a_G, e->h_range.data());
+          KT_HIP(e, hipMemcpyAsync(e->d_range_a.p, e->h_range.data(), e->h_range.size() * 4, hipMemcpyHostToDevice, s));
+          KT_HIP(e, hipStreamSynchronize(s));
         }
         const size_t na = (size_t)e->pod_rows_hi + 1;
         KT_HIP(e, e->d_va_meta.reserve(na));

@@ -336,24 +336,19 @@ void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_onl
   hipLaunchKernelGGL(kt_ns_scatter, g, b, lds_scat, s, pods.meta, n, countable_only ? 1 : 0, n_keys, cursor, out_rows);
 }
 
-// kt_plan_wg_ranges — which records of a namespace-ordered list every workgroup of a scan owns: contiguous ranges of about
+// plan_wg_ranges — which records of a namespace-ordered list every workgroup of a scan owns: contiguous ranges of about
 // n / G records whose ends are moved to a namespace boundary when one lies close enough.  A workgroup walks the index chunks
 // that hold words of ITS namespaces; with ranges cut at fixed multiples of tiles nearly every workgroup straddled two
 // namespaces and opened the chunks of both (configs[4]: 14.6 chunk passes per workgroup where one namespace needs 8).
 // ns_end[k] = end of namespace k's records in the list (what kt_ns_scatter leaves in its cursor words); cap = the most
 // records one workgroup may own (the packed fold's fields are proven for it).  range[g] .. range[g + 1]; range[G + 1] = the
-// largest range handed out.
-constexpr uint32_t kPlanLdsKeys = 8192;  // namespace rows whose ends the planner keeps in LDS (64 KB): its loop is one thread's chain of
-                                          // dependent reads — from global memory 270 us for 256 workgroups x 256 namespaces, from LDS a fifth
-__global__ __launch_bounds__(256) void kt_plan_wg_ranges(const unsigned long long* ns_end_g, uint32_t n_keys, uint64_t n, uint32_t G, uint32_t cap,
-                                                          uint32_t* range) {
-  __shared__ unsigned long long ns_end_l[kPlanLdsKeys];
-  const bool in_lds = n_keys <= kPlanLdsKeys;
-  if (in_lds)
-    for (uint32_t k = threadIdx.x; k < n_keys; k += 256u) ns_end_l[k] = ns_end_g[k];
-  __syncthreads();
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  auto ns_end = [&](uint32_t k) -> unsigned long long { return in_lds ? ns_end_l[k] : ns_end_g[k]; };
+// largest range handed out.  On the HOST (round 6): the walk is one thread's chain of dependent steps — G iterations of 64-bit
+// divisions and a binary search — which ONE GPU thread took 388 us for (profiles/r05_r05g_cfg4_kernel_stats.csv: the only kernel
+// of a view build that is not a stream), while the engine synchronises for the row count right there anyway; the host does it in
+// microseconds from a copy of the n_keys cursor words.
+void plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n_, int G_, uint32_t* range) {
+  const uint64_t n = (uint64_t)(n_ > 0 ? n_ : 0);
+  const uint32_t G = (uint32_t)(G_ > 0 ? G_ : 0), cap = wg_range_cap(n_, G_);
   uint64_t pos = 0, largest = 0;
   range[0] = 0u;
   for (uint32_t g = 0; g < G; ++g) {
@@ -371,11 +366,11 @@ __global__ __launch_bounds__(256) void kt_plan_wg_ranges(const unsigned long lon
         uint32_t a = 0, b = n_keys;
         while (a < b) {
           const uint32_t m = (a + b) / 2;
-          if (ns_end(m) < ideal) a = m + 1; else b = m;
+          if (ns_end[m] < ideal) a = m + 1; else b = m;
         }
         uint64_t best = 0, best_d = ~0ull;
         for (uint32_t k = (a > 2 ? a - 2 : 0); k < n_keys && k <= a + 1; ++k) {
-          const uint64_t e = ns_end(k);
+          const uint64_t e = ns_end[k];
           if (e < lo || e > hi) continue;
           const uint64_t d = e > ideal ? e - ideal : ideal - e;
           if (d < best_d) best_d = d, best = e;
@@ -394,9 +389,6 @@ __global__ __launch_bounds__(256) void kt_plan_wg_ranges(const unsigned long lon
 uint32_t wg_range_cap(int64_t n, int G) {
   const int64_t share = (n + G - 1) / (G > 0 ? G : 1);
   return (uint32_t)(share + share / 4 + 64);
-}
-void launch_plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range, hipStream_t s) {
-  hipLaunchKernelGGL(kt_plan_wg_ranges, dim3(1), dim3(256), 0, s, ns_end, n_keys, (uint64_t)(n > 0 ? n : 0), (uint32_t)G, wg_range_cap(n, G), range);
 }
 
 // kt_build_scan_view — the records the namespace-ordered scans stream, copied into scan order once per ordering so that

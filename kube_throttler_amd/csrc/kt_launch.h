@@ -34,10 +34,11 @@ void launch_compact_countable(const PodTable& pods, int64_t n, int64_t* out_rows
 void launch_order_rows_by_ns(const PodTable& pods, int64_t n, bool countable_only, uint32_t n_keys, unsigned long long* cursor,
                              int64_t* out_rows, unsigned long long* out_n, hipStream_t s);
 // contiguous record ranges of a namespace-ordered list for the G workgroups of a scan, ends moved to namespace boundaries
-// (kt_plan_wg_ranges): range[0 .. G], range[G + 1] = the largest range; no range holds more than wg_range_cap(n, G) records.
-// ns_end = the cursor words launch_order_rows_by_ns leaves behind (end of every namespace's records)
+// (host code, kt_kernels.hip: plan_wg_ranges): range[0 .. G], range[G + 1] = the largest range; no range holds more than
+// wg_range_cap(n, G) records.  ns_end = a host copy of the cursor words launch_order_rows_by_ns leaves behind (end of every
+// namespace's records); range: G + 2 host words
 uint32_t wg_range_cap(int64_t n, int G);
-void launch_plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range, hipStream_t s);
+void plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range);
 // scan-ordered copies of meta / atom row (/ request row when v_req is given) of the listed rows
 struct PackPlan;  // kt_index.h
 // pk + v_pk (nullable): also the packed request words of every listed pod

@@ -995,11 +995,47 @@ static void pack_plan_cases() {
   printf("pack plan: %d packed, %d refused\n", packed, refused);
 }
 
+// ---- plan_wg_ranges (kt_kernels.hip, host code since round 6): the record ranges of the workgroups of a namespace-ordered scan
+namespace kt {
+uint32_t wg_range_cap(int64_t n, int G);
+void plan_wg_ranges(const unsigned long long* ns_end, uint32_t n_keys, int64_t n, int G, uint32_t* range);
+}
+static void plan_ranges_cases() {
+  std::mt19937_64 rng(777);
+  long at_boundary = 0, ends = 0;
+  for (int it = 0; it < 2000; ++it) {
+    const uint32_t n_keys = 1 + (uint32_t)(rng() % (it % 5 == 0 ? 3000 : 300));
+    const int G = 1 + (int)(rng() % 256);
+    std::vector<unsigned long long> ns_end(n_keys);
+    unsigned long long pos = 0;
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      const int kind = (int)(rng() % 8);
+      pos += kind == 0 ? 0 : kind == 1 ? rng() % 200000 : rng() % 6000;  // empty, huge and ordinary namespaces
+      ns_end[k] = pos;
+    }
+    const int64_t n = (int64_t)pos;
+    std::vector<uint32_t> range((size_t)G + 2, 0xDEADBEEFu);
+    plan_wg_ranges(ns_end.data(), n_keys, n, G, range.data());
+    const uint32_t cap = wg_range_cap(n, G);
+    uint32_t largest = 0;
+    EXPECT(range[0] == 0u && range[G] == (uint32_t)n, "ranges cover [0, %lld): %u .. %u", (long long)n, range[0], range[G]);
+    for (int g = 0; g < G; ++g) {
+      EXPECT(range[g + 1] >= range[g] && range[g + 1] - range[g] <= cap, "range %d of %d: %u .. %u (cap %u)", g, G, range[g], range[g + 1], cap);
+      largest = std::max(largest, range[g + 1] - range[g]);
+      if (g + 1 < G && range[g + 1] > range[g] && range[g + 1] < (uint32_t)n) ++ends, at_boundary += std::binary_search(ns_end.begin(), ns_end.end(), (unsigned long long)range[g + 1]);
+    }
+    EXPECT(range[G + 1] == largest, "largest range %u, reported %u", largest, range[G + 1]);
+  }
+  printf("workgroup ranges: %ld of %ld inner ends at a namespace boundary\n", at_boundary, ends);
+  EXPECT(at_boundary * 4 > ends, "hardly any range ends at a namespace boundary (%ld of %ld)", at_boundary, ends);
+}
+
 static int run_anchored(int argc, char** argv);
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--anchored")) return run_anchored(argc, argv);
   if (argc > 1) return run_file(argv[1], argc > 2 ? (uint32_t)atoi(argv[2]) : 80u * 1024u - check_fixed_lds());
   pack_plan_cases();
+  plan_ranges_cases();
   long chunks_seen = 0, matches = 0, simple_seen = 0;
   auto acc = [&](long r) {
     if (r >= 500000000L) r -= 500000000L, ++simple_seen;

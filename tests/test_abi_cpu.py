@@ -56,7 +56,8 @@ def test_invalid_config_rejected(built_lib):
 
 def test_product_never_reaches_for_the_oracle():
     """oracle/ is test infrastructure: nothing under kube_throttler_amd/ may import, load or link it, bench.py only in
-    its cpu_baseline leg, __graft_entry__ only in build() (compiling the checker) and smoke() (checking)."""
+    its cpu_baseline leg and in the checker of `--verify` (verify_against_oracle: the run's result held against the oracle AFTER
+    the timed region, never measured), __graft_entry__ only in build() (compiling the checker) and smoke() (checking)."""
     import ast
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,9 +72,15 @@ def test_product_never_reaches_for_the_oracle():
     src = open(os.path.join(root, "bench.py")).read()
     tree = ast.parse(src)
     imports = [n for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
-    assert len(imports) == 1
+    assert len(imports) == 2
     guard = next(n for n in ast.walk(tree) if isinstance(n, ast.If) and "no_cpu_baseline" in ast.unparse(n.test))
-    assert guard.lineno < imports[0].lineno <= guard.end_lineno
+    checker = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "verify_against_oracle")
+    inside = lambda node, imp: node.lineno < imp.lineno <= node.end_lineno
+    assert sorted((inside(guard, i), inside(checker, i)) for i in imports) == [(False, True), (True, False)]
+    # ... and the checker is only ever called under `if args.verify`
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "verify_against_oracle"]
+    verify_ifs = [n for n in ast.walk(tree) if isinstance(n, ast.If) and "args.verify" in ast.unparse(n.test)]
+    assert calls and all(any(inside(g, c) for g in verify_ifs) for c in calls)
     assert not [n for n in ast.walk(tree) if isinstance(n, ast.Import) and any(a.name.startswith("oracle") for a in n.names)]
 
 

@@ -304,6 +304,61 @@ def test_event_sized_batches_match_bulk(shape, oracle_mod, monkeypatch):
         bulk.close()
 
 
+@pytest.mark.parametrize("incremental", [False, True])
+@pytest.mark.parametrize("size", ["event", "coalesced", "bulk"])
+def test_rows_named_twice_in_one_batch(size, incremental, oracle_mod):
+    """Coalesced informer events: ONE kt_upsert_pods batch names pod rows two or three times with different labels, requests and
+    phases (Add, then Update of the same pod — throttle_controller.go:400-536 sees them one by one).  The LAST entry of a row
+    wins, in every feed path — kt_feed_few (<= 4 entries), kt_feed_small (<= 256), the staged bulk ingest — and for an incremental
+    engine, whose delta scans must take the earlier entry out again (the unfused path let two threads write one row)."""
+    final = W.generate(W.small(seed=57, n_pods=600, n_thr=64, n_cluster=32, n_invalid_pod_sel=1))
+    other = W.generate(W.small(seed=58, n_pods=600, n_thr=64, n_cluster=32))
+    P = final.n_pods
+    variant = E.VARIANT_INDEXED | (E.VARIANT_INCREMENTAL if incremental else 0)
+    eng = E.Engine(final.D, final.L, P + 8, final.n_thr + 4, final.n_ns + 4, -1, variant)
+    try:
+        eng.upsert_namespaces(final)
+        eng.upsert_throttles(final)
+        eng.reconcile(NOW, apply=False)  # compiles the program: the batches below are translated (and delta-scanned) as they arrive
+        rng = np.random.default_rng(57)
+        per = {"event": 2, "coalesced": 40, "bulk": P}[size]   # distinct rows per batch; every batch names most of them several times
+        order = rng.permutation(P)
+        for k in range(0, P, per):
+            mine = order[k:k + per]
+            # entries: garbage (the OTHER cluster's pod at that row) for a random subset, possibly twice, then the final content —
+            # scrambled, except that a row's final entry comes after its garbage
+            entries = []
+            for r in mine:
+                for _ in range(int(rng.integers(0, 3))):
+                    entries.append((float(rng.random()) * 0.9, int(r), False))
+                entries.append((0.9 + float(rng.random()) * 0.1, int(r), True))
+            entries.sort()
+            rows = np.array([r for _, r, _ in entries], dtype=np.int64)
+            eng.upsert_pods(_gather_pods([(final if f else other, r) for _, r, f in entries]), rows=rows)
+        bulk = E.Engine.for_snapshot(final, E.VARIANT_INDEXED)
+        try:
+            gv, gp = eng.fetch_pod_requests(n=P)
+            bv, bp = bulk.fetch_pod_requests(n=P)
+            np.testing.assert_array_equal(gp, bp, err_msg="pod request presence")
+            np.testing.assert_array_equal(gv, bv, err_msg="pod request values")
+        finally:
+            bulk.close()
+        o = oracle_mod.Oracle(final)
+        rows_t = responsible_rows(final)
+        want = o.reconcile(NOW, rows=rows_t)
+        got = eng.reconcile(NOW, apply=True)
+        np.testing.assert_array_equal(got.used.v[rows_t], want.used.v[:len(rows_t)])
+        np.testing.assert_array_equal(got.used.present[rows_t], want.used.present[:len(rows_t)])
+        np.testing.assert_array_equal(got.used.count[rows_t], want.used.count[:len(rows_t)])
+        final.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows_t)
+        st_w, sm_w = o.check()
+        st_g, sm_g = eng.check(n=P, want_status=True)
+        np.testing.assert_array_equal(st_g, st_w)
+        np.testing.assert_array_equal(sm_g, sm_w)
+    finally:
+        eng.close()
+
+
 def _with_pods(base, src_rows):
     """A copy of `base` (same namespaces / throttles) whose pod row r holds base's pod src_rows[r] (-1: row deleted)."""
     import copy
@@ -476,15 +531,20 @@ def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
 
 def _permute_pods(snap, rows):
     """A pods-only batch holding snap's pods in the order given by rows."""
-    rows = np.asarray(rows)
-    b = S.Snapshot(snap.D, snap.L)
+    return _gather_pods([(snap, int(r)) for r in np.asarray(rows)])
+
+
+def _gather_pods(entries):
+    """A pods-only batch whose entry i is pod row r of snapshot s for entries[i] = (s, r) (same D / L everywhere)."""
+    first = entries[0][0]
+    b = S.Snapshot(first.D, first.L)
     b.alloc_namespaces(0, 0)
     b.alloc_throttles(0, 0, 0)
-    nl = int(sum(snap.pod_label_off[r + 1] - snap.pod_label_off[r] for r in rows))
-    nc = int(sum(snap.pod_ctr_off[r + 1] - snap.pod_ctr_off[r] for r in rows))
-    b.alloc_pods(len(rows), nl, nc)
+    nl = int(sum(s.pod_label_off[r + 1] - s.pod_label_off[r] for s, r in entries))
+    nc = int(sum(s.pod_ctr_off[r + 1] - s.pod_ctr_off[r] for s, r in entries))
+    b.alloc_pods(len(entries), nl, nc)
     lo = co = 0
-    for i, r in enumerate(rows):
+    for i, (snap, r) in enumerate(entries):
         b.pod_ns[i], b.pod_flags[i] = snap.pod_ns[r], snap.pod_flags[r]
         l0, l1 = int(snap.pod_label_off[r]), int(snap.pod_label_off[r + 1])
         b.pod_label_key[lo:lo + l1 - l0] = snap.pod_label_key[l0:l1]
@@ -809,17 +869,7 @@ def test_api_errors():
         eng.check(rows=np.array([99], dtype=np.int64))
     assert ei.value.code == -2
     eng.close()
-    # an incremental engine applies a batch row by row through delta scans: naming a row twice would apply it twice
-    inc = E.Engine(snap.D, max(snap.L, 1), 16, max(snap.n_thr, 1), max(snap.n_ns, 1), -1, E.VARIANT_INDEXED | E.VARIANT_INCREMENTAL)
-    try:
-        inc.upsert_namespaces(snap)
-        inc.upsert_throttles(snap)
-        with pytest.raises(E.EngineError) as ei:
-            inc.upsert_pods(_permute_pods(snap, np.array([0, 1, 2])), rows=np.array([3, 5, 3], dtype=np.int64))
-        assert ei.value.code == -1
-        inc.upsert_pods(_permute_pods(snap, np.array([0, 1, 2])), rows=np.array([3, 5, 4], dtype=np.int64))
-    finally:
-        inc.close()
+    # (a batch that names a row twice is legal since round 6 — the last entry wins: test_rows_named_twice_in_one_batch)
 
 
 @pytest.mark.parametrize("budget", [None, 6000])
@@ -968,7 +1018,7 @@ def test_partials_must_match_the_throttle_set(oracle_mod):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json full-size configurations: parity on samples + size-independent properties
 # ---------------------------------------------------------------------------------------------------
-def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="full"):
+def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="full", row_stride=10):
     """NOTHING is sampled: every responsible throttle's reconcile result and every pod's summary word are compared with
     the oracle (the C restatement runs the whole configuration in seconds on the GPU box's host cores), a pod sample
     additionally with full status rows, and the dense (reference-shaped) kernels must agree with the indexed ones."""
@@ -1025,10 +1075,10 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="fu
         assert not rec_sw.calc_updated[:T].any()
         if level == "core":  # every `used`, every summary word, the sweep: the other shards of a sharded configuration
             return sm_all
-        #     ... and EVERY TENTH pod with its full status row — which throttle blocks the pod, not only how many of each kind
-        #     (a summary word cannot tell a per-pair error that preserves the three counts).  The matrix of all P x T pairs
-        #     would be 1-12 GB; the strided tenth goes through in slices of <= 2^27 cells.
-        sample = np.arange(0, P, 10, dtype=np.int64)
+        #     ... and the full status ROWS — which throttle blocks the pod, not only how many of each kind (a summary word cannot
+        #     tell a per-pair error that preserves the three counts): of EVERY pod where the matrix is a gigabyte (configs[2] /
+        #     [3]: 10^9 cells, row_stride = 1), of every tenth pod on a configs[4] shard (1.25e10 cells); in slices of <= 2^27 cells.
+        sample = np.arange(0, P, row_stride, dtype=np.int64)
         step = max(1, (1 << 27) // max(T, 1))
         for k0 in range(0, len(sample), step):
             part = sample[k0:k0 + step]
@@ -1062,16 +1112,17 @@ def _full_size_checks(cfg, oracle_mod, with_dense=True, nthreads=None, level="fu
 
 
 def test_config2_full_size(oracle_mod):
-    """configs[2]: 1M pods x 1k Throttle+ClusterThrottle, D=8 — ALL 10^6 summary words (both isThrottledOnEqual values),
-    ALL throttles' `used` / thresholds / flags against the oracle, every tenth pod with its full status row, and the dense
-    (reference-shaped) kernels agree with the indexed ones on all 10^9 decisions and every `used` vector."""
-    _full_size_checks(W.preset(2), oracle_mod)
+    """configs[2]: 1M pods x 1k Throttle+ClusterThrottle, D=8 — NOTHING sampled: ALL 10^6 summary words (both
+    isThrottledOnEqual values), ALL throttles' `used` / thresholds / flags, and the full status row of EVERY pod (all 10^9
+    (pod, throttle) cells, eight slices) against the oracle; the dense (reference-shaped) kernels agree with the indexed ones
+    on all 10^9 decisions and every `used` vector."""
+    _full_size_checks(W.preset(2), oracle_mod, row_stride=1)
 
 
 def test_config3_overrides_full_size(oracle_mod):
     """configs[3]: same with temporaryThresholdOverrides active (time-window branch)."""
     cfg = W.preset(3)
-    _full_size_checks(cfg, oracle_mod)
+    _full_size_checks(cfg, oracle_mod, row_stride=1)
     # the override branch really is exercised: thresholds differ from config 2's
     snap = W.generate(cfg)
     assert snap.n_ovr > 2 * snap.n_thr

@@ -2,8 +2,8 @@
 bench.py --gpus N cuts them, every shard runs through its own engine (kt_aggregate_launch into a caller
 buffer), the partial-`used` buffers are summed the way the RCCL all-reduce sums them, the sum is handed back to every
 shard's engine (kt_use_partial_buffer + kt_finalize_launch, APPLY) and each shard's PreFilter sweep follows.  Everything
-that comes out — `used`, calculated thresholds, throttled flags of every sampled throttle, the status rows and summary
-words of every sampled pod of every shard — must equal the CPU oracle's answer on the UNSHARDED snapshot, bit for bit
+that comes out — `used`, calculated thresholds, throttled flags of EVERY throttle, the summary word of EVERY pod of every
+shard and the full status rows of a pod sample — must equal the CPU oracle's answer on the UNSHARDED snapshot, bit for bit
 (throttle_controller.go:116-133 semantics: one reconcile over all pods).  Integer sums are associative, so this is the
 result any number of GPUs produces; what an 8-GPU node adds is only the transport of the sum."""
 import numpy as np
@@ -23,10 +23,11 @@ def _responsible(snap):
 
 def _sharded_pipeline(full_cfg, world, oracle_mod, n_thr_sample, n_pod_sample, nthreads=32):
     import torch
+    nthreads = nthreads or oracle_mod.effective_cpus()
     full = W.generate(full_cfg)
     now = (full_cfg.now_s, 0)
     T, D = full.n_thr, full.D
-    words = T * (2 * D + 2)
+    words = T * E.partial_layout(D)["stride"]  # (the library's own statement of the row layout: kt_partial_layout)
     # ---- pass 1: every shard's partial buffer; the host-side sum stands in for the all-reduce
     total = torch.zeros(words, dtype=torch.int64, device="cuda")
     shard_rows = []
@@ -85,8 +86,10 @@ def _sharded_pipeline(full_cfg, world, oracle_mod, n_thr_sample, n_pod_sample, n
             st_g, sm_g = eng.check(rows=local, want_status=True)
             np.testing.assert_array_equal(st_g, st_w, err_msg=f"shard {r} status rows")
             np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"shard {r} summaries")
+            # the PreFilter sweep of the shard: EVERY pod's summary word
             _, sm_all = eng.check(n=n, want_status=False)
-            np.testing.assert_array_equal(sm_all[local], sm_w, err_msg=f"shard {r} sweep")
+            _, sm_all_w = o.check(rows=np.arange(begin, begin + n, dtype=np.int64), want_status=False, nthreads=nthreads)
+            np.testing.assert_array_equal(sm_all, sm_all_w, err_msg=f"shard {r} sweep")
             eng.use_partial_buffer(None, 0)
         finally:
             eng.close()
@@ -94,7 +97,7 @@ def _sharded_pipeline(full_cfg, world, oracle_mod, n_thr_sample, n_pod_sample, n
 
 def test_eight_shards_of_a_multi_term_program(oracle_mod):
     """configs[4] scaled down (80k pods x 2k throttles, 2-4 terms per throttle, every selector operator, 256
-    namespaces): 8 shards, every throttle and 2048 pods per shard against the oracle."""
+    namespaces): 8 shards, every throttle, every pod's summary word and the status rows of 2048 pods per shard against the oracle."""
     cfg = W.preset(4)
     cfg.n_pods_total = cfg.n_pods = 80000
     cfg.n_thr, cfg.n_cluster = 2000, 1000
@@ -102,9 +105,10 @@ def test_eight_shards_of_a_multi_term_program(oracle_mod):
 
 
 def test_eight_shards_of_config2(oracle_mod):
-    """configs[2] at full size (1M pods x 1k throttles) in 8 shards of 125k pods: 200 throttles' `used` and 8192 pods
-    per shard against the oracle on the unsharded snapshot."""
-    _sharded_pipeline(W.preset(2), 8, oracle_mod, n_thr_sample=200, n_pod_sample=8192, nthreads=64)
+    """configs[2] at full size (1M pods x 1k throttles) in 8 shards of 125k pods, nothing sampled where it counts: ALL 1000
+    throttles' `used` / thresholds / flags and EVERY pod's summary word of every shard against the oracle on the unsharded
+    snapshot (plus the full status rows of 8192 pods per shard)."""
+    _sharded_pipeline(W.preset(2), 8, oracle_mod, n_thr_sample=1000, n_pod_sample=8192, nthreads=None)
 
 
 def test_partial_buffer_is_laid_out_as_the_query_says(oracle_mod):
@@ -164,7 +168,7 @@ def test_three_uneven_shards_with_selector_errors(oracle_mod):
     full = W.generate(cfg)
     now = (cfg.now_s, 0)
     T, D = full.n_thr, full.D
-    words = T * (2 * D + 2)
+    words = T * E.partial_layout(D)["stride"]  # (the library's own statement of the row layout: kt_partial_layout)
     total = torch.zeros(words, dtype=torch.int64, device="cuda")
     for r in range(3):
         eng = E.Engine.for_snapshot(W.generate(cfg.shard(r, 3)))
