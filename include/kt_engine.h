@@ -322,6 +322,8 @@ const char* kt_kernel_name(kt_engine* e, int32_t kernel);
                                          passes a namespace-ordered scan makes per namespace, summed */
 #define KT_COUNTER_INDEX_IMAGE_WORDS 7 /* words over all chunk images (>= INDEX_WORDS: the grouped plan keeps copies of a word in
                                           the chunks of every group of namespaces that visits it) */
+#define KT_COUNTER_SLOW_THROTTLES 8 /* throttles of the compiled program that are walked term by term instead of through the index
+                                      (an unconvertible podSelector term; more than 512 selector terms) */
 int64_t kt_counter(kt_engine* e, int32_t which);
 /* ---- More resource names than one engine has dimensions (KT_MAX_DIMS): PAGES.  The reference sums and compares any resource
  *      name (pkg/resourcelist/resourcelist.go:27-54, resource_amount.go:127-159).  The host builds the same cluster once per

@@ -196,7 +196,7 @@ struct kt_engine {
   std::vector<uint32_t> h_range;                 // ... and the ranges planned from it, on their way to the device
   bool cut_plain = false;                        // a scan needed the plain fold: the index chunks stay cut for plain records
   void* cur_launch_lock = nullptr;               // the LaunchLock of the launch-side call in progress (set and cleared under op_mu)
-  std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0};
+  std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0}, ctr_slow_throttles{0};
   DevBuf<uint64_t> d_vc_pk;                      // packed request words of the countable list, scan order
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA
@@ -870,6 +870,7 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
   e->ctr_ns_rows.store((int64_t)e->hindex.n_ns, std::memory_order_relaxed);
   e->ctr_ns_word_visits.store(e->hindex.ns_word_visits, std::memory_order_relaxed);
   e->ctr_ns_chunk_visits.store(e->hindex.ns_chunk_visits, std::memory_order_relaxed);
+  e->ctr_slow_throttles.store((int64_t)e->hindex.slow_thr.size(), std::memory_order_relaxed);
   e->agg_valid = false;  // a new selector program: the maintained partials are void
   KT_HIP(e, e->d_slab.reserve((size_t)e->hindex.bm_slab_bytes + 64));
   {
@@ -2127,7 +2128,7 @@ static int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused = 
       const size_t nc = (size_t)e->view_cap_c + 1;
       // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
       // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
-      if (!e->incremental && !e->wide && !e->sw[kSw_NO_PACK]) {
+      if (!e->incremental && !e->wide && !e->sw[kSw_NO_PACK] && !e->dindex.has_long) {
         uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
         // (planned ranges hold up to wg_range_cap records)
         if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
@@ -2617,7 +2618,7 @@ int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t fl
     if ((r = aggregate_locked(e, s, /*allow_fused=*/true)) != KT_OK) return r;
     return finalize_locked(e, now_s, now_ns, flags, s, /*consume=*/!e->incremental);
   };
-  bool fused = e->cfg.kernel_variant != 1 && !e->incremental && e->dindex.n_chunks == 1 && e->dindex.n_slow == 0 && !e->hindex.has_slow &&
+  bool fused = e->cfg.kernel_variant != 1 && !e->incremental && e->dindex.n_chunks == 1 && e->dindex.n_slow == 0 && !e->hindex.has_slow && !e->dindex.has_long &&
                e->n_overflow == 0 && e->thr_rows_hi > 0 && n > 0 && kt::dt_bucket_ix(e->D) == 8 && !e->sw[kSw_NO_SWEEP] &&
                !e->sw[kSw_NO_FUSED] && !e->sw[kSw_NO_PACK];
   if (!fused) return one_after_the_other();
@@ -2741,7 +2742,7 @@ static inline bool few_shape_ok(const kt_engine* e, int64_t n, const int64_t* po
 // Under the SHARED lock (+ small_mu): nothing of the engine's host state is modified except the fields only this path
 // touches.  Returns 1 when served, 0 when the caller has to take the exclusive path, < 0 on error.
 static int32_t check_few_shared(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_equal, uint64_t* out_summary) {
-  if (!e->few_ready || e->program_dirty || e->status_host_dirty || e->hindex.has_slow || e->dindex.n_slow != 0 || e->n_overflow != 0 ||
+  if (!e->few_ready || e->program_dirty || e->status_host_dirty || e->hindex.has_slow || e->dindex.has_long || e->dindex.n_slow != 0 || e->n_overflow != 0 ||
       e->thr_rows_hi <= 0 || e->dindex.n_chunks == 0)
     return 0;
   for (int64_t i = 0; i < n; ++i)
@@ -3014,6 +3015,7 @@ int64_t kt_counter(kt_engine* e, int32_t which) {
     case KT_COUNTER_NS_WORD_VISITS: return e->ctr_ns_word_visits.load(std::memory_order_relaxed);
     case KT_COUNTER_NS_CHUNK_VISITS: return e->ctr_ns_chunk_visits.load(std::memory_order_relaxed);
     case KT_COUNTER_INDEX_IMAGE_WORDS: return e->ctr_index_image_words.load(std::memory_order_relaxed);
+    case KT_COUNTER_SLOW_THROTTLES: return e->ctr_slow_throttles.load(std::memory_order_relaxed);
     default: return -1;
   }
 }

@@ -21,13 +21,13 @@ struct BT {  // one indexed term (plain data: tens of thousands of them are buil
   uint32_t g, t;
   bool adj;                                 // owner has several terms
   bool slow;                                // needs the generic walk to confirm a candidate
-  uint32_t need;                            // positive requirements (exact terms); 1 for slow terms with an anchor
-  // positive requirements that enter `any`, one per key (at most 3 are kept; a slow term keeps its anchor): an explicit
+  uint32_t need;                            // positive requirements that are kept and counted (<= 5; slow terms: their five anchors)
+  // positive requirements that enter `any`, one per key (at most 5 are kept): an explicit
   // set of pair atoms (pos_key < 0), or — Exists, not narrowed by an In on the same key — EVERY atom a pod carrying that
   // key can show up with (pos_key = the key: the atoms are those of whole_key(key), expanded only where rows are set).
   // The pair atoms of all kept positives sit side by side in the atom pool.
   uint32_t n_pos;
-  int64_t pos_key[3];
+  int64_t pos_key[5];
   uint32_t pos_off, pos_cnt;                // atom pool: pair atoms of the positive requirements
   uint32_t neg_off, neg_cnt;                // atom pool: pair atoms of the NotIn requirements
   uint32_t nk_off, nk_cnt;                  // key pool: keys of the DoesNotExist requirements (all atoms of the key)
@@ -182,11 +182,19 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         break;
       }
   }
-  // a throttle with more than 64 selector terms: its run of term numbers could not stay inside one 64-bit word (the scans
-  // settle "reported once" per word) — walked term by term like the throttles with unconvertible selectors
+  // A throttle with more than 64 selector terms: its run of term numbers spans several 64-bit words.  The wordwise settle of
+  // the lean scans applies "reported once" per WORD (run masks), so a program that holds such a throttle is scanned by the
+  // instantiations that dedupe match by match (a lane meets its matches in ascending number, and a repeat of its previous
+  // throttle is dropped — across words too): the FULL check and the plain fold (HostIndex::has_long, IndexDev::has_long).
+  // Until round 5 these throttles went to the slow list — walked term by term for every pod: 16.9 ms per step at 100k pods
+  // where the same terms in the index take a fraction of a millisecond (profiles/r05_offpath_timing.jsonl).  The run never
+  // straddles a chunk (cut_chunks: splittable), so a throttle whose terms do not fit ONE chunk image still takes the slow
+  // list: kMaxIndexedTerms.
   for (size_t t = 0; t < T; ++t) {
     if (is_slow_thr[t] || !thr_info((uint32_t)t).live) continue;
-    if (thr_term_off[t + 1] - thr_term_off[t] > 64u) out.slow_thr.push_back((uint32_t)t), is_slow_thr[t] = 1;
+    const uint32_t nt = thr_term_off[t + 1] - thr_term_off[t];
+    if (nt > kMaxIndexedTerms) out.slow_thr.push_back((uint32_t)t), is_slow_thr[t] = 1;
+    else if (nt > 64u) out.has_long = true;
   }
   // ---- referenced atoms.  A pod label (k, v) is ONE atom: the pair (k, v) when some In / NotIn requirement names it,
   //      else the key atom of k when some Exists / DoesNotExist requirement names k (else nothing).  A key-level
@@ -347,24 +355,33 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       for (size_t q = 0; q < n_pos; ++q)
         if (!pos_by_key[q].whole && pos_by_key[q].atoms.empty()) never = true;  // In with no values (or contradictory In sets): never satisfied
       if (never) continue;
-      // exact shape: <= 3 positive keys (their atom sets are disjoint by construction)
+      // exact shape: <= 5 positive keys (their atom sets are disjoint by construction; the scans count hits per term as a
+      // 2-bit number for programs whose terms stop at three keys, as a 3-bit number otherwise)
       size_t keep0 = 0, keep1 = n_pos;  // the positives that are kept: [keep0, keep1)
-      if (n_pos <= 3) {
+      constexpr size_t kMaxNeed = 5;
+      if (n_pos <= kMaxNeed) {
         b.need = (uint32_t)n_pos;
       } else {
-        // candidates through the requirement with the fewest atoms (a bare key atom last), confirmed by the generic walk
-        size_t best = 0, best_cost = ~(size_t)0;
-        for (size_t i = 0; i < n_pos; ++i) {
-          size_t cost = pos_by_key[i].whole ? 0 : pos_by_key[i].atoms.size();
-          if (pos_by_key[i].whole) {
-            auto it = pairs_of_key.find(pos_by_key[i].key);
-            const size_t n_atoms = (it == pairs_of_key.end() ? 0 : it->second.size()) + 1;  // its pairs + the key atom
-            cost = n_atoms == 1 ? ((size_t)1 << 20) : n_atoms;
-          }
-          if (cost < best_cost) best_cost = cost, best = i;
+        // More positive keys than the count holds: the term keeps its FIVE most selective positives (fewest atoms; a bare
+        // key atom last) with need = 5 and is flagged `slow`: a pod that meets those is a candidate, the generic walk
+        // confirms the rest.  (Until round 5 a term with more than three positive keys kept ONE anchor: every pod that
+        // carried it — several per cent of the pods per term — went through the lane-divergent walk, 13.6x the step of the
+        // same cluster with <= 3 keys per term, profiles/r05_offpath_timing.jsonl.)
+        auto cost_of = [&](size_t i) -> size_t {
+          if (!pos_by_key[i].whole) return pos_by_key[i].atoms.size();
+          auto it = pairs_of_key.find(pos_by_key[i].key);
+          const size_t n_atoms = (it == pairs_of_key.end() ? 0 : it->second.size()) + 1;  // its pairs + the key atom
+          return n_atoms == 1 ? ((size_t)1 << 20) : n_atoms;
+        };
+        // selection sort of the cheapest to the front (the order of the kept requirements does not matter)
+        for (size_t a = 0; a < kMaxNeed; ++a) {
+          size_t best = a;
+          for (size_t i = a + 1; i < n_pos; ++i)
+            if (cost_of(i) < cost_of(best)) best = i;
+          if (best != a) std::swap(pos_by_key[a], pos_by_key[best]);
         }
-        keep0 = best, keep1 = best + 1;
-        b.need = 1;
+        keep0 = 0, keep1 = kMaxNeed;
+        b.need = (uint32_t)kMaxNeed;
         b.slow = true;
       }
       b.n_pos = (uint32_t)(keep1 - keep0);
@@ -533,7 +550,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
       for (uint32_t q = grp_first[g]; q < grp_first[g + 1]; ++q) {
         const BT& b = bts[tcs[q].bt];
         if (b.neg_cnt != 0u || b.nk_cnt != 0u) form[g] |= 2u;
-        if (!b.slow && b.need >= 3u) form[g] |= 1u;
+        if (b.need >= 3u) form[g] |= 1u;
       }
     std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
       if (x.first != y.first) return x.first < y.first;
@@ -591,7 +608,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
         if (b.pos_key[i] >= 0) whole_keys.insert((uint32_t)b.pos_key[i]);
       out.has_veto |= b.neg_cnt != 0u || b.nk_cnt != 0u;
       out.has_slow |= b.slow;
-      if (!b.slow) out.max_need = std::max(out.max_need, b.need);
+      out.max_need = std::max(out.max_need, b.need);  // (a `slow` term counts its three kept positives like any other)
     }
     for (uint32_t k : whole_keys)
       for (uint32_t a : whole_key(k)) distinct.insert(a);
@@ -640,7 +657,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
   any.assign((size_t)R * W, 0ull), vet.assign(veto ? (size_t)R * W : 0, 0ull), nsrows.assign((size_t)n_ns * W, 0ull);
   std::vector<WordHdr>& hdr = out.full_hdr;
-  hdr.assign(W, WordHdr{0, 0, 0, 0});
+  hdr.assign(W, WordHdr{0, 0, 0, 0, 0, 0});
   std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
   term_t.assign((size_t)W * 64, 0u), term_g.assign((size_t)W * 64, 0u), term_rank.assign((size_t)W * 64, 0u);
   std::vector<uint8_t>& real = out.full_real;  // term number in use (not padding)
@@ -723,6 +740,8 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
           for (uint32_t r : rows_of_key.find(key_pool[q])->second) vet[(size_t)r * W + w] |= bit;
         if (b.need >= 2) hdr[w].m2 |= bit;
         if (b.need >= 3) hdr[w].m3 |= bit;
+        if (b.need >= 4) hdr[w].m4 |= bit;
+        if (b.need >= 5) hdr[w].m5 |= bit;
         if (b.slow) hdr[w].slow |= bit;
         if (grp_own_adm[tc.grp]) {  // a copy of a >64-term throttle: its own admission set
           flush();
@@ -1256,6 +1275,7 @@ hipError_t upload_index(const HostIndex& h, IndexDev& d, hipStream_t s) {
   d.bm_max_lds = h.bm_max_lds, d.bm_max_thr = h.bm_max_thr, d.bm_max_words = h.bm_max_words, d.bm_rows = h.bm_rows;
   d.bm_words = h.img_words;
   d.cut_thr_bytes = h.cut_thr_bytes;
+  d.has_long = h.has_long;
   d.bm_slab_bytes = h.bm_slab_bytes;
   d.has_veto = h.has_veto ? 1u : 0u;
   d.max_need = h.max_need;

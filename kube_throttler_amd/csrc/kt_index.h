@@ -16,19 +16,20 @@
 // word, and neither does a group: for any pod exactly one group of a throttle is live and its copies sit side by side
 // in one word (the scans report a throttle once by keeping the lowest match of such a run), and the words are class-pure
 // even when the terms of a ClusterThrottle select different namespaces — a pod only visits words of classes that admit
-// its namespace.  A throttle with more than 64 terms cannot keep that promise and joins the slow list (below).
+// its namespace.  A throttle with more than 64 terms is ONE group whose run spans words (its copies keep their own admission
+// sets): the scans that dedupe match by match take such a program (HostIndex::has_long); beyond kMaxIndexedTerms: the slow list.
 // Two bitmap families over c, one row per atom:
 //     any [a] : terms with a POSITIVE requirement (In / Exists) that atom a satisfies
 //     veto[a] : terms with a NEGATIVE requirement (NotIn / DoesNotExist) that atom a violates
 // The positive requirements of a term are merged per KEY (In S1 and In S2 = In S1∩S2, In S and Exists = In S), and a pod
 // carries one atom per key: the number of rows of `any` in which a term's bit is met while OR-ing the pod's atom rows
 // IS the number of its positive keys the pod satisfies.  With need(c) = number of positive keys (0..3):
-//     match(pod)[w] = hits>=need (any / two / three accumulators, masks m2 m3) & ~OR veto & nsmask[ns][w]
-// is EXACT — no TermRec, no second-pair compare, no inline extras.  Terms with more than three positive keys keep only
-// their anchor requirement in `any` and are flagged in the word header's `slow` mask: their candidates are decided by
-// the generic requirement walk.  Throttles that contain an unconvertible podSelector term (error semantics of
-// throttle_selector.go:30-42 depend on term order) or more than 64 terms go to a "slow list" and are walked term by
-// term in order.
+//     match(pod)[w] = hits>=need (a 2- or 3-bit count per term, masks m2 .. m5) & ~OR veto & nsmask[ns][w]
+// is EXACT — no TermRec, no second-pair compare, no inline extras — for terms with up to FIVE positive keys (three until round
+// 5).  Terms with more keep their five most selective positives (need = 5) and are flagged in the word header's `slow` mask: a
+// pod that meets those five is a candidate, decided by the generic requirement walk.  Throttles that contain an unconvertible podSelector term (error semantics of
+// throttle_selector.go:30-42 depend on term order) or more than kMaxIndexedTerms terms go to a "slow list" and are walked
+// term by term in order.
 // The namespace side of every term (implicit namespace equality of a Throttle, throttle_controller.go:249;
 // namespaceSelector of a ClusterThrottle) is pre-evaluated into SelProgram::ns_term_ok and enters as per-namespace
 // (word, mask) lists.
@@ -45,6 +46,7 @@
 namespace kt {
 
 constexpr uint32_t kKeyAtom = 0x80000000u;
+constexpr uint32_t kMaxIndexedTerms = 512;  // selector terms of ONE throttle the index takes (8 words in one chunk); beyond: the slow list
 constexpr uint32_t kCheckWordLds = 64u * 8u + 560u;  // = check_word_lds(16): TermInfo[64] + WordVerdict<16> per word (the worst case)
 
 // term_t[] entry of a chunk image: throttle row | flags
@@ -63,8 +65,10 @@ struct ThrInfo {
 struct alignas(16) WordHdr {
   uint64_t univ;  // terms without a positive requirement (hit by every pod)
   uint64_t m2;    // terms that need >= 2 positive hits
-  uint64_t m3;    // terms that need 3
+  uint64_t m3;    // terms that need >= 3
   uint64_t slow;  // candidates that the generic requirement walk has to confirm
+  uint64_t m4;    // terms that need >= 4 (round 6: programs with four or five positive keys per term take the NEED = 5
+  uint64_t m5;    // instantiations, which count hits as 3-bit numbers) / that need 5
 };
 // one entry of a namespace's word list
 struct alignas(16) NsWord {
@@ -137,10 +141,11 @@ struct HostIndex {
   uint32_t bm_words = 0;  // W: 64-bit words per full bitmap row
   uint32_t bm_rows = 0;   // A + 1 (row 0 = no atom: all zero)
   bool has_veto = false;  // some indexed term has a NotIn / DoesNotExist requirement
-  uint32_t max_need = 0;  // largest number of positive requirements of an exactly-indexed term (<= 3)
+  uint32_t max_need = 0;  // largest number of counted positive requirements of a term (<= 5; > 3: the NEED = 5 instantiations)
   uint32_t n_pair_keys = 0, n_key_atoms = 0;  // distinct keys behind the referenced pair atoms / referenced key atoms
   uint32_t n_keys = 0;                        // distinct keys referenced either way
   bool has_slow = false;  // some indexed term needs the generic walk
+  bool has_long = false;  // some indexed throttle has more than 64 terms: its run of numbers spans words (see build_index)
   uint32_t la = 8;        // atom slots per pod the scan kernels are instantiated for (8 / 16 / 32)
   bool rich = false;      // image in the {any, veto} form, kernels in the <VETO, NEED 3> instantiation
   std::vector<AtomId> atoms;               // referenced atom -> id (1..A)
@@ -258,6 +263,7 @@ struct IndexDev {
   uint32_t has_veto = 0, max_need = 0, n_atoms = 0, has_key_atoms = 0, la = 8;
   uint32_t bm_words = 0;  // 64-bit words over all chunk images (HostIndex::img_words): what the verdict images are sized for
   uint32_t cut_thr_bytes = 0;  // HostIndex::cut_thr_bytes
+  bool has_long = false;       // HostIndex::has_long: only the match-by-match instantiations may scan this index
   bool rich = false;
   size_t cap_bm_blob = 0, cap_bm_chunks = 0, cap_bm_rank_t = 0, cap_bm_chunk_ns = 0, cap_atom_table = 0, cap_slow = 0;
 };

@@ -19,12 +19,6 @@ struct TileRecAgg {
   int64_t v[PK ? 1 : DT];             // plain fold: the request row
   unsigned long long pw[PK ? 4 : 1];  // packed fold: the packed words
 };
-// (requesting a tile's records ahead of the tile: measured, not kept — see kTilePrefetch in kt_kernels_check.hip)
-#ifdef KT_TILE_PREFETCH
-constexpr bool kAggPrefetch = true;
-#else
-constexpr bool kAggPrefetch = false;
-#endif
 
 struct BmAggArgs {
   const uint64_t* meta;  // pod tables
@@ -139,16 +133,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   // (timing probes, profiles/r05_probe_breakdown.txt): of the aggregate's 0.70 ms the scan is 0.30, the extraction loop 0.18,
   // the atomics 0.22.  The lane therefore QUEUES what the scan finds and the wave folds only when some lane's queue is full
   // or the tile is done — a step of the fold then serves nearly every lane that has anything left:
-  //   * word queue (default): the match words themselves, (word number, 64 bits) x kWq — one predicated push per visit, the
-  //     extraction runs inside the balanced steps: 0.53 -> 0.48 ms on the shard with the namespace-aligned ranges in place;
-  //   * term-number queue (-DKT_AGG_TERM_QUEUE): 16-bit chunk-local term numbers, extracted per word — halves the atomic
-  //     instructions as well (0.22 -> 0.12 ms) but keeps the lopsided extraction loop (+0.04): 0.53 ms.
-  // -DKT_AGG_NO_QUEUE restores the word-by-word fold (A/B).
-#ifndef KT_AGG_NO_QUEUE
+  // the match words themselves, (word number, 64 bits) x kWq — one predicated push per visit, the extraction runs inside the
+  // balanced steps: 0.53 -> 0.48 ms on the shard.  (A queue of 16-bit term numbers halved the atomic instructions as well but kept
+  // the lopsided extraction loop: 0.53 ms; it and the other A/B forms of round 5 are in the git history of this file.)
   constexpr bool kFoldQueue = PK && LA <= 8;  // (16 / 32 atom slots: the queue does not fit the registers — 40 B of scratch at 16)
-#else
-  constexpr bool kFoldQueue = false;
-#endif
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
@@ -199,7 +187,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const uint32_t tab_bytes = (n_thr * rec + 15u) & ~15u;
     KT_LDS unsigned char* tab = lds + a.off_tab;
     // the tile's records — meta word, atom row AND the request words: every lane's, so that the request does not hang off
-    // the meta word by another trip to memory (kAggPrefetch: requested ahead of the tile — measured, not kept)
+    // the meta word by another trip to memory
     const uint32_t wt0 = by_ns ? t_lo + wave : blockIdx.x * (uint32_t)(kBlockIx / kWave) + wave;
     const uint32_t wt_step = by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
     auto fetch_tile = [&](uint32_t wt) {
@@ -222,12 +210,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       return r;
     };
     TileRecAgg<DT, LA, PK> cur{};
-    if (kAggPrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     __syncthreads();  // nobody reads the previous image / table any more
     for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
-#ifdef KT_DYN_TILES
     if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
-#endif
     {  // the image and the ranks of the chunk's term numbers: one batch of loads
       const StageSeg segs[2] = {chunk_image_segment(a.ix, ch),
                                 StageSeg{a.off_rank, (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u}};
@@ -252,7 +237,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     }
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
     __syncthreads();
-#ifdef KT_DYN_TILES
     auto next_tile = [&](uint32_t prev) -> uint32_t {  // (see kt_check_bitmap)
       if (!by_ns) return prev + wt_step;
       uint32_t t = 0u;
@@ -260,12 +244,9 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       return __builtin_amdgcn_readfirstlane(t);
     };
     for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
-#else
-    for (uint32_t wt = wt0; wt < t_hi; wt += wt_step) {
-#endif
       // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
       //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
-      if (!kAggPrefetch) cur = fetch_tile(wt);
+      cur = fetch_tile(wt);
       const uint32_t i = rec0 + wt * kWave + lane;
       const bool in = i < rec_end;
       const uint32_t p = cur.p;
@@ -278,12 +259,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       // (isNotFinished, pod_util.go:26-28) and only matter for error detection (slow list)
       const bool countable = in && (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
       const bool counted = countable && !(st & kPodFinished);
-      TileRecAgg<DT, LA, PK> nxt{};  // (only looked at when there is a next tile)
-      if (__ballot(countable) == 0ull) {
-        if (kAggPrefetch && wt + wt_step < t_hi) nxt = fetch_tile(wt + wt_step);
-        cur = nxt;
-        continue;
-      }
+      if (__ballot(countable) == 0ull) continue;  // (wave-uniform: nobody of the tile counts)
       const uint32_t ns = countable ? (uint32_t)(meta & kMetaNsMask) : 0u;
       const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
       // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
@@ -317,16 +293,8 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
         agg_walk_without_rank(a.sp, a.slow_thr, a.n_slow, a.T, a.lpair, a.lkey, a.LS, a.req, D, DS, a.partial, a.sign, a.limb, p, ns, countable,
                               counted, overflow, present);
 
-      // the next tile's records: in flight during this tile's scan where the registers are there (the packed fold)
-      const bool more = wt + wt_step < t_hi;  // wave-uniform
-      constexpr bool EARLY = PK && LA <= 16;  // (32 atom slots: the second record does not fit the registers)
-      if (kAggPrefetch && EARLY && more) nxt = fetch_tile(wt + wt_step);
       uint32_t last_r = 0xFFFFFFFFu;
-#ifdef KT_PROBE_FOLD_WORDS  // timing probe (results are wrong): only the first words of the plan are added
-      const uint32_t pk_nw = min((uint32_t)KT_PROBE_FOLD_WORDS, __builtin_amdgcn_readfirstlane(a.pk.nw));
-#else
       const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
-#endif
       // one matched term number of the lane's pod, given its rank word
       auto add_match = [&](bool has, uint32_t tr) {
             const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
@@ -340,9 +308,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
                 // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
                 // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
                 // testing the words lane by lane only bought exec-mask juggling
-#ifdef KT_PROBE_FOLD_WORDS
-                if (pk_nw > 0u)
-#endif
                 lds_add64(tv, pw[0]);
                 if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
                 if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
@@ -368,23 +333,13 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
       auto confirm_slow = [&](uint32_t c) {
         return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
       };
-#ifndef KT_AGG_PEEL_ONE
-      constexpr bool kFoldPairs = PK;
-#else
-      constexpr bool kFoldPairs = false;
-#endif
-#ifndef KT_AGG_TERM_QUEUE
       if constexpr (kFoldQueue) {
-        // WORD queue (the default; -DKT_AGG_TERM_QUEUE: the queue of term numbers below, -DKT_AGG_NO_QUEUE: the word-by-word fold): the lane keeps the match words of the last visits as they are — (word number, 64 match bits), kWq of them,
+        // WORD queue: the lane keeps the match words of the last visits as they are — (word number, 64 match bits), kWq of them,
         // newest first — and nothing is extracted while the scan runs: ONE predicated push per visit.  When some lane's queue is
         // full (or the tile is done) the wave folds: every step each lane that has anything takes the lowest bit of its newest
         // word, so a step serves nearly every lane that has matches left — and the bit extraction, which the term-number queue
         // pays in a loop that runs as often as the BUSIEST lane of every single word has matches, runs in these balanced steps too.
-#ifdef KT_AGG_WQ
-        constexpr int kWq = KT_AGG_WQ;
-#else
         constexpr int kWq = 4;  // (measured on the configs[4] shard: 2 words 0.512, 3: 0.484, 4: 0.476, 5: 0.483 ms)
-#endif
         uint64_t qx[kWq];
         // word numbers, 10 bits each (newest lowest: cut_chunks keeps a chunk below 1024 words); entries in use
         typedef typename std::conditional<(kWq > 3), uint64_t, uint32_t>::type qw_t;
@@ -410,14 +365,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             const uint32_t cw = ((uint32_t)qw & 1023u) * 64u;
             const uint32_t c = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
             qx[0] &= qx[0] - 1ull;
-#ifdef KT_AGG_WQ_PAIRS  // two matches of the newest word per step: both rank reads in flight together
-            const bool has2 = has && qx[0] != 0ull;
-            const uint32_t c2 = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
-            qx[0] &= qx[0] - 1ull;
-            const uint32_t r = trank[has ? c : 0u] & 0x7FFFu, r2 = trank[has2 ? c2 : 0u] & 0x7FFFu;
-#else
             const uint32_t r = trank[has ? c : 0u] & 0x7FFFu;
-#endif
             if (has && qx[0] == 0ull) {  // the newest word is used up: the older ones move up
 #pragma unroll
               for (int k = 0; k + 1 < kWq; ++k) qx[k] = qx[k + 1];
@@ -426,9 +374,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
               qn -= 1u;
             }
             add_rank(has, r);
-#ifdef KT_AGG_WQ_PAIRS
-            add_rank(has2, r2);
-#endif
           }
         };
         const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
@@ -452,79 +397,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             },
             [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
         flush();
-      } else
-#endif
-      if constexpr (kFoldQueue) {
-        // lane-private queue: kQueueCap 16-bit chunk-local term numbers, newest in the low half of q[0] (entries past qn are zero)
-#ifndef KT_AGG_QUEUE_CAP
-#define KT_AGG_QUEUE_CAP 12
-#endif
-        constexpr uint32_t kQueueCap = KT_AGG_QUEUE_CAP;
-        constexpr int NQ = (int)kQueueCap / 2;
-        static_assert(kQueueCap % 2 == 0 && kQueueCap >= 4, "queue entries come in pairs");
-        uint32_t q[NQ], qn = 0u;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) q[k] = 0u;
-        auto add_rank = [&](bool has, uint32_t r) {
-          if (has) {
-            KT_LDS unsigned char* rp = tab + __umul24(r, rec);
-            lds_u64wp tv = (lds_u64wp)rp;
-#ifdef KT_PROBE_FOLD_WORDS
-            if (pk_nw > 0u)
-#endif
-            lds_add64(tv, pw[0]);
-            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
-            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
-            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
-            if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        };
-        auto flush = [&]() {
-#ifdef KT_PROBE_NO_FLUSH  // timing probe (results are wrong): the queue is filled and thrown away
-          if (qn < 1000000u) { qn = 0u; return; }
-#endif  // two queued matches per step: both rank reads in flight together
-          while (__ballot(qn != 0u) != 0ull) {
-            const bool h1 = qn >= 1u, h2 = qn >= 2u;
-            const uint32_t c1 = q[0] & 0xFFFFu, c2 = q[0] >> 16;
-#pragma unroll
-            for (int k = 0; k + 1 < NQ; ++k) q[k] = q[k + 1];
-            q[NQ - 1] = 0u;
-            qn = h2 ? qn - 2u : 0u;
-            const uint32_t r1 = trank[c1] & 0x7FFFu, r2 = trank[c2] & 0x7FFFu;
-            add_rank(h1, r1);
-            add_rank(h2, r2);
-          }
-        };
-        const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
-        KT_LDS const u64x2* segp = (KT_LDS const u64x2*)(lds + a.off_seg);
-        scan_tile<LA, VETO, NEED, VETO>(
-            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
-            [&](uint32_t w, uint64_t x, const u64x2& seg) -> uint64_t {
-              if (seg_on) {  // a throttle with several terms is counted once: the lowest match of every run
-                const uint64_t v = x | seg.y;
-                x = andn_64(x, v - seg.x);
-              }
-#ifdef KT_PROBE_NO_FOLD  // timing probe (results are wrong): the scan without the fold
-              if (x == 0x123456789ull) qn = 1u;
-              return 0ull;
-#endif
-              while (__ballot(x != 0ull) != 0ull) {
-                if (__ballot(qn >= kQueueCap) != 0ull) flush();
-                const bool has = x != 0ull;
-                const uint32_t c = w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u;
-                x &= x - 1ull;
-                if (has) {
-#pragma unroll
-                  for (int k = NQ - 1; k > 0; --k) q[k] = __builtin_amdgcn_alignbit(q[k], q[k - 1], 16);
-                  q[0] = q[0] << 16 | c;
-                  qn += 1u;
-                }
-              }
-              return 0ull;
-            },
-            [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
-        flush();
-      } else if constexpr (kFoldPairs) {
+      } else if constexpr (PK) {
         // the packed fold takes a word's matches where the scan produced them (scan_tile's post hook), TWO per step: both
         // rank reads are in flight together and the wave steps ceil(matches / 2) times per word instead of once per match
         // through scan_tile's peel (ascending term numbers per lane, as the run rule of add_match needs)
@@ -549,8 +422,6 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
         scan_tile<LA, VETO, NEED, VETO>(
             bm, scan_counted, ns, ro, [&](bool has, uint32_t c) { add_match(has, trank[c]); }, confirm_slow);
       }
-      if (kAggPrefetch && !EARLY && more) nxt = fetch_tile(wt + wt_step);
-      cur = nxt;
     }
     __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
     u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
@@ -713,8 +584,9 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   // the packed fold: full scans over the scan view, records no larger than the plain ones (the slab areas were sized for those)
   // (ix.cut_thr_bytes: the record size the chunks' tables and slab areas were cut for — the plain record, or the packed fold's
   //  for a program of several chunks; the engine cuts again before it launches a fold whose records are larger)
+  // (ix.has_long: the packed fold applies "counted once" per word — a throttle whose run spans words takes the plain fold)
   const bool packed = bm_args.v_pk != nullptr && bm_args.ix.by_ns && !sc.counts && sc.sign == 1 && sc.nonneg &&
-                      bm_args.pk.rec_bytes <= ix.cut_thr_bytes;
+                      bm_args.pk.rec_bytes <= ix.cut_thr_bytes && !ix.has_long;
   if (bm_args.v_pk != nullptr && !packed) return nullptr;  // the engine only hands over packed words it may use
   if (!packed && agg_rec_bytes(pods.D, sc.counts) > ix.cut_thr_bytes) return nullptr;
   int nb = aggregate_blocks(n_rows);
@@ -739,6 +611,11 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   KT_AGG_BM_CASE(8, 8, false, 2)
 #else
   if (!ix.rich) { if (DT <= 8) KT_AGG_BM_CASE(8, 8, false, 2) else KT_AGG_BM_CASE(16, 8, false, 2) }
+  else if (ix.max_need > 3u) {  // terms that count four or five positive keys: hits as 3-bit numbers
+    if (LA <= 8) { if (DT <= 8) KT_AGG_BM_CASE(8, 8, true, 5) else KT_AGG_BM_CASE(16, 8, true, 5) }
+    else if (LA <= 16) { if (DT <= 8) KT_AGG_BM_CASE(8, 16, true, 5) else KT_AGG_BM_CASE(16, 16, true, 5) }
+    else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 5) else KT_AGG_BM_CASE(16, 32, true, 5) }
+  }
   else if (LA <= 8) { if (DT <= 8) KT_AGG_BM_CASE(8, 8, true, 3) else KT_AGG_BM_CASE(16, 8, true, 3) }
   else if (LA <= 16) { if (DT <= 8) KT_AGG_BM_CASE(8, 16, true, 3) else KT_AGG_BM_CASE(16, 16, true, 3) }
   else { if (DT <= 8) KT_AGG_BM_CASE(8, 32, true, 3) else KT_AGG_BM_CASE(16, 32, true, 3) }

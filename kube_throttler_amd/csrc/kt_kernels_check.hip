@@ -141,15 +141,9 @@ struct TileRec {
   unsigned long long carried;  // class counters of the earlier chunks
   int64_t v[NV];               // AGG (kt_sweep): the request row — ResourceAmountOfPod of the reconcile half
 };
-// Requesting a tile's records early — the first tile's before the chunk is staged, every later one's behind the scan of
-// the tile before it — was measured and NOT kept (round 4: check 28.0 -> 31.6 us at 1M pods, 79.9 -> 85.3 at 4M; the
-// aggregate 23.4 -> 25.1): the kernels are bound by instruction issue, not by the chain of trips to memory, and the
-// second record costs registers.  -DKT_TILE_PREFETCH builds that form.
-#ifdef KT_TILE_PREFETCH
-constexpr bool kTilePrefetch = true;
-#else
-constexpr bool kTilePrefetch = false;
-#endif
+// (Requesting a tile's records early — before the chunk is staged, or behind the previous tile's scan — was measured in rounds 4
+//  and 5 and not kept: the kernels are bound by instruction issue, not by the chain of trips to memory, and the second record
+//  costs registers.  The forms are in the git history of this file.)
 
 struct BmCheckArgs {
   const uint64_t* meta;  // pod tables
@@ -254,41 +248,19 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   // (pieces of the three rows per batch: 12 registers each — the whole rows of a 16-dimension engine would be 96 registers
   //  of a 128-register kernel: four pieces per batch at most, two batches there)
   constexpr int kDrainUnroll = WPE >= 8 ? 1 : (DT / 2 > 4 ? 4 : DT / 2);  // drains in the middle of a scan (the list ran full)
-#ifndef KT_DRAIN_FINAL_8
-#define KT_DRAIN_FINAL_8 2  // (4 = the whole rows at once costs the 64-VGPR instantiation 80 B of scratch inside the scan)
-#endif
-#ifdef KT_DRAIN_SERIAL
-  constexpr int kDrainFinalUnroll = kDrainUnroll;
-#else
-#ifdef KT_DRAIN_PREFETCH
-  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : (!SMALL && !ONE && !AGG && !FULL) ? 2 : DT / 2;  // (the next tile's record is live across it)
-#else
-  constexpr int kDrainFinalUnroll = WPE >= 8 ? KT_DRAIN_FINAL_8 : (DT / 2 > 4 ? 4 : DT / 2);  // the drain behind the scan
-#endif
-#endif
+  // the drain behind the scan (two pieces per batch in the 64-VGPR form: the whole rows at once cost it 80 B of scratch)
+  constexpr int kDrainFinalUnroll = WPE >= 8 ? 2 : (DT / 2 > 4 ? 4 : DT / 2);
   // WORDWISE: matches that need no comparison are settled per 64-bit word with mask algebra (WordVerdict) instead of
   // being peeled one by one: three popcounts per visited word, and only the matches of tight throttles go through the
   // peel.  Round 3 had it in the one-workgroup-per-CU instantiation only (config 4's 130 matches per pod: 1.27 -> 0.92 ms):
   // with one mask per dimension its registers did not fit the 64-VGPR budget of the two-per-CU one (config 2: 33.6 -> 38.2
   // us, 56 B of scratch).  With the per-nibble tables (WordVerdict::act_nib) a visit holds 12 mask registers instead of
   // 28, and the two-per-CU instantiation takes it too: config 2's peel was 10.7 steps per tile at 21 % busy lanes,
-  // half of the kernel's instructions (KT_CHECK_PEEL=1 at build time restores the peel there: A/B).
-#ifdef KT_CHECK_PEEL
-  constexpr bool WORDWISE = !FULL && WPE < 8;
-#else
+  // half of the kernel's instructions.
   constexpr bool WORDWISE = !FULL;
-#endif
   // the verdict masks of a word are requested together with its atom rows (scan_tile's pre hook) where registers allow;
   // the 64-VGPR instantiation reads them when the rows have been consumed
   constexpr bool PREFETCH = WPE < 8;
-  // PF: the NEXT tile's records are requested behind this tile's scan, ahead of its drain and summary write — the wait for them
-  // (a trip to memory per (tile, chunk): 12 % of the wave cycles of the configs[4] sweep) then lies behind the drain's own
-  // trips.  Only where the scan's registers are dead by then and 128 are available: the lean multi-chunk form.
-#if defined(KT_DRAIN_PREFETCH)
-  constexpr bool PF = kTilePrefetch || (!SMALL && !ONE && !AGG && !FULL && WPE < 8);
-#else
-  constexpr bool PF = kTilePrefetch;
-#endif
 #ifdef KT_PROFILE_PHASES
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   KT_PROF_T(t_kernel0);
@@ -336,7 +308,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     const bool first = ONE || ci == (SMALL ? 0u : first_ci), last = ONE || ci == last_ci;
     const BmChunk ch = a.ix.chunks[ci];
     // the tile's records, always from valid addresses: lanes past the end re-read the last pod and are switched off by
-    // `on` (kTilePrefetch: requested ahead of the tile — measured, not kept)
+    // `on`
     const uint32_t wt0 = SMALL ? (wave == 0 ? blockIdx.y : n_wtiles) : by_ns ? t_lo + wave : blockIdx.x * (kBlockIx / kWave) + wave;
     const uint32_t wt_step = SMALL ? n_wtiles : by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
     auto fetch_tile = [&](uint32_t wt) {
@@ -352,15 +324,12 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       return r;
     };
     TileRec<LA, AGG ? DT : 1> cur{};
-    if (kTilePrefetch && wt0 < t_hi) cur = fetch_tile(wt0);
     KT_PROF_T(t_b0);
     __syncthreads();  // nobody reads the previous image any more
     KT_PROF_T(t_b1);
     KT_PROF_ADD(0, t_b1 - t_b0);
     const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
-#ifdef KT_DYN_TILES
     if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
-#endif
     const bool from_images = !SMALL && !ONE && !FULL && a.wv_img != nullptr;  // (kernel argument: uniform)
     // (tables built in place: the first term word of every thread is requested AHEAD of the image — it arrives with that batch,
     //  and the dependent read of the CheckRec flags is the prologue's second trip to memory instead of its third)
@@ -384,7 +353,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       const uint32_t tab_bytes = (ch.n_thr * a.pk_rec + 15u) & ~15u;
       for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
     }
-#ifndef KT_PROBE_NO_PROLOGUE  // (timing probe, results wrong: the chunk prologue without the TermInfo / WordVerdict build)
     if (from_images) {
       // (the tables of this chunk's words came with the image: kt_build_verdict_images built them once per generation of CheckRecs)
     } else {
@@ -392,7 +360,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       for (uint32_t c = threadIdx.x; c < ch.n_words * 64u; c += kBlockIx)
         build_term_verdicts<DT, WORDWISE>(c == threadIdx.x ? tt_first : term_t[c], c, g_rflags, tinfo, (KT_LDS WordVerdict<DT>*)(lds + a.off_wv));
     }
-#endif
     KT_PROF_T(t_b2);
     __syncthreads();
     KT_PROF_T(t_b3);
@@ -402,26 +369,19 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     // namespace-ordered sweeps: the waves of the workgroup take the tiles of its range as they get free (a counter in LDS) —
     // with a fixed stride every chunk pass ended with the waves that own five tiles while those that own four waited
     auto next_tile = [&](uint32_t prev) -> uint32_t {
-#ifdef KT_DYN_TILES
       if (by_ns) {
         uint32_t t = 0u;
         if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
         return __builtin_amdgcn_readfirstlane(t);
       }
-#endif
       return prev + wt_step;
     };
-#ifdef KT_DYN_TILES
     uint32_t wt = by_ns ? next_tile(0u) : wt0;
-#else
-    uint32_t wt = wt0;
-#endif
-    if (PF && !kTilePrefetch && wt < t_hi) cur = fetch_tile(wt);
     uint32_t wt_next = 0u;
     for (; wt < t_hi; wt = wt_next) {
-      // ---- the tile's records (PF: requested behind the previous tile's scan)
+      // ---- the tile's records
       KT_PROF_T(t_f0);
-      if (!PF) cur = fetch_tile(wt);
+      cur = fetch_tile(wt);
 #ifdef KT_PROFILE_PHASES
       __builtin_amdgcn_s_waitcnt(0);  // (vmcnt / lgkmcnt / expcnt = 0: the wait for the records is charged to the fetch)
       KT_PROF_T(t_f1);
@@ -614,11 +574,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       auto fetch = [&](uint32_t w) -> VerdictRegs {
         KT_LDS const unsigned char* q = wv + __umul24(w, (uint32_t)sizeof(WordVerdict<DT>));
         VerdictRegs r;
-#ifdef KT_PROBE_NO_SETTLE
-        r.seg = r.te = r.ai = u64x2{0ull, 0ull};
-        for (int k = 0; k < DT / 4; ++k) r.nib[k] = 0ull;
-        return r;
-#endif
         r.seg = u64x2{0ull, 0ull};
         if (seg_on) r.seg = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, seg_lo));  // {seg_lo, seg_hi}
         r.te = *(KT_LDS const u64x2*)(q + offsetof(WordVerdict<DT>, tight));              // {tight, exc}
@@ -658,10 +613,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         }
       };
       auto settle = [&](uint32_t w, uint64_t x, const VerdictRegs& q) -> uint64_t {
-#ifdef KT_PROBE_NO_SETTLE  // timing probe (results are wrong): the scan without the verdicts
-        n_exc += (uint32_t)(x == 0x123456789ull);
-        return 0ull;
-#endif
         if (seg_on) {  // a throttle with several terms is reported once: the lowest match of every run
           const uint64_t v = x | q.seg.y;
           x = andn_64(x, v - q.seg.x);  // (= x & (v ^ (v - seg_lo)) & v, x being part of v)
@@ -676,9 +627,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
         n_exc = (uint32_t)__popc((uint32_t)xe) + ((uint32_t)__popc((uint32_t)(xe >> 32)) + n_exc);
         n_act = (uint32_t)__popc((uint32_t)xa) + ((uint32_t)__popc((uint32_t)(xa >> 32)) + n_act);
         n_ins = (uint32_t)__popc((uint32_t)xi) + ((uint32_t)__popc((uint32_t)(xi >> 32)) + n_ins);
-#ifdef KT_PROBE_NO_TIGHT  // timing probe (results are wrong): no match goes through the comparison
-        return x & q.te.x & 0x8000000000000000ull & (uint64_t)(n_exc == 0x12345u);
-#endif
         return x & q.te.x;
       };
       auto confirm_slow = [&](uint32_t c) {
@@ -700,9 +648,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
       }
       my = (unsigned long long)n_exc << 4 | (unsigned long long)n_act << 24 | (unsigned long long)n_ins << 44;
       }
-      TileRec<LA, AGG ? DT : 1> nxt{};  // (only looked at when there is a next tile)
       wt_next = next_tile(wt);
-      if (PF && wt_next < t_hi) nxt = fetch_tile(wt_next);  // (wave-uniform)
 #ifdef KT_PROFILE_PHASES
       KT_PROF_T(t_s1);
       KT_PROF_ADD(4, t_s1 - t_f1);
@@ -743,7 +689,6 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
           *carry_w = c | (pod_err ? 2ull : 0ull);
         }
       }
-      cur = nxt;
 #ifdef KT_PROFILE_PHASES
       __builtin_amdgcn_s_waitcnt(0);
       KT_PROF_T(t_d1);
@@ -784,6 +729,15 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
     else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false, false, false)                        \
   }
 
+// programs whose terms count four or five positive keys (ix.max_need > 3): the NEED = 5 instantiations — small, full and the
+// lean one-workgroup-per-CU form (the two-per-CU and fused-sweep forms are not built for them)
+#define KT_BM_CASE5(DT_, LA_)                                                           \
+  {                                                                                     \
+    if (small) KT_BM_LAUNCH(DT_, LA_, true, 5, 4, true, true, false)                    \
+    else if (full) KT_BM_LAUNCH(DT_, LA_, true, 5, 4, true, false, false)               \
+    else KT_BM_LAUNCH(DT_, LA_, true, 5, 4, false, false, false)                        \
+  }
+
 // returns the dispatched kernel's symbol, or nullptr when a chunk of the index does not fit the workgroup's LDS
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
@@ -813,8 +767,11 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
     bm_args.wv_img = by_ns->wv_img, bm_args.wv_total_words = by_ns->wv_total_words;
     bm_args.wg_range = by_ns->wg_range_G == check_sweep_blocks(n) ? by_ns->wg_range : nullptr;
   }
-  const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods;  // the lean instantiation serves the PreFilter sweep
-  const bool two_per_cu = !full && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
+  // the lean instantiation serves the PreFilter sweep; a throttle whose run of term numbers spans words (ix.has_long) needs the
+  // match-by-match peel of the full one ("reported once" across words)
+  const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods || ix.has_long;
+  const bool need5 = ix.max_need > 3u;
+  const bool two_per_cu = !full && !need5 && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;
@@ -829,6 +786,11 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   KT_BM_CASE(8, 8, false, 2)
 #else
   if (!rich) { if (DT <= 8) KT_BM_CASE(8, 8, false, 2) else KT_BM_CASE(16, 8, false, 2) }
+  else if (need5) {
+    if (LA <= 8) { if (DT <= 8) KT_BM_CASE5(8, 8) else KT_BM_CASE5(16, 8) }
+    else if (LA <= 16) { if (DT <= 8) KT_BM_CASE5(8, 16) else KT_BM_CASE5(16, 16) }
+    else { if (DT <= 8) KT_BM_CASE5(8, 32) else KT_BM_CASE5(16, 32) }
+  }
   else if (LA <= 8) { if (DT <= 8) KT_BM_CASE(8, 8, true, 3) else KT_BM_CASE(16, 8, true, 3) }
   else if (LA <= 16) { if (DT <= 8) KT_BM_CASE(8, 16, true, 3) else KT_BM_CASE(16, 16, true, 3) }
   else { if (DT <= 8) KT_BM_CASE(8, 32, true, 3) else KT_BM_CASE(16, 32, true, 3) }
@@ -847,7 +809,7 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
 const char* launch_sweep_indexed(const PodTable& pods, int64_t n, const SelProgram& sp, const SelProgram* sp_dev, const IndexDev& ix,
                                  const void* recs, uint64_t* summary, const PackPlan& pk, void* slab, uint32_t* slab_tag, uint32_t epoch,
                                  int* launched_blocks, hipStream_t s) {
-  if (n <= 0 || ix.n_chunks != 1 || ix.n_slow != 0 || pk.nw == 0) return nullptr;
+  if (n <= 0 || ix.n_chunks != 1 || ix.n_slow != 0 || ix.has_long || ix.max_need > 3u || pk.nw == 0) return nullptr;
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (DT != 8) return nullptr;  // (the packed fold's records are planned for the 8-dimension instantiation, as in kt_aggregate_bitmap)
   uint32_t bm_total = 0;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
     const u32x4 e = *(const u32x4*)(nsl + k);  // {w, -, mask lo, mask hi}
     const uint32_t w = e.x;
     const WordHdr h = hdr[w];
-    uint64_t any = h.univ, two = 0, three = 0, vet = 0;
+    uint64_t any = h.univ, two = 0, three = 0, four = 0, five = 0, vet = 0;
     const unsigned char* col = img + (size_t)w * ch.col_rows * 8u;  // the word's column of the `any` plane
     // (a word without a veto column reads the plane's all-zero column: kt_index.h, image layout)
     const unsigned char* colv = (ch.zero_col == 0u || (e.y & kNsWordVeto) != 0u) ? col + (size_t)ch.n_words * ch.col_rows * 8u : img + ch.zero_col;
@@ -78,6 +78,8 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
     for (int l = 0; l < LA; ++l) {
       const uint64_t r = *(const unsigned long long*)(col + ro[l]);
       if (VETO) vet |= *(const unsigned long long*)(colv + ro[l]);
+      if (NEED >= 5) five |= four & r;
+      if (NEED >= 4) four |= three & r;
       if (NEED >= 3) three |= two & r;
       if (NEED >= 2) two |= any & r;
       any |= r;
@@ -85,6 +87,8 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
     uint64_t xx = any;
     if (NEED >= 2) xx = (any & ~h.m2) | (two & h.m2);
     if (NEED >= 3) xx = (xx & ~h.m3) | (three & h.m3);
+    if (NEED >= 4) xx = (xx & ~h.m4) | (four & h.m4);
+    if (NEED >= 5) xx = (xx & ~h.m5) | (five & h.m5);
     xx &= ~vet & ((uint64_t)e.z | (uint64_t)e.w << 32);
     uint32_t last_t = 0xFFFFFFFFu;
     while (xx) {
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(64) void kt_check_few(const FewArgs a) {
 // a path this kernel does not have
 bool launch_check_few(const PodTable& pods, int n, const int64_t* rows_host, const SelProgram& sp, const IndexDev& ix, const void* recs,
                       unsigned long long* acc, uint32_t* ticket, uint64_t* host_summary, uint64_t* host_seq, uint64_t seq, hipStream_t s) {
-  if (n < 1 || n > 8 || ix.n_slow != 0 || ix.n_chunks == 0) return false;
+  // (ix.has_long: a throttle whose run of term numbers spans words — lane = (pod, word) cannot apply "reported once" across lanes)
+  // (ix.max_need > 3: terms with four or five positive keys — the staged small launch has the NEED = 5 instantiation)
+  if (n < 1 || n > 8 || ix.n_slow != 0 || ix.has_long || ix.max_need > 3u || ix.n_chunks == 0) return false;
   FewArgs a{};
   a.meta = pods.meta, a.latom = pods.latom, a.req = pods.req, a.recs = recs, a.ns_valid = sp.ns_valid;
   a.blob = ix.bm_blob, a.chunks = ix.bm_chunks, a.acc = acc, a.ticket = ticket, a.host_summary = host_summary, a.host_seq = host_seq;

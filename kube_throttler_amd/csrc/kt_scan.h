@@ -25,11 +25,7 @@
 
 // Namespace-ordered scans hand the tiles of a workgroup's range to its waves as they get free (a counter in LDS) — with a fixed
 // stride every chunk pass ended with the waves that own one tile more (configs[4] check: 12.8 % of the wave cycles at the
-// barrier, 6.6 % with the counter; 0.532 -> 0.494 ms).  -DKT_STATIC_TILES restores the stride (A/B); the tile prefetch
-// experiment (-DKT_TILE_PREFETCH) needs it.
-#if !defined(KT_STATIC_TILES) && !defined(KT_TILE_PREFETCH) && !defined(KT_DYN_TILES)
-#define KT_DYN_TILES 1
-#endif
+// barrier, 6.6 % with the counter; 0.532 -> 0.494 ms).
 
 namespace kt {
 
@@ -83,10 +79,6 @@ struct BmView {
   KT_LDS const u32x2* nsl_rng;       // [n_ns] {begin, end} of the namespace's word list
   KT_LDS const NsWord* nsl;
   const uint32_t* term_g;            // (HBM) selector-program term of every number: `slow` candidates only
-#ifdef KT_PROBE_UNIFORM
-  const unsigned char* img_g;        // (timing probe) the image in global memory: uniform per-word data through scalar loads
-  uint32_t off_nsl_g, off_hdr_g;
-#endif
   uint32_t col_bytes;                // bytes per word column
   uint32_t veto_off;                 // from a cell of the `any` plane to the same cell of the veto plane (words with a veto column)
   uint32_t zero_col;                 // offset (from rows) of the veto plane's all-zero column: what a word WITHOUT a veto column reads
@@ -176,9 +168,6 @@ __device__ __forceinline__ BmView open_chunk(KT_LDS unsigned char* lds, const Bm
   v.nsl_rng = (KT_LDS const u32x2*)(base + ch.off_nsl_rng);
   v.nsl = (KT_LDS const NsWord*)(base + ch.off_nsl);
   v.term_g = (const uint32_t*)(a.blob + ch.img_off + ch.off_term_g);
-#ifdef KT_PROBE_UNIFORM
-  v.img_g = a.blob + ch.img_off, v.off_nsl_g = ch.off_nsl, v.off_hdr_g = ch.off_hdr;
-#endif
   v.col_bytes = ch.col_rows * 8u;
   v.veto_off = VETO ? ch.n_words * ch.col_rows * 8u : 0u;
   v.zero_col = VETO ? ch.zero_col : 0u;
@@ -225,6 +214,19 @@ __device__ __forceinline__ void count8(const uint64_t (&r)[8], uint64_t& ones, u
   twos = or3_64(c1, c2, c3) | maj3_64(s1, s2, s3);
 }
 
+// ... and as a 3-bit number (ones, twos, fours) for programs whose terms count up to five positive keys (NEED = 5): exact as
+// long as no bit is met more than seven times — a term keeps at most five positives.  13 three-input operations per half.
+__device__ __forceinline__ void count8_wide(const uint64_t (&r)[8], uint64_t& ones, uint64_t& twos, uint64_t& fours) {
+  const uint64_t s1 = xor3_64(r[0], r[1], r[2]), k1 = maj3_64(r[0], r[1], r[2]);
+  const uint64_t s2 = xor3_64(r[3], r[4], r[5]), k2 = maj3_64(r[3], r[4], r[5]);
+  const uint64_t s3 = r[6] ^ r[7], k3 = r[6] & r[7];
+  ones = xor3_64(s1, s2, s3);
+  const uint64_t k4 = maj3_64(s1, s2, s3);
+  const uint64_t t = xor3_64(k1, k2, k3), f1 = maj3_64(k1, k2, k3);  // the four carries of weight two
+  twos = t ^ k4;
+  fours = f1 | (t & k4);
+}
+
 // A pod's atom row (PodTable::latom, LA u16 ids) as byte offsets of its cells inside a word column: LA/8 128-bit loads,
 // issued from an always-valid address.
 template <int LA>
@@ -240,13 +242,8 @@ __device__ __forceinline__ void atom_row_offsets(const u32x4 (&raw)[LA / 8], uin
     const uint32_t w[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-#ifdef KT_PROBE_ROW0  // timing probe (results are wrong): every lane reads row 0 — the gathers without their bank conflicts
-      ro[8 * q + 2 * k] = (w[k] & 0x0u) << 3;
-      ro[8 * q + 2 * k + 1] = w[k] >> 31 >> 1;
-#else
       ro[8 * q + 2 * k] = (w[k] & 0xFFFFu) << 3;
       ro[8 * q + 2 * k + 1] = (w[k] >> 16) << 3;
-#endif
     }
   }
 }
@@ -281,17 +278,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
   uint64_t x = 0;
   uint32_t w = 0;
   u32x4 e_next = {0u, 0u, 0u, 0u};
-#ifdef KT_PROBE_UNIFORM  // timing probe (wrong for tiles whose lanes differ in namespace): the list entry and the word header as
-                         // SCALAR loads from the image in L2, as if every lane of the tile walked the same list
-  typedef const __attribute__((address_space(4))) u32x4* cst_u4p;
-  auto entry_u = [&](uint32_t kk) -> u32x4 {
-    const uint32_t ku = __builtin_amdgcn_readfirstlane(kk);
-    return *(cst_u4p)(b.img_g + b.off_nsl_g + (size_t)ku * 16u);
-  };
-  if (PIPE) e_next = entry_u(k < k1 ? k : 0u);
-#else
   if (PIPE) e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));
-#endif
   for (;;) {
     const bool has = x != 0;
     if (__ballot(has) != 0ull) {
@@ -306,23 +293,13 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
       if (PIPE) {
         e = e_next;
         k += adv ? 1u : 0u;
-#ifdef KT_PROBE_UNIFORM
-        e_next = entry_u(k < k1 ? k : 0u);
-#else
         e_next = *(lds_u4p)(b.nsl + (k < k1 ? k : 0u));  // the entry of the next advance, in flight behind this word's reads
-#endif
       } else {
         e = *(lds_u4p)(b.nsl + (adv ? k : 0u));
         k += adv ? 1u : 0u;
       }
       w = e.x;
-#ifdef KT_PROBE_UNIFORM
-      typedef const __attribute__((address_space(4))) u64x2* cst_u64x2p;
-      const uint32_t w_u = __builtin_amdgcn_readfirstlane(w);
-      const u64x2 h0 = *(cst_u64x2p)(b.img_g + b.off_hdr_g + (size_t)w_u * 32u);
-#else
       const u64x2 h0 = *(KT_LDS const u64x2*)(b.hdr + w);  // {univ, m2}
-#endif
       const auto pf = pre(w);
       KT_LDS const unsigned char* col = b.rows + __umul24(w, b.col_bytes);  // (word < 2^10, column bytes < 2^18)
       // (the veto plane holds the columns of the words that have a veto bit somewhere and one all-zero column: a lane whose word
@@ -335,26 +312,16 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
         // different forms takes the general path, which is right for every word.
         //   no veto bit in any row  : only the `any` plane is read (8 bytes per atom instead of 16: these
         //                             gathers are what the scans of large programs wait for)
-        //   no need-3 term          : the OR / XOR accumulation of the simple form (below) instead of the counting tree
         // (only in the instantiations with room for it — the PIPE ones with eight atom slots: the 64-VGPR forms and the
-        //  16 / 32-slot ones spill over the second path)
-#ifndef KT_NO_WORD_FORMS
+        //  16 / 32-slot ones spill over the second path.  A second form — the OR / XOR accumulation of the simple instantiation
+        //  for words without a need-3 term, NsWord::flags carries the bit — saved VALU only and spilled in the 128-VGPR forms.)
         constexpr bool FORMS = PIPE && LA == 8;
         const bool w_veto = VETO && (!FORMS || __ballot(adv && (e.y & kNsWordVeto) != 0u) != 0ull);
-#ifdef KT_WORD_FORM_NEED3
-        const bool w_need3 = !FORMS || __ballot(adv && (e.y & kNsWordNeed3) != 0u) != 0ull;
-#else
-        const bool w_need3 = true;  // (the OR / XOR path saves VALU only, and the instantiations with 128 VGPRs spill over it)
-#endif
-#else
-        const bool w_veto = VETO, w_need3 = true;
-#endif
         // hits per term as a 2-bit number (c1 c0): a pod carries at most one atom of any requirement and an exactly
         // indexed term has at most three positive keys, so the count never passes 3.  Eight rows at a time through a
         // small adder tree of three-input operations (count8); the groups of eight are added as 2-bit numbers.
         static_assert(LA % 8 == 0, "atom slots come in eights");
-        // (c0 / c1: the 2-bit counter of the counting form — or, in a word without need-3 terms, the OR and the XOR of the rows)
-        uint64_t c0 = w_need3 ? 0ull : h0.x, c1 = 0;
+        uint64_t c0 = 0, c1 = 0, c2 = 0;  // the 2-bit counter (NEED = 5: 3 bits)
 #pragma unroll
         for (int g8 = 0; g8 < LA / 8; ++g8) {
           // (one set of registers for both forms: the veto halves of a veto-free word are zeroed instead of read)
@@ -363,9 +330,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
             // Eight atom slots: the veto plane's reads go first and are folded into `vet` before the `any` plane's are
             // issued — two dependent LDS round trips instead of one, but 16 registers are live at a time instead of 32: the
             // 128-VGPR forms lose their scratch (configs[4] lean check 16 -> 0 B, 0.422 -> 0.410 ms; issued together in
-            // either order: 0.421; -DKT_VETO_TOGETHER restores that).  With 16 / 32 slots the groups of eight overlap anyway
-            // and the split costs registers.
-#ifndef KT_VETO_TOGETHER
+            // either order: 0.421).  With 16 / 32 slots the groups of eight overlap anyway and the split costs registers.
             if (LA == 8) {
 #pragma unroll
               for (int l = 0; l < 8; ++l) v8[l] = *(KT_LDS const unsigned long long*)(colv + ro[8 * g8 + l]);
@@ -373,9 +338,7 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
               asm volatile("" : "+v"(vet));  // (the fold stays ahead of the next batch of reads)
 #pragma unroll
               for (int l = 0; l < 8; ++l) v8[l] = 0ull, r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
-            } else
-#endif
-            {
+            } else {
 #pragma unroll
               for (int l = 0; l < 8; ++l) {
                 r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]);
@@ -387,7 +350,18 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
             for (int l = 0; l < 8; ++l) r[l] = *(KT_LDS const unsigned long long*)(col + ro[8 * g8 + l]), v8[l] = 0ull;  // (the `any` plane only)
           }
           if (VETO) vet |= or3_64(or3_64(v8[0], v8[1], v8[2]), or3_64(v8[3], v8[4], v8[5]), v8[6] | v8[7]);
-          if (w_need3) {
+          if (NEED >= 4) {
+            uint64_t ones, twos, fours;
+            count8_wide(r, ones, twos, fours);
+            if (g8 == 0) {
+              c0 = ones, c1 = twos, c2 = fours;
+            } else {  // (3-bit add; the total does not pass 7)
+              const uint64_t k0 = c0 & ones;
+              c0 ^= ones;
+              c2 |= fours | maj3_64(c1, twos, k0);
+              c1 = xor3_64(c1, twos, k0);
+            }
+          } else {
             uint64_t ones, twos;
             count8(r, ones, twos);
             if (g8 == 0) {
@@ -396,24 +370,20 @@ __device__ __forceinline__ void scan_tile(const BmView& b, bool lane_on, uint32_
               c1 |= twos | (c0 & ones);
               c0 ^= ones;
             }
-          } else {
-            c0 = or3_64(or3_64(r[0], r[1], r[2]), or3_64(r[3], r[4], r[5]), or3_64(r[6], r[7], c0));
-            c1 = xor3_64(xor3_64(r[0], r[1], r[2]), xor3_64(r[3], r[4], r[5]), xor3_64(r[6], r[7], c1));
           }
         }
-#ifdef KT_PROBE_UNIFORM
-        const u64x2 h1 = *(cst_u64x2p)(b.img_g + b.off_hdr_g + (size_t)w_u * 32u + 16u);
-#else
         const u64x2 h1 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 16);  // {m3, slow}
-#endif
-        if (w_need3) {
+        if (NEED >= 4) {
+          const u64x2 h2 = *(KT_LDS const u64x2*)((KT_LDS const unsigned char*)(b.hdr + w) + 32);  // {m4, m5}
+          const uint64_t any = or3_64(h0.x, c0, c1) | c2, two = c1 | c2, three = c2 | (c0 & c1), five = c2 & (c0 | c1);  // >= 1, 2, 3, 5; >= 4 is c2
+          xx = mux_64(any, two, h0.y);
+          xx = mux_64(xx, three, h1.x);
+          xx = mux_64(xx, c2, h2.x);
+          xx = mux_64(xx, five, h2.y);
+        } else {
           const uint64_t any = or3_64(h0.x, c0, c1), two = c1, three = c0 & c1;  // >= 1 (or no positive requirement), >= 2, == 3
           xx = mux_64(any, two, h0.y);    // (any & ~m2) | (two & m2)
           xx = mux_64(xx, three, h1.x);   // (xx & ~m3) | (three & m3)
-        } else {
-          // at most two positive keys per term, each met by at most one of the pod's atoms: under m2 "both met" = "met, and in
-          // an even number of rows"
-          xx = and_nand_64(c0, c1, h0.y);
         }
         xx = and_not_and_64(xx, vet, (uint64_t)e.z | (uint64_t)e.w << 32);
         xx = adv ? xx : 0ull;

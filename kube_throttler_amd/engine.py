@@ -42,6 +42,7 @@ EXPORTS = [
     "kt_set_wide_sums", "kt_partial_words", "kt_partial_layout", "kt_debug_reload_env", "kt_affected_pods", "kt_paged_check", "kt_paged_reconcile",
 ]
 COUNTER_FEW_CHECKS, COUNTER_COMPILES, COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS, COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS = range(6)
+COUNTER_NS_CHUNK_VISITS, COUNTER_INDEX_IMAGE_WORDS, COUNTER_SLOW_THROTTLES = 6, 7, 8
 
 
 def partial_layout(n_dims: int) -> dict:
@@ -365,10 +366,12 @@ class Engine:
     def index_stats(self) -> dict:
         """The compiled selector index (after the first launch): LDS-sized chunks, 64-bit words of term numbers, namespace rows,
         and the words a pod visits on average over the namespace rows in use."""
-        ch, words, visits, rows = (int(lib().kt_counter(self._h, k)) for k in (COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS,
-                                                                                COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS))
-        return {"chunks": ch, "words": words, "namespace_rows": rows,
-                "word_visits_per_namespace": round(visits / rows, 3) if rows > 0 else None}
+        ch, words, visits, rows, cvis, iw, slow = (int(lib().kt_counter(self._h, k)) for k in (
+            COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS, COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS, COUNTER_NS_CHUNK_VISITS, COUNTER_INDEX_IMAGE_WORDS,
+            COUNTER_SLOW_THROTTLES))
+        return {"chunks": ch, "words": words, "image_words": iw, "namespace_rows": rows,
+                "word_visits_per_namespace": round(visits / rows, 3) if rows > 0 else None,
+                "chunks_per_namespace": round(cvis / rows, 3) if rows > 0 else None, "slow_throttles": slow}
 
     def partial_words(self) -> int:
         return self.throttle_rows() * partial_layout(self.D)["stride"]

@@ -272,16 +272,20 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
         g_word_keys += __builtin_popcount(word_key_masks(ix)[ci][w]);
       }
       g_admitted += __builtin_popcountll(nsl[k].mask);
-      uint64_t any = hdr[w].univ, two = 0, three = 0, vet = 0, par = 0;
+      uint64_t any = hdr[w].univ, two = 0, three = 0, four = 0, five = 0, vet = 0, par = 0;
       for (uint32_t id : ids) {
         EXPECT(id < ix.bm_rows, "row %u of %u", id, ix.bm_rows);
         const uint64_t r = cell_any(ch, rows, id, w);
         if (ix.rich) vet |= cell_veto(ch, rows, id, w);
+        five |= four & r;
+        four |= three & r;
         three |= two & r;
         two |= any & r;
         any |= r;
         par ^= r;
       }
+      EXPECT((hdr[w].m5 & ~hdr[w].m4) == 0 && (hdr[w].m4 & ~hdr[w].m3) == 0 && (hdr[w].m3 & ~hdr[w].m2) == 0, "need masks of word %u are not nested", w);
+      EXPECT(ix.max_need > 3 || hdr[w].m4 == 0, "a need-4 term in an index that says max_need %u", ix.max_need);
       // the word's form (NsWord::flags): what scan_tile's cheaper paths rely on
       const uint32_t fl = nsl[k].flags;
       EXPECT(((fl & kNsWordNeed3) != 0u) == (hdr[w].m3 != 0ull), "need-3 flag of word %u", w);
@@ -294,6 +298,8 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
       if (any & nsl[k].mask) ++g_word_useful;
       uint64_t x = (any & ~hdr[w].m2) | (two & hdr[w].m2);
       x = (x & ~hdr[w].m3) | (three & hdr[w].m3);
+      x = (x & ~hdr[w].m4) | (four & hdr[w].m4);
+      x = (x & ~hdr[w].m5) | (five & hdr[w].m5);
       if (x & ~vet & nsl[k].mask) ++g_word_hit;
       if (!ix.rich) EXPECT(hdr[w].m3 == 0 && hdr[w].slow == 0, "simple image with need-3 / slow terms");
       x &= ~vet & nsl[k].mask;
@@ -393,6 +399,17 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
     EXPECT(p.thr[t].live, "dead throttle %u indexed", t);
   }
   for (uint32_t t : ix.slow_thr) EXPECT(!seen_t.count(t) && p.thr[t].live, "slow throttle %u", t);
+  // the slow list is for unconvertible pod selectors and for throttles beyond kMaxIndexedTerms; a throttle with 65 .. 512 terms is
+  // indexed as one run of numbers across words (round 6) and flags the index has_long
+  bool any_long = false;
+  for (uint32_t t : ix.slow_thr) {
+    bool invalid = false;
+    for (uint32_t g = p.thr_term_off[t]; g < p.thr_term_off[t + 1]; ++g) invalid |= (p.term_flags[g] & KT_TERM_POD_SEL_INVALID) != 0;
+    EXPECT(invalid || p.thr_term_off[t + 1] - p.thr_term_off[t] > kMaxIndexedTerms, "throttle %u with %u convertible terms is on the slow list", t,
+           p.thr_term_off[t + 1] - p.thr_term_off[t]);
+  }
+  for (uint32_t t : seen_t) any_long |= p.thr_term_off[t + 1] - p.thr_term_off[t] > 64u;
+  EXPECT(!any_long || ix.has_long, "an indexed throttle has more than 64 terms, yet the index does not say has_long");
   // atom ids are dense, unique and fit 16 bits; the table finds every one of them
   EXPECT(ix.atoms.size() + 1 == ix.bm_rows && ix.bm_rows <= 65536, "atom ids");
   for (const AtomId& a : ix.atoms) EXPECT(atom_id_of(ix, a.atom) == (a.id | a.home << 16) && a.id >= 1 && a.id < ix.bm_rows && a.home < ix.la, "atom %u", a.atom);
@@ -829,14 +846,16 @@ static int run_file(const char* path, uint32_t chk_budget) {
           for (int l = 0; l < 64; ++l)
             if (k[l] < k1[l]) {
               const uint32_t w = nsl[k[l]].w;
-              uint64_t any = hd[w].univ, two = 0, three = 0, vet = 0;
+              uint64_t any = hd[w].univ, two = 0, three = 0, four = 0, five = 0, vet = 0;
               for (uint32_t id : ids[l]) {
                 const uint64_t r = cell_any(ch, rows, id, w);
                 if (ix.rich) vet |= cell_veto(ch, rows, id, w);
-                three |= two & r, two |= any & r, any |= r;
+                five |= four & r, four |= three & r, three |= two & r, two |= any & r, any |= r;
               }
               uint64_t xx = (any & ~hd[w].m2) | (two & hd[w].m2);
               xx = (xx & ~hd[w].m3) | (three & hd[w].m3);
+              xx = (xx & ~hd[w].m4) | (four & hd[w].m4);
+              xx = (xx & ~hd[w].m5) | (five & hd[w].m5);
               x[l] = xx & ~vet & nsl[k[l]].mask;
               ++k[l];
               adv = true;
@@ -1057,10 +1076,13 @@ int main(int argc, char** argv) {
   acc(run_case(77, 10000, 64, 16, 16, 5, 3, 0.0, 160 << 10, 140 << 10, 72, 64));
   // more than 4096 terms with single-namespace classes (128-bit class granularity) and a universe of 1 namespace
   acc(run_case(78, 3000, 1, 10, 8, 3, 2, 0.001, 60 << 10, 60 << 10, 152, 64));
-  // four and five requirements per term: shapes beyond three positive requirements take the slow confirmation
+  // four to six requirements per term: up to five positive keys are counted by the bitmaps (max_need 4-5: the NEED = 5 kernels),
+  // a term with six keeps five and takes the slow confirmation; eight requirements: most terms are slow
   acc(run_case(79, 300, 5, 12, 3, 3, 6, 0.0, 160 << 10, 160 << 10, 72, 400));
-  // throttles with up to 150 selector terms: beyond 64 a throttle's run of numbers could not stay inside one word — it
-  // joins the slow list (walked term by term), everything else keeps the bitmaps
+  acc(run_case(82, 200, 4, 14, 2, 2, 8, 0.0, 160 << 10, 160 << 10, 72, 400));
+  acc(run_case(83, 120, 3, 10, 1, 2, 8, 0.0, 160 << 10, 160 << 10, 72, 600));  // one value per key: a pod that carries the five anchor keys is a candidate
+  // throttles with up to 150 selector terms: beyond 64 a throttle's run of numbers spans words — ONE group, its copies with their
+  // own admission sets; scan() dedupes match by match across the words as the full check and the plain fold do (has_long)
   acc(run_case(80, 24, 6, 8, 3, 150, 2, 0.0, 160 << 10, 160 << 10, 72, 150));
   acc(run_case(81, 60, 3, 6, 3, 70, 2, 0.01, 20000, 16000, 72, 150));
   // more keys than atom slots: 12 and 20 keys in programs whose pods carry at most 8 labels

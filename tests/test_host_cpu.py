@@ -162,17 +162,17 @@ def test_index_builder_against_cpu_scan_replay(tool):
     # is how the round-3 rewrite of the builder's phases was accepted, together with the fingerprints of the dumped
     # BASELINE programs); a change of the index LAYOUT moves it on purpose — then re-pin it here after the GPU parity
     # tests have passed on the new layout.
-    assert "fingerprint of all indexes 2c88ef0baed90af9" in out.stdout, out.stdout[-400:]
+    assert "fingerprint of all indexes 97e18acd9ec60929" in out.stdout, out.stdout[-400:]
     # the builder's phases on several host threads (only programs beyond 16k throttles split by themselves): parts built
     # side by side and joined must give the same indexes
     out3 = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_INDEX_THREADS="3"))
     assert out3.returncode == 0, out3.stderr[-2000:]
-    assert "fingerprint of all indexes 2c88ef0baed90af9" in out3.stdout, out3.stdout[-400:]
+    assert "fingerprint of all indexes 97e18acd9ec60929" in out3.stdout, out3.stdout[-400:]
     # the GROUPED plan of cut_chunks (chunks per group of namespaces, words copied between groups: KT_CUT_PLAN=grouped — measured
     # on the GPU in round 6 and not the default) must describe the same matches: every throttle reported once, nothing missed
     outg = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_CUT_PLAN="grouped"))
     assert outg.returncode == 0 and "all expectations held" in outg.stdout, outg.stdout[-400:] + outg.stderr[-2000:]
-    assert "fingerprint of all indexes 9aa4b03ca8ab825a" in outg.stdout, outg.stdout[-400:]
+    assert "fingerprint of all indexes b9252c8272e1ee8c" in outg.stdout, outg.stdout[-400:]
 
 
 def test_anchor_split_against_brute_force(tool, tmp_path):

@@ -8,7 +8,7 @@
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
-WANT="2c88ef0baed90af9 81e0ec977f2b20af 75dbd44a87782bd5"
+WANT="97e18acd9ec60929 40be2435a2c8e184 c05f915b566f3c4c"
 make -C kube_throttler_amd/csrc 2>&1 | grep -E "error|warning"
 make -C kube_throttler_amd/host index_sim_test 2>&1 | grep -E "error|warning"
 for c in 2 4; do

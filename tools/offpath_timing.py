@@ -47,6 +47,8 @@ def main():
     # (b) throttles with 130 terms (slow list) beside ordinary ones, and the same cluster with <= 8 terms
     time_step(W.small(seed=840, n_pods=100000, n_thr=48, n_cluster=24, K=16, V=8, L=6, terms=(1, 130), reqs=(1, 3)), "1-130 terms per throttle, 100k pods")
     time_step(W.small(seed=840, n_pods=100000, n_thr=48, n_cluster=24, K=16, V=8, L=6, terms=(1, 8), reqs=(1, 3)), "same cluster, <= 8 terms per throttle")
+    # ... and about the same NUMBER of terms (3170 there) spread over throttles of at most 64: the fair twin of (b)
+    time_step(W.small(seed=840, n_pods=100000, n_thr=96, n_cluster=48, K=16, V=8, L=6, terms=(1, 64), reqs=(1, 3)), "twice the throttles, <= 64 terms each (same number of terms)")
 
 
 if __name__ == "__main__":
