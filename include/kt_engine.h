@@ -265,7 +265,9 @@ int32_t kt_check(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t on_eq
  * error (unknown namespace object, an unconvertible selector reached first).  The caller adds shouldCountIn
  * (throttle_controller.go:217-219: it knows scheduler name and node of its pods).  This is what unreserveAffectedPods
  * (throttle_controller.go:135-155) iterates over: behind a reconcile, a reservation is released only for a pod that is in the
- * reconciled throttle's affected set — a pod whose labels changed after Reserve is not.  Cost: one small check launch. */
+ * reconciled throttle's affected set — a pod whose labels changed after Reserve is not.  Cost: one small check launch, on the
+ * engine's ONE check slot: a kt_check_launch that was pending is dropped (its kt_check_fetch answers KT_ERR_NOT_READY; kt_check,
+ * the one-call form a shim uses beside other threads, is not affected). */
 int32_t kt_affected_pods(kt_engine* e, int64_t n, const int64_t* pod_rows, int32_t m, const int32_t* throttle_rows, uint8_t* out);
 /* ---- sequential admission with reservation: for i = 0..n-1 IN ORDER,
  *      PreFilter(pod_rows[i]) (plugin.go:148-215) and, on Success, Reserve(pod_rows[i]) (plugin.go:217-239 ->
@@ -340,7 +342,10 @@ int32_t kt_paged_check(kt_engine* const* pages, int32_t n_pages, int64_t n, cons
 /* kt_reconcile_launch + kt_reconcile_fetch on every page: page_out[k] receives page k's result for throttle rows [0, n) —
  * `used`, calculatedThreshold and `throttled` are per resource name, each name comes from the page that owns it; the pod
  * counts and the pod flag are the same in every page.  replaced_any[i] (nullable) = calculatedThreshold replaced in some
- * page (it is replaced as a whole), error_any[i] (nullable) = the reconcile of row i failed. */
+ * page (it is replaced as a whole), error_any[i] (nullable) = the reconcile of row i failed.
+ * Failure: with KT_RECONCILE_APPLY every page is first reconciled as a dry run — a page that cannot (LDS budgets, sums out of
+ * range) fails the call before ANY page has stored a new status; an error after that (device errors) is returned once every
+ * launched page's result has been drained, never with pending reconciles left behind. */
 int32_t kt_paged_reconcile(kt_engine* const* pages, int32_t n_pages, int64_t now_s, int32_t now_ns, uint32_t flags, int32_t n,
                            const kt_status* page_out, uint8_t* replaced_any, uint8_t* error_any);
 

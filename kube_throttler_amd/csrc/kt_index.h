@@ -390,7 +390,7 @@ void launch_build_verdict_images(const IndexDev& ix, uint32_t total_words, const
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
                           uint8_t* status, hipStream_t s, const CheckSmall* small = nullptr, bool overflow_pods = false,
-                          const CheckByNs* by_ns = nullptr);
+                          const CheckByNs* by_ns = nullptr, bool one_per_cu = false);
 // kt_sweep: the PreFilter sweep of pod rows [0, n) and the packed reconcile scan of the same rows as ONE launch
 // (kt_check_bitmap's AGG instantiation: single-chunk programs without a slow list; pk sized for aggregate_slab_pods(n,
 // aggregate_blocks(n))).  The slabs are left for launch_reduce_finalize_packed (*launched_blocks of them).  nullptr: not

@@ -724,8 +724,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
   {                                                                                          \
     if (small) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, true, false)                    \
     else if (full) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, true, false, false)               \
-    else if (two_per_cu && one) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false, true)  \
-    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false, false)        \
+    else if (two_per_cu) KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 8, false, false, true)         \
     else KT_BM_LAUNCH(DT_, LA_, VETO_, NEED_, 4, false, false, false)                        \
   }
 
@@ -742,7 +741,7 @@ __global__ __launch_bounds__(kBlockIx, WPE) void kt_check_bitmap(const BmCheckAr
 // beside the working buffers (a single throttle with thousands of terms)
 const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t* rows_dev, const SelProgram& sp,
                           const SelProgram* sp_dev, const IndexDev& ix, const void* recs, uint64_t* summary,
-                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods, const CheckByNs* by_ns) {
+                          uint8_t* status, hipStream_t s, const CheckSmall* sm, bool overflow_pods, const CheckByNs* by_ns, bool one_per_cu) {
   if (n <= 0) return "";
   const int DT = dt_bucket_ix(pods.D), LA = pods.LA;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)n * (size_t)sp.T, s);
@@ -750,9 +749,6 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   BmCheckArgs bm_args = make_bm_check_args(pods, n, rows_dev, sp, sp_dev, ix, recs, summary, status, &bm_total);
   if (bm_total > (uint32_t)kMaxLds) return nullptr;
   const size_t lds_bytes = bm_total;
-  // two workgroups per CU (8 waves per SIMD) when two LDS footprints fit; KT_CHECK_WGS_PER_CU=1 forces one (A/B runs)
-  const char* force_env = getenv("KT_CHECK_WGS_PER_CU");  // (read per launch: tests switch it)
-  const int force_wgs = force_env ? atoi(force_env) : 0;
   const bool small = sm != nullptr && n <= kCheckSmallMax;
   if (small) {
     (void)hipMemsetAsync(summary, 0, (size_t)n * 8, s);  // the counters meet by atomics
@@ -771,7 +767,13 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   // match-by-match peel of the full one ("reported once" across words)
   const bool full = status != nullptr || ix.n_slow != 0 || overflow_pods || ix.has_long;
   const bool need5 = ix.max_need > 3u;
-  const bool two_per_cu = !full && !need5 && (force_wgs ? force_wgs >= 2 && 2 * bm_total <= (uint32_t)kMaxLds : 2 * bm_total <= (uint32_t)kMaxLds);
+  // Two workgroups per CU (8 waves per SIMD, 64 VGPRs) for the ONE form — the index is one chunk scanned in row order and two
+  // LDS footprints fit — unless the caller asks for one (KT_CHECK_ONE_PER_CU: A/B runs and a parity test).  A multi-chunk sweep
+  // always runs one per CU: the generic 64-VGPR form carried 116-330 B of scratch, and where its LDS would have allowed it (a
+  // 16-dimension engine whose plain fold cuts the chunks small) one per CU is the faster one — 76.3 -> 67.4 us at 1M x 1k, D = 16
+  // (round 6; the instantiation is gone).
+  const bool one = ix.n_chunks == 1 && bm_args.ix.by_ns == 0u;
+  const bool two_per_cu = one && !full && !small && !need5 && !one_per_cu && 2 * bm_total <= (uint32_t)kMaxLds;
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;
@@ -781,7 +783,6 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds) fprintf(stderr, "kt_check_bitmap: lds=%u (%d per CU) chunks=%u LA=%d veto=%u need=%u\n", bm_total, two_per_cu ? 2 : 1, ix.n_chunks, LA, ix.has_veto, ix.max_need);
   const bool rich = ix.rich;
-  const bool one = ix.n_chunks == 1 && bm_args.ix.by_ns == 0u && !getenv("KT_CHECK_NO_ONE");  // (A/B: the generic two-per-CU form)
 #ifdef KT_FAST_BUILD
   KT_BM_CASE(8, 8, false, 2)
 #else

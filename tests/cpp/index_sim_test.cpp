@@ -740,7 +740,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
   uint32_t L = 1;
   for (size_t i = 0; i + 1 < loff.size(); ++i) L = std::max(L, loff[i + 1] - loff[i]);
   HostIndex ix;
-  const uint32_t thr_bytes = 8 * D + 8;
+  const uint32_t thr_bytes = getenv("KT_SIM_THR_BYTES") ? (uint32_t)atoi(getenv("KT_SIM_THR_BYTES")) : 8 * D + 8;  // (a 16-dimension engine: 136)
   const uint32_t agg_budget = 160u * 1024u - aggregate_fixed_lds();
   // the per-term admission sets as the engine hands them over (it caches them per throttle): [term][namespace words]
   const uint32_t nsw = (NS + 31) / 32;

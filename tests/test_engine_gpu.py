@@ -151,7 +151,7 @@ def test_lean_sweep_shapes(shape, oracle_mod, monkeypatch):
            "simple-12-dims": W.small(seed=33, n_pods=3000, n_thr=96, n_cluster=48, D=12, rich_ops=0, terms=(1, 2), reqs=(1, 2)),
            "rich-one-per-cu": W.small(seed=34, n_pods=3000, n_thr=96, n_cluster=48)}[shape]
     if shape == "rich-one-per-cu":
-        monkeypatch.setenv("KT_CHECK_WGS_PER_CU", "1")
+        monkeypatch.setenv("KT_CHECK_ONE_PER_CU", "1")
     run_full_parity(W.generate(cfg), oracle_mod, E.VARIANT_INDEXED)
 
 
