@@ -165,8 +165,8 @@ extern thread_local std::string g_create_error;  // text of the last kt_engine_c
 // and again on kt_debug_reload_env, which tools/latency_bench.py calls after it flips one on a live engine — instead of by
 // getenv on every pod event and launch (getenv is not safe beside a setenv of another thread, and the pod event
 // path is tuned to a few microseconds).
-enum EnvSwitch { kSw_FEED_NO_STAGE, kSw_FORCE_NS_ORDER, kSw_INGEST_EVENT_WAIT, kSw_NO_FEED_FEW, kSw_NO_FEED_FUSION, kSw_NO_FUSED, kSw_NO_NS_ORDER, kSw_NO_PACK, kSw_NO_SCAN_VIEW, kSw_NO_SWEEP, kSw_NO_VERDICT_IMAGES, kSw_NO_WG_RANGES, kSw_SYNC_INGEST, kSw_INGEST_TRUST_FENCE, kSw_NO_VIEW_PATCH, kSw_CHECK_ONE_PER_CU, kSwCount };
-static const char* const kEnvSwitchName[kSwCount] = {"KT_FEED_NO_STAGE", "KT_FORCE_NS_ORDER", "KT_INGEST_EVENT_WAIT", "KT_NO_FEED_FEW", "KT_NO_FEED_FUSION", "KT_NO_FUSED", "KT_NO_NS_ORDER", "KT_NO_PACK", "KT_NO_SCAN_VIEW", "KT_NO_SWEEP", "KT_NO_VERDICT_IMAGES", "KT_NO_WG_RANGES", "KT_SYNC_INGEST", "KT_INGEST_TRUST_FENCE", "KT_NO_VIEW_PATCH", "KT_CHECK_ONE_PER_CU"};
+enum EnvSwitch { kSw_FEED_NO_STAGE, kSw_FORCE_NS_ORDER, kSw_INGEST_EVENT_WAIT, kSw_NO_FEED_FEW, kSw_NO_FEED_FUSION, kSw_NO_FUSED, kSw_NO_NS_ORDER, kSw_NO_PACK, kSw_NO_SCAN_VIEW, kSw_NO_SWEEP, kSw_NO_VERDICT_IMAGES, kSw_NO_WG_RANGES, kSw_SYNC_INGEST, kSw_INGEST_TRUST_FENCE, kSw_NO_VIEW_PATCH, kSw_CHECK_ONE_PER_CU, kSw_AGG_SMALL_WINDOW, kSwCount };
+static const char* const kEnvSwitchName[kSwCount] = {"KT_FEED_NO_STAGE", "KT_FORCE_NS_ORDER", "KT_INGEST_EVENT_WAIT", "KT_NO_FEED_FEW", "KT_NO_FEED_FUSION", "KT_NO_FUSED", "KT_NO_NS_ORDER", "KT_NO_PACK", "KT_NO_SCAN_VIEW", "KT_NO_SWEEP", "KT_NO_VERDICT_IMAGES", "KT_NO_WG_RANGES", "KT_SYNC_INGEST", "KT_INGEST_TRUST_FENCE", "KT_NO_VIEW_PATCH", "KT_CHECK_ONE_PER_CU", "KT_AGG_SMALL_WINDOW"};
 struct kt_engine {
   bool sw[kSwCount] = {};  // EnvSwitch values (load_env_switches)
   kt_config cfg{};

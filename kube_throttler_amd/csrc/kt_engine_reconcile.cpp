@@ -326,6 +326,7 @@ int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused) {
         kt::AggScan sc;
         sc.n = (int64_t)e->n_countable, sc.rows = e->d_countable.p, sc.counts = e->incremental, sc.nonneg = !e->neg_seen;
         sc.overflow_pods = e->n_overflow != 0;
+        sc.small_window = e->sw[kSw_AGG_SMALL_WINDOW];
         sc.limb = limb;
         // contiguous tile ranges over the scan view; with a single chunk the order of the list does not matter
         sc.by_ns = !e->sw[kSw_NO_SCAN_VIEW] && (e->countable_by_ns || e->dindex.n_chunks == 1);
@@ -364,6 +365,7 @@ int32_t delta_scan(kt_engine* e, int64_t n, const int64_t* rows_dev, int64_t row
   if (!e->incremental || !e->agg_valid || n <= 0 || e->thr_rows_hi == 0) return KT_OK;
   kt::AggScan sc;
   sc.n = n, sc.rows = rows_dev, sc.row0 = row0, sc.counts = true, sc.sign = sign, sc.overflow_pods = e->n_overflow != 0;
+  sc.small_window = e->sw[kSw_AGG_SMALL_WINDOW];
   int32_t rc = slab_tags(e, sc, s);
   if (rc != KT_OK) return rc;
   const char* k = kt::launch_aggregate_indexed(e->pods, sc, e->sp, e->d_sp.p, e->dindex, e->d_agg.p, e->d_slab.p, s, nullptr);

@@ -657,7 +657,7 @@ void build_index(HostIndex& out, const std::vector<uint32_t>& thr_term_off, cons
   std::vector<uint64_t>&any = out.full_any, &vet = out.full_veto, &nsrows = out.full_nsrows;
   any.assign((size_t)R * W, 0ull), vet.assign(veto ? (size_t)R * W : 0, 0ull), nsrows.assign((size_t)n_ns * W, 0ull);
   std::vector<WordHdr>& hdr = out.full_hdr;
-  hdr.assign(W, WordHdr{0, 0, 0, 0, 0, 0});
+  hdr.assign(W, WordHdr{0, 0, 0, 0, 0, 0, {0, 0}});
   std::vector<uint32_t>&term_t = out.full_term_t, &term_g = out.full_term_g, &term_rank = out.full_term_rank;
   term_t.assign((size_t)W * 64, 0u), term_g.assign((size_t)W * 64, 0u), term_rank.assign((size_t)W * 64, 0u);
   std::vector<uint8_t>& real = out.full_real;  // term number in use (not padding)
@@ -817,6 +817,7 @@ struct Cutter {
   std::vector<uint32_t> word_groups;  // groups (= ranks = slab records) whose numbers start in word w
   std::vector<std::vector<uint32_t>> ns_words;  // words every namespace visits, ascending
   bool all_splittable = true;
+  bool windowed = false;  // the aggregate may scan a chunk once per window of ranks (kt_kernels_aggregate.hip): only a minimal table counts
 
   Cutter(HostIndex& o, uint32_t agg, uint32_t chk, uint32_t tb, uint32_t cw)
       : out(o), W(o.bm_words), R(o.bm_rows), Rp(image_col_rows(o.bm_rows)), n_ns(o.n_ns), veto(o.rich), fam(o.rich ? 2 : 1),
@@ -865,7 +866,8 @@ struct Cutter {
   // packed fold queues chunk-local word numbers as 10-bit values)
   struct Maxima { size_t lds = 0, thr = 0, nw = 0; };
   bool fits(size_t lds, size_t nw, size_t nthr, const Maxima& mx) const {
-    const size_t lds_hi = std::max(lds, mx.lds), thr_hi = std::max(nthr, mx.thr), nw_hi = std::max(nw, mx.nw);
+    const size_t lds_hi = std::max(lds, mx.lds), nw_hi = std::max(nw, mx.nw);
+    const size_t thr_hi = windowed ? std::min<size_t>(std::max(nthr, mx.thr), 256) : std::max(nthr, mx.thr);
     return lds_hi + nw_hi * chk_word <= chk_budget && lds_hi + align16(nw_hi * 64 * 2) + nw_hi * 16 + thr_hi * thr_bytes + 16 <= agg_budget &&
            nthr < 0x8000u && nw < 1024;
   }
@@ -1198,9 +1200,24 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   const char* force = getenv("KT_CUT_PLAN");
   const bool want_global = force && !strcmp(force, "global"), want_grouped = force && !strcmp(force, "grouped");
   std::vector<ChunkPlan> plan;
+  out.agg_windowed = false;
   {
     Cutter cut(out, agg_budget, chk_budget, thr_bytes, chk_word);
     plan = cut.plan_global();
+    if (plan.size() > 1) {
+      // Only the aggregate's table stands against ONE chunk (the image and the check's tables fit)?  Then the program stays
+      // in one chunk and the aggregate scans it once per window of ranks: the check keeps its single-chunk form — two
+      // workgroups per CU, no namespace order, no carry words — and the reconcile pays a second scan instead of a second
+      // chunk (a 16-dimension engine at 1M x 1k: check 67 -> 3x us, round 6).
+      Cutter one(out, agg_budget, chk_budget, thr_bytes, chk_word);
+      one.windowed = true;
+      std::vector<ChunkPlan> p1 = one.plan_global();
+      if (p1.size() == 1 && !getenv("KT_NO_AGG_WINDOW")) {
+        out.agg_windowed = true;
+        one.emit(p1);
+        return;
+      }
+    }
     if (plan.size() <= 1 || !cut.all_splittable) {
       cut.emit(plan);
       return;

@@ -62,13 +62,14 @@ struct ThrInfo {
 };
 
 // per-word header of a chunk image
-struct alignas(16) WordHdr {
+struct alignas(64) WordHdr {  // (64 bytes: the address of word w's header is a shift, not a 64-bit multiply-add)
   uint64_t univ;  // terms without a positive requirement (hit by every pod)
   uint64_t m2;    // terms that need >= 2 positive hits
   uint64_t m3;    // terms that need >= 3
   uint64_t slow;  // candidates that the generic requirement walk has to confirm
   uint64_t m4;    // terms that need >= 4 (round 6: programs with four or five positive keys per term take the NEED = 5
   uint64_t m5;    // instantiations, which count hits as 3-bit numbers) / that need 5
+  uint64_t pad[2];
 };
 // one entry of a namespace's word list
 struct alignas(16) NsWord {
@@ -162,6 +163,7 @@ struct HostIndex {
   uint64_t bm_slab_bytes = 0;  // aggregate scratch: one table per (chunk, workgroup)
   uint32_t cut_chk_budget = 0; // the check budget the chunks were last cut for
   uint32_t cut_thr_bytes = 0;  // the record size the aggregate's tables and slabs were sized for (plain, or the packed fold's)
+  bool agg_windowed = false;   // ONE chunk whose table of records does not fit the aggregate's LDS: it scans the chunk per window of ranks
   bool cut_grouped = false;    // the chunks are those of the grouped plan (kt_index.cpp: cut_chunks): per group of namespaces
   uint32_t img_words = 0;      // words over all chunk images (>= bm_words: the grouped plan copies words); BmChunk::w0 counts in these
   int64_t ns_word_visits = 0;  // entries of all word lists = (namespace, visited word) pairs
@@ -336,6 +338,7 @@ struct AggScan {
   const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
   const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
   int limb = 0;                  // wide sums: the limb of every request this scan adds (limb_of, kt_device.h)
+  bool small_window = false;     // test switch: fold through rank windows of 64 records whatever fits (kt_kernels_aggregate.hip)
   bool defer_reduce = false;     // packed scans: leave the slabs as they are — kt_reduce_finalize_packed takes them from there
   mutable int launched_blocks = 0;  // out: workgroups (= slabs per chunk) of the scan launch
   mutable bool launched_packed = false;

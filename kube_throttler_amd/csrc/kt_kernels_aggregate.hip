@@ -49,6 +49,7 @@ struct BmAggArgs {
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
   int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
+  uint32_t win_recs;     // 0: the table holds every record of a chunk; else the RANK WINDOW — records the LDS table holds at a time
   PackPlan pk;           // PK instantiations: the packed fold (kt_index.h)
   const uint64_t* v_pk;  //   [n_rows][pk.stride] packed request words in scan order
 };
@@ -68,7 +69,25 @@ static BmAggArgs make_bm_agg_args(const PodTable& pods, const AggScan& sc, const
   uint32_t o = 0;
   auto take = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   a.off_rank = take(ix.bm_max_words * 64u * 2u);
-  a.off_tab = take(packed ? ix.bm_max_thr * a.pk.rec_bytes : agg_tab_bytes(ix.bm_max_thr, pods.D, sc.counts));
+  // The table of the largest chunk next to the largest image — or, where that does not fit the workgroup's LDS, a RANK WINDOW
+  // (round 6): the kernel scans the chunk once per window of `win_recs` ranks and folds only the matches whose record the
+  // table holds at that time.  cut_chunks keeps a program in ONE chunk when only the aggregate's table stands against it (a
+  // 16-dimension engine's 144-byte plain records at 1k throttles): the check then keeps its single-chunk form, the reconcile
+  // pays a second scan instead of a second chunk.
+  const uint32_t rec_bytes = packed ? a.pk.rec_bytes : agg_rec_bytes(pods.D, sc.counts);
+  const uint32_t other = o + ((packed ? ix.bm_max_words * 16u : 0u) + 15u & ~15u) + 16u + ((ix.bm_max_lds + 15u) & ~15u);
+  const uint32_t full_tab = (ix.bm_max_thr * rec_bytes + 15u) & ~15u;
+  a.win_recs = 0u;
+  uint32_t tab_bytes = full_tab;
+  if (sc.small_window && ix.bm_max_thr > 64u) {  // (KT_AGG_SMALL_WINDOW: the parity tests run small clusters through many windows)
+    a.win_recs = 64u;
+    tab_bytes = (a.win_recs * rec_bytes + 15u) & ~15u;
+  } else if (other + full_tab > (uint32_t)kMaxLds && other < (uint32_t)kMaxLds) {
+    a.win_recs = (((uint32_t)kMaxLds - other) / rec_bytes) & ~1u;  // (even: a window's byte offset in the slab stays 16-byte aligned)
+    tab_bytes = (a.win_recs * rec_bytes + 15u) & ~15u;
+    if (a.win_recs < 64u) a.win_recs = 0u, tab_bytes = full_tab;  // no room for a useful window: the launch is refused below
+  }
+  a.off_tab = take(tab_bytes);
   a.off_seg = take(packed ? ix.bm_max_words * 16u : 0u);
   a.off_next = take(16);
   plan_bitmap_index(ix, a.ix, take);
@@ -124,7 +143,10 @@ __device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram
 //     no negative requests, sign +1).
 // (One workgroup per CU: two packed ones fit when the record is squeezed to 32 bytes, but the 64-VGPR form spills and the
 //  32-byte stride lands 8 records on one bank group — measured 33 us against 24 us at 1M x 1k.)
-template <int DT, int LA, bool VETO, int NEED, bool PK>
+// WIN: the table holds a WINDOW of the chunk's records at a time (BmAggArgs::win_recs) and the tiles are scanned once per window;
+//      its own instantiation, so that the kernels whose tables fit (every BASELINE configuration) do not pay the window test of
+//      every fold step — measured as one loop with a run-time window: aggregate 0.458 -> 0.481 ms on the configs[4] shard.
+template <int DT, int LA, bool VETO, int NEED, bool PK, bool WIN = false>
 __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs a) {
   const int D = a.D, DS = a.DS;
   // QUEUED FOLD (round 5, the packed instantiations).  Folding a word's matches where the scan produced them steps as often as
@@ -184,249 +206,255 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
     const BmChunk ch = a.ix.chunks[ci];
     const uint32_t n_thr = ch.n_thr;
     const uint32_t rec = PK ? a.pk.rec_bytes : agg_rec_bytes(D, counts);
-    const uint32_t tab_bytes = (n_thr * rec + 15u) & ~15u;
+    const uint32_t slab_pitch = (n_thr * rec + 15u) & ~15u;  // a workgroup's records of this chunk in the slab scratch
     KT_LDS unsigned char* tab = lds + a.off_tab;
-    // the tile's records — meta word, atom row AND the request words: every lane's, so that the request does not hang off
-    // the meta word by another trip to memory
-    const uint32_t wt0 = by_ns ? t_lo + wave : blockIdx.x * (uint32_t)(kBlockIx / kWave) + wave;
-    const uint32_t wt_step = by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
-    auto fetch_tile = [&](uint32_t wt) {
-      TileRecAgg<DT, LA, PK> r;
-      const uint32_t ic = min(rec0 + wt * kWave + lane, rec_end - 1u);
-      r.p = a.rows ? (uint32_t)a.rows[ic] : (uint32_t)a.row0 + ic;
-      r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
-      load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
-      if constexpr (!PK) {
-        load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : r.p, r.v);
-      } else {
-        const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
-        const u64x2 q0 = q[0];
-        r.pw[0] = q0.x, r.pw[1] = q0.y, r.pw[2] = 0ull, r.pw[3] = 0ull;
-        if (a.pk.stride > 2u) {
-          const u64x2 q1 = q[1];
-          r.pw[2] = q1.x, r.pw[3] = q1.y;
+    // the rank window (make_bm_agg_args): all records at once, or win_recs of them per pass over the workgroup's tiles
+    const uint32_t win = WIN ? a.win_recs : (n_thr ? n_thr : 1u);
+    for (uint32_t r0 = 0; r0 == 0u || (WIN && r0 < n_thr); r0 += win) {
+      const uint32_t nrec = WIN ? (n_thr > r0 ? min(win, n_thr - r0) : 0u) : n_thr;
+      const uint32_t tab_bytes = (nrec * rec + 15u) & ~15u;
+      // the tile's records — meta word, atom row AND the request words: every lane's, so that the request does not hang off
+      // the meta word by another trip to memory
+      const uint32_t wt0 = by_ns ? t_lo + wave : blockIdx.x * (uint32_t)(kBlockIx / kWave) + wave;
+      const uint32_t wt_step = by_ns ? (uint32_t)(kBlockIx / kWave) : wstep;
+      auto fetch_tile = [&](uint32_t wt) {
+        TileRecAgg<DT, LA, PK> r;
+        const uint32_t ic = min(rec0 + wt * kWave + lane, rec_end - 1u);
+        r.p = a.rows ? (uint32_t)a.rows[ic] : (uint32_t)a.row0 + ic;
+        r.meta = by_ns ? a.v_meta[ic] : a.meta[r.p];
+        load_atoms<LA>(by_ns ? a.v_latom : a.latom, by_ns ? ic : r.p, r.raw);
+        if constexpr (!PK) {
+          load_requests<DT>(by_ns ? a.v_req : a.req, DS, by_ns ? ic : r.p, r.v);
+        } else {
+          const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
+          const u64x2 q0 = q[0];
+          r.pw[0] = q0.x, r.pw[1] = q0.y, r.pw[2] = 0ull, r.pw[3] = 0ull;
+          if (a.pk.stride > 2u) {
+            const u64x2 q1 = q[1];
+            r.pw[2] = q1.x, r.pw[3] = q1.y;
+          }
+        }
+        return r;
+      };
+      TileRecAgg<DT, LA, PK> cur{};
+      __syncthreads();  // nobody reads the previous image / table any more
+      for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
+      if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
+      if (r0 == 0u) {  // the image and the ranks of the chunk's term numbers: one batch of loads (they stay for the later windows)
+        const StageSeg segs[2] = {chunk_image_segment(a.ix, ch),
+                                  StageSeg{a.off_rank, (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u}};
+        lds_stage_segments<2>(lds, segs);
+      }
+      if constexpr (kFoldQueue) {
+        // the run masks of the chunk's words, by ballot from the rank words (a wave per word, lane = term number): lowest /
+        // highest number of every run of one group's terms — a throttle with several terms is counted once, and with the
+        // masks that rule is applied to a whole word at a time (as kt_check_bitmap's WordVerdict does), so that the order
+        // in which a lane's matches are folded no longer matters
+        if (ch.has_adj && r0 == 0u) {
+          const uint16_t* g_rank = (const uint16_t*)(a.ix.blob + ch.img_off + ch.off_term_rank);
+          for (uint32_t w = wave; w < ch.n_words; w += (uint32_t)(kBlockIx / kWave)) {
+            const uint32_t tr = g_rank[w * 64u + lane];
+            const uint32_t tp = (uint32_t)__shfl_up((int)tr, 1), tn = (uint32_t)__shfl_down((int)tr, 1);
+            const bool adj = (tr & kRankAdj) != 0u;
+            const bool same_prev = lane > 0u && adj && tp == tr, same_next = lane < 63u && adj && tn == tr;
+            const uint64_t m_lo = __ballot(!same_prev), m_hi = __ballot(!same_next);
+            if (lane < 2u) ((lds_u64wp)(lds + a.off_seg))[w * 2u + lane] = lane == 0u ? m_lo : m_hi;
+          }
         }
       }
-      return r;
-    };
-    TileRecAgg<DT, LA, PK> cur{};
-    __syncthreads();  // nobody reads the previous image / table any more
-    for (uint32_t i = threadIdx.x; i < tab_bytes / 4; i += kBlockIx) ((lds_u32wp)(lds + a.off_tab))[i] = 0u;
-    if (by_ns && threadIdx.x == 0) *(lds_u32wp)(lds + a.off_next) = t_lo;
-    {  // the image and the ranks of the chunk's term numbers: one batch of loads
-      const StageSeg segs[2] = {chunk_image_segment(a.ix, ch),
-                                StageSeg{a.off_rank, (const u32x4*)(a.ix.blob + ch.img_off + ch.off_term_rank), ch.n_words * 8u}};
-      lds_stage_segments<2>(lds, segs);
-    }
-    if constexpr (kFoldQueue) {
-      // the run masks of the chunk's words, by ballot from the rank words (a wave per word, lane = term number): lowest /
-      // highest number of every run of one group's terms — a throttle with several terms is counted once, and with the
-      // masks that rule is applied to a whole word at a time (as kt_check_bitmap's WordVerdict does), so that the order
-      // in which a lane's matches are folded no longer matters
-      if (ch.has_adj) {
-        const uint16_t* g_rank = (const uint16_t*)(a.ix.blob + ch.img_off + ch.off_term_rank);
-        for (uint32_t w = wave; w < ch.n_words; w += (uint32_t)(kBlockIx / kWave)) {
-          const uint32_t tr = g_rank[w * 64u + lane];
-          const uint32_t tp = (uint32_t)__shfl_up((int)tr, 1), tn = (uint32_t)__shfl_down((int)tr, 1);
-          const bool adj = (tr & kRankAdj) != 0u;
-          const bool same_prev = lane > 0u && adj && tp == tr, same_next = lane < 63u && adj && tn == tr;
-          const uint64_t m_lo = __ballot(!same_prev), m_hi = __ballot(!same_next);
-          if (lane < 2u) ((lds_u64wp)(lds + a.off_seg))[w * 2u + lane] = lane == 0u ? m_lo : m_hi;
+      const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
+      __syncthreads();
+      auto next_tile = [&](uint32_t prev) -> uint32_t {  // (see kt_check_bitmap)
+        if (!by_ns) return prev + wt_step;
+        uint32_t t = 0u;
+        if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
+        return __builtin_amdgcn_readfirstlane(t);
+      };
+      for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
+        // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
+        //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
+        cur = fetch_tile(wt);
+        const uint32_t i = rec0 + wt * kWave + lane;
+        const bool in = i < rec_end;
+        const uint32_t p = cur.p;
+        const uint64_t meta = cur.meta;
+        u32x4 raw[LA / 8];
+#pragma unroll
+        for (int q = 0; q < LA / 8; ++q) raw[q] = cur.raw[q];
+        const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
+        // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
+        // (isNotFinished, pod_util.go:26-28) and only matter for error detection (slow list)
+        const bool countable = in && (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
+        const bool counted = countable && !(st & kPodFinished);
+        if (__ballot(countable) == 0ull) continue;  // (wave-uniform: nobody of the tile counts)
+        const uint32_t ns = countable ? (uint32_t)(meta & kMetaNsMask) : 0u;
+        const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
+        // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
+        // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
+        const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
+        // ResourceAmountOfPod: the request row (or its packed words) travelled with the record — every lane's, so that
+        // the request does not hang off the meta word by another trip to memory.  What a pod that is not counted brought
+        // is never looked at: its lane takes no part in the scan (scan_counted), so no match is ever handed to it.
+        int64_t v[DT];             // plain fold (dead in the PK instantiations)
+        unsigned long long pw[4];  // packed fold (dead in the others)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) v[d] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[k] = 0ull;
+        if constexpr (!PK) {
+#pragma unroll
+          for (int d = 0; d < DT; ++d) v[d] = limb_of(cur.v[d], a.limb);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pw[k] = cur.pw[k];
         }
-      }
-    }
-    const BmView bm = open_chunk<VETO>(lds, a.ix, ch);
-    __syncthreads();
-    auto next_tile = [&](uint32_t prev) -> uint32_t {  // (see kt_check_bitmap)
-      if (!by_ns) return prev + wt_step;
-      uint32_t t = 0u;
-      if (lane == 0u) t = lds_add((lds_u32wp)(lds + a.off_next), 1u);
-      return __builtin_amdgcn_readfirstlane(t);
-    };
-    for (uint32_t wt = by_ns ? next_tile(0u) : wt0; wt < t_hi; wt = next_tile(wt)) {
-      // ---- the tile's records, always from valid addresses (lanes past the end re-read the last row and are off);
-      //      requested before the chunk was staged / behind the previous tile's peel (fetch_tile)
-      cur = fetch_tile(wt);
-      const uint32_t i = rec0 + wt * kWave + lane;
-      const bool in = i < rec_end;
-      const uint32_t p = cur.p;
-      const uint64_t meta = cur.meta;
-      u32x4 raw[LA / 8];
-#pragma unroll
-      for (int q = 0; q < LA / 8; ++q) raw[q] = cur.raw[q];
-      const uint32_t st = (uint32_t)(meta >> kMetaStateShift) & 0xFu;
-      // shouldCountIn (throttle_controller.go:217-219); terminated pods are matched but not counted
-      // (isNotFinished, pod_util.go:26-28) and only matter for error detection (slow list)
-      const bool countable = in && (st & (kPodValid | kPodSchedMatch | kPodScheduled)) == (kPodValid | kPodSchedMatch | kPodScheduled);
-      const bool counted = countable && !(st & kPodFinished);
-      if (__ballot(countable) == 0ull) continue;  // (wave-uniform: nobody of the tile counts)
-      const uint32_t ns = countable ? (uint32_t)(meta & kMetaNsMask) : 0u;
-      const uint32_t present = (uint32_t)(meta >> kMetaPresentShift) & 0xFFFFu;
-      // kt_finalize calls a key present when its contributor count OR its sum is non-zero: the presence mask only has
-      // to travel for keys this pod carries with the value 0 — unless negative requests exist (sums can cancel)
-      const bool need_pres = !a.nonneg || (present & ~(uint32_t)(meta >> kMetaNzShift)) != 0u;
-      // ResourceAmountOfPod: the request row (or its packed words) travelled with the record — every lane's, so that
-      // the request does not hang off the meta word by another trip to memory.  What a pod that is not counted brought
-      // is never looked at: its lane takes no part in the scan (scan_counted), so no match is ever handed to it.
-      int64_t v[DT];             // plain fold (dead in the PK instantiations)
-      unsigned long long pw[4];  // packed fold (dead in the others)
-#pragma unroll
-      for (int d = 0; d < DT; ++d) v[d] = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pw[k] = 0ull;
-      if constexpr (!PK) {
-#pragma unroll
-        for (int d = 0; d < DT; ++d) v[d] = limb_of(cur.v[d], a.limb);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pw[k] = cur.pw[k];
-      }
-      const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
-      uint32_t ro[LA];
-      atom_row_offsets<LA>(raw, ro);
+        const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
+        uint32_t ro[LA];
+        atom_row_offsets<LA>(raw, ro);
 
-      // ---- throttles with unconvertible selectors have no rank: walked once (with the first chunk), straight to the
-      //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).
-      const bool overflow = a.has_overflow && countable && (meta & kMetaOverflow) != 0;
-      const bool scan_counted = counted && !overflow;
-      if (ci == first_ci && (a.n_slow || a.has_overflow))
-        agg_walk_without_rank(a.sp, a.slow_thr, a.n_slow, a.T, a.lpair, a.lkey, a.LS, a.req, D, DS, a.partial, a.sign, a.limb, p, ns, countable,
-                              counted, overflow, present);
+        // ---- throttles with unconvertible selectors have no rank: walked once (with the first chunk), straight to the
+        //      result buffer.  So is EVERY throttle for a pod whose relevant atoms did not fit its atom row (kMetaOverflow).
+        const bool overflow = a.has_overflow && countable && (meta & kMetaOverflow) != 0;
+        const bool scan_counted = counted && !overflow;
+        if (ci == first_ci && r0 == 0u && (a.n_slow || a.has_overflow))
+          agg_walk_without_rank(a.sp, a.slow_thr, a.n_slow, a.T, a.lpair, a.lkey, a.LS, a.req, D, DS, a.partial, a.sign, a.limb, p, ns, countable,
+                                counted, overflow, present);
 
-      uint32_t last_r = 0xFFFFFFFFu;
-      const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
-      // one matched term number of the lane's pod, given its rank word
-      auto add_match = [&](bool has, uint32_t tr) {
-            const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
-            // a throttle with several terms is counted once
-            const bool ok = has && !((tr & kRankAdj) && r == last_r);
-            if (ok) {
-              last_r = r;
-              KT_LDS unsigned char* rp = tab + __umul24(r, rec);  // the throttle's record (rank < 2^15, record <= 272 bytes)
-              lds_u64wp tv = (lds_u64wp)rp;
-              if constexpr (PK) {
-                // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
-                // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
-                // testing the words lane by lane only bought exec-mask juggling
-                lds_add64(tv, pw[0]);
-                if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
-                if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
-                if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
-                if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return;
-              }
-              lds_u32wp tu = (lds_u32wp)(rp + (uint32_t)D * 8);
-#pragma unroll
-              for (int d = 0; d < DT; ++d)
-                if (v[d] != 0) lds_add64(tv + d, (unsigned long long)v[d]);  // padding dimensions hold 0
-              if (counts) {
+        uint32_t last_r = 0xFFFFFFFFu;
+        const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
+        // one matched term number of the lane's pod, given its rank word
+        auto add_match = [&](bool has, uint32_t tr) {
+              const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
+              // a throttle with several terms is counted once
+              const bool ok = has && !((tr & kRankAdj) && r == last_r);
+              if (ok) last_r = r;
+              if (ok && (!WIN || r - r0 < nrec)) {  // (WIN: is the record in the table during this window — wave-uniform bounds, unsigned compare)
+                KT_LDS unsigned char* rp = tab + __umul24(WIN ? r - r0 : r, rec);  // the throttle's record (rank < 2^15, record <= 272 bytes)
+                lds_u64wp tv = (lds_u64wp)rp;
+                if constexpr (PK) {
+                  // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
+                  // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
+                  // testing the words lane by lane only bought exec-mask juggling
+                  lds_add64(tv, pw[0]);
+                  if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+                  if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+                  if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+                  if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  return;
+                }
+                lds_u32wp tu = (lds_u32wp)(rp + (uint32_t)D * 8);
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
-                  if ((present >> d) & 1u) lds_add(tu + d, 1u);
-                lds_add(tu + D, 1u);
-              } else {
-                if (need_pres) (void)__hip_atomic_fetch_or(tu, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                lds_add(tu + 1, 1u);
-              }
-            }
-      };
-      auto confirm_slow = [&](uint32_t c) {
-        return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
-      };
-      if constexpr (kFoldQueue) {
-        // WORD queue: the lane keeps the match words of the last visits as they are — (word number, 64 match bits), kWq of them,
-        // newest first — and nothing is extracted while the scan runs: ONE predicated push per visit.  When some lane's queue is
-        // full (or the tile is done) the wave folds: every step each lane that has anything takes the lowest bit of its newest
-        // word, so a step serves nearly every lane that has matches left — and the bit extraction, which the term-number queue
-        // pays in a loop that runs as often as the BUSIEST lane of every single word has matches, runs in these balanced steps too.
-        constexpr int kWq = 4;  // (measured on the configs[4] shard: 2 words 0.512, 3: 0.484, 4: 0.476, 5: 0.483 ms)
-        uint64_t qx[kWq];
-        // word numbers, 10 bits each (newest lowest: cut_chunks keeps a chunk below 1024 words); entries in use
-        typedef typename std::conditional<(kWq > 3), uint64_t, uint32_t>::type qw_t;
-        static_assert(kWq * 10 <= 64, "ten bits per queued word number");
-        qw_t qw = 0;
-        uint32_t qn = 0u;
+                  if (v[d] != 0) lds_add64(tv + d, (unsigned long long)v[d]);  // padding dimensions hold 0
+                if (counts) {
 #pragma unroll
-        for (int k = 0; k < kWq; ++k) qx[k] = 0ull;
-        auto add_rank = [&](bool has, uint32_t r) {
-          if (has) {
-            KT_LDS unsigned char* rp = tab + __umul24(r, rec);
-            lds_u64wp tv = (lds_u64wp)rp;
-            lds_add64(tv, pw[0]);
-            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
-            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
-            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
-            if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+                  for (int d = 0; d < DT; ++d)
+                    if ((present >> d) & 1u) lds_add(tu + d, 1u);
+                  lds_add(tu + D, 1u);
+                } else {
+                  if (need_pres) (void)__hip_atomic_fetch_or(tu, present, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  lds_add(tu + 1, 1u);
+                }
+              }
         };
-        auto flush = [&]() {
-          while (__ballot(qn != 0u) != 0ull) {
-            const bool has = qn != 0u;
-            const uint32_t cw = ((uint32_t)qw & 1023u) * 64u;
-            const uint32_t c = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
-            qx[0] &= qx[0] - 1ull;
-            const uint32_t r = trank[has ? c : 0u] & 0x7FFFu;
-            if (has && qx[0] == 0ull) {  // the newest word is used up: the older ones move up
-#pragma unroll
-              for (int k = 0; k + 1 < kWq; ++k) qx[k] = qx[k + 1];
-              qx[kWq - 1] = 0ull;
-              qw >>= 10;
-              qn -= 1u;
-            }
-            add_rank(has, r);
-          }
+        auto confirm_slow = [&](uint32_t c) {
+          return term_match_mem(*a.sp, bm.term_g[c], a.lpair + (uint64_t)p * (uint32_t)a.LS, a.lkey + (uint64_t)p * (uint32_t)a.LS, a.LS);
         };
-        const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
-        KT_LDS const u64x2* segp = (KT_LDS const u64x2*)(lds + a.off_seg);
-        scan_tile<LA, VETO, NEED, VETO>(
-            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
-            [&](uint32_t w, uint64_t x, const u64x2& seg) -> uint64_t {
-              if (seg_on) {  // a throttle with several terms is counted once: the lowest match of every run
-                const uint64_t v = x | seg.y;
-                x = andn_64(x, v - seg.x);
-              }
-              if (__ballot(x != 0ull && qn >= (uint32_t)kWq) != 0ull) flush();
-              if (x != 0ull) {
+        if constexpr (kFoldQueue) {
+          // WORD queue: the lane keeps the match words of the last visits as they are — (word number, 64 match bits), kWq of them,
+          // newest first — and nothing is extracted while the scan runs: ONE predicated push per visit.  When some lane's queue is
+          // full (or the tile is done) the wave folds: every step each lane that has anything takes the lowest bit of its newest
+          // word, so a step serves nearly every lane that has matches left — and the bit extraction, which the term-number queue
+          // pays in a loop that runs as often as the BUSIEST lane of every single word has matches, runs in these balanced steps too.
+          constexpr int kWq = 4;  // (measured on the configs[4] shard: 2 words 0.512, 3: 0.484, 4: 0.476, 5: 0.483 ms)
+          uint64_t qx[kWq];
+          // word numbers, 10 bits each (newest lowest: cut_chunks keeps a chunk below 1024 words); entries in use
+          typedef typename std::conditional<(kWq > 3), uint64_t, uint32_t>::type qw_t;
+          static_assert(kWq * 10 <= 64, "ten bits per queued word number");
+          qw_t qw = 0;
+          uint32_t qn = 0u;
 #pragma unroll
-                for (int k = kWq - 1; k > 0; --k) qx[k] = qx[k - 1];
-                qx[0] = x;
-                qw = (qw_t)(qw << 10) | (qw_t)w;
-                qn += 1u;
+          for (int k = 0; k < kWq; ++k) qx[k] = 0ull;
+          auto add_rank = [&](bool has, uint32_t r) {
+            if (has && (!WIN || r - r0 < nrec)) {
+              KT_LDS unsigned char* rp = tab + __umul24(WIN ? r - r0 : r, rec);
+              lds_u64wp tv = (lds_u64wp)rp;
+              lds_add64(tv, pw[0]);
+              if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+              if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+              if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+              if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          };
+          auto flush = [&]() {
+            while (__ballot(qn != 0u) != 0ull) {
+              const bool has = qn != 0u;
+              const uint32_t cw = ((uint32_t)qw & 1023u) * 64u;
+              const uint32_t c = cw + (uint32_t)__ffsll((unsigned long long)qx[0]) - 1u;
+              qx[0] &= qx[0] - 1ull;
+              const uint32_t r = trank[has ? c : 0u] & 0x7FFFu;
+              if (has && qx[0] == 0ull) {  // the newest word is used up: the older ones move up
+#pragma unroll
+                for (int k = 0; k + 1 < kWq; ++k) qx[k] = qx[k + 1];
+                qx[kWq - 1] = 0ull;
+                qw >>= 10;
+                qn -= 1u;
               }
-              return 0ull;
-            },
-            [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
-        flush();
-      } else if constexpr (PK) {
-        // the packed fold takes a word's matches where the scan produced them (scan_tile's post hook), TWO per step: both
-        // rank reads are in flight together and the wave steps ceil(matches / 2) times per word instead of once per match
-        // through scan_tile's peel (ascending term numbers per lane, as the run rule of add_match needs)
-        scan_tile<LA, VETO, NEED, VETO>(
-            bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
-            [&](uint32_t w, uint64_t x, int) -> uint64_t {
-              uint64_t xf = x;
-              while (__ballot(xf != 0ull) != 0ull) {
-                const bool h1 = xf != 0ull;
-                const uint32_t c1 = h1 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
-                xf &= xf - 1ull;
-                const bool h2 = xf != 0ull;
-                const uint32_t c2 = h2 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
-                xf &= xf - 1ull;
-                const uint32_t tr1 = trank[c1], tr2 = trank[c2];
-                add_match(h1, tr1);
-                add_match(h2, tr2);
-              }
-              return 0ull;
-            });
-      } else {
-        scan_tile<LA, VETO, NEED, VETO>(
-            bm, scan_counted, ns, ro, [&](bool has, uint32_t c) { add_match(has, trank[c]); }, confirm_slow);
+              add_rank(has, r);
+            }
+          };
+          const bool seg_on = ch.has_adj != 0u;  // wave-uniform: some throttle of the chunk has several terms
+          KT_LDS const u64x2* segp = (KT_LDS const u64x2*)(lds + a.off_seg);
+          scan_tile<LA, VETO, NEED, VETO>(
+              bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
+              [&](uint32_t w, uint64_t x, const u64x2& seg) -> uint64_t {
+                if (seg_on) {  // a throttle with several terms is counted once: the lowest match of every run
+                  const uint64_t v = x | seg.y;
+                  x = andn_64(x, v - seg.x);
+                }
+                if (__ballot(x != 0ull && qn >= (uint32_t)kWq) != 0ull) flush();
+                if (x != 0ull) {
+#pragma unroll
+                  for (int k = kWq - 1; k > 0; --k) qx[k] = qx[k - 1];
+                  qx[0] = x;
+                  qw = (qw_t)(qw << 10) | (qw_t)w;
+                  qn += 1u;
+                }
+                return 0ull;
+              },
+              [&](uint32_t w) -> u64x2 { return seg_on ? segp[w] : u64x2{0ull, 0ull}; });
+          flush();
+        } else if constexpr (PK) {
+          // the packed fold takes a word's matches where the scan produced them (scan_tile's post hook), TWO per step: both
+          // rank reads are in flight together and the wave steps ceil(matches / 2) times per word instead of once per match
+          // through scan_tile's peel (ascending term numbers per lane, as the run rule of add_match needs)
+          scan_tile<LA, VETO, NEED, VETO>(
+              bm, scan_counted, ns, ro, [&](bool, uint32_t) {}, confirm_slow,
+              [&](uint32_t w, uint64_t x, int) -> uint64_t {
+                uint64_t xf = x;
+                while (__ballot(xf != 0ull) != 0ull) {
+                  const bool h1 = xf != 0ull;
+                  const uint32_t c1 = h1 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+                  xf &= xf - 1ull;
+                  const bool h2 = xf != 0ull;
+                  const uint32_t c2 = h2 ? w * 64u + (uint32_t)__ffsll((unsigned long long)xf) - 1u : 0u;
+                  xf &= xf - 1ull;
+                  const uint32_t tr1 = trank[c1], tr2 = trank[c2];
+                  add_match(h1, tr1);
+                  add_match(h2, tr2);
+                }
+                return 0ull;
+              });
+        } else {
+          scan_tile<LA, VETO, NEED, VETO>(
+              bm, scan_counted, ns, ro, [&](bool has, uint32_t c) { add_match(has, trank[c]); }, confirm_slow);
+        }
       }
-    }
-    __syncthreads();  // spill this (chunk, workgroup)'s table: coalesced 16-byte stores
-    u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * tab_bytes);
-    lds_u4p src = (lds_u4p)(lds + a.off_tab);
-    for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+      __syncthreads();  // spill this (chunk, workgroup)'s table — this window of it — : coalesced 16-byte stores
+      u32x4* dst = (u32x4*)(a.slab + (size_t)ch.slab_off * 16 + (size_t)blockIdx.x * slab_pitch + (size_t)r0 * rec);
+      lds_u4p src = (lds_u4p)(lds + a.off_tab);
+      for (uint32_t i = threadIdx.x; i < tab_bytes / 16; i += kBlockIx) dst[i] = src[i];
+    }  // rank windows
     if (threadIdx.x == 0) a.slab_tag[ci * kSlabTagStride + blockIdx.x] = a.epoch;  // the reduction skips slabs this launch left alone
   }
 }
@@ -544,17 +572,18 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_packed_slabs(const unsign
   }
 }
 
+#define KT_AGG_BM_LAUNCH(DT_, LA_, VETO_, NEED_, PK_, WIN_)                                                    \
+  {                                                                                                           \
+    auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_, PK_, WIN_>;                                        \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);     \
+    hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                      \
+  }
 #define KT_AGG_BM_CASE(DT_, LA_, VETO_, NEED_)                                                                \
   {                                                                                                           \
-    if (!packed) {                                                                                            \
-      auto kfn = kt_aggregate_bitmap<DT_, LA_, VETO_, NEED_, false>;                                          \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
-      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
-    } else {                                                                                                  \
-      auto kfn = kt_aggregate_bitmap<8, LA_, VETO_, NEED_, true>;                                             \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);   \
-      hipLaunchKernelGGL(kfn, g_, b_, lds_bm, s, bm_args);                                                    \
-    }                                                                                                         \
+    if (!packed && !windowed) KT_AGG_BM_LAUNCH(DT_, LA_, VETO_, NEED_, false, false)                          \
+    else if (!packed) KT_AGG_BM_LAUNCH(DT_, LA_, VETO_, NEED_, false, true)                                   \
+    else if (!windowed) KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, false)                                   \
+    else KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, true)                                                   \
   }
 
 static_assert(kCUs <= kMaxSlabsPerRecord, "packed_record_sums takes four slabs per lane");
@@ -603,6 +632,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   }
   dim3 g_(nb), b_(kBlockIx);
   const size_t lds_bm = bm_total;
+  const bool windowed = bm_args.win_recs != 0u;
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds)
     fprintf(stderr, "kt_aggregate_bitmap: lds=%u chunks=%u largest LDS part=%u max thr=%u T=%d packed=%d nw=%u rec=%u\n", bm_total, ix.n_chunks,

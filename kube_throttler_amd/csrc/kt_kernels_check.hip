@@ -773,7 +773,9 @@ const char* launch_check_indexed(const PodTable& pods, int64_t n, const int64_t*
   // 16-dimension engine whose plain fold cuts the chunks small) one per CU is the faster one — 76.3 -> 67.4 us at 1M x 1k, D = 16
   // (round 6; the instantiation is gone).
   const bool one = ix.n_chunks == 1 && bm_args.ix.by_ns == 0u;
-  const bool two_per_cu = one && !full && !small && !need5 && !one_per_cu && 2 * bm_total <= (uint32_t)kMaxLds;
+  // (16 / 32 atom slots: the 64-VGPR form carries 92-330 B of scratch where the 128-VGPR one has 20-144, at the same time —
+  //  0.0805 against 0.0803 ms at 1M x 1k with 16 labels per pod: one per CU there)
+  const bool two_per_cu = one && !full && !small && !need5 && !one_per_cu && LA <= 8 && 2 * bm_total <= (uint32_t)kMaxLds;
   int64_t nb = (n + kBlockIx - 1) / kBlockIx;
   const int64_t max_b = two_per_cu ? 2 * kCUs : kCUs;
   if (nb > max_b) nb = max_b;

@@ -343,14 +343,18 @@ static std::map<uint32_t, int> scan(const Program& p, const HostIndex& ix, const
   return out;
 }
 
+static uint32_t g_chk_word = kCheckWordLds;  // the check's table bytes per word the index was cut for (file mode: KT_SIM_CHK_WORD)
 static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_budget, uint32_t chk_budget, uint32_t thr_bytes) {
   uint32_t w = 0, rank = 0;
   std::set<uint32_t> seen_t;
   EXPECT(ix.cut_thr_bytes != 0 && ix.cut_thr_bytes <= thr_bytes, "record size of the cut: %u (plain: %u)", ix.cut_thr_bytes, thr_bytes);
   thr_bytes = ix.cut_thr_bytes;  // (the packed fold's record size when the caller offered it and the program needs several chunks)
+  // (agg_windowed: ONE chunk whose table the aggregate holds a window of ranks at a time — only a minimal table has to fit)
+  EXPECT(!ix.agg_windowed || ix.bm_chunks.size() == 1, "a windowed aggregate is for single-chunk programs (%zu chunks)", ix.bm_chunks.size());
   auto fits_one = [&](const BmChunk& ch) {
-    return (size_t)ch.lds_bytes + (size_t)ch.n_words * kCheckWordLds <= chk_budget &&
-           (size_t)ch.lds_bytes + (((size_t)ch.n_words * 128 + 15) & ~(size_t)15) + (size_t)ch.n_words * 16 + (size_t)ch.n_thr * thr_bytes + 16 <= agg_budget;
+    const size_t thr = ix.agg_windowed ? std::min<size_t>(ch.n_thr, 256) : ch.n_thr;
+    return (size_t)ch.lds_bytes + (size_t)ch.n_words * g_chk_word <= chk_budget &&
+           (size_t)ch.lds_bytes + (((size_t)ch.n_words * 128 + 15) & ~(size_t)15) + (size_t)ch.n_words * 16 + thr * thr_bytes + 16 <= agg_budget;
   };
   for (size_t i = 0; i < ix.bm_chunks.size(); ++i) {
     const BmChunk& ch = ix.bm_chunks[i];
@@ -385,8 +389,9 @@ static void check_structure(const Program& p, const HostIndex& ix, uint32_t agg_
   bool all_fit = true;
   for (const BmChunk& ch : ix.bm_chunks) all_fit &= fits_one(ch);
   if (all_fit) {
-    EXPECT((size_t)ix.bm_max_lds + (size_t)ix.bm_max_words * kCheckWordLds <= chk_budget, "maxima exceed the check budget");
-    EXPECT((size_t)ix.bm_max_lds + (((size_t)ix.bm_max_words * 128 + 15) & ~(size_t)15) + (size_t)ix.bm_max_words * 16 + (size_t)ix.bm_max_thr * thr_bytes + 16 <= agg_budget,
+    EXPECT((size_t)ix.bm_max_lds + (size_t)ix.bm_max_words * g_chk_word <= chk_budget, "maxima exceed the check budget");
+    EXPECT((size_t)ix.bm_max_lds + (((size_t)ix.bm_max_words * 128 + 15) & ~(size_t)15) + (size_t)ix.bm_max_words * 16 +
+               (ix.agg_windowed ? std::min<size_t>(ix.bm_max_thr, 256) : (size_t)ix.bm_max_thr) * thr_bytes + 16 <= agg_budget,
            "maxima exceed the aggregate budget");
   }
   EXPECT(w == ix.img_words && w >= ix.bm_words, "chunk images hold %u words, index says %u (program: %u)", w, ix.img_words, ix.bm_words);
@@ -750,6 +755,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
     for (size_t g = 0; g < G; ++g)
       if ((p.ns_term_ok[(size_t)n * p.gw + (g >> 5)] >> (g & 31)) & 1u) adm_all[g * nsw + (n >> 5)] |= 1u << (n & 31);
   const int reps = getenv("KT_SIM_BUILD_REPS") ? atoi(getenv("KT_SIM_BUILD_REPS")) : 1;
+  if (getenv("KT_SIM_CHK_WORD")) g_chk_word = (uint32_t)atoi(getenv("KT_SIM_CHK_WORD"));
   for (int rep = 0; rep < reps; ++rep) {
     const auto t0 = std::chrono::steady_clock::now();
     build_index(ix, p.thr_term_off, p.term_thr, p.term_flags, p.term_req_off, p.req_op, p.req_key, p.req_val_off, p.req_val,

@@ -141,6 +141,45 @@ def test_random_small_rich(seed, variant, oracle_mod):
     assert set(np.unique(st)) >= {S.NOT_AFFECTED, S.NOT_THROTTLED, S.ACTIVE}
 
 
+@pytest.mark.parametrize("shape", ["packed", "plain-negative", "sixteen-dims", "multiterm-rich", "incremental", "chunked"])
+def test_aggregate_rank_windows(shape, oracle_mod, monkeypatch):
+    """The aggregate's table of per-throttle records does not have to fit LDS at once (round 6): the kernel scans a chunk once per
+    WINDOW of ranks and folds only the matches whose record the table holds at that time — what keeps a 16-dimension engine's
+    program in ONE index chunk (tests/test_engine_gpu.py::test_sixteen_dims_sixteen_labels_1m runs it at full size).  Here
+    KT_AGG_SMALL_WINDOW forces windows of 64 records on small clusters (150-400 ranks: three to seven passes) in every fold form —
+    the packed word queue, the plain fold (a negative request), 16 dimensions, throttles with several terms (the run rule across a
+    window boundary), an incremental engine's delta scans, a multi-chunk index — and everything is compared with the oracle."""
+    monkeypatch.setenv("KT_AGG_SMALL_WINDOW", "1")
+    if shape == "chunked":
+        monkeypatch.setenv("KT_CHUNK_BUDGET", "9000")
+    cfg = {"packed": W.small(seed=61, n_pods=5000, n_thr=300, n_cluster=150),
+           "plain-negative": W.small(seed=62, n_pods=5000, n_thr=240, n_cluster=120),
+           "sixteen-dims": W.small(seed=63, n_pods=4000, n_thr=200, n_cluster=100, D=16),
+           "multiterm-rich": W.small(seed=64, n_pods=4000, n_thr=160, n_cluster=80, terms=(1, 4), reqs=(1, 3)),
+           "incremental": W.small(seed=65, n_pods=3000, n_thr=200, n_cluster=100),
+           "chunked": W.small(seed=66, n_pods=4000, n_thr=260, n_cluster=130, terms=(1, 3), reqs=(1, 3))}[shape]
+    snap = W.generate(cfg)
+    if shape == "plain-negative":  # one negative request: the engine leaves the packed fold for good
+        snap.ctr_req[int(snap.pod_ctr_off[7]), 0] = -5
+    variant = E.VARIANT_INDEXED | (E.VARIANT_INCREMENTAL if shape == "incremental" else 0)
+    st, sm, rec = run_full_parity(snap, oracle_mod, variant)
+    assert (st != S.NOT_AFFECTED).any()
+    if shape == "incremental":  # the maintained partials: pods rewritten in place go out and in through windowed delta scans
+        eng = E.Engine.for_snapshot(snap, variant)
+        try:
+            eng.reconcile(NOW, apply=False)
+            rows = np.arange(0, snap.n_pods, 7, dtype=np.int64)
+            eng.upsert_pods(_permute_pods(snap, rows), rows=rows)
+            o = oracle_mod.Oracle(snap)
+            rows_t = responsible_rows(snap)
+            want = o.reconcile(NOW, rows=rows_t)
+            got = eng.reconcile(NOW, apply=False)
+            np.testing.assert_array_equal(got.used.v[rows_t], want.used.v[:len(rows_t)])
+            np.testing.assert_array_equal(got.used.count[rows_t], want.used.count[:len(rows_t)])
+        finally:
+            eng.close()
+
+
 @pytest.mark.parametrize("shape", ["simple-multiterm", "rich-16-dims", "simple-12-dims", "rich-one-per-cu"])
 def test_lean_sweep_shapes(shape, oracle_mod, monkeypatch):
     """The PreFilter sweep (summary words only) settles matches per 64-bit word with the WordVerdict masks and the

@@ -162,17 +162,17 @@ def test_index_builder_against_cpu_scan_replay(tool):
     # is how the round-3 rewrite of the builder's phases was accepted, together with the fingerprints of the dumped
     # BASELINE programs); a change of the index LAYOUT moves it on purpose — then re-pin it here after the GPU parity
     # tests have passed on the new layout.
-    assert "fingerprint of all indexes 97e18acd9ec60929" in out.stdout, out.stdout[-400:]
+    assert "fingerprint of all indexes f610dd7cf5b008e7" in out.stdout, out.stdout[-400:]
     # the builder's phases on several host threads (only programs beyond 16k throttles split by themselves): parts built
     # side by side and joined must give the same indexes
     out3 = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_INDEX_THREADS="3"))
     assert out3.returncode == 0, out3.stderr[-2000:]
-    assert "fingerprint of all indexes 97e18acd9ec60929" in out3.stdout, out3.stdout[-400:]
+    assert "fingerprint of all indexes f610dd7cf5b008e7" in out3.stdout, out3.stdout[-400:]
     # the GROUPED plan of cut_chunks (chunks per group of namespaces, words copied between groups: KT_CUT_PLAN=grouped — measured
     # on the GPU in round 6 and not the default) must describe the same matches: every throttle reported once, nothing missed
     outg = subprocess.run([os.path.join(HOST, "index_sim_test")], capture_output=True, text=True, env=dict(os.environ, KT_CUT_PLAN="grouped"))
     assert outg.returncode == 0 and "all expectations held" in outg.stdout, outg.stdout[-400:] + outg.stderr[-2000:]
-    assert "fingerprint of all indexes b9252c8272e1ee8c" in outg.stdout, outg.stdout[-400:]
+    assert "fingerprint of all indexes 25dee9f5734fec01" in outg.stdout, outg.stdout[-400:]
 
 
 def test_anchor_split_against_brute_force(tool, tmp_path):
@@ -281,7 +281,9 @@ def test_scan_replay_on_the_10k_throttle_program(tool, tmp_path):
     # (round 6: the global plan — consecutive word ranges — with the veto columns of veto-free words elided; and the GROUPED
     #  plan, KT_CUT_PLAN=grouped: chunks per group of namespaces, more of them and far fewer per namespace)
     for budget, plan, lo, hi, per_ns in (("147000", "global", 20, 45, 9.0), ("65000", "global", 50, 100, 14.0), ("147000", "grouped", 60, 200, 5.5)):
-        out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump), budget], capture_output=True, text=True, env=dict(os.environ, KT_CUT_PLAN=plan))
+        # (the engine's figures for an 8-dimension engine: 816 bytes of check tables per word, 40-byte packed records)
+        out = subprocess.run([os.path.join(HOST, "index_sim_test"), str(dump), budget], capture_output=True, text=True,
+                             env=dict(os.environ, KT_CUT_PLAN=plan, KT_SIM_CHK_WORD="816", KT_SIM_PACKED="40"))
         assert out.returncode == 0, out.stdout + out.stderr
         chunks = int(re.search(r"-> (\d+) chunks", out.stdout).group(1))
         assert "10000 throttles" in out.stdout and lo <= chunks <= hi and "rich {any, veto}" in out.stdout, out.stdout

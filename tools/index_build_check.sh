@@ -8,7 +8,7 @@
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO
-WANT="97e18acd9ec60929 40be2435a2c8e184 c05f915b566f3c4c"
+WANT="f610dd7cf5b008e7 472beb285d32e619 6a27f5073695a18e"
 make -C kube_throttler_amd/csrc 2>&1 | grep -E "error|warning"
 make -C kube_throttler_amd/host index_sim_test 2>&1 | grep -E "error|warning"
 for c in 2 4; do
