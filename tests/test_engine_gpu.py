@@ -180,6 +180,43 @@ def test_aggregate_rank_windows(shape, oracle_mod, monkeypatch):
             eng.close()
 
 
+def test_chunks_are_cut_again_when_the_plain_fold_is_needed(oracle_mod, monkeypatch):
+    """A program of several index chunks is cut for the packed fold's 40-byte records (round 6: more words per chunk).  The first
+    scan that needs the PLAIN fold — here a pod with a negative request arrives after the program was compiled — finds tables and
+    slab areas too small for its 80-byte records: the engine cuts the index again for plain records (one recompile, the launch that
+    noticed upgrades its lock) and every result stays the oracle's, before and after."""
+    monkeypatch.setenv("KT_CHUNK_BUDGET", "9000")
+    snap = W.generate(W.small(seed=67, n_pods=4000, n_thr=260, n_cluster=130, terms=(1, 3), reqs=(1, 3)))
+    o = oracle_mod.Oracle(snap)
+    rows_t = responsible_rows(snap)
+    eng = E.Engine.for_snapshot(snap, E.VARIANT_INDEXED)
+    try:
+        got = eng.reconcile(NOW, apply=False)
+        want = o.reconcile(NOW, rows=rows_t)
+        np.testing.assert_array_equal(got.used.v[rows_t], want.used.v[:len(rows_t)])
+        assert eng.index_stats()["chunks"] > 1 and eng.kernel_name(E.KERNEL_AGGREGATE).startswith("kt_aggregate_bitmap_packed")
+        compiles = eng.compiles()
+        # a counted pod gets a negative request (resource.Quantity allows it; the packed words do not)
+        counted = np.nonzero((snap.pod_flags & (S.POD_VALID | S.POD_SCHED_MATCH | S.POD_SCHEDULED | S.POD_FINISHED)) ==
+                             (S.POD_VALID | S.POD_SCHED_MATCH | S.POD_SCHEDULED))[0]
+        row = int(counted[3])
+        snap.ctr_req[int(snap.pod_ctr_off[row]), 0] = -7
+        eng.upsert_pods(_permute_pods(snap, np.array([row])), rows=np.array([row], dtype=np.int64))
+        o2 = oracle_mod.Oracle(snap)
+        got2 = eng.reconcile(NOW, apply=True)
+        want2 = o2.reconcile(NOW, rows=rows_t)
+        np.testing.assert_array_equal(got2.used.v[rows_t], want2.used.v[:len(rows_t)])
+        np.testing.assert_array_equal(got2.used.count[rows_t], want2.used.count[:len(rows_t)])
+        np.testing.assert_array_equal(got2.thrl_flag[rows_t], want2.thrl_flag[:len(rows_t)])
+        assert eng.compiles() == compiles + 1 and not eng.kernel_name(E.KERNEL_AGGREGATE).startswith("kt_aggregate_bitmap_packed")
+        snap.apply_status(want2.used, want2.calc, want2.calc_updated, want2.thrl_flag, want2.thrl_has, want2.thrl_pod, want2.error, rows=rows_t)
+        _, sm_w = o2.check(want_status=False)
+        _, sm_g = eng.check(n=snap.n_pods, want_status=False)
+        np.testing.assert_array_equal(sm_g, sm_w)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("shape", ["simple-multiterm", "rich-16-dims", "simple-12-dims", "rich-one-per-cu"])
 def test_lean_sweep_shapes(shape, oracle_mod, monkeypatch):
     """The PreFilter sweep (summary words only) settles matches per 64-bit word with the WordVerdict masks and the
