@@ -354,7 +354,7 @@ uint64_t aggregate_slab_pods(int64_t n_rows, int blocks);
 const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& scan, const SelProgram& sp, const SelProgram* sp_dev,
                               const IndexDev& ix, unsigned long long* partial, void* slab, hipStream_t s,
                               const std::function<void()>& after_scan = nullptr);
-// the slab reduction of a packed scan + kt_finalize as one launch (kt_kernels.hip: kt_reduce_finalize_packed); one GPU
+// the slab reduction of a packed scan + kt_finalize as one launch (kt_kernels_finalize.hip: kt_reduce_finalize_packed); one GPU
 struct ThrTables;
 struct ReconcileOut;
 struct ReqBound;

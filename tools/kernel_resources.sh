@@ -7,7 +7,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$REPO/kube_throttler_amd/csrc
 TMP=$(mktemp -d)
 printf "%-62s %6s %6s %8s %9s %5s\n" kernel VGPRs SGPRs scratchB sgprSpill occ
-for f in ${FILES:-kt_kernels_check.hip kt_kernels_aggregate.hip kt_kernels_few.hip kt_kernels_admit.hip kt_kernels.hip}; do
+for f in ${FILES:-kt_kernels_check.hip kt_kernels_aggregate.hip kt_kernels_few.hip kt_kernels_admit.hip kt_kernels.hip kt_kernels_finalize.hip}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 ${FLAGS:-} -I$REPO/include -I$SRC -S --cuda-device-only \
       -Rpass-analysis=kernel-resource-usage $SRC/$f -o $TMP/out.s 2>&1 |
     awk '/Function Name:/ {name=$(NF-1)} /TotalSGPRs:/ {sg=$(NF-1)} / VGPRs:/ {vg=$(NF-1)} /ScratchSize/ {sc=$(NF-1)}
