@@ -811,7 +811,8 @@ struct Cutter {
   const uint32_t W, R, Rp, n_ns;
   const bool veto;
   const size_t fam;
-  const uint32_t agg_budget, chk_budget, thr_bytes, chk_word;
+  const uint32_t agg_budget, chk_budget, chk_word;
+  uint32_t thr_bytes;  // the record size the aggregate's tables are sized for (cut_chunks tries the plain one, then the packed fold's)
   std::vector<uint8_t> splittable;    // a chunk may START at word w
   std::vector<uint32_t> word_form;    // NsWord::flags of every word
   std::vector<uint32_t> word_groups;  // groups (= ranks = slab records) whose numbers start in word w
@@ -821,7 +822,7 @@ struct Cutter {
 
   Cutter(HostIndex& o, uint32_t agg, uint32_t chk, uint32_t tb, uint32_t cw)
       : out(o), W(o.bm_words), R(o.bm_rows), Rp(image_col_rows(o.bm_rows)), n_ns(o.n_ns), veto(o.rich), fam(o.rich ? 2 : 1),
-        agg_budget(agg), chk_budget(chk), thr_bytes(tb), chk_word(cw) {
+        agg_budget(agg), chk_budget(chk), chk_word(cw), thr_bytes(tb) {
     const std::vector<uint32_t>& term_rank = out.full_term_rank;
     const std::vector<uint8_t>& real = out.full_real;
     splittable.assign(W + 1, 1);
@@ -1149,7 +1150,7 @@ struct Cutter {
         }
       std::vector<WordHdr> ihdr(nw);
       for (uint32_t w = 0; w < nw; ++w) ihdr[w] = hdr[words[w]];
-      out.ns_word_visits += (int64_t)nsl.size();
+      for (uint32_t n = 0; n < n_ns; ++n) out.ns_word_visits += (int64_t)(nsl_rng[(size_t)n * 2 + 1] - nsl_rng[(size_t)n * 2]);  // (pairs, whatever lists are shared)
       {  // which namespaces have words here (the namespace-ordered scans skip the chunk for workgroups without any of them)
         const size_t b0 = out.bm_chunk_ns.size();
         out.bm_chunk_ns.resize(b0 + out.ns_words, 0u);
@@ -1199,36 +1200,32 @@ void cut_chunks(HostIndex& out, uint32_t agg_budget, uint32_t chk_budget, uint32
   out.cut_grouped = false;
   const char* force = getenv("KT_CUT_PLAN");
   const bool want_global = force && !strcmp(force, "global"), want_grouped = force && !strcmp(force, "grouped");
-  std::vector<ChunkPlan> plan;
   out.agg_windowed = false;
-  {
-    Cutter cut(out, agg_budget, chk_budget, thr_bytes, chk_word);
-    plan = cut.plan_global();
-    if (plan.size() > 1) {
-      // Only the aggregate's table stands against ONE chunk (the image and the check's tables fit)?  Then the program stays
-      // in one chunk and the aggregate scans it once per window of ranks: the check keeps its single-chunk form — two
-      // workgroups per CU, no namespace order, no carry words — and the reconcile pays a second scan instead of a second
-      // chunk (a 16-dimension engine at 1M x 1k: check 67 -> 3x us, round 6).
-      Cutter one(out, agg_budget, chk_budget, thr_bytes, chk_word);
-      one.windowed = true;
-      std::vector<ChunkPlan> p1 = one.plan_global();
-      if (p1.size() == 1 && !getenv("KT_NO_AGG_WINDOW")) {
-        out.agg_windowed = true;
-        one.emit(p1);
-        return;
-      }
-    }
-    if (plan.size() <= 1 || !cut.all_splittable) {
-      cut.emit(plan);
+  Cutter cut(out, agg_budget, chk_budget, thr_bytes, chk_word);  // (one pass over the numbered program; the plans below share it)
+  std::vector<ChunkPlan> plan = cut.plan_global();
+  if (plan.size() > 1) {
+    // Only the aggregate's table stands against ONE chunk (the image and the check's tables fit)?  Then the program stays
+    // in one chunk and the aggregate scans it once per window of ranks: the check keeps its single-chunk form — two
+    // workgroups per CU, no namespace order, no carry words — and the reconcile pays a second scan instead of a second
+    // chunk (a 16-dimension engine at 1M x 1k: check 67 -> 32 us, round 6).
+    cut.windowed = true;
+    std::vector<ChunkPlan> p1 = cut.plan_global();
+    if (p1.size() == 1 && !getenv("KT_NO_AGG_WINDOW")) {
+      out.agg_windowed = true;
+      cut.emit(p1);  // (still `windowed`: emit holds the real image against the same rule)
       return;
     }
+    cut.windowed = false;
+  }
+  if (plan.size() <= 1 || !cut.all_splittable) {
+    cut.emit(plan);
+    return;
   }
   // several chunks: the tables (and slabs) of the aggregate are sized for the packed fold's records where the caller offers
   // that — more words per chunk, fewer chunk passes
   const uint32_t tb = thr_bytes_packed && thr_bytes_packed < thr_bytes && !getenv("KT_CUT_PLAIN") ? thr_bytes_packed : thr_bytes;
   out.cut_thr_bytes = tb;
-  Cutter cut(out, agg_budget, chk_budget, tb, chk_word);
-  if (tb != thr_bytes) plan = cut.plan_global();
+  if (tb != thr_bytes) cut.thr_bytes = tb, plan = cut.plan_global();
   (void)want_global;
   if (want_grouped || getenv("KT_CUT_PLAN_AUTO")) {
     std::vector<ChunkPlan> grouped = cut.plan_grouped();
