@@ -251,7 +251,7 @@ struct kt_engine {
   DevBuf<int64_t> d_order_all;                   // every pod row ordered by namespace: the check sweep's scan order
   bool order_all_valid = false;
   DevBuf<unsigned long long> d_ns_cursor;        // counting-sort scratch (one word per namespace row)
-  // record ranges of the workgroups of a namespace-ordered scan, ends at namespace boundaries (kt_plan_wg_ranges): the all-rows
+  // record ranges of the workgroups of a namespace-ordered scan, ends at namespace boundaries (plan_wg_ranges, host side): the all-rows
   // list (check sweep) and the countable list (aggregate); *_G = the grid they were planned for (0: none)
   DevBuf<uint32_t> d_range_a, d_range_c;
   int range_a_G = 0, range_c_G = 0;

@@ -333,7 +333,7 @@ struct AggScan {
   const int64_t* v_req = nullptr;
   uint32_t* slab_tag = nullptr;  // [chunks][kSlabTagStride] epoch of the last launch that spilled this (chunk, workgroup) slab
   uint32_t epoch = 0;            // this launch's epoch (> 0, different from the previous launches')
-  const uint32_t* wg_range = nullptr;  // by_ns: record range of every workgroup (launch_plan_wg_ranges for aggregate_blocks(n) workgroups)
+  const uint32_t* wg_range = nullptr;  // by_ns: record range of every workgroup (plan_wg_ranges for aggregate_blocks(n) workgroups)
   int wg_range_G = 0;                  //        ... and the number of workgroups they were planned for
   const PackPlan* pk = nullptr;  // packed fold (full scans over the scan view only): the plan v_pk was built with
   const uint64_t* v_pk = nullptr;  // [n][pk->stride] packed request words, scan order
@@ -380,7 +380,7 @@ struct CheckByNs {
   // every workgroup then rebuilds them per chunk
   const unsigned char* wv_img = nullptr;
   uint32_t wv_total_words = 0;
-  // record range of every workgroup of the sweep (launch_plan_wg_ranges for check_sweep_blocks(n) workgroups), or nullptr:
+  // record range of every workgroup of the sweep (plan_wg_ranges for check_sweep_blocks(n) workgroups), or nullptr:
   // fixed ranges of ceil(tiles / workgroups) tiles
   const uint32_t* wg_range = nullptr;
   int wg_range_G = 0;  // the workgroups the ranges were planned for (a launch with another grid ignores them)

@@ -45,7 +45,7 @@ struct BmAggArgs {
   const uint64_t* v_meta;  // namespace order (ix.by_ns): scan-ordered copies, record j belongs to pod rows[j]
   const uint16_t* v_latom;
   const int64_t* v_req;
-  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (kt_plan_wg_ranges)
+  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (plan_wg_ranges, host side)
   uint32_t* slab_tag;    // [chunks][kSlabTagStride]: epoch of the launch that last spilled the (chunk, workgroup) slab
   uint32_t epoch;
   int32_t limb;          // wide sums: which limb of every request this scan adds (limb_of, kt_device.h); 0 = the request
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   uint32_t t_lo = 0, t_hi = n_wtiles;
   uint32_t ns_lo = 0, ns_hi = 0;
   // the records the workgroup's tiles are cut from: [rec0, rec_end) — everything, or this workgroup's planned range of a
-  // namespace-ordered view (ends at a namespace boundary where one lies close: see kt_plan_wg_ranges)
+  // namespace-ordered view (ends at a namespace boundary where one lies close: see plan_wg_ranges, kt_kernels.hip)
   uint32_t rec0 = 0, rec_end = n_rows;
   if (by_ns && a.wg_range) {
     rec0 = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x]), rec_end = __builtin_amdgcn_readfirstlane(a.wg_range[blockIdx.x + 1u]);

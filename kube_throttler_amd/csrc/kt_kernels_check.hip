@@ -172,7 +172,7 @@ struct BmCheckArgs {
   const uint64_t* v_meta;
   const uint16_t* v_latom;
   uint64_t* carry;         // [n] class counters between chunks
-  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (kt_plan_wg_ranges)
+  const uint32_t* wg_range;  // nullable: record range of every workgroup, cut at namespace boundaries (plan_wg_ranges, host side)
   uint32_t n_inline;       // > 0: the pod rows travel in the argument block (no staging copy)
   int64_t inline_rows[8];
   // namespace-ordered lean sweeps of multi-chunk programs: TermInfo + WordVerdict of EVERY word, built once per generation

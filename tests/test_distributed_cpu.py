@@ -41,8 +41,27 @@ def _worker(rank, world, port, n_pods, q):
     r = O.Oracle(snap).reconcile(now)
     buf = torch.from_numpy(KD.pack_partial(r.used.v, r.used.present, r.used.count, r.error, snap.D).copy())
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    # bench.py's self-verification of a multi-rank run, over the same transport primitives: every rank "finalizes" the reduced
+    # buffer (replicated) and hashes it next to its own summary words; the ranks gather the hashes and must agree on the
+    # replicated part (bench.result_hashes / ranks_agree) — and a rank that reduced something else must be caught
+    import types
+    import bench
+    v, present, count, has_count, err = KD.unpack_partial(buf.numpy(), snap.D)
+    T = snap.n_thr
+    rec = types.SimpleNamespace(used=types.SimpleNamespace(v=v, count=count, present=present), thrl_flag=np.zeros(T, np.uint32),
+                                thrl_has=np.zeros(T, np.uint8), thrl_pod=np.zeros(T, np.uint8), error=err)
+    own = np.arange(snap.n_pods, dtype=np.uint64) + np.uint64(1000 * rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, dict(bench.result_hashes(rec, own), rank=rank))
+    agree = bench.ranks_agree(gathered)
+    if rank == 1:
+        rec.used.v = rec.used.v.copy()
+        rec.used.v[3, 0] += 1  # this rank's exchange "went wrong"
+    gathered_bad = [None] * world
+    dist.all_gather_object(gathered_bad, dict(bench.result_hashes(rec, own), rank=rank))
+    caught = not bench.ranks_agree(gathered_bad)
     if rank == 0:
-        q.put(buf.numpy().copy())
+        q.put((buf.numpy().copy(), agree, caught, [g["own"] for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +76,8 @@ def test_two_rank_allreduce_matches_single_process(n_pods, oracle_mod):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pods, q)) for r in range(2)]
     for p in procs:
         p.start()
-    reduced = q.get(timeout=900)  # the children re-import torch: minutes on a cold page cache
+    reduced, agree, caught, own_hashes = q.get(timeout=900)  # the children re-import torch: minutes on a cold page cache
+    assert agree and caught and own_hashes[0] != own_hashes[1]
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
