@@ -3,7 +3,10 @@
 The HIP kernels cannot run here, so each rank produces its partial-`used` buffer with the CPU oracle on ITS
 pod shard; what is under test is everything around the kernels: the generator's shard determinism, the
 partial-buffer layout (presence as counts), the sum all-reduce, and that the reduced buffer reproduces the
-single-process result bit for bit.
+single-process result bit for bit.  In one sentence: this tests the ALGEBRA and the LAYOUT of the exchange (the layout comes
+from the library's own kt_partial_layout), not the kernels — those are pinned per shard on one GPU by tests/test_sharded_gpu.py.
+The same two ranks also run bench.py's self-verification of a multi-rank run (result_hashes / ranks_agree over
+all_gather_object): agreement on the replicated tables, and a rank whose exchange went wrong is caught.
 """
 import os
 import socket
