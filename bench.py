@@ -167,7 +167,7 @@ def extra_leg(index, min_seconds):
             pmc = json.load(fh)
         key = "config%d_indexed" % index
         if pmc.get("_source", {}).get(key, {}).get("engine_version") == E.version():
-            sym = lambda k: k.replace("_chunked", "").replace("_packed", "")
+            sym = lambda k: k.replace("_chunked", "").replace("_packed", "") if k.startswith("kt_aggregate") or k.startswith("kt_check") else k
             prof_ms = {}
             for name, fam in (("check", E.KERNEL_CHECK), ("aggregate", E.KERNEL_AGGREGATE), ("reduce", E.KERNEL_REDUCE), ("finalize", E.KERNEL_FINALIZE)):
                 ns = pmc.get(key, {}).get(sym(eng.kernel_name(fam)), {}).get("rocprof_avg_ns")
