@@ -326,6 +326,8 @@ const char* kt_kernel_name(kt_engine* e, int32_t kernel);
                                           the chunks of every group of namespaces that visits it) */
 #define KT_COUNTER_SLOW_THROTTLES 8 /* throttles of the compiled program that are walked term by term instead of through the index
                                       (an unconvertible podSelector term; more than 512 selector terms) */
+#define KT_COUNTER_PACKED_WORDS 9   /* 64-bit words per pod of the packed fold the last full aggregate scan ran with (1..8; 0: the
+                                      plain fold — a negative request, sums beyond int64, fields that do not fit) */
 int64_t kt_counter(kt_engine* e, int32_t which);
 /* ---- More resource names than one engine has dimensions (KT_MAX_DIMS): PAGES.  The reference sums and compares any resource
  *      name (pkg/resourcelist/resourcelist.go:27-54, resource_amount.go:127-159).  The host builds the same cluster once per

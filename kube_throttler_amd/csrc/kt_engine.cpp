@@ -523,6 +523,7 @@ int64_t kt_counter(kt_engine* e, int32_t which) {
     case KT_COUNTER_NS_CHUNK_VISITS: return e->ctr_ns_chunk_visits.load(std::memory_order_relaxed);
     case KT_COUNTER_INDEX_IMAGE_WORDS: return e->ctr_index_image_words.load(std::memory_order_relaxed);
     case KT_COUNTER_SLOW_THROTTLES: return e->ctr_slow_throttles.load(std::memory_order_relaxed);
+    case KT_COUNTER_PACKED_WORDS: return e->ctr_packed_words.load(std::memory_order_relaxed);
     default: return -1;
   }
 }

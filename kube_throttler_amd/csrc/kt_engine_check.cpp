@@ -180,7 +180,7 @@ int32_t kt_sweep_launch(kt_engine* e, int64_t now_s, int32_t now_ns, uint32_t fl
   if (e->wide) return one_after_the_other();
   // the packed fold's plan for THIS scan: every row of [0, n) in row order, aggregate_blocks(n) workgroups
   const int nb = kt::aggregate_blocks(n);
-  kt::PackPlan plan = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, kt::aggregate_slab_pods(n, nb), /*pad_odd=*/true);
+  kt::PackPlan plan = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, kt::aggregate_slab_pods(n, nb), /*pad_odd=*/true, /*max_words=*/4);
   if (!plan.nw || plan.rec_bytes > kt::agg_rec_bytes(e->D, false)) return one_after_the_other();  // (slab areas hold plain records)
   const size_t words = (size_t)e->thr_rows_hi * kt::partial_stride(e->D);
   if (e->ext_partial && (int64_t)words > e->ext_partial_words)

@@ -166,11 +166,11 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     const uint32_t lds_all = 160u * 1024u;
     const uint32_t agg_budget = hook ? (uint32_t)atoi(hook) : lds_all - kt::aggregate_fixed_lds();
     const uint32_t thr_bytes = kt::agg_rec_bytes(D, e->incremental);
-    // a program of several chunks is cut for the packed fold's records (at most 40 bytes: PackPlan) while this engine's scans
+    // a program of several chunks is cut for the packed fold's records (at most 40 bytes, 72 beyond 8 dimensions: PackPlan) while this engine's scans
     // can pack — a chunk then holds more words, a namespace-ordered scan makes fewer chunk passes; the first scan that needs
     // the plain fold (a negative request, sums beyond int64, KT_NO_PACK) has the program cut again for plain records
     // (aggregate_locked: cut_plain)
-    const uint32_t thr_packed = (!e->incremental && !e->wide && !e->neg_seen && !e->cut_plain && !e->sw[kSw_NO_PACK]) ? kt::kPackedRecMax : 0u;
+    const uint32_t thr_packed = (!e->incremental && !e->wide && !e->neg_seen && !e->cut_plain && !e->sw[kSw_NO_PACK]) ? kt::packed_rec_max(D) : 0u;
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();

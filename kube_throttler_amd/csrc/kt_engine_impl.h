@@ -203,7 +203,7 @@ struct kt_engine {
   std::vector<uint32_t> h_range;                 // ... and the ranges planned from it, on their way to the device
   bool cut_plain = false;                        // a scan needed the plain fold: the index chunks stay cut for plain records
   void* cur_launch_lock = nullptr;               // the LaunchLock of the launch-side call in progress (set and cleared under op_mu)
-  std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0}, ctr_slow_throttles{0};
+  std::atomic<int64_t> ctr_index_chunks{0}, ctr_index_words{0}, ctr_index_image_words{0}, ctr_ns_rows{0}, ctr_ns_word_visits{0}, ctr_ns_chunk_visits{0}, ctr_slow_throttles{0}, ctr_packed_words{0};
   DevBuf<uint64_t> d_vc_pk;                      // packed request words of the countable list, scan order
   DevBuf<uint16_t> d_latom;                      // pods.latom: rewritten per selector program (kt_translate_pods)
   DevBuf<unsigned long long> d_overflow;         // valid pods whose relevant atoms did not fit pods.LA

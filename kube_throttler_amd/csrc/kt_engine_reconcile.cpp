@@ -273,7 +273,7 @@ int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused) {
         uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
         // (planned ranges hold up to wg_range_cap records)
         if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
-        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true);
+        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true, kt::pack_max_words(e->D));
         if (e->pack.nw && e->pack.rec_bytes > e->dindex.cut_thr_bytes) e->pack = kt::PackPlan();  // the slab areas hold records of that size
       }
       if (!e->pack.nw && kt::agg_rec_bytes(e->D, e->incremental) > e->dindex.cut_thr_bytes) {
@@ -342,6 +342,7 @@ int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused) {
                                                      pass == 0 ? std::function<void()>(after_scan) : std::function<void()>());
         if (!k) return e->fail(KT_ERR_UNSUPPORTED, "a chunk of the selector index exceeds the aggregate kernel's LDS budget (use kernel_variant 1)");
         e->last_kernel[KT_KERNEL_AGGREGATE] = k;
+        e->ctr_packed_words.store(sc.launched_packed ? (int64_t)e->pack.nw : 0, std::memory_order_relaxed);
         if (sc.defer_reduce && sc.launched_packed) e->fused_pending = true, e->fused_nb = sc.launched_blocks, e->fused_epoch = sc.epoch, e->fused_pack = e->pack;
         e->last_kernel[KT_KERNEL_REDUCE] = e->fused_pending ? "(in kt_reduce_finalize_packed)" : sc.launched_packed ? "kt_reduce_packed_slabs" : "kt_reduce_bitmap_slabs";
       }

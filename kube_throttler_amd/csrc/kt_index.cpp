@@ -1315,15 +1315,17 @@ void release_index(IndexDev& d) {
   d = IndexDev();
 }
 
-PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd) {
+PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd,
+                        uint32_t max_words) {
   PackPlan pk;
   if (neg_seen || D < 1 || D > 16 || n_slab_pods == 0) return pk;
+  const int MW = (int)std::min<uint32_t>(max_words ? max_words : 1u, kPackMaxWords);
   auto bitlen = [](unsigned __int128 x) { int b = 0; while (x) ++b, x >>= 1; return b; };
   constexpr int H = kPackHeadroomBits;
   // fields in placement order per word: dimension (-1: the pod count), position, width
   struct F { int d; uint32_t pos, w; };
-  std::vector<F> fields[4];
-  uint32_t fill[4] = {0, 0, 0, 0};
+  std::vector<F> fields[kPackMaxWords];
+  uint32_t fill[kPackMaxWords] = {0, 0, 0, 0, 0, 0, 0, 0};
   // every field at least H bits (it is its lower neighbour's headroom) and at most 64 - H (its own sum over the slabs)
   pk.cnt_width = (uint8_t)std::max(bitlen(n_slab_pods), H);
   if (pk.cnt_width > 64 - H) return PackPlan();
@@ -1336,8 +1338,8 @@ PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t*
     const int w = std::max(bitlen((max_abs[d] >> sh) * (unsigned __int128)n_slab_pods), H);
     if (w > 64 - H) return PackPlan();
     int k = 0;
-    while (k < 4 && fill[k] + (uint32_t)w > 64u) ++k;
-    if (k == 4) return PackPlan();
+    while (k < MW && fill[k] + (uint32_t)w > 64u) ++k;
+    if (k == MW) return PackPlan();
     pk.word[d] = (uint8_t)k, pk.pos[d] = (uint8_t)fill[k], pk.width[d] = (uint8_t)w, pk.shift[d] = (uint8_t)sh;
     fields[k].push_back({d, fill[k], (uint32_t)w});
     fill[k] += (uint32_t)w;
@@ -1356,7 +1358,7 @@ PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t*
     }
   }
   pk.nw = nw;
-  pk.stride = nw <= 2 ? 2u : 4u;
+  pk.stride = nw <= 2 ? 2u : nw <= 4 ? 4u : 8u;
   uint32_t units = nw + 1u;
   if (pad_odd && !(units & 1u)) ++units;
   pk.rec_bytes = units * 8u;

@@ -193,8 +193,9 @@ __host__ __device__ inline uint32_t agg_rec_bytes(int D, bool counts) {
 // pod count and the two everyday resources (cpu, memory) normally share word 0, so a match costs ONE atomic — and the
 // slab reduction takes the fields apart again.  No field can carry into its neighbour: sum <= n_slab_pods * max < 2^width.
 struct PackPlan {
-  uint32_t nw = 0;         // 64-bit words per pod; 0: the requests of this engine do not pack (negative values, > 4 words)
-  uint32_t stride = 0;     // words per pod in the scan view (2 or 4: whole 16-byte loads)
+  uint32_t nw = 0;         // 64-bit words per pod (1..8; more than 4: the NW = 8 instantiations of the fold — round 6, engines with
+                           // more than 8 dimensions); 0: the requests of this engine do not pack (negative values, > 8 words)
+  uint32_t stride = 0;     // words per pod in the scan view (2, 4 or 8: whole 16-byte loads)
   uint32_t rec_bytes = 0;  // record of the LDS table / slab: nw words, then one word whose low half is the OR of the
                            // request-key masks of pods that carry a key with the value 0 (+ padding)
   uint8_t word[16] = {0}, pos[16] = {0}, width[16] = {0}, shift[16] = {0};
@@ -205,22 +206,29 @@ struct PackPlan {
   // kPackHeadroomBits wide — so inside `word & even[k]` (and `word & low[k] & ~even[k]`, low[k] = bits below the top
   // field) every field has that many zero bits above it, and the sum of 256 such words carries nowhere.  desc[d] /
   // cnt_desc: where the lane of dimension d / the pod count is found afterwards (pack_desc).
-  uint64_t even[4] = {0, 0, 0, 0};
-  uint8_t top_pos[4] = {0, 0, 0, 0};
+  uint64_t even[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint8_t top_pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t desc[16] = {0};
   uint32_t cnt_desc = 0;
 };
 constexpr int kPackHeadroomBits = 8;
-constexpr uint32_t kPackedRecMax = 40;  // the largest packed record: nw <= 4 words + the zero-key word, padded to an odd count (make_pack_plan)
+constexpr uint32_t kPackMaxWords = 8;
+// What an engine of D dimensions asks of the packed fold: up to 4 words at D <= 8 (every fold form takes those — 40-byte records
+// at most, half of the plain 80), up to 8 beyond (kt_aggregate_bitmap's NW = 8 instantiations: 72-byte records against 144)
+__host__ __device__ inline uint32_t pack_max_words(int D) { return D <= 8 ? 4u : kPackMaxWords; }
+// the largest packed record of such a plan: the words + the zero-key word, padded to an odd count of units (make_pack_plan)
+__host__ __device__ inline uint32_t packed_rec_max(int D) { return (pack_max_words(D) + 1u) * 8u; }
 constexpr int kPackClasses = 3;  // even fields, odd fields, the top field
-// desc: bits 0-3 = 4 * word + class (0: even mask, 1: odd, 2: top field — already shifted down), 8-13 = pos,
+// desc: bits 0-4 = 4 * word + class (0: even mask, 1: odd, 2: top field — already shifted down), 8-13 = pos,
 // 16-22 = bits to keep (field + headroom; 0: no field), 24-29 = shift
 __host__ __device__ inline uint32_t pack_desc(uint32_t word, uint32_t cls, uint32_t pos, uint32_t wext, uint32_t shift) {
   return (word * 4u + cls) | pos << 8 | wext << 16 | shift << 24;
 }
 // or_abs[d]: OR of every |request| fed for dimension d (its trailing zeros are common to all of them);
 // pad_odd: pad the record to an odd number of 8-byte words (LDS bank spread) instead of the smallest size
-PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd);
+// max_words: the most words the caller's fold takes (4: the fused sweep's and the plain instantiations; 8: kt_aggregate_bitmap's NW = 8)
+PackPlan make_pack_plan(int D, const unsigned __int128* max_abs, const uint64_t* or_abs, bool neg_seen, uint64_t n_slab_pods, bool pad_odd,
+                        uint32_t max_words = kPackMaxWords);
 
 // what kt_patch_scan_views (kt_kernels.hip) needs of the scan views a pod event batch is applied to in place
 struct ViewPatch {

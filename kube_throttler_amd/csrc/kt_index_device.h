@@ -138,7 +138,7 @@ __device__ __forceinline__ void block_record_sums(const RecSlabLoads& sl, const 
   unsigned long long ev = ~0ull, low = ~0ull;
   uint32_t tp = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < (int)kPackMaxWords; ++j) {
     const bool me = k == (uint32_t)j && (uint32_t)j < nw;
     ev = me ? pk.even[j] : ev;
     low = me ? (1ull << pk.top_pos[j]) - 1ull : low;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void block_record_sums(const RecSlabLoads& sl, const 
 // a total (in request units) of the record whose first unit is ub, for the lane that asks: desc = pk.desc[k] of
 // dimension k (0: no field) or pk.cnt_desc (the pod count)
 __device__ __forceinline__ unsigned long long packed_field(const RecSumsLds& lds, uint32_t ub, uint32_t desc) {
-  const uint32_t sel = desc & 15u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
+  const uint32_t sel = desc & 31u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
   const unsigned long long s = lds.tot[ub + (sel >> 2)][sel & 3u];
   const unsigned long long m = wext >= 64u ? ~0ull : (1ull << wext) - 1ull;
   return wext ? ((s >> pos) & m) << shift : 0ull;

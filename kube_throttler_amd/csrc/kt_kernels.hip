@@ -410,16 +410,18 @@ __device__ __forceinline__ void write_view_record(const PodTable& pods, int64_t 
   if (v_pk) {
     // ResourceAmountOfPod as packed words (PackPlan, kt_index.h): pod count 1 from bit 0 of word 0, every non-zero
     // request as its field; the plan proved that no value of this engine needs more bits than its field has
-    uint64_t w[4] = {1ull, 0ull, 0ull, 0ull};
+    uint64_t w[kPackMaxWords] = {1ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     for (int d = 0; d < pods.D; ++d) {
       const uint64_t f = (uint64_t)pods.req[p * DS + d] >> pk.shift[d];
       const uint64_t piece = pk.width[d] ? f << pk.pos[d] : 0ull;
       const uint32_t k = pk.word[d];
-      w[0] |= k == 0u ? piece : 0ull, w[1] |= k == 1u ? piece : 0ull, w[2] |= k == 2u ? piece : 0ull, w[3] |= k == 3u ? piece : 0ull;
+#pragma unroll
+      for (uint32_t q = 0; q < kPackMaxWords; ++q) w[q] |= k == q ? piece : 0ull;  // (select chain: no indexed access to registers)
     }
     uint64_t* o = v_pk + j * pk.stride;
     o[0] = w[0], o[1] = w[1];
     if (pk.stride > 2u) o[2] = w[2], o[3] = w[3];
+    if (pk.stride > 4u) o[4] = w[4], o[5] = w[5], o[6] = w[6], o[7] = w[7];
   }
 }
 

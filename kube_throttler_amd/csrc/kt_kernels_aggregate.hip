@@ -11,13 +11,16 @@ namespace kt {
 __host__ __device__ inline uint32_t agg_tab_bytes(uint32_t n_thr, int D, bool counts) { return n_thr * agg_rec_bytes(D, counts); }
 
 // what a tile needs of its 64 pods before it can start (kt_aggregate_bitmap's fetch_tile)
+// (packed fold: DT does not size a request row there — it picks the number of packed words the lane holds: 4 at DT = 8, 8 at DT = 16)
+template <int DT, bool PK>
+constexpr int pk_words() { return PK ? (DT > 8 ? 8 : 4) : 1; }
 template <int DT, int LA, bool PK>
 struct TileRecAgg {
   uint32_t p;
   uint64_t meta;
   u32x4 raw[LA / 8];
-  int64_t v[PK ? 1 : DT];             // plain fold: the request row
-  unsigned long long pw[PK ? 4 : 1];  // packed fold: the packed words
+  int64_t v[PK ? 1 : DT];                      // plain fold: the request row
+  unsigned long long pw[pk_words<DT, PK>()];  // packed fold: the packed words
 };
 
 struct BmAggArgs {
@@ -137,7 +140,8 @@ __device__ __attribute__((noinline)) void agg_walk_without_rank(const SelProgram
 // of the LDS table (v i64[D] | presence mask u32 | pods u32) for every term scan_tile reports (ds_add_u64 per non-zero dimension) — then the table is spilled to this
 // (chunk, workgroup)'s slab; kt_reduce_bitmap_slabs sums the slabs into the partial buffer.
 // No global atomics except for throttles with unconvertible selectors (the "slow" list).
-// PK: the packed fold — the lane holds its pod's contribution as 1..4 packed words (PackPlan) and adds whole words: one
+// PK: the packed fold — the lane holds its pod's contribution as 1..4 packed words (PackPlan; 5..8 in the DT = 16 instantiations:
+//     engines with more than 8 dimensions) and adds whole words: one
 //     ds_add_u64 where the plain fold issues one per non-zero dimension plus the pod count; the record is nw words + the
 //     OR of the key masks of pods that carry a key with the value 0.  Full scans over the scan view only (no counts mode,
 //     no negative requests, sign +1).
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
   // balanced steps: 0.53 -> 0.48 ms on the shard.  (A queue of 16-bit term numbers halved the atomic instructions as well but kept
   // the lopsided extraction loop: 0.53 ms; it and the other A/B forms of round 5 are in the git history of this file.)
   constexpr bool kFoldQueue = PK && LA <= 8;  // (16 / 32 atom slots: the queue does not fit the registers — 40 B of scratch at 16)
+  constexpr int NW = pk_words<DT, PK>();
   KT_LDS unsigned char* lds = (KT_LDS unsigned char*)kt_smem;
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform: LDS bases stay scalar
@@ -229,7 +234,10 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
           const u64x2* q = (const u64x2*)(a.v_pk + (uint64_t)ic * a.pk.stride);
           const u64x2 q0 = q[0];
           r.pw[0] = q0.x, r.pw[1] = q0.y, r.pw[2] = 0ull, r.pw[3] = 0ull;
-          if (a.pk.stride > 2u) {
+          if constexpr (NW > 4) {  // (these instantiations only run plans of 5..8 words: stride 8)
+            const u64x2 q1 = q[1], q2 = q[2], q3 = q[3];
+            r.pw[2] = q1.x, r.pw[3] = q1.y, r.pw[4] = q2.x, r.pw[5] = q2.y, r.pw[6] = q3.x, r.pw[7] = q3.y;
+          } else if (a.pk.stride > 2u) {
             const u64x2 q1 = q[1];
             r.pw[2] = q1.x, r.pw[3] = q1.y;
           }
@@ -296,17 +304,17 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
         // the request does not hang off the meta word by another trip to memory.  What a pod that is not counted brought
         // is never looked at: its lane takes no part in the scan (scan_counted), so no match is ever handed to it.
         int64_t v[DT];             // plain fold (dead in the PK instantiations)
-        unsigned long long pw[4];  // packed fold (dead in the others)
+        unsigned long long pw[NW > 4 ? NW : 4];  // packed fold (dead in the others)
 #pragma unroll
         for (int d = 0; d < DT; ++d) v[d] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pw[k] = 0ull;
+        for (int k = 0; k < (NW > 4 ? NW : 4); ++k) pw[k] = 0ull;
         if constexpr (!PK) {
 #pragma unroll
           for (int d = 0; d < DT; ++d) v[d] = limb_of(cur.v[d], a.limb);
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pw[k] = cur.pw[k];
+          for (int k = 0; k < NW; ++k) pw[k] = cur.pw[k];
         }
         const uint32_t zero_keys = present & ~(uint32_t)(meta >> kMetaNzShift) & 0xFFFFu;  // keys carried with the value 0
         uint32_t ro[LA];
@@ -322,6 +330,22 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
 
         uint32_t last_r = 0xFFFFFFFFu;
         const uint32_t pk_nw = __builtin_amdgcn_readfirstlane(a.pk.nw);
+        // the lane's packed words onto a record: every word of the plan (wave-uniform count — 5..8 in the NW = 8 forms, whose
+        // first five are unconditional)
+        auto add_words = [&](lds_u64wp tv) {
+          if constexpr (NW > 4) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) lds_add64(tv + k, pw[k]);
+            if (pk_nw > 5u) lds_add64(tv + 5, pw[5]);
+            if (pk_nw > 6u) lds_add64(tv + 6, pw[6]);
+            if (pk_nw > 7u) lds_add64(tv + 7, pw[7]);
+          } else {
+            lds_add64(tv, pw[0]);
+            if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
+            if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
+            if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+          }
+        };
         // one matched term number of the lane's pod, given its rank word
         auto add_match = [&](bool has, uint32_t tr) {
               const uint32_t r = tr & 0x7FFFu;  // chunk-local throttle rank
@@ -335,10 +359,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
                   // every word of the plan, whatever it holds (the number of words is wave-uniform: scalar branches): an
                   // LDS atomic costs per instruction, not per lane, and some lane of the step always has a non-zero word —
                   // testing the words lane by lane only bought exec-mask juggling
-                  lds_add64(tv, pw[0]);
-                  if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
-                  if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
-                  if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+                  add_words(tv);
                   if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                   return;
                 }
@@ -379,10 +400,7 @@ __global__ __launch_bounds__(kBlockIx) void kt_aggregate_bitmap(const BmAggArgs 
             if (has && (!WIN || r - r0 < nrec)) {
               KT_LDS unsigned char* rp = tab + __umul24(WIN ? r - r0 : r, rec);
               lds_u64wp tv = (lds_u64wp)rp;
-              lds_add64(tv, pw[0]);
-              if (pk_nw > 1u) lds_add64(tv + 1, pw[1]);
-              if (pk_nw > 2u) lds_add64(tv + 2, pw[2]);
-              if (pk_nw > 3u) lds_add64(tv + 3, pw[3]);
+              add_words(tv);
               if (zero_keys) (void)__hip_atomic_fetch_or((lds_u32wp)(rp + a.pk.nw * 8u), zero_keys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           };
@@ -582,8 +600,10 @@ __global__ __launch_bounds__(kRecBlock) void kt_reduce_packed_slabs(const unsign
   {                                                                                                           \
     if (!packed && !windowed) KT_AGG_BM_LAUNCH(DT_, LA_, VETO_, NEED_, false, false)                          \
     else if (!packed) KT_AGG_BM_LAUNCH(DT_, LA_, VETO_, NEED_, false, true)                                   \
-    else if (!windowed) KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, false)                                   \
-    else KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, true)                                                   \
+    else if (!windowed && !wide_pk) KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, false)                      \
+    else if (!wide_pk) KT_AGG_BM_LAUNCH(8, LA_, VETO_, NEED_, true, true)                                     \
+    else if (!windowed) KT_AGG_BM_LAUNCH(16, LA_, VETO_, NEED_, true, false)                                  \
+    else KT_AGG_BM_LAUNCH(16, LA_, VETO_, NEED_, true, true)                                                  \
   }
 
 static_assert(kCUs <= kMaxSlabsPerRecord, "packed_record_sums takes four slabs per lane");
@@ -633,6 +653,7 @@ const char* launch_aggregate_indexed(const PodTable& pods, const AggScan& sc, co
   dim3 g_(nb), b_(kBlockIx);
   const size_t lds_bm = bm_total;
   const bool windowed = bm_args.win_recs != 0u;
+  const bool wide_pk = packed && bm_args.pk.nw > 4u;  // 5..8 packed words: the DT = 16 instantiations of the packed fold
   static const bool dbg_lds = getenv("KT_DEBUG_LDS") != nullptr;
   if (dbg_lds)
     fprintf(stderr, "kt_aggregate_bitmap: lds=%u chunks=%u largest LDS part=%u max thr=%u T=%d packed=%d nw=%u rec=%u\n", bm_total, ix.n_chunks,

@@ -42,7 +42,7 @@ EXPORTS = [
     "kt_set_wide_sums", "kt_partial_words", "kt_partial_layout", "kt_debug_reload_env", "kt_affected_pods", "kt_paged_check", "kt_paged_reconcile",
 ]
 COUNTER_FEW_CHECKS, COUNTER_COMPILES, COUNTER_INDEX_CHUNKS, COUNTER_INDEX_WORDS, COUNTER_NS_WORD_VISITS, COUNTER_NS_ROWS = range(6)
-COUNTER_NS_CHUNK_VISITS, COUNTER_INDEX_IMAGE_WORDS, COUNTER_SLOW_THROTTLES = 6, 7, 8
+COUNTER_NS_CHUNK_VISITS, COUNTER_INDEX_IMAGE_WORDS, COUNTER_SLOW_THROTTLES, COUNTER_PACKED_WORDS = 6, 7, 8, 9
 
 
 def partial_layout(n_dims: int) -> dict:
@@ -372,6 +372,10 @@ class Engine:
         return {"chunks": ch, "words": words, "image_words": iw, "namespace_rows": rows,
                 "word_visits_per_namespace": round(visits / rows, 3) if rows > 0 else None,
                 "chunks_per_namespace": round(cvis / rows, 3) if rows > 0 else None, "slow_throttles": slow}
+
+    def packed_words(self) -> int:
+        """64-bit words per pod of the packed fold the last full aggregate scan ran with (0: the plain fold)."""
+        return int(lib().kt_counter(self._h, COUNTER_PACKED_WORDS))
 
     def partial_words(self) -> int:
         return self.throttle_rows() * partial_layout(self.D)["stride"]

@@ -919,7 +919,7 @@ static int run_file(const char* path, uint32_t chk_budget) {
 // its field, 256 such slabs must not carry out of the field's headroom, and the unpacked sums must be the plain sums.
 static void pack_plan_cases() {
   std::mt19937_64 rng(4242);
-  int packed = 0, refused = 0;
+  int packed = 0, refused = 0, wide = 0;
   for (int it = 0; it < 4000; ++it) {
     const int D = 1 + (int)(rng() % 16);
     const uint64_t n_slab = 1 + rng() % (it % 3 == 0 ? 5000 : 70000);
@@ -941,16 +941,19 @@ static void pack_plan_cases() {
       }
     }
     const bool pad = it & 1;
-    const PackPlan pk = make_pack_plan(D, max_abs, or_abs, false, n_slab, pad);
+    const uint32_t max_words = it % 5 == 0 ? 4u : pack_max_words(D);  // (the sweep always asks for 4)
+    const PackPlan pk = make_pack_plan(D, max_abs, or_abs, false, n_slab, pad, max_words);
+    if (pk.nw > 4) ++wide;
     if (pk.nw == 0) {
       ++refused;
       continue;
     }
     ++packed;
-    if (pk.nw > 4 || (pk.stride != 2 && pk.stride != 4) || pk.stride < pk.nw || pk.rec_bytes < (pk.nw + 1) * 8 || (pad && !((pk.rec_bytes / 8) & 1)))
+    if (pk.nw > max_words || (pk.stride != 2 && pk.stride != 4 && pk.stride != 8) || pk.stride < pk.nw || pk.stride >= 2 * std::max(pk.nw, 2u) ||
+        pk.rec_bytes > packed_rec_max(D) || pk.rec_bytes < (pk.nw + 1) * 8 || (pad && !((pk.rec_bytes / 8) & 1)))
       ++g_fail, fprintf(stderr, "FAIL: pack plan shape nw=%u stride=%u rec=%u\n", pk.nw, pk.stride, pk.rec_bytes);
     // no overlap, nothing crosses a word, the count owns the low bits of word 0
-    uint64_t occ[4] = {(1ull << pk.cnt_width) - 1ull, 0, 0, 0};
+    uint64_t occ[8] = {(1ull << pk.cnt_width) - 1ull, 0, 0, 0, 0, 0, 0, 0};
     if (pk.cnt_width < 64 && (n_slab >> pk.cnt_width) != 0) ++g_fail, fprintf(stderr, "FAIL: the pod count field is too narrow\n");
     for (int d = 0; d < D; ++d) {
       if (!pk.width[d]) {
@@ -971,17 +974,17 @@ static void pack_plan_cases() {
     // others a full slab of the per-dimension maxima (the worst case the headroom has to hold)
     std::vector<unsigned __int128> want(D, 0);
     unsigned __int128 want_pods = 0;
-    uint64_t cls[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    uint64_t cls[8][3] = {};
     for (int sl = 0; sl < n_slabs; ++sl) {
-      uint64_t acc[4] = {0, 0, 0, 0};
+      uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (sl == 0) {
         for (int i = 0; i < n; ++i) {
-          uint64_t w[4] = {1ull, 0, 0, 0};
+          uint64_t w[8] = {1ull, 0, 0, 0, 0, 0, 0, 0};
           for (int d = 0; d < D; ++d) {
             want[d] += v[i][d];
             if (pk.width[d]) w[pk.word[d]] += (v[i][d] >> pk.shift[d]) << pk.pos[d];
           }
-          for (int k = 0; k < 4; ++k) acc[k] += w[k];
+          for (int k = 0; k < 8; ++k) acc[k] += w[k];
         }
         want_pods += (unsigned)n;
       } else {
@@ -1000,7 +1003,7 @@ static void pack_plan_cases() {
       }
     }
     auto field = [&](uint32_t desc) -> unsigned __int128 {  // packed_field
-      const uint32_t sel = desc & 15u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
+      const uint32_t sel = desc & 31u, pos = (desc >> 8) & 63u, wext = (desc >> 16) & 127u, shift = (desc >> 24) & 63u;
       if (!wext) return 0;
       return (unsigned __int128)((cls[sel >> 2][sel & 3u] >> pos) & (wext >= 64 ? ~0ull : (1ull << wext) - 1ull)) << shift;
     };
@@ -1016,8 +1019,9 @@ static void pack_plan_cases() {
     mx[0] = (unsigned __int128)1 << 50, oa[0] = 1ull << 50 | 1ull;
     if (make_pack_plan(1, mx, oa, false, 1000, false).nw != 0) ++g_fail, fprintf(stderr, "FAIL: a field whose sum over the slabs leaves 64 bits packed\n");
   }
-  if (packed < 1000 || refused < 10) ++g_fail, fprintf(stderr, "FAIL: pack plan cases too one-sided (%d packed, %d refused)\n", packed, refused);
-  printf("pack plan: %d packed, %d refused\n", packed, refused);
+  if (packed < 1000 || refused < 10 || wide < 100)
+    ++g_fail, fprintf(stderr, "FAIL: pack plan cases too one-sided (%d packed, %d refused, %d of more than four words)\n", packed, refused, wide);
+  printf("pack plan: %d packed (%d of more than four words), %d refused\n", packed, wide, refused);
 }
 
 // ---- plan_wg_ranges (kt_kernels.hip, host code since round 6): the record ranges of the workgroups of a namespace-ordered scan

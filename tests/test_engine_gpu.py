@@ -180,6 +180,59 @@ def test_aggregate_rank_windows(shape, oracle_mod, monkeypatch):
             eng.close()
 
 
+@pytest.mark.parametrize("shape", ["simple", "rich-8-labels", "rich-16-labels", "rich-32-labels", "five-keys", "windows", "chunked", "nine-dims"])
+def test_packed_fold_of_more_than_four_words(shape, oracle_mod, monkeypatch):
+    """An engine with more than 8 dimensions packs its requests into up to EIGHT 64-bit words (round 6: until then `PackPlan` held
+    four and a 16-dimension engine ran the plain fold — 144-byte records, up to 17 LDS atomics per match).  The NW = 8
+    instantiations of kt_aggregate_bitmap in every form that exists — no veto columns, 8 / 16 / 32 atom slots, terms with four
+    or five positive keys, rank windows, a multi-chunk index — and the reduction / fused finalize over 72-byte records: the
+    engine must report the packed kernel with 5..8 words, and everything is compared with the oracle."""
+    if shape == "windows":
+        monkeypatch.setenv("KT_AGG_SMALL_WINDOW", "1")
+    if shape == "chunked":
+        monkeypatch.setenv("KT_CHUNK_BUDGET", "12000")
+    cfg = {"simple": W.small(seed=801, n_pods=6000, n_thr=96, n_cluster=48, D=16, rich_ops=0, terms=(1, 1), reqs=(1, 2)),
+           "rich-8-labels": W.small(seed=802, n_pods=6000, n_thr=120, n_cluster=60, D=16, L=6, K=12),
+           "rich-16-labels": W.small(seed=803, n_pods=6000, n_thr=120, n_cluster=60, D=16, L=14, K=24),
+           "rich-32-labels": W.small(seed=804, n_pods=5000, n_thr=100, n_cluster=50, D=16, L=28, K=40),
+           "five-keys": W.small(seed=805, n_pods=8000, n_thr=100, n_cluster=50, D=16, n_ns=8, K=16, V=3, L=10, terms=(1, 3), reqs=(3, 5)),
+           "windows": W.small(seed=806, n_pods=5000, n_thr=300, n_cluster=150, D=16, terms=(1, 4), reqs=(1, 3)),
+           "chunked": W.small(seed=807, n_pods=5000, n_thr=260, n_cluster=130, D=16, terms=(1, 3), reqs=(1, 3)),
+           "nine-dims": W.small(seed=808, n_pods=5000, n_thr=90, n_cluster=45, D=9)}[shape]
+    snap = W.generate(cfg)
+    if shape == "nine-dims":  # nine wide fields: more than four words although the engine has barely more than 8 dimensions
+        n_ctr = int(snap.pod_ctr_off[snap.n_pods])
+        snap.ctr_present[:n_ctr] |= 0x1FF  # (every container names all nine resources)
+        base = snap.ctr_req[:n_ctr, :9] & 0xFFF
+        for shift in range(3, 16):  # the narrowest fields that no longer fit four words
+            snap.ctr_req[:n_ctr, :9] = (base << shift) | 1
+            probe = E.Engine.for_snapshot(snap, E.VARIANT_INDEXED)
+            try:
+                probe.reconcile(NOW, apply=False)
+                if probe.packed_words() > 4:
+                    break
+            finally:
+                probe.close()
+    st, sm, rec = run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    assert (st != S.NOT_AFFECTED).any() and (rec.used.v != 0).any()
+    eng = E.Engine.for_snapshot(snap, E.VARIANT_INDEXED)
+    try:
+        rows = responsible_rows(snap)
+        want = oracle_mod.Oracle(snap).reconcile(NOW, rows=rows)
+        got = eng.reconcile(NOW, apply=False)
+        assert eng.kernel_name(E.KERNEL_AGGREGATE).startswith("kt_aggregate_bitmap_packed"), eng.kernel_name(E.KERNEL_AGGREGATE)
+        assert 4 < eng.packed_words() <= 8, eng.packed_words()
+        if shape == "chunked":
+            assert eng.index_stats()["chunks"] > 1
+        assert_reconcile_equal(_rows_of(got, rows, snap.D), want, len(rows))
+        # the separate reduction over the same slabs (kt_aggregate_launch -> kt_finalize_launch: kt_reduce_packed_slabs)
+        eng.aggregate_launch()
+        eng.finalize_launch(NOW, apply=False)
+        assert_reconcile_equal(_rows_of(eng.reconcile_fetch(), rows, snap.D), want, len(rows))
+    finally:
+        eng.close()
+
+
 def test_chunks_are_cut_again_when_the_plain_fold_is_needed(oracle_mod, monkeypatch):
     """A program of several index chunks is cut for the packed fold's 40-byte records (round 6: more words per chunk).  The first
     scan that needs the PLAIN fold — here a pod with a negative request arrives after the program was compiled — finds tables and
