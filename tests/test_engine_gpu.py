@@ -570,14 +570,15 @@ def test_incremental_event_path(budget, oracle_mod, monkeypatch):
         eng.close()
 
 
-@pytest.mark.parametrize("budget", [None, 5000])
-def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("budget,dims", [(None, 8), (5000, 8), (None, 16), (9000, 16)])
+def test_pod_events_between_sweeps(budget, dims, oracle_mod, monkeypatch):
     """The scan lists and scan-ordered record copies (namespace order with a multi-chunk index) are rebuilt after pod
     events: adds, updates that move pods to other namespaces / labels / requests, deletes and a throttle change between
-    full sweeps of a NON-incremental engine — every reconcile + check equals the oracle on the pods currently held."""
+    full sweeps of a NON-incremental engine — every reconcile + check equals the oracle on the pods currently held.
+    (16 dimensions: the view records carry eight packed words — kt_patch_scan_views and the rebuilds with that stride.)"""
     if budget:
         monkeypatch.setenv("KT_CHUNK_BUDGET", str(budget))
-    base = W.generate(W.small(seed=73, n_pods=2600, n_thr=96, n_cluster=48))
+    base = W.generate(W.small(seed=73, n_pods=2600, n_thr=96, n_cluster=48, D=dims))
     # pod 2599 carries a cpu request larger than every other and with odd low bits: when it arrives, the packed request
     # words of the scan view (PackPlan: field widths / common trailing zeros proved per view) no longer hold — rebuild
     k99 = int(base.pod_ctr_off[2599])
@@ -618,6 +619,8 @@ def test_pod_events_between_sweeps(budget, oracle_mod, monkeypatch):
             base.thr_flags, base.thr_thrl_flag, base.thr_thrl_has = snap.thr_flags, snap.thr_thrl_flag, snap.thr_thrl_has
 
         sweep()
+        if dims > 8:
+            assert eng.packed_words() > 4, eng.packed_words()
         add_rows = np.arange(1500, 2100)
         state[add_rows] = np.arange(1500, 2100)
         eng.upsert_pods(_permute_pods(base, state[add_rows]), rows=add_rows)
