@@ -300,11 +300,25 @@ def main():
         args.native_comm = True  # the product's own exchange is what a multi-GPU run measures
     if world > 1 and not args.native_comm:
         eng.set_exchange_world(world)  # the exact-range guard must cover the sum over all ranks
+    native_comm_error = None
     if args.native_comm:  # the framework-free exchange: torch.distributed only carries the 128-byte id to the ranks
-        ids = [E.Engine.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(rank, world, ids[0])
+        try:
+            ids = [E.Engine.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(rank, world, ids[0])
+        except Exception as ex:  # the native exchange has never met more than one rank on hardware: say so and go on
+            native_comm_error = "%s: %s" % (type(ex).__name__, ex)
+        if world > 1:  # every rank takes the same exchange: one failure moves all of them to torch.distributed (also RCCL)
+            errs = [None] * world
+            dist.all_gather_object(errs, native_comm_error)
+            native_comm_error = next((e for e in errs if e), None)
+        if native_comm_error:
+            if world == 1:
+                raise SystemExit("kt_comm_init failed: " + native_comm_error)
+            print("bench.py: native exchange unavailable (%s): using torch.distributed" % native_comm_error, file=sys.stderr)
+            args.native_comm = False
+            eng.set_exchange_world(world)
 
     xchg_events = []  # (start, stop) around the exchange, recorded only in the instrumented pass
 
@@ -698,6 +712,7 @@ def main():
                        "overlap_identical_to_serial": overlap_identical, "results_sha1": results_sha1,
                        "kernel_variant": args.variant, "parallelism": f"pods row-sharded x{world}, throttles replicated",
                        "exchange": "kt_comm (RCCL, native)" if args.native_comm else ("torch.distributed (RCCL)" if world > 1 else "none"),
+                       "native_exchange_error": native_comm_error,
                        "generate_s": round(t_gen, 2), "load_s": round(t_load, 2), "engine_version": engine_version},
             "per_rank_ms_per_step": [round(x, 6) for x in rank_ms],
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 6),
