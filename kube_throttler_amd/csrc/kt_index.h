@@ -62,7 +62,8 @@ struct ThrInfo {
 };
 
 // per-word header of a chunk image
-struct alignas(64) WordHdr {  // (64 bytes: the address of word w's header is a shift, not a 64-bit multiply-add)
+struct alignas(16) WordHdr {  // (64 bytes: the address of word w's header is a shift, not a 64-bit multiply-add; an image places
+                              //  the headers at a 16-byte boundary — 16-byte reads —, so the type claims no more than that)
   uint64_t univ;  // terms without a positive requirement (hit by every pod)
   uint64_t m2;    // terms that need >= 2 positive hits
   uint64_t m3;    // terms that need >= 3
@@ -71,6 +72,7 @@ struct alignas(64) WordHdr {  // (64 bytes: the address of word w's header is a 
   uint64_t m5;    // instantiations, which count hits as 3-bit numbers) / that need 5
   uint64_t pad[2];
 };
+static_assert(sizeof(WordHdr) == 64, "the scans address a word's header by a shift");
 // one entry of a namespace's word list
 struct alignas(16) NsWord {
   uint32_t w;
