@@ -1,0 +1,95 @@
+"""Randomised shapes through the whole path (GPU): every case draws its own cluster shape — dimensions, labels per pod, key /
+value universe, namespaces, terms per throttle, requirements per term, rich operators, invalid selectors, missing namespaces —
+AND the switches that select kernel instantiations (index chunk budget, rank windows of the aggregate, incremental engine), then
+runs `run_full_parity` (reconcile -> stored status -> check matrix + lean sweep + fused sweep, both isThrottledOnEqual values)
+against the oracle.  The fixed-shape tests of test_engine_gpu.py pin the forms one by one; this file crosses them.
+
+KT_FUZZ_CASES (default 24, ~1 minute) sizes the run, KT_FUZZ_SEED moves it; a failing case prints the line that reproduces it:
+    KT_FUZZ_ONLY=<case seed> python -m pytest tests/test_fuzz_gpu.py -m gpu -x -q
+"""
+import os
+
+import numpy as np
+import pytest
+
+from kube_throttler_amd import engine as E
+from kube_throttler_amd import snapshot as S
+from kube_throttler_amd import workload as W
+from test_engine_gpu import run_full_parity
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ("KT_CHUNK_BUDGET", "KT_AGG_SMALL_WINDOW", "KT_CUT_PLAN")
+
+
+def draw_case(seed):
+    """(workload config kwargs, environment switches, engine variant, post-processing of the snapshot) of one case."""
+    r = np.random.default_rng(seed)
+    D = int(r.choice([1, 2, 3, 4, 5, 8, 8, 9, 12, 16]))
+    L = int(r.choice([1, 2, 4, 6, 8, 8, 12, 16, 24, 30]))
+    t_hi = int(r.integers(1, 6))
+    q_hi = int(r.integers(1, 6))
+    K = int(min(64, max(L, q_hi, int(r.integers(L, 2 * L + 4)))))  # (a term names distinct keys: the generator needs K >= requirements)
+    V = int(r.integers(2, 9))
+    n_thr = int(r.choice([8, 24, 64, 96, 160, 300, 420]))
+    kw = dict(seed=int(r.integers(1, 1 << 30)), n_pods=int(r.integers(300, 5000)), n_thr=n_thr, n_cluster=int(r.integers(0, n_thr + 1)), D=D,
+              n_ns=int(r.integers(1, 40)), K=K, V=V, L=L, terms=(1, t_hi), reqs=(int(r.integers(0, 2)), q_hi), rich_ops=int(r.integers(0, 2)),
+              overrides=int(r.integers(0, 2)))
+    if r.random() < .06:  # throttles with more than 64 terms: runs of term numbers across words (the match-by-match forms)
+        kw.update(n_thr=int(r.choice([8, 24, 48])), terms=(1, int(r.integers(66, 140))))
+        kw["n_cluster"] = int(r.integers(0, kw["n_thr"] + 1))
+    if r.random() < .1:
+        kw["n_pods"] = int(r.integers(5000, 30000))
+    if r.random() < .25:
+        kw.update(n_invalid_pod_sel=int(r.integers(0, 3)), n_invalid_ns_sel=int(r.integers(0, 3)), n_missing_ns=int(r.integers(0, 2)))
+    env = {}
+    if r.random() < .5:
+        env["KT_CHUNK_BUDGET"] = str(int(r.choice([5000, 9000, 16000, 30000])))
+    if r.random() < .3:
+        env["KT_AGG_SMALL_WINDOW"] = "1"
+    if r.random() < .2:
+        env["KT_CUT_PLAN"] = "grouped"
+    variant = E.VARIANT_INDEXED | (E.VARIANT_INCREMENTAL if r.random() < .2 else 0)
+    post = str(r.choice(["none", "none", "none", "negative", "large", "zero"]))
+    return kw, env, variant, post
+
+
+def shape_snapshot(snap, post, seed):
+    """A few request populations the generator does not draw: a negative request (the plain fold for good), large values with odd
+    low bits (wider packed fields, more packed words), pods that request nothing."""
+    r = np.random.default_rng(seed ^ 0x5EED)
+    nc = int(snap.pod_ctr_off[snap.n_pods])
+    if nc == 0 or post == "none":
+        return
+    if post == "negative":
+        snap.ctr_req[int(r.integers(0, nc)), int(r.integers(0, snap.D))] = -int(r.integers(1, 1000))
+        snap.ctr_present[:nc] |= (1 << snap.D) - 1
+    elif post == "large":
+        d = int(r.integers(0, snap.D))
+        snap.ctr_req[:nc, d] = np.where(snap.ctr_req[:nc, d] != 0, ((snap.ctr_req[:nc, d] & 0xFFFFF) << int(r.integers(4, 16))) | 1, 0)
+    elif post == "zero":
+        snap.ctr_req[:nc:3, :] = 0
+
+
+def case_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930"))
+    return [base + 7919 * i for i in range(int(os.environ.get("KT_FUZZ_CASES", "24")))]
+
+
+@pytest.mark.parametrize("seed", case_seeds())
+def test_random_shape_and_switches(seed, oracle_mod, monkeypatch):
+    kw, env, variant, post = draw_case(seed)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    snap = W.generate(W.small(**kw))
+    shape_snapshot(snap, post, seed)
+    try:
+        run_full_parity(snap, oracle_mod, variant, on_equals=(False, True) if seed % 2 else (True,))
+    except Exception:
+        print(f"\nfuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}  requests={post}")
+        raise
