@@ -93,3 +93,86 @@ def test_random_shape_and_switches(seed, oracle_mod, monkeypatch):
     except Exception:
         print(f"\nfuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}  requests={post}")
         raise
+
+
+def event_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930")) + 13
+    return [base + 104729 * i for i in range(int(os.environ.get("KT_FUZZ_EVENT_CASES", "8")))]
+
+
+@pytest.mark.parametrize("seed", event_seeds())
+def test_random_event_sequences(seed, oracle_mod, monkeypatch):
+    """Pod events on a random shape: bursts of adds / rewrites / deletes of random size (single pods: the lists and scan views are
+    patched in place; larger batches: rebuilt; the same row several times in one batch: the last entry wins) between sweeps of an
+    engine that may be incremental, with a Throttle event now and then; after every burst reconcile + lean check equal the oracle
+    on the pods currently held."""
+    from test_engine_gpu import NOW, _permute_pods, _rows_of, _with_pods, assert_reconcile_equal, responsible_rows
+    kw, env, variant, post = draw_case(seed)
+    kw["n_pods"] = min(kw["n_pods"], 3000)
+    kw.pop("n_missing_ns", None)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    base = W.generate(W.small(**kw))
+    shape_snapshot(base, post if post != "negative" else "none", seed)
+    r = np.random.default_rng(seed ^ 0xE7E27)
+    n_src = base.n_pods
+    P = max(64, int(n_src * 0.8))
+    state = np.full(P, -1, dtype=np.int64)
+    n0 = P // 2
+    state[:n0] = r.integers(0, n_src, n0)
+    eng = E.Engine(base.D, max(base.L, 1), P, max(base.n_thr, 1), max(base.n_ns, 1), -1, variant)
+    try:
+        eng.upsert_namespaces(base)
+        eng.upsert_throttles(base)
+        eng.upsert_pods(_permute_pods(base, state[:n0]), rows=np.arange(n0))
+
+        def sweep(step):
+            used = np.nonzero(state >= 0)[0]
+            n = int(used.max()) + 1 if len(used) else 1
+            snap = _with_pods(base, state[:n])
+            o = oracle_mod.Oracle(snap)
+            rows = responsible_rows(snap)
+            want = o.reconcile(NOW, rows=rows)
+            got = _rows_of(eng.reconcile(NOW, apply=True), rows, snap.D)
+            try:
+                assert_reconcile_equal(got, want, len(rows))
+                snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows)
+                _, sm_w = o.check(on_equal=bool(step & 1), want_status=False, nthreads=4)
+                _, sm_g = eng.check(n=n, on_equal=bool(step & 1), want_status=False)
+                np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"summary words after burst {step}")
+            except Exception:
+                print(f"\nevent fuzz case {seed} (burst {step}): KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}  requests={post}")
+                raise
+            base.thr_used, base.thr_calc = snap.thr_used, snap.thr_calc
+            base.thr_flags, base.thr_thrl_flag, base.thr_thrl_has = snap.thr_flags, snap.thr_thrl_flag, snap.thr_thrl_has
+
+        sweep(0)
+        for step in range(1, 9):
+            kind = r.random()
+            size = int(r.choice([1, 1, 2, 7, 40, 300]))
+            if kind < .6:      # upserts (adds and rewrites), rows may repeat inside the batch: the last entry wins
+                rows = r.integers(0, P, size)
+                src = r.integers(0, n_src, size)
+                eng.upsert_pods(_permute_pods(base, src), rows=rows.astype(np.int64))
+                for i in range(size):
+                    state[rows[i]] = src[i]
+            elif kind < .85:   # deletes
+                rows = np.unique(r.integers(0, P, size)).astype(np.int64)
+                eng.delete_pods(rows)
+                state[rows] = -1
+            else:              # a Throttle event: the tables go up again (selectors unchanged), or a responsibility flip (recompile)
+                rr = responsible_rows(base)
+                if len(rr) > 1 and r.random() < .5:
+                    t = int(rr[int(r.integers(0, len(rr)))])
+                    base.thr_flags[t] &= 0xFFFFFFFF ^ S.THR_RESPONSIBLE
+                    eng.upsert_throttles(base.throttle_batch([t]), rows=np.array([t], dtype=np.int32))
+                else:
+                    eng.upsert_throttles(base)
+            sweep(step)
+    finally:
+        eng.close()
