@@ -176,3 +176,82 @@ def test_random_event_sequences(seed, oracle_mod, monkeypatch):
             sweep(step)
     finally:
         eng.close()
+
+
+def entry_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930")) + 29
+    return [base + 15485863 * i for i in range(int(os.environ.get("KT_FUZZ_ENTRY_CASES", "8")))]
+
+
+@pytest.mark.parametrize("seed", entry_seeds())
+def test_random_shapes_through_the_other_entry_points(seed, oracle_mod, monkeypatch):
+    """The entry points beside the two sweeps, on a random shape: reconciles of single workqueue keys (the others keep their stored
+    status), single PreFilter calls (kt_check with n <= 8: the few-pod kernels, their own scan), the status row of listed pods,
+    `affectedPods` of listed (pod, throttle) pairs against the status matrix, and a pending queue admitted in order with reservation
+    (dry run, then committed) — each against the oracle."""
+    from test_engine_gpu import NOW, _rows_of, _stored_status, assert_reconcile_equal, responsible_rows
+    kw, env, variant, post = draw_case(seed)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    snap = W.generate(W.small(**kw))
+    shape_snapshot(snap, post, seed)
+    r = np.random.default_rng(seed ^ 0xA11)
+    T, P = snap.n_thr, snap.n_pods
+    _stored_status(snap, oracle_mod)        # what UpdateStatus persisted before this engine came up
+    # (the admission queue wants head-room: thresholds doubled AFTER the status was stored is what a spec edit looks like)
+    o = oracle_mod.Oracle(snap)
+    eng = E.Engine.for_snapshot(snap, variant & ~E.VARIANT_INCREMENTAL)
+    try:
+        resp = responsible_rows(snap)
+        try:
+            # ---- single keys
+            if len(resp):
+                keys = np.sort(r.choice(resp, size=max(1, len(resp) // int(r.integers(2, 6))), replace=False))
+                want = o.reconcile(NOW, rows=keys)
+                got_all = eng.reconcile_rows(NOW, keys.astype(np.int32), apply=True)
+                assert_reconcile_equal(_rows_of(got_all, keys, snap.D), want, len(keys))
+                snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=keys)
+            # ---- PreFilter calls of 1..8 pods, and the status rows of a few more
+            on_equal = bool(seed & 1)
+            for n in (1, 1, 2, 5, 8):
+                rows = r.integers(0, P, n).astype(np.int64)
+                st_w, sm_w = o.check(rows, on_equal=on_equal)
+                _, sm_g = eng.check(rows, on_equal=on_equal, want_status=False)
+                np.testing.assert_array_equal(sm_g, sm_w, err_msg=f"kt_check of {n} pods")
+            rows = np.unique(r.integers(0, P, 40)).astype(np.int64)
+            st_w, sm_w = o.check(rows, on_equal=on_equal)
+            st_g, sm_g = eng.check(rows, on_equal=on_equal, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w)
+            np.testing.assert_array_equal(sm_g, sm_w)
+            # ---- affectedPods of the listed pairs: exactly the cells of the matrix that are not "not affected" (Error rows: 255)
+            trs = np.unique(r.integers(0, T, min(T, 12))).astype(np.int32)
+            aff = eng.affected_pods(rows, trs)
+            err_rows = (S.summary_fields(sm_w)[0] == S.VERDICT_ERROR)
+            want_aff = (st_w[:, trs] != S.NOT_AFFECTED).astype(np.uint8)
+            want_aff[err_rows] = 255
+            valid_thr = (snap.thr_flags[trs] & S.THR_VALID) != 0
+            np.testing.assert_array_equal(aff[:, valid_thr], want_aff[:, valid_thr], err_msg="kt_affected_pods")
+            # ---- a pending queue admitted in order, reserving on the way
+            fl = snap.pod_flags[:P]
+            pending = np.nonzero(((fl & S.POD_VALID) != 0) & ((fl & S.POD_SCHEDULED) == 0))[0]
+            if len(pending):
+                queue = r.permutation(pending)[:int(r.integers(1, 400))].astype(np.int64)
+                st_w, sm_w, res_w = o.admit(queue, on_equal=on_equal)
+                st_d, sm_d = eng.admit(queue, on_equal=on_equal, commit=False)
+                np.testing.assert_array_equal(st_d, st_w)
+                np.testing.assert_array_equal(sm_d, sm_w)
+                st_g, sm_g = eng.admit(queue, on_equal=on_equal, commit=True)
+                np.testing.assert_array_equal(sm_g, sm_w)
+                res_g = eng.fetch_reserved()
+                for f in ("v", "present", "count", "has_count"):
+                    np.testing.assert_array_equal(getattr(res_g, f)[resp], getattr(res_w, f)[resp], err_msg=f"reserved.{f}")
+        except Exception:
+            print(f"\nentry-point fuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  requests={post}")
+            raise
+    finally:
+        eng.close()
