@@ -1,4 +1,6 @@
 """tests/test_paging_cpu.py with the HIP engines as the per-page evaluators (kube_throttler_amd.paging.PagedEngine)."""
+import os
+
 import pytest
 
 from kube_throttler_amd import paging
@@ -7,7 +9,8 @@ from test_paging_cpu import check_against_model, wide_cluster
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 8])
+# (KT_FUZZ_PAGED=n adds the seeds 100 .. 100 + n: profiles/r06_fuzz.txt)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 8] + list(range(100, 100 + int(os.environ.get("KT_FUZZ_PAGED", "0")))))
 def test_paged_engines_equal_the_manifest_model(seed):
     state = {}
 
