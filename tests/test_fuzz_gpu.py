@@ -255,3 +255,144 @@ def test_random_shapes_through_the_other_entry_points(seed, oracle_mod, monkeypa
             raise
     finally:
         eng.close()
+
+
+def conc_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930")) + 57
+    return [base + 32452843 * i for i in range(int(os.environ.get("KT_FUZZ_CONC_CASES", "3")))]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", conc_seeds())
+def test_concurrent_events_prefilters_and_reconciles(seed, oracle_mod, monkeypatch):
+    """One engine, four kinds of callers at once (the scheduler's PreFilter goroutines, the informers' pod handlers, the two
+    controllers' workers): a thread feeds a pre-drawn sequence of pod upserts / deletes (single rows and small batches), two threads
+    issue PreFilter calls of 1-8 pods without pause (the few-pod path under the shared lock) and whole sweeps, one thread
+    reconciles (apply) in a loop, one reconciles single keys.  No call may fail or hang; afterwards the engine holds exactly the
+    pods of the sequence's end state: reconcile + status matrix equal the oracle on them."""
+    import threading
+    from test_engine_gpu import NOW, _permute_pods, _rows_of, _with_pods, assert_reconcile_equal, responsible_rows
+    kw, env, variant, post = draw_case(seed)
+    kw["n_pods"] = min(kw["n_pods"], 2500)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    base = W.generate(W.small(**kw))
+    shape_snapshot(base, post if post != "negative" else "none", seed)
+    r = np.random.default_rng(seed ^ 0xC0C0)
+    n_src = base.n_pods
+    P = max(64, int(n_src * 0.8))
+    state = np.full(P, -1, dtype=np.int64)
+    n0 = P // 2
+    state[:n0] = r.integers(0, n_src, n0)
+    # the event sequence, drawn up front (the feeder thread only replays it)
+    events = []
+    for _ in range(int(os.environ.get("KT_FUZZ_CONC_EVENTS", "150"))):
+        size = int(r.choice([1, 1, 1, 2, 6, 30]))
+        if r.random() < .7:
+            events.append(("up", r.integers(0, P, size).astype(np.int64), r.integers(0, n_src, size)))
+        else:
+            events.append(("del", np.unique(r.integers(0, P, size)).astype(np.int64), None))
+    eng = E.Engine(base.D, max(base.L, 1), P, max(base.n_thr, 1), max(base.n_ns, 1), -1, variant)
+    errors, stop = [], threading.Event()
+    hung = False
+
+    def guarded(fn):
+        def run(*a):
+            try:
+                fn(*a)
+            except Exception as ex:  # noqa: BLE001 — collected, re-raised on the main thread
+                errors.append(ex)
+                stop.set()
+        return run
+
+    @guarded
+    def feeder():
+        for kind, rows, src in events:
+            if stop.is_set():
+                return
+            if kind == "up":
+                eng.upsert_pods(_permute_pods(base, src), rows=rows)
+            else:
+                eng.delete_pods(rows)
+
+    @guarded
+    def prefilter(k):
+        rr = np.random.default_rng(seed + k)
+        while not stop.is_set():
+            n = int(rr.choice([1, 1, 3, 8]))
+            eng.check_atomic(rows=rr.integers(0, P, n).astype(np.int64), on_equal=bool(k & 1), want_status=False)
+            if rr.random() < .05:
+                eng.check_atomic(n=P, on_equal=False, want_status=False)
+
+    @guarded
+    def reconciler():
+        while not stop.is_set():
+            eng.reconcile(NOW, apply=True)
+
+    @guarded
+    def key_worker():
+        rr = np.random.default_rng(seed + 99)
+        rows = responsible_rows(base)
+        while not stop.is_set() and len(rows):
+            eng.reconcile_rows(NOW, rr.choice(rows, size=min(len(rows), 3), replace=False).astype(np.int32), apply=True)
+
+    try:
+        eng.upsert_namespaces(base)
+        eng.upsert_throttles(base)
+        eng.upsert_pods(_permute_pods(base, state[:n0]), rows=np.arange(n0))
+        eng.reconcile(NOW, apply=True)
+        # (both sides start from the same stored status: whether a threshold counts as replaced depends on what was stored)
+        snap0 = _with_pods(base, state[:n0])
+        rows0 = responsible_rows(snap0)
+        w0 = oracle_mod.Oracle(snap0).reconcile(NOW, rows=rows0)
+        snap0.apply_status(w0.used, w0.calc, w0.calc_updated, w0.thrl_flag, w0.thrl_has, w0.thrl_pod, w0.error, rows=rows0)
+        base.thr_used, base.thr_calc = snap0.thr_used, snap0.thr_calc
+        base.thr_flags, base.thr_thrl_flag, base.thr_thrl_has = snap0.thr_flags, snap0.thr_thrl_flag, snap0.thr_thrl_has
+        workers = [threading.Thread(target=prefilter, args=(k,), daemon=True) for k in range(2)]
+        workers += [threading.Thread(target=reconciler, daemon=True), threading.Thread(target=key_worker, daemon=True)]
+        fd = threading.Thread(target=feeder, daemon=True)
+        for th in workers:
+            th.start()
+        fd.start()
+        fd.join(timeout=240)
+        stop.set()
+        for th in workers:
+            th.join(timeout=60)
+        hung = fd.is_alive() or any(th.is_alive() for th in workers)
+        try:
+            assert not hung, "a caller did not return"
+            if errors:
+                raise errors[0]
+            for kind, rows, src in events:  # the end state of the sequence (inside a batch the last entry of a row wins)
+                if kind == "up":
+                    for i in range(len(rows)):
+                        state[rows[i]] = src[i]
+                else:
+                    state[rows] = -1
+            used = np.nonzero(state >= 0)[0]
+            n = int(used.max()) + 1 if len(used) else 1
+            snap = _with_pods(base, state[:n])
+            o = oracle_mod.Oracle(snap)
+            rows_t = responsible_rows(snap)
+            want = o.reconcile(NOW, rows=rows_t)
+            got = _rows_of(eng.reconcile(NOW, apply=True), rows_t, snap.D)
+            # (calc_updated depends on what the racing reconciles stored before: everything else is a function of the end state)
+            got.calc_updated[:] = want.calc_updated[:len(got.calc_updated)]
+            assert_reconcile_equal(got, want, len(rows_t))
+            snap.apply_status(want.used, want.calc, want.calc_updated, want.thrl_flag, want.thrl_has, want.thrl_pod, want.error, rows=rows_t)
+            st_w, sm_w = o.check(on_equal=False, nthreads=4)
+            st_g, sm_g = eng.check(n=n, on_equal=False, want_status=True)
+            np.testing.assert_array_equal(st_g, st_w)
+            np.testing.assert_array_equal(sm_g, sm_w)
+        except Exception:
+            print(f"\nconcurrency fuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}  requests={post}")
+            raise
+    finally:
+        stop.set()
+        if not hung:  # (a caller still inside the library: leave the engine alone)
+            eng.close()
