@@ -170,7 +170,9 @@ int32_t compile_program(kt_engine* e, hipStream_t s) {
     // can pack — a chunk then holds more words, a namespace-ordered scan makes fewer chunk passes; the first scan that needs
     // the plain fold (a negative request, sums beyond int64, KT_NO_PACK) has the program cut again for plain records
     // (aggregate_locked: cut_plain)
-    const uint32_t thr_packed = (!e->incremental && !e->wide && !e->neg_seen && !e->cut_plain && !e->sw[kSw_NO_PACK]) ? kt::packed_rec_max(D) : 0u;
+    // (scans that gather through the row lists — KT_NO_SCAN_VIEW, KT_NO_NS_ORDER — fold plain records)
+    const uint32_t thr_packed = (!e->incremental && !e->wide && !e->neg_seen && !e->cut_plain && !e->sw[kSw_NO_PACK] && !e->sw[kSw_NO_SCAN_VIEW] &&
+                                 !e->sw[kSw_NO_NS_ORDER]) ? kt::packed_rec_max(D) : 0u;
     // the check kernel runs two workgroups per CU when the whole program fits half the LDS; otherwise the chunks are cut
     // for one workgroup per CU (fewer, larger chunks)
     const uint32_t chk_half = hook ? (uint32_t)atoi(hook) : lds_all / 2 - kt::check_fixed_lds();

@@ -259,31 +259,35 @@ int32_t aggregate_locked(kt_engine* e, hipStream_t s, bool allow_fused) {
       KT_HIP(e, hipStreamSynchronize(s));  // (1 KB; h_range is reused)
     }
     e->pack = kt::PackPlan();
+    // room for the pods that become countable before the next rebuild (kt_patch_scan_views appends them)
+    const int64_t headroom = std::min<int64_t>(std::max<int64_t>(65536, (int64_t)e->n_countable / 16), e->cfg.pod_capacity - (int64_t)e->n_countable);
+    // will the full scans stream the scan view?  (The packed fold exists in that form only: a scan that gathers through the row
+    // list — KT_NO_SCAN_VIEW, KT_NO_NS_ORDER on a multi-chunk index — folds plain records.)
+    const bool view_scan = !e->sw[kSw_NO_SCAN_VIEW] && (e->countable_by_ns || e->dindex.n_chunks == 1);
+    // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
+    // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
+    if (view_scan && !e->incremental && !e->wide && !e->sw[kSw_NO_PACK] && !e->dindex.has_long) {
+      const int64_t cap = (int64_t)e->n_countable + headroom;
+      uint64_t slab_pods = kt::aggregate_slab_pods(cap, kt::aggregate_blocks(cap));
+      // (planned ranges hold up to wg_range_cap records)
+      if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
+      e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true, kt::pack_max_words(e->D));
+      if (e->pack.nw && e->pack.rec_bytes > e->dindex.cut_thr_bytes) e->pack = kt::PackPlan();  // the slab areas hold records of that size
+    }
+    if (!e->pack.nw && kt::agg_rec_bytes(e->D, e->incremental) > e->dindex.cut_thr_bytes) {
+      // the plain fold is coming and the chunks were cut for the packed fold's records: cut again, for plain ones (once —
+      // the engine then stays with plain-sized chunks), and start over on the new index
+      upgrade_launch_lock(e);
+      e->cut_plain = true, e->program_dirty = true;
+      e->countable_valid = false;
+      return aggregate_locked(e, s, allow_fused);
+    }
     if (!e->sw[kSw_NO_SCAN_VIEW]) {
       // scan-ordered copies of the listed pods' records: the scan streams them instead of gathering through the list
       // (namespace order for a multi-chunk index, ascending rows otherwise)
-      // room for the pods that become countable before the next rebuild (kt_patch_scan_views appends them)
-      const int64_t headroom = std::min<int64_t>(std::max<int64_t>(65536, (int64_t)e->n_countable / 16), e->cfg.pod_capacity - (int64_t)e->n_countable);
       e->view_cap_c = (int64_t)e->n_countable + headroom;
       e->view_extra = 0;
       const size_t nc = (size_t)e->view_cap_c + 1;
-      // packed fold (PackPlan, kt_index.h) when every request of this engine is non-negative and the fields fit: sized
-      // for the pods ONE workgroup scans with one workgroup per CU (two per CU scan fewer)
-      if (!e->incremental && !e->wide && !e->sw[kSw_NO_PACK] && !e->dindex.has_long) {
-        uint64_t slab_pods = kt::aggregate_slab_pods(e->view_cap_c, kt::aggregate_blocks(e->view_cap_c));
-        // (planned ranges hold up to wg_range_cap records)
-        if (e->range_c_G) slab_pods = std::max<uint64_t>(slab_pods, (uint64_t)kt::wg_range_cap((int64_t)e->n_countable, e->range_c_G) + 64u);
-        e->pack = kt::make_pack_plan(e->D, e->max_abs, e->or_abs, e->neg_seen, slab_pods, /*pad_odd=*/true, kt::pack_max_words(e->D));
-        if (e->pack.nw && e->pack.rec_bytes > e->dindex.cut_thr_bytes) e->pack = kt::PackPlan();  // the slab areas hold records of that size
-      }
-      if (!e->pack.nw && kt::agg_rec_bytes(e->D, e->incremental) > e->dindex.cut_thr_bytes) {
-        // the plain fold is coming and the chunks were cut for the packed fold's records: cut again, for plain ones (once —
-        // the engine then stays with plain-sized chunks), and start over on the new index
-        upgrade_launch_lock(e);
-        e->cut_plain = true, e->program_dirty = true;
-        e->countable_valid = false;
-        return aggregate_locked(e, s, allow_fused);
-      }
       KT_HIP(e, e->d_vc_meta.reserve(nc));
       KT_HIP(e, e->d_vc_latom.reserve(nc * (size_t)e->pods.LA));
       if (e->pack.nw) KT_HIP(e, e->d_vc_pk.reserve(nc * (size_t)e->pack.stride));

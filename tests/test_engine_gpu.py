@@ -180,6 +180,25 @@ def test_aggregate_rank_windows(shape, oracle_mod, monkeypatch):
             eng.close()
 
 
+@pytest.mark.parametrize("switch", ["KT_NO_NS_ORDER", "KT_NO_SCAN_VIEW"])
+def test_row_list_scans_of_a_multi_chunk_program(switch, oracle_mod, monkeypatch):
+    """A program of several chunks is cut for the packed fold's records — but a full scan that gathers through the row list instead of
+    streaming the scan view (the A/B switches KT_NO_NS_ORDER / KT_NO_SCAN_VIEW) folds PLAIN records: the engine must plan no packed
+    fold then and cut the chunks for plain records.  Found by tests/test_fuzz_gpu.py in round 6 (the reconcile answered "a chunk of
+    the selector index exceeds the aggregate kernel's LDS budget": the plan was made for a scan that never used it)."""
+    monkeypatch.setenv("KT_CHUNK_BUDGET", "9000")
+    monkeypatch.setenv(switch, "1")
+    snap = W.generate(W.small(seed=97, n_pods=4000, n_thr=160, n_cluster=40, D=5, n_ns=11, K=12, V=4, L=8, terms=(1, 3), reqs=(0, 4)))
+    run_full_parity(snap, oracle_mod, E.VARIANT_INDEXED)
+    eng = E.Engine.for_snapshot(snap, E.VARIANT_INDEXED)
+    try:
+        eng.reconcile(NOW, apply=False)
+        assert eng.index_stats()["chunks"] > 1 and eng.packed_words() == 0
+        assert not eng.kernel_name(E.KERNEL_AGGREGATE).startswith("kt_aggregate_bitmap_packed")
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("shape", ["simple", "rich-8-labels", "rich-16-labels", "rich-32-labels", "five-keys", "windows", "chunked", "nine-dims"])
 def test_packed_fold_of_more_than_four_words(shape, oracle_mod, monkeypatch):
     """An engine with more than 8 dimensions packs its requests into up to EIGHT 64-bit words (round 6: until then `PackPlan` held

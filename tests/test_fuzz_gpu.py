@@ -19,7 +19,12 @@ from test_engine_gpu import run_full_parity
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("KT_CHUNK_BUDGET", "KT_AGG_SMALL_WINDOW", "KT_CUT_PLAN")
+# the A/B switches of the engine (kt_engine_impl.h: EnvSwitch, read at engine creation): every one selects a path that stays in the
+# library — the plain fold, scans that gather through the row lists, unfused reductions, feeds without the few-row kernels ...
+PATH_SWITCHES = ("KT_FEED_NO_STAGE", "KT_FORCE_NS_ORDER", "KT_NO_FEED_FEW", "KT_NO_FEED_FUSION", "KT_NO_FUSED", "KT_NO_NS_ORDER", "KT_NO_PACK",
+                 "KT_NO_SCAN_VIEW", "KT_NO_SWEEP", "KT_NO_VERDICT_IMAGES", "KT_NO_WG_RANGES", "KT_SYNC_INGEST", "KT_NO_VIEW_PATCH",
+                 "KT_CHECK_ONE_PER_CU")
+SWITCHES = ("KT_CHUNK_BUDGET", "KT_AGG_SMALL_WINDOW", "KT_CUT_PLAN") + PATH_SWITCHES
 
 
 def draw_case(seed):
@@ -51,6 +56,10 @@ def draw_case(seed):
         env["KT_CUT_PLAN"] = "grouped"
     variant = E.VARIANT_INDEXED | (E.VARIANT_INCREMENTAL if r.random() < .2 else 0)
     post = str(r.choice(["none", "none", "none", "negative", "large", "zero"]))
+    r2 = np.random.default_rng(seed ^ 0x5317C4)  # (its own stream: the shapes above stay what they were before these were drawn)
+    if r2.random() < .4:
+        for k in r2.choice(PATH_SWITCHES, size=int(r2.integers(1, 4)), replace=False):
+            env[str(k)] = "1"
     return kw, env, variant, post
 
 
