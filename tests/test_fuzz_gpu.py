@@ -60,6 +60,10 @@ def draw_case(seed):
     if r2.random() < .4:
         for k in r2.choice(PATH_SWITCHES, size=int(r2.integers(1, 4)), replace=False):
             env[str(k)] = "1"
+    if r2.random() < .08 and not (variant & E.VARIANT_INCREMENTAL):
+        variant = E.VARIANT_DENSE  # the dense cross-check kernels (no index)
+    if r2.random() < .02:
+        kw["n_pods"] = int(r2.integers(60000, 200000))  # hundreds of workgroups: planned ranges, every slab in use
     return kw, env, variant, post
 
 
