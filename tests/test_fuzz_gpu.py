@@ -409,3 +409,53 @@ def test_concurrent_events_prefilters_and_reconciles(seed, oracle_mod, monkeypat
         stop.set()
         if not hung:  # (a caller still inside the library: leave the engine alone)
             eng.close()
+
+
+def wide_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930")) + 71
+    return [base + 49979687 * i for i in range(int(os.environ.get("KT_FUZZ_WIDE_CASES", "6")))]
+
+
+@pytest.mark.parametrize("seed", wide_seeds())
+def test_random_shapes_with_sums_beyond_int64(seed, oracle_mod, monkeypatch):
+    """resource.Quantity never overflows: on a random shape one resource is requested in amounts of 2^59..2^59.6 per pod (a second one
+    partly negative), so that `used` of every throttle with a few dozen pods leaves int64 — the two limb scans, the 128-bit join in
+    kt_finalize, the wide status the check reads: against the oracle's __int128 arithmetic (test_engine_gpu._wide_parity)."""
+    from test_engine_gpu import NOW, _wide_parity, responsible_rows
+    kw, env, variant, post = draw_case(seed)
+    kw["n_pods"] = min(kw["n_pods"], 4000)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    snap = W.generate(W.small(**kw))
+    r = np.random.default_rng(seed ^ 0x1D3)
+    first = snap.pod_ctr_off[:snap.n_pods]
+    nc = int(snap.pod_ctr_off[snap.n_pods])
+    if nc == 0:
+        pytest.skip("no containers")
+    d0 = int(r.integers(0, snap.D))
+    snap.ctr_req[:nc, d0] = 0
+    snap.ctr_req[first, d0] = (1 << 59) + r.integers(0, 1 << 58, len(first))  # (the C-ABI takes requests up to 2^60: KT_ERR_OVERFLOW_RISK)
+    snap.ctr_present[first] |= 1 << d0
+    if snap.D > 1 and r.random() < .5:  # a second resource whose sums are wide AND signed
+        d1 = (d0 + 1) % snap.D
+        snap.ctr_req[:nc, d1] = 0
+        snap.ctr_req[first[::2], d1] = -(1 << 59) - r.integers(0, 1 << 20, len(first[::2]))
+        snap.ctr_req[first[1::2], d1] = (1 << 59) + r.integers(0, 1 << 20, len(first[1::2]))
+        snap.ctr_present[first] |= 1 << d1
+    T = snap.n_thr
+    snap.thr_spec.v[:T, d0] = (r.integers(1, 7, T).astype(np.int64) << 60) + 7   # thresholds the wide sums are compared with
+    snap.thr_spec.present[:T] |= 1 << d0
+    rows = responsible_rows(snap)
+    want = oracle_mod.Oracle(snap).reconcile(NOW, rows=rows, wide=True)
+    if want.error[:len(rows)].any() or not (want.used_hi[:len(rows)] != (want.used.v[:len(rows)] < 0) * -1).any():
+        pytest.skip("no throttle of this shape counts enough pods to leave int64")
+    try:
+        _wide_parity(snap, oracle_mod, variant & ~E.VARIANT_INCREMENTAL)
+    except Exception:
+        print(f"\nwide fuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}")
+        raise
