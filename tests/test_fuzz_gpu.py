@@ -459,3 +459,32 @@ def test_random_shapes_with_sums_beyond_int64(seed, oracle_mod, monkeypatch):
     except Exception:
         print(f"\nwide fuzz case {seed}: KT_FUZZ_ONLY={seed}  shape={kw}  env={env}  variant={variant}")
         raise
+
+
+def shard_seeds():
+    only = os.environ.get("KT_FUZZ_ONLY")
+    if only:
+        return [int(only)]
+    base = int(os.environ.get("KT_FUZZ_SEED", "20260930")) + 83
+    return [base + 67867967 * i for i in range(int(os.environ.get("KT_FUZZ_SHARD_CASES", "4")))]
+
+
+@pytest.mark.parametrize("seed", shard_seeds())
+def test_random_shapes_in_shards(seed, oracle_mod, monkeypatch):
+    """The multi-GPU result on ONE GPU (tests/test_sharded_gpu.py: shards cut as bench.py --gpus N cuts them, partial buffers summed
+    as the all-reduce sums them, the sum finalized by every shard's engine, every shard's sweep) on a random shape, 2-8 shards,
+    under random switches: every throttle and every pod's summary word against the oracle on the UNSHARDED snapshot."""
+    from test_sharded_gpu import _sharded_pipeline
+    kw, env, variant, post = draw_case(seed)
+    for k in ("n_invalid_pod_sel", "n_invalid_ns_sel", "n_missing_ns"):  # (the pipeline asserts error-free reconciles)
+        kw.pop(k, None)
+    for k in SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    world = int(np.random.default_rng(seed ^ 0x5A4D).integers(2, 9))
+    try:
+        _sharded_pipeline(W.small(**kw), world, oracle_mod, n_thr_sample=kw["n_thr"], n_pod_sample=512, nthreads=4)
+    except Exception:
+        print(f"\nshard fuzz case {seed}: KT_FUZZ_ONLY={seed}  world={world}  shape={kw}  env={env}")
+        raise
