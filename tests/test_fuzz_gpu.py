@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 # library — the plain fold, scans that gather through the row lists, unfused reductions, feeds without the few-row kernels ...
 PATH_SWITCHES = ("KT_FEED_NO_STAGE", "KT_FORCE_NS_ORDER", "KT_NO_FEED_FEW", "KT_NO_FEED_FUSION", "KT_NO_FUSED", "KT_NO_NS_ORDER", "KT_NO_PACK",
                  "KT_NO_SCAN_VIEW", "KT_NO_SWEEP", "KT_NO_VERDICT_IMAGES", "KT_NO_WG_RANGES", "KT_SYNC_INGEST", "KT_NO_VIEW_PATCH",
-                 "KT_CHECK_ONE_PER_CU")
+                 "KT_CHECK_ONE_PER_CU", "KT_INGEST_EVENT_WAIT", "KT_INGEST_TRUST_FENCE")
 SWITCHES = ("KT_CHUNK_BUDGET", "KT_AGG_SMALL_WINDOW", "KT_CUT_PLAN") + PATH_SWITCHES
 
 
